@@ -1,0 +1,361 @@
+"""``SympyProblem``: symbolic definition of an ODE and of everything the adjoint needs.
+
+Keeps the constructor, attributes and semantics of the reference class
+(/root/reference/sunode/symode/problem.py:24-158) -- same symbols
+(states ``positive=True`` ``:78``, parameters ``real=True`` ``:79``, ``time``
+``:67``), same derived objects (``J = df/dy`` ``:142``, ``df/dp`` ``:144``,
+adjoint rhs ``-lam^T J`` ``:147``, quadrature rhs ``lam^T df/dp`` ``:148``) and
+the same ``user_data_dtype`` (``:150-158``) -- but instead of numba C callbacks
+(``:251-433``) it emits HIP C++ device functions (see ``codegen.py``) that the
+batched BDF kernels include.  The ``make_*`` methods still exist and return
+host callables with the reference's call signatures (used by ``EvalRhs`` and by
+user code that evaluates the right-hand side directly); they are host-side
+conveniences, not part of the device path.
+"""
+from __future__ import annotations
+
+from itertools import product
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+import sympy as sym
+
+from sunode_amd import dtypesubset
+from sunode_amd.symode import codegen
+
+Path = Tuple[str, ...]
+Shape = Tuple[int, ...]
+
+data_dtype = np.dtype(np.float64)
+
+
+def _scalarize(item: np.ndarray) -> Any:
+    if hasattr(item, "shape") and item.shape == ():
+        return item.item()
+    return item
+
+
+class SympyProblem:
+    def __init__(
+        self,
+        params: Dict[str, Any],
+        states: Dict[str, Any],
+        rhs_sympy: Callable[[sym.Symbol, Any, Any], Dict[str, Any]],
+        derivative_params: List[Path],
+        coords: Optional[Dict[str, pd.Index]] = None,
+        simplify: Optional[Callable[[sym.Expr], sym.Expr]] = None,
+    ):
+        self.params_subset = dtypesubset.DTypeSubset(
+            params, derivative_params, fixed_dtype=data_dtype, coords=coords)
+        self.coords = self.params_subset.coords
+        self.params_dtype = self.params_subset.dtype
+        self.state_subset = dtypesubset.DTypeSubset(
+            states, [], fixed_dtype=data_dtype, coords=self.coords)
+        self.state_dtype = self.state_subset.dtype
+        self._rhs_sympy_func = rhs_sympy
+        self._simplify = np.vectorize(simplify if simplify is not None else (lambda e: e),
+                                      otypes=[object])
+
+        self._sym_time = sym.Symbol("time", real=True)
+
+        # -- symbols: one sympy symbol per scalar slot, named '<path>_<idx>' ----
+        # (reference :70-95; scalar leaves get sympy's trailing underscore name)
+        self._varmap: Dict[str, Tuple[Any, ...]] = {}
+        self._c_slots: Dict[str, str] = {"time": "t"}
+
+        state_syms = self._declare(self.state_subset, "state", positive=True)
+        param_syms = self._declare(self.params_subset, "params", real=True)
+
+        sub_paths = set(self.params_subset.subset_paths)
+        deriv = [param_syms[p].ravel() for p in self.params_subset.paths if p in sub_paths]
+        fixed = [param_syms[p].ravel() for p in self.params_subset.paths if p not in sub_paths]
+        self._sym_deriv_paramsvec = np.concatenate(deriv) if deriv else np.zeros((0,), dtype=object)
+        self._sym_fixed_paramsvec = np.concatenate(fixed) if fixed else np.zeros((0,), dtype=object)
+        svec = [state_syms[p].ravel() for p in self.state_subset.paths]
+        self._sym_statevec = np.concatenate(svec) if svec else np.zeros((0,), dtype=object)
+
+        for j, s in enumerate(self._sym_deriv_paramsvec):
+            self._c_slots[s.name] = "ps[%d]" % j
+        for j, s in enumerate(self._sym_fixed_paramsvec):
+            self._c_slots[s.name] = "pr[%d]" % j
+        for i, s in enumerate(self._sym_statevec):
+            self._c_slots[s.name] = "y[%d]" % i
+
+        self._sym_params = self.params_subset.as_dataclass(
+            "Params", self._sym_deriv_paramsvec, self._sym_fixed_paramsvec, item_map=_scalarize)
+        self._sym_states = self.state_subset.as_dataclass(
+            "State", [], self._sym_statevec, item_map=_scalarize)
+
+        dydt = self._make_dydt()
+        self._sym_dydt = np.array(dydt).ravel()
+
+        n, p = self.n_states, self.n_params
+        self._sym_sens = sym.symarray("sens", (p, n))
+        self._sym_lamda = sym.symarray("lamda", n)
+        for i in range(n):
+            self._varmap[self._sym_lamda[i].name] = ("lamda", (i,))
+            self._c_slots[self._sym_lamda[i].name] = "lam[%d]" % i
+        for idx in product(range(p), range(n)):
+            self._varmap[self._sym_sens[idx].name] = ("sens", idx)
+
+        if n:
+            self._sym_dydt_jac = np.array(dydt.jacobian(list(self._sym_statevec))).reshape(n, n)
+        else:
+            self._sym_dydt_jac = np.zeros((0, 0), dtype=object)
+        if n and p:
+            self._sym_dydp = np.array(dydt.jacobian(list(self._sym_deriv_paramsvec))).reshape(n, p)
+        else:
+            self._sym_dydp = np.zeros((n, p), dtype=object)
+        self._sym_dlamdadt = -self._sym_lamda @ self._sym_dydt_jac if n else np.zeros((0,), object)
+        self._sym_quad_rhs = self._sym_lamda @ self._sym_dydp if (n and p) else np.zeros((p,), object)
+
+        self.user_data_dtype = np.dtype([
+            ("params", self.params_subset.dtype),
+            ("tmp_nstates_nstates", np.float64, (n, n)),
+            ("tmp_nparams_nstates", np.float64, (p, n)),
+            ("tmp2_nparams_nstates", np.float64, (p, n)),
+            ("error_states", self.state_dtype),
+            ("error_rhs", np.float64, (n,)),
+            ("error_jac", np.float64, (n, n)),
+        ])
+        self._native_source: Optional[str] = None
+        self._host_funcs: Dict[str, Any] = {}
+
+    # ------------------------------------------------------------------
+    def _declare(self, subset: dtypesubset.DTypeSubset, kind: str, **assumptions) -> Dict[Path, np.ndarray]:
+        out: Dict[Path, np.ndarray] = {}
+        for path, shape in subset.flat_shapes.items():
+            arr = sym.symarray("_".join(path), shape, **assumptions)
+            out[path] = arr
+            for idx in product(*[range(k) for k in shape]):
+                var = arr[idx]
+                self._varmap[var.name] = (kind, *path) if idx == () else (kind, *path, idx)
+        return out
+
+    @property
+    def n_states(self) -> int:
+        return self.state_subset.n_items
+
+    @property
+    def n_params(self) -> int:
+        """Number of *differentiated* parameters (reference problem.py:96-98)."""
+        return self.params_subset.n_subset
+
+    @property
+    def n_remainder(self) -> int:
+        return self.params_subset.n_items - self.params_subset.n_subset
+
+    # ------------------------------------------------------------------
+    def _make_dydt(self) -> sym.Matrix:
+        """Call the user's rhs and flatten its nested result in state order
+        (reference :160-230)."""
+        rhs = self._rhs_sympy_func(self._sym_time, self._sym_states, self._sym_params)
+        flat_dims = {k: names for k, (_, names) in dtypesubset.as_flattened(self.state_subset.dims).items()}
+
+        def flatten(label: str, value: Any, shape: Shape, dims: Tuple[str, ...]) -> List[Any]:
+            if hasattr(value, "shape"):
+                if tuple(value.shape) != tuple(shape):
+                    raise ValueError(
+                        "Invalid shape for right-hand-side state %s. It is %s but we expected %s."
+                        % (label, value.shape, shape))
+                if isinstance(value, sym.NDimArray):
+                    return list(value.reshape(int(np.prod(shape, dtype=int))))
+                data = getattr(value, "data", value)      # xarray.DataArray duck-typing
+                return list(np.asarray(data, dtype=object).reshape(-1))
+            if isinstance(value, (list, tuple)):
+                if not shape or len(value) != shape[0]:
+                    raise ValueError("Invalid shape for right-hand-side state %s." % label)
+                out: List[Any] = []
+                for item in value:
+                    out.extend(flatten(label, item, shape[1:], dims[1:]))
+                return out
+            if isinstance(value, dict):
+                if not shape or len(value) != shape[0]:
+                    raise ValueError("Invalid shape for right-hand-side state %s." % label)
+                out = []
+                for key in self.coords[dims[0]]:
+                    out.extend(flatten(label, value[key], shape[1:], dims[1:]))
+                return out
+            if shape == ():
+                return [value]
+            raise ValueError("Unknown righ-hand-side for state %s." % label)
+
+        def copy_nested(node: Any) -> Any:
+            return {k: copy_nested(v) for k, v in node.items()} if isinstance(node, dict) else node
+
+        rest = copy_nested(rhs)
+        items: List[Any] = []
+        for path in self.state_subset.paths:
+            node = rest
+            for key in path[:-1]:
+                if key not in node:
+                    raise ValueError("No right-hand-side for state %s" % ".".join(path))
+                node = node[key]
+            if path[-1] not in node:
+                raise ValueError("No right-hand-side for state %s" % ".".join(path))
+            value = node.pop(path[-1])
+            items.extend(flatten(".".join(path), value,
+                                 self.state_subset.flat_shapes[path], tuple(flat_dims[path])))
+        leftover = dtypesubset.as_flattened(rest)
+        if leftover:
+            raise ValueError("Unknown state variables: %s" % [".".join(p) for p in leftover])
+        return sym.Matrix(items) if items else sym.Matrix(0, 1, [])
+
+    # ------------------------------------------------------------------
+    # parameter plumbing on the host-side user_data record (reference :232-249)
+    def make_user_data(self) -> np.ndarray:
+        return np.zeros((), dtype=self.user_data_dtype).view(np.recarray)
+
+    def update_params(self, user_data: np.ndarray, params: np.ndarray) -> None:
+        user_data.params.fill(params)
+
+    def update_subset_params(self, user_data: np.ndarray, params: np.ndarray) -> None:
+        user_data.params.view(self.params_subset.subset_view_dtype).fill(params)
+
+    def update_remaining_params(self, user_data: np.ndarray, params: np.ndarray) -> None:
+        user_data.params.view(self.params_subset.remainder.subset_view_dtype).fill(params)
+
+    def extract_params(self, user_data: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        if out is None:
+            out = np.full((1,), np.nan, dtype=self.params_dtype)[0]
+        out.fill(user_data.params)
+        return out
+
+    def flat_params(self, user_data: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """(ps, pr): differentiated / remaining parameters as flat float64 vectors."""
+        full = np.array(user_data.params).reshape(1).view(np.float64) if self.params_dtype.itemsize \
+            else np.zeros(0)
+        return (np.ascontiguousarray(full[self.params_subset.subset_index]),
+                np.ascontiguousarray(full[self.params_subset.remainder_index]))
+
+    def flat_solution_as_dict(self, solution: np.ndarray) -> Dict[str, Any]:
+        views = {}
+        for path in self.state_subset.paths:
+            shape = (-1,) + self.state_subset.flat_shapes[path]
+            views[path] = solution[:, self.state_subset.flat_slices[path]].reshape(shape)
+        return dtypesubset.as_nested(views)
+
+    def solution_to_xarray(self, tvals, solution, user_data, sensitivity=None,
+                           *, unstack_state=True, unstack_params=True):
+        """Reference problem.py:100-145 (needs xarray, which is optional here)."""
+        import xarray as xr
+
+        assert sensitivity is None, "TODO"
+        solution = solution.view(self.state_dtype)[..., 0]
+        params = self.extract_params(user_data)
+
+        def unpack(array, dims, prefix):
+            out = {}
+            for name in array.dtype.names:
+                if array[name].dtype == np.float64:
+                    out["_".join(prefix + [name])] = (tuple(dims[name][1]), array[name])
+                else:
+                    out.update(unpack(array[name], dims[name], prefix + [name]))
+            return out
+
+        data = xr.Dataset(coords=self.coords)
+        data["time"] = ("time", tvals)
+        if unstack_state:
+            for name, (dims, vals) in unpack(solution, self.state_subset.dims, ["solution"]).items():
+                if name in data:
+                    raise ValueError(f"Variable {name} is not unique.")
+                data[name] = (("time",) + dims, vals)
+        else:
+            data["solution"] = ("time", solution)
+        if unstack_params:
+            for name, (dims, vals) in unpack(params, self.params_subset.dims, ["parameters"]).items():
+                if name in data:
+                    raise ValueError(f"Variable {name} is not unique.")
+                data[name] = (dims, vals)
+        else:
+            data["parameters"] = params
+        return data
+
+    # ------------------------------------------------------------------
+    # device / host native source
+    def native_source(self) -> str:
+        """Generated header with the five callbacks (HIP ``__device__`` and host C)."""
+        if self._native_source is None:
+            desc = "states=%s params=%s deriv=%s" % (
+                [".".join(p) for p in self.state_subset.paths],
+                [".".join(p) for p in self.params_subset.paths],
+                [".".join(p) for p in self.params_subset.subset_paths])
+            self._native_source = codegen.generate_problem_source(
+                n_states=self.n_states, n_sub=self.n_params, n_rem=self.n_remainder,
+                symbol_map=self._c_slots,
+                dydt=self._simplify(np.array(self._sym_dydt, dtype=object)),
+                jac=self._simplify(np.array(self._sym_dydt_jac, dtype=object)),
+                dlamdadt=self._simplify(np.array(self._sym_dlamdadt, dtype=object)),
+                quad=self._simplify(np.array(self._sym_quad_rhs, dtype=object)),
+                description=desc,
+            )
+        return self._native_source
+
+    # ------------------------------------------------------------------
+    # host callables with the reference's signatures (reference :251-433)
+    def _host(self, key: str, expr: np.ndarray, with_lamda: bool):
+        if key not in self._host_funcs:
+            args = [self._sym_time, list(self._sym_statevec)]
+            if with_lamda:
+                args.append(list(self._sym_lamda))
+            args += [list(self._sym_deriv_paramsvec), list(self._sym_fixed_paramsvec)]
+            flat = [sym.sympify(e) for e in np.asarray(expr, dtype=object).ravel()]
+            fn = sym.lambdify(args, flat, modules=[_HOST_HELPERS, "numpy"], cse=True)
+            self._host_funcs[key] = (fn, np.asarray(expr, dtype=object).shape)
+        return self._host_funcs[key]
+
+    def _eval_host(self, key, expr, with_lamda, out, t, y, lamda, user_data):
+        fn, shape = self._host(key, expr, with_lamda)
+        yv = np.asarray(y).reshape(1).view(np.float64) if np.asarray(y).dtype.fields else np.asarray(y, float)
+        ps, pr = self.flat_params(user_data) if user_data is not None else (np.zeros(0), np.zeros(0))
+        with np.errstate(all="ignore"):
+            if with_lamda:
+                vals = fn(float(t), list(yv), list(np.asarray(lamda, float)), list(ps), list(pr))
+            else:
+                vals = fn(float(t), list(yv), list(ps), list(pr))
+        out[...] = np.asarray(vals, dtype=float).reshape(shape)
+        return 0 if np.isfinite(out).all() else 1
+
+    def make_rhs(self, *, debug=False):
+        def rhs(out, t, y, user_data):
+            code = self._eval_host("rhs", self._sym_dydt, False, out, t, y, None, user_data)
+            if code and user_data is not None:
+                user_data.error_rhs[:] = out
+            return code
+        return rhs
+
+    def make_adjoint_rhs(self, *, debug=False):
+        def adjoint(out, t, y, lamda, user_data):
+            return self._eval_host("adj", self._sym_dlamdadt, True, out, t, y, lamda, user_data)
+        return adjoint
+
+    def make_adjoint_quad_rhs(self, *, debug=False):
+        def quad_rhs(out, t, y, lamda, user_data):
+            return self._eval_host("quad", self._sym_quad_rhs, True, out, t, y, lamda, user_data)
+        return quad_rhs
+
+    def make_jac_dense(self, *, debug=False):
+        def jac_dense(out, t, y, fy, user_data):
+            return self._eval_host("jac", self._sym_dydt_jac, False, out, t, y, None, user_data)
+        return jac_dense
+
+    def make_adjoint_jac_dense(self, *, debug=False):
+        def jac_dense(out, t, y, yB, fyB, user_data):
+            return self._eval_host("adjjac", -self._sym_dydt_jac.T, False, out, t, y, None, user_data)
+        return jac_dense
+
+
+def _logaddexp(a, b):
+    return np.logaddexp(a, b)
+
+
+def _expit(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+_HOST_HELPERS = {
+    "logaddexp": _logaddexp,
+    "expit": _expit,
+    "dexpit": lambda x: _expit(x) * _expit(-x),
+}
