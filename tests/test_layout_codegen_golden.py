@@ -1,0 +1,104 @@
+"""Layout + generated callbacks vs vectors produced by the REFERENCE's symbolic half
+(tests/golden/{layout,callbacks}.json, generator: tools/make_golden_callbacks.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_oracle, make_problem
+from tools.problems import PROBLEMS
+
+NAMES = list(PROBLEMS)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, "layout.json")) as fh:
+        layout = json.load(fh)
+    with open(os.path.join(golden_dir, "callbacks.json")) as fh:
+        callbacks = json.load(fh)
+    return layout, callbacks
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_layout_matches_reference(name, golden):
+    ref = golden[0][name]
+    prob = make_problem(name)
+    ps = prob.params_subset
+    assert prob.n_states == ref["n_states"]
+    assert prob.n_params == ref["n_params"]
+    assert ps.n_items == ref["n_items"]
+    assert [list(p) for p in prob.state_subset.paths] == ref["state_paths"]
+    assert [list(p) for p in ps.paths] == ref["param_paths"]
+    assert [list(p) for p in ps.subset_paths] == ref["subset_paths"]
+    assert [list(p) for p in ps.remainder.subset_paths] == ref["remainder_subset_paths"]
+    assert {".".join(q): [s.start, s.stop] for q, s in ps.flat_slices.items()} == ref["param_slices"]
+    assert {".".join(q): list(s) for q, s in ps.flat_shapes.items()} == ref["param_shapes"]
+    assert {".".join(q): [s.start, s.stop] for q, s in prob.state_subset.flat_slices.items()} == ref["state_slices"]
+    assert prob.params_dtype.itemsize == ref["params_itemsize"]
+    assert prob.state_dtype.itemsize == ref["state_itemsize"]
+    assert ps.subset_dtype.itemsize == ref["subset_itemsize"]
+    view, rview = ps.subset_view_dtype, ps.remainder.subset_view_dtype
+    assert [int(view.fields[n][1]) for n in (view.names or ())] == ref["subset_view_offsets"]
+    assert [int(rview.fields[n][1]) for n in (rview.names or ())] == ref["remainder_view_offsets"]
+    assert prob.user_data_dtype.itemsize == ref["user_data_itemsize"]
+    # index maps are consistent with the slices
+    sub = np.concatenate([np.arange(*ref["param_slices"][".".join(p)]) for p in ref["subset_paths"]]) \
+        if ref["subset_paths"] else np.zeros(0, int)
+    assert ps.subset_index.tolist() == sub.tolist()
+    assert sorted(ps.subset_index.tolist() + ps.remainder_index.tolist()) == list(range(ref["n_items"]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_generated_c_callbacks_match_reference(name, golden):
+    """Host-compiled generated C (same text the HIP kernels include) vs the reference's lambdify output."""
+    prob = make_problem(name)
+    orc = make_oracle(name)
+    ps_idx, pr_idx = prob.params_subset.subset_index, prob.params_subset.remainder_index
+    for pt in golden[1][name]:
+        par = np.array(pt["params"])
+        got = orc.eval(pt["t"], pt["y"], pt["lam"], par[ps_idx], par[pr_idx])
+        for key in ("rhs", "jac", "adj", "quad", "adjjac"):
+            want = np.array(pt[key], dtype=float)
+            # expression order differs (CSE / expanded powers): allow rounding relative to the
+            # largest entry of the same output (cancellation), nothing more
+            scale = float(np.max(np.abs(want))) if want.size else 0.0
+            np.testing.assert_allclose(got[key], want.reshape(got[key].shape), rtol=1e-13,
+                                       atol=4e-15 * scale, err_msg="%s/%s" % (name, key))
+        assert got["codes"].tolist() == pt["codes"]
+
+
+@pytest.mark.parametrize("name", ["lv", "seir", "misc"])
+def test_host_callables_match_reference(name, golden):
+    """make_rhs()/make_jac_dense()/... host conveniences keep the reference's call signatures."""
+    prob = make_problem(name)
+    n, p = prob.n_states, prob.n_params
+    for pt in golden[1][name][:3]:
+        ud = prob.make_user_data()
+        pv = np.zeros((), dtype=prob.params_dtype)
+        pv.reshape(1).view(np.float64)[:] = pt["params"]
+        prob.update_params(ud, pv)
+        y = np.zeros((), dtype=prob.state_dtype)
+        y.reshape(1).view(np.float64)[:] = pt["y"]
+        lam = np.array(pt["lam"])
+        out = np.zeros(n)
+        assert prob.make_rhs()(out, pt["t"], y, ud) == pt["codes"][0]
+        np.testing.assert_allclose(out, pt["rhs"], rtol=1e-13)
+        J = np.zeros((n, n))
+        prob.make_jac_dense()(J, pt["t"], y, None, ud)
+        np.testing.assert_allclose(J, pt["jac"], rtol=1e-13)
+        prob.make_adjoint_rhs()(out, pt["t"], y, lam, ud)
+        np.testing.assert_allclose(out, pt["adj"], rtol=1e-12, atol=1e-14)
+        q = np.zeros(p)
+        prob.make_adjoint_quad_rhs()(q, pt["t"], y, lam, ud)
+        np.testing.assert_allclose(q, pt["quad"], rtol=1e-12, atol=1e-14)
+        prob.make_adjoint_jac_dense()(J, pt["t"], y, lam, None, ud)
+        np.testing.assert_allclose(J, pt["adjjac"], rtol=1e-13)
+
+
+def test_nonfinite_is_recoverable_error():
+    """Reference symode/problem.py:266-269: non-finite output -> return code 1."""
+    orc = make_oracle("misc")
+    got = orc.eval(0.1, [-1.0, 0.5], [1.0, 1.0], [1.0, 1.0, 1.0], [1.0])   # sqrt(-1), log(0)
+    assert got["codes"][0] == 1

@@ -1,0 +1,171 @@
+"""Pin the CPU oracle (oracle/cvodes_oracle.c) against independent references.
+
+The reference's own tests assert no numeric result on the hot path and CVODES is not
+buildable here ("parity unpinned" at the CVODES boundary), so the
+oracle is pinned by: scipy DVODE statistics, tight-tolerance truth solutions and the
+reference notebook's printed known-answer (notebooks/from_sympy.ipynb:240-242).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_oracle, make_problem
+
+STAT = dict(nst=0, nfe=1, nsetups=2, nje=3, nni=4, ncfn=5, netf=6, qlast=7)
+
+
+@pytest.fixture(scope="module")
+def dvode(golden_dir):
+    with open(os.path.join(golden_dir, "dvode_stats.json")) as fh:
+        return json.load(fh)
+
+
+def _run_plain(name, case, mode):
+    orc = make_oracle(name)
+    prob = make_problem(name)
+    par = np.array(case["params"])
+    cfg = orc.config(rtol=case["rtol"], atol=case["atol"])
+    ps, pr = par[prob.params_subset.subset_index], par[prob.params_subset.remainder_index]
+    fn = orc.solve if mode == "plain" else orc.solve_forward
+    y, status, stats = fn(cfg, [case["y0"]], [ps], pr, case["tvals"][0], np.array(case["tvals"]))
+    assert status[0] == 0
+    return y[0], stats[0]
+
+
+@pytest.mark.parametrize("key", ["lv_readme_1e-08", "lv_readme_1e-10"] + ["lv_batch_%d" % i for i in range(8)])
+@pytest.mark.parametrize("mode", ["plain", "adjoint_forward"])
+def test_lv_forward_statistics_equal_dvode(dvode, key, mode):
+    """Step/order bookkeeping of the restated CVODE controller == Fortran DVODE, counter by counter."""
+    case = dvode[key]
+    y, st = _run_plain("lv", case, mode)
+    got = {k: int(st[i]) for k, i in STAT.items()}
+    want = dict(nst=case["nst"], nfe=case["nfe"], nsetups=case["nlu"], nje=case["nje"], nni=case["nni"],
+                ncfn=case["ncfn"], netf=case["netf"], qlast=case["qlast"])
+    assert got == want
+    np.testing.assert_allclose(y, np.array(case["y"]), rtol=1e-9, atol=0)
+    if mode == "adjoint_forward":
+        assert st[8] == case["nst"] + 1          # stored data points = steps + initial point
+
+
+def test_readme_example_end_state(dvode):
+    """Config 1 (README.md:96-118): y(10) = [1.32497001, 1.04585428] at the default 1e-10."""
+    y, _ = _run_plain("lv", dvode["lv_readme_1e-10"], "plain")
+    np.testing.assert_allclose(y[-1], [1.32497001, 1.04585428], rtol=2e-8)
+
+
+@pytest.mark.parametrize("key", ["robertson_4e4", "robertson_4e10"])
+def test_robertson_forward_close_to_dvode(dvode, key):
+    """Stiff problem: CVODE and DVODE differ in details (h0 bound, Jacobian reuse), so counters
+    agree only approximately; states agree to integration accuracy."""
+    case = dvode[key]
+    y, st = _run_plain("robertson", case, "plain")
+    assert abs(int(st[0]) - case["nst"]) <= 0.08 * case["nst"]
+    assert abs(int(st[1]) - case["nfe"]) <= 0.10 * case["nfe"]
+    ref = np.array(case["y"])
+    np.testing.assert_allclose(y[1:], ref[1:], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(y.sum(axis=1), 1.0, rtol=1e-7)          # mass conservation
+
+
+def test_robertson_stiff_transient_trace_equals_dvode(dvode):
+    """Through the stiff transient (t <= 40, 312 steps incl. 18 error-test failures, 6 Jacobian
+    evaluations, 55 LU factorisations) every step time, step order and counter equals DVODE's;
+    later the two codes drift apart through round-off (different h at the 1e-12 level)."""
+    case = dvode["robertson_trace_T40"]
+    orc = make_oracle("robertson")
+    cfg = orc.config(rtol=1e-8, atol=1e-10)
+    _, st, stats = orc.solve_forward(cfg, [[1.0, 0.0, 0.0]], [[0.04, 1e4, 3e7]], np.zeros(0), 0.0,
+                                     np.array([0.0, 40.0]))
+    t, _, order = orc.trajectory(0)
+    assert st[0] == 0 and len(t) - 1 == case["nst"] == len(case["t"])
+    np.testing.assert_allclose(t[1:151], case["t"][:150], rtol=1e-9)
+    np.testing.assert_allclose(t[1:], case["t"], rtol=1e-4)
+    assert order[1:].tolist() == case["q"]
+    got = {k: int(stats[0][i]) for k, i in STAT.items() if k != "qlast"}
+    assert got == dict(nst=case["nst"], nfe=case["nfe"], nsetups=case["nlu"], nje=case["nje"],
+                       nni=case["nni"], ncfn=case["ncfn"], netf=case["netf"])
+
+
+@pytest.mark.parametrize("name,rtol,atol,tol_y,tol_g", [
+    ("lv", 1e-8, 1e-8, 1e-5, 4e-6),
+    ("lv", 1e-10, 1e-10, 2e-7, 1e-7),
+    ("robertson", 1e-8, 1e-10, 1e-5, 1e-5),
+    ("robertson", 1e-10, 1e-12, 2e-7, 2e-7),
+    ("seir", 1e-8, 1e-8, 1e-5, 3e-5),
+    ("seir", 1e-10, 1e-10, 2e-7, 5e-7),
+])
+def test_forward_and_adjoint_match_truth(golden_dir, name, rtol, atol, tol_y, tol_g):
+    """States and adjoint gradients vs DOP853/Radau + sensitivity-equation truth.
+    grad_out = dL/dp, -lamda_out = dL/dy0 (solver.py:783-784, as_pytensor.py:294-308)."""
+    d = np.load(os.path.join(golden_dir, "truth_%s.npz" % name))
+    orc = make_oracle(name)
+    cfg = orc.config(rtol=rtol, atol=atol, rtolB=rtol, atolB=atol, rtolQB=rtol, atolQB=atol)
+    tvals = d["tvals"]
+    y, st, _ = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], float(d["t0"]), tvals)
+    g, lam, st2, stats = orc.solve_backward(cfg, tvals[-1], float(d["t0"]), tvals, d["grads"])
+    assert (st == 0).all() and (st2 == 0).all()
+    scale_y = np.abs(d["y_out"]).max(axis=(0, 1))
+    assert np.max(np.abs(y - d["y_out"]) / scale_y) < tol_y
+    gt = d["grad_params"]
+    scale_g = np.maximum(np.abs(gt).max(axis=1, keepdims=True), 1e-300)
+    assert np.max(np.abs(g - gt) / scale_g) < tol_g
+    scale_l = np.abs(d["grad_y0"]).max(axis=1, keepdims=True)
+    assert np.max(np.abs(-lam - d["grad_y0"]) / scale_l) < tol_g
+
+
+def test_readme_lv_nontrivial_cotangent(golden_dir):
+    d = np.load(os.path.join(golden_dir, "truth_lv_readme.npz"))
+    orc = make_oracle("lv")
+    cfg = orc.config(rtol=1e-10, atol=1e-10)
+    y, st, _ = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, d["tvals"])
+    g, lam, st2, _ = orc.solve_backward(cfg, d["tvals"][-1], 0.0, d["tvals"], d["grads"])
+    np.testing.assert_allclose(g, d["grad_params"], rtol=2e-7)
+    np.testing.assert_allclose(-lam, d["grad_y0"], rtol=2e-7)
+
+
+def test_notebook_known_answer():
+    """notebooks/from_sympy.ipynb cells 2,8-12: loss 185.95454144, dL/db, dL/dd with seed-42 inputs,
+    through AdjointSolver defaults (1e-10).  y0 = [arange(3)+d0^2, b^3]; val = sum(solution**2)."""
+    rng = np.random.RandomState(42)
+    b = rng.randn(2)
+    dd = rng.randn(3)
+    orc = make_oracle("notebook")
+    cfg = orc.config()
+    tvals = np.arange(20) / 100
+    y0 = np.concatenate([np.arange(3.0) + dd[0] ** 2, b ** 3])
+    f = np.linspace(0, 1, 50)
+    y, st, _ = orc.solve_forward(cfg, [y0], [dd], f, 0.0, tvals)
+    assert st[0] == 0
+    val = (y[0] ** 2).sum()
+    g, lam, st2, _ = orc.solve_backward(cfg, tvals[-1], 0.0, tvals, 2 * y[0])
+    assert st2[0] == 0
+    dy0 = -lam[0]
+    grad_b = dy0[3:] * 3 * b ** 2
+    grad_d = g[0].copy()
+    grad_d[0] += dy0[:3].sum() * 2 * dd[0]
+    np.testing.assert_allclose(val, 185.95454144, rtol=2e-9)
+    np.testing.assert_allclose(grad_b, [12.06638293, 0.86567236], rtol=2e-8)
+    np.testing.assert_allclose(grad_d, [252.23687613, 12.10402814, 21.63579496], rtol=2e-8)
+
+
+def test_det_pow_accuracy():
+    """The oracle (and the kernel) replace libm pow in the step-size controller by a
+    deterministic +,-,*,/ implementation; it must be accurate far beyond what the
+    controller needs (eta is thresholded at 1.5 / clipped to [0.1, 10])."""
+    orc = make_oracle("lv")
+    rng = np.random.RandomState(0)
+    for x in np.concatenate([10.0 ** rng.uniform(-12, 6, 400), [1.0, 6.0, 1e-300, 1e300]]):
+        for k in (1, 2, 3, 4, 5, 6, 7):
+            got = orc.det_pow(float(x), 1.0 / k)
+            assert abs(got - x ** (1.0 / k)) <= 4e-15 * x ** (1.0 / k)
+    assert orc.det_pow(0.0, 0.5) == 0.0 and orc.det_pow(-1.0, 0.5) == 0.0
+
+
+def test_failure_reporting():
+    """Unreachable tolerance / step budget -> per-instance CVODES status code and NaN outputs."""
+    orc = make_oracle("robertson")
+    cfg = orc.config(rtol=1e-8, atol=1e-10, mxstep=20, max_retries_fwd=2)
+    y, st, stats = orc.solve(cfg, [[1.0, 0, 0]], [[0.04, 1e4, 3e7]], np.zeros(0), 0.0, np.array([0.0, 4e4]))
+    assert st[0] == -1 and np.isnan(y[0]).all()        # CV_TOO_MUCH_WORK after the retries
+    assert stats[0][13] == 2

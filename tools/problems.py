@@ -1,0 +1,185 @@
+"""Benchmark / test problem definitions in the reference's ``rhs_sympy(t, y, p)`` form.
+
+Config numbering follows BASELINE.json; definitions follow SURVEY.md Appendix D.
+Only config 1/2 (Lotka-Volterra) comes from the reference
+(/root/reference/README.md:57-91); the others are BASELINE-specified workloads.
+The module has no dependency on the engine so that the golden-vector generator
+can feed the *same* definitions to the reference's own ``SympyProblem``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED = 20260928
+
+
+# --------------------------------------------------------------------------
+# problem definitions: name -> dict(params, states, rhs, derivative_params)
+# --------------------------------------------------------------------------
+def lotka_volterra(t, y, p):
+    return {
+        "hares": p.alpha * y.hares - p.beta * y.lynx * y.hares,
+        "lynx": p.delta * y.hares * y.lynx - p.gamma * y.lynx,
+    }
+
+
+def robertson(t, y, p):
+    return {
+        "y1": -p.k1 * y.y1 + p.k2 * y.y2 * y.y3,
+        "y2": p.k1 * y.y1 - p.k2 * y.y2 * y.y3 - p.k3 * y.y2 ** 2,
+        "y3": p.k3 * y.y2 ** 2,
+    }
+
+
+def seir(t, y, p):
+    N = y.S + y.E + y.I + y.R
+    force = [sum(p.beta[i] * p.C[i, j] * y.I[j] / N[j] for j in range(4)) for i in range(4)]
+    return {
+        "S": [-force[i] * y.S[i] for i in range(4)],
+        "E": [force[i] * y.S[i] - p.rates.sigma * y.E[i] for i in range(4)],
+        "I": [p.rates.sigma * y.E[i] - p.rates.gamma * y.I[i] for i in range(4)],
+        "R": [p.rates.gamma * y.I[i] for i in range(4)],
+    }
+
+
+def make_network(n):
+    def network(t, y, p):
+        x = y.x
+        tot = sum(x)
+        return {"x": [sum(p.K[i, j] * x[j] for j in range(n))
+                      - p.scale[0] * x[i] * sum(p.K[j, i] for j in range(n))
+                      - p.scale[1] * x[i] * tot / (p.scale[2] + tot) + p.scale[3] for i in range(n)]}
+    return network
+
+
+def notebook_linear(t, y, params):
+    """notebooks/from_sympy.ipynb cell 2."""
+    return {
+        "a": params.c.d * y.a + params.f[20],
+        "b": {"c": [3.0, 4.0]},
+    }
+
+
+def misc_functions(t, y, p):
+    """Exercises the printer surface ('codegen surface')."""
+    import sympy as sym
+    return {
+        "u": -p.a * y.u ** 2 + sym.exp(-p.b * y.v) * sym.sin(t) + sym.sqrt(y.u) / (1 + y.v ** 3),
+        "v": p.a * sym.log(1 + y.u) - y.v ** sym.Rational(3, 2) + sym.tanh(p.c[1] * y.u) - p.c[0] * sym.cos(y.v),
+    }
+
+
+PROBLEMS = {
+    "lv": dict(
+        params={"alpha": (), "beta": (), "gamma": (), "delta": ()},
+        states={"hares": (), "lynx": ()},
+        rhs=lotka_volterra,
+        derivative_params=[("alpha",), ("beta",)],
+    ),
+    "robertson": dict(
+        params={"k1": (), "k2": (), "k3": ()},
+        states={"y1": (), "y2": (), "y3": ()},
+        rhs=robertson,
+        derivative_params=[("k1",), ("k2",), ("k3",)],
+    ),
+    "seir": dict(
+        params={"beta": (4,), "C": (4, 4), "rates": {"sigma": (), "gamma": (), "mu": (), "nu": ()}},
+        states={"S": (4,), "E": (4,), "I": (4,), "R": (4,)},
+        rhs=seir,
+        derivative_params=[("beta",), ("rates", "sigma"), ("rates", "gamma"), ("rates", "mu"), ("rates", "nu")],
+    ),
+    "network8": dict(
+        params={"K": (8, 8), "scale": (4,)},
+        states={"x": (8,)},
+        rhs=make_network(8),
+        derivative_params=[("scale",)],
+    ),
+    "notebook": dict(
+        params={"c": {"d": (3,)}, "f": (50,)},
+        states={"a": (3,), "b": {"c": (2,)}},
+        rhs=notebook_linear,
+        derivative_params=[("c", "d")],
+    ),
+    "misc": dict(
+        params={"a": (), "b": (), "c": (2,)},
+        states={"u": (), "v": ()},
+        rhs=misc_functions,
+        derivative_params=[("a",), ("c",)],
+    ),
+}
+
+
+def network100():
+    return dict(
+        params={"K": (100, 100), "scale": (4,)},
+        states={"x": (100,)},
+        rhs=make_network(100),
+        derivative_params=[("scale",)],
+    )
+
+
+# --------------------------------------------------------------------------
+# repo-owned counter-based generator: splitmix64 -> Box-Muller
+# --------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed: int, idx: np.ndarray) -> np.ndarray:
+    """splitmix64 output for counter ``idx`` (vectorised, uint64 wraparound)."""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + (np.asarray(idx, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def std_normal(seed: int, stream: int, n: int) -> np.ndarray:
+    """n standard normals; element i depends only on (seed, stream, i)."""
+    idx = np.arange(n, dtype=np.uint64)
+    base = np.uint64(stream) << np.uint64(40)
+    u1 = (splitmix64(seed, base + np.uint64(2) * idx) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    u2 = (splitmix64(seed, base + np.uint64(2) * idx + np.uint64(1)) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    u1 = np.maximum(u1, 1.0 / 9007199254740992.0)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+# --------------------------------------------------------------------------
+# synthetic batches (BASELINE.json configs 2-5)
+# --------------------------------------------------------------------------
+def lv_batch(B: int, seed: int = SEED):
+    """Config 2: p = p0*exp(0.25 z), y0 = (1, 0.1)*exp(0.1 z').  Returns full params [B,4]
+    in declaration order (alpha, beta, gamma, delta), y0 [B,2], tvals, t0."""
+    p0 = np.array([0.1, 0.2, 0.3, 0.4])
+    z = np.stack([std_normal(seed, s, B) for s in range(4)], axis=1)
+    zy = np.stack([std_normal(seed, 8 + s, B) for s in range(2)], axis=1)
+    params = p0 * np.exp(0.25 * z)
+    y0 = np.array([1.0, 0.1]) * np.exp(0.1 * zy)
+    return dict(params=params, y0=y0, tvals=np.linspace(0, 10), t0=0.0,
+                rtol=1e-8, atol=1e-8)
+
+
+def robertson_batch(B: int, seed: int = SEED):
+    """Config 3: k = k0*exp(0.1 z), y0 = (1, 0, 0), T = 4e4, rtol 1e-8 / atol 1e-10."""
+    k0 = np.array([0.04, 1e4, 3e7])
+    z = np.stack([std_normal(seed, 16 + s, B) for s in range(3)], axis=1)
+    params = k0 * np.exp(0.1 * z)
+    y0 = np.tile(np.array([1.0, 0.0, 0.0]), (B, 1))
+    tvals = np.array([0.0] + [0.4 * 10.0 ** k for k in range(6)])
+    return dict(params=params, y0=y0, tvals=tvals, t0=0.0, rtol=1e-8, atol=1e-10)
+
+
+def seir_batch(B: int, seed: int = SEED):
+    """Config 4: 4 groups x (S,E,I,R); beta + 4 rates differentiated, C shared."""
+    beta0 = np.array([0.30, 0.25, 0.35, 0.20])
+    rates0 = np.array([0.2, 0.1, 0.01, 0.02])          # sigma, gamma, mu, nu
+    C = np.array([[1.0, 0.3, 0.2, 0.1],
+                  [0.3, 1.0, 0.3, 0.2],
+                  [0.2, 0.3, 1.0, 0.3],
+                  [0.1, 0.2, 0.3, 1.0]])
+    z = np.stack([std_normal(seed, 32 + s, B) for s in range(8)], axis=1)
+    sub = np.concatenate([beta0, rates0]) * np.exp(0.1 * z)          # [B, 8] subset order
+    pop = np.array([1000.0, 800.0, 1200.0, 600.0])
+    I0 = np.array([1.0, 0.0, 2.0, 0.0])
+    y0 = np.concatenate([pop - I0, np.zeros(4), I0, np.zeros(4)])
+    return dict(ps=sub, pr=C.ravel(), y0=np.tile(y0, (B, 1)), tvals=np.linspace(0, 100, 51), t0=0.0,
+                rtol=1e-8, atol=1e-8)
