@@ -1,0 +1,137 @@
+/*
+ * sunode_amd.h -- C ABI of the MI355X batched BDF + adjoint engine (libsunode_amd.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of pymc-devs/sunode: where the
+ * reference binds SUNDIALS CVODES through cffi (/root/reference/sunode/build_cvodes.py:60-75,
+ * declarations /root/reference/include/cvodes/16_cvodes.h) and drives one integrator
+ * per call, this library drives B integrators per call on one GPU.  Each entry point
+ * names the reference call sequence it replaces.  Plain pointers and sizes only.
+ *
+ * Memory spaces: every array argument of one call lives either in host memory
+ * (SA_MEM_HOST: the library stages it through its own device buffers and returns after
+ * the results are back) or in device memory of the solver's GPU (SA_MEM_DEVICE: the
+ * call only enqueues work on the solver's stream; use sa_synchronize()).
+ * The caller owns every array; the library owns the handle, the per-instance
+ * trajectory arena (CVODES' adjoint "data points") and its staging buffers.
+ *
+ * Per-instance failures never abort a batch: status[b] carries the CVODES return code
+ * (16_cvodes.h:45-106; 0 = CV_SUCCESS, -1 = CV_TOO_MUCH_WORK after the retry budget, ...)
+ * and the instance's outputs are NaN (mirrors wrappers/as_pytensor.py:289-290,339-341).
+ * Function return values < 0 are API / HIP errors (see SA_ERR_*; text via sa_last_error()).
+ *
+ * Threading: one handle per device; calls on one handle must be serialised by the caller
+ * (same rule as one CVODES memory block per sunode solver object).
+ */
+#ifndef SUNODE_AMD_H
+#define SUNODE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_ABI_VERSION 1
+
+#define SA_MEM_HOST 0
+#define SA_MEM_DEVICE 1
+
+#define SA_OK 0
+#define SA_ERR_HIP (-1001)        /* a HIP runtime call failed */
+#define SA_ERR_ARG (-1002)        /* invalid argument / call sequence */
+#define SA_ERR_MODULE (-1003)     /* code object missing, wrong arch or ABI mismatch */
+
+/* statistics slots: stats[b*SA_N_STATS + slot], int64 (CVodeGetNumSteps & friends,
+   16_cvodes.h:208-235, 15_cvodes_ls.h:94-106; summed over the backward restarts) */
+#define SA_N_STATS 16
+#define SA_ST_NST 0        /* accepted BDF steps */
+#define SA_ST_NFE 1        /* right-hand-side evaluations */
+#define SA_ST_NSETUPS 2    /* LU factorisations of I - gamma*J */
+#define SA_ST_NJE 3        /* Jacobian evaluations */
+#define SA_ST_NNI 4        /* Newton iterations */
+#define SA_ST_NCFN 5       /* nonlinear convergence failures */
+#define SA_ST_NETF 6       /* error-test failures */
+#define SA_ST_QLAST 7      /* order of the last step */
+#define SA_ST_NPTS 8       /* stored trajectory points */
+#define SA_ST_NFQE 9       /* quadrature rhs evaluations (backward) */
+#define SA_ST_NETFQ 10     /* quadrature error-test failures (backward) */
+#define SA_ST_NINTERP 11   /* y(t) interpolations (backward) */
+#define SA_ST_NREBUILD 12  /* divided-difference table rebuilds (backward) */
+#define SA_ST_RETRIES 13   /* CV_TOO_MUCH_WORK returns absorbed by the retry loop */
+#define SA_ST_ATTEMPTS 14  /* step attempts = trips through the kernel's main loop */
+
+typedef struct sa_solver sa_solver;
+
+/* Solver configuration; mirrors the keyword arguments / hard-coded settings of
+   Solver.__init__ (solver.py:242-254) and AdjointSolver.__init__/_init_backward
+   (solver.py:531-533, 599, 614-615). */
+typedef struct sa_options {
+    int32_t struct_size;       /* = sizeof(sa_options) */
+    int32_t device;            /* HIP device ordinal */
+    double rtol;               /* forward reltol (CVodeSStolerances / SVtolerances) */
+    const double *atol;        /* forward abstol, host pointer to n_states values */
+    double rtolB, atolB;       /* backward problem (CVodeSStolerancesB; sunode hard-codes 1e-10) */
+    double rtolQB, atolQB;     /* backward quadratures (CVodeQuadSStolerancesB; 1e-10), errconQB = 1 */
+    int32_t mxstep;            /* internal steps per CVode call (CVODES default 500) */
+    int32_t max_retries_fwd;   /* sunode: 5  (solver.py:467) */
+    int32_t max_retries_bwd;   /* sunode: 50 (solver.py:724) */
+    int32_t traj_capacity;     /* stored points per instance (CVodeAdjInit steps; arena rows) */
+} sa_options;
+
+int sa_abi_version(void);
+const char *sa_last_error(void);
+
+/* Load the per-problem code object (generated callbacks + integrator kernels, built by
+   sunode_amd._native from bdf_kernels.hip) on opt->device.
+   Replaces CVodeCreate/CVodeInit/CVodeSetUserData/SUNLinSol_Dense/CVodeSetLinearSolver/
+   CVodeSetJacFn (+ CVodeAdjInit/CVodeCreateB/CVodeInitB/...B), solver.py:214-240, 565-622. */
+int sa_solver_create(const char *code_object_path, const sa_options *opt, sa_solver **out);
+void sa_solver_destroy(sa_solver *s);
+int sa_solver_set_options(sa_solver *s, const sa_options *opt);   /* tolerances / budgets */
+int sa_solver_sizes(const sa_solver *s, int32_t *n_states, int32_t *n_sub, int32_t *n_rem);
+
+/* Solver.solve without sensitivities (solver.py:467-527): CVodeReInit + CVode(CV_NORMAL)
+   per tval with <= max_retries_fwd CV_TOO_MUCH_WORK retries.
+   y0 [B][n], ps [B][p], pr [B][r] (rem_stride = r) or [r] (rem_stride = 0), tvals [n_t],
+   y_out [B][n_t][n], status [B] int32, stats [B][SA_N_STATS] int64. */
+int sa_solve_batch(sa_solver *s, int mem, int32_t B, const double *y0, const double *ps,
+                   const double *pr, int32_t rem_stride, double t0, const double *tvals, int32_t n_t,
+                   double *y_out, int32_t *status, int64_t *stats);
+
+/* AdjointSolver.solve_forward (solver.py:682-721): CVodeReInit + CVodeAdjReInit + CVodeF per
+   tval; every internal step is stored in the solver's trajectory arena. */
+int sa_solve_forward_batch(sa_solver *s, int mem, int32_t B, const double *y0, const double *ps,
+                           const double *pr, int32_t rem_stride, double t0, const double *tvals,
+                           int32_t n_t, double *y_out, int32_t *status, int64_t *stats);
+
+/* AdjointSolver.solve_backward (solver.py:723-784) for the batch of the preceding
+   sa_solve_forward_batch: per observation interval CVodeReInitB/CVodeQuadReInitB/CVodeB/
+   CVodeGetB/CVodeGetQuadB, lamda -= grads[k] jumps.  t0 = final time, tend = initial time
+   (sunode's argument naming).  grads [B][n_t][n] (grads_stride = n_t*n) or [n_t][n]
+   (grads_stride = 0); grad_out [B][p] = dL/dp; lamda_out [B][n] = -dL/dy0. */
+int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const double *ps, const double *pr,
+                            int32_t rem_stride, double t0, double tend, const double *tvals,
+                            int32_t n_t, const double *grads, int64_t grads_stride,
+                            double *grad_out, double *lamda_out, int32_t *status, int64_t *stats);
+
+/* Evaluate the generated callbacks on the device (what make_sundials_rhs / _jac_dense /
+   _adjoint_rhs / _adjoint_quad_rhs / _adjoint_jac_dense compute, problem.py:156-383).
+   t [npts], y/lam [npts][n], ps [npts][p], pr [npts][r]; jac/adjjac column-major n*n;
+   codes [npts][5] callback return codes (1 = non-finite output). */
+int sa_eval_callbacks(sa_solver *s, int mem, int32_t npts, const double *t, const double *y,
+                      const double *lam, const double *ps, const double *pr, double *rhs, double *jac,
+                      double *adj, double *quad, double *adjjac, int32_t *codes);
+
+/* Device arithmetic probe used by the parity tests (deterministic pow, sqrt, divide). Host arrays. */
+int sa_math_probe(sa_solver *s, int32_t n, const double *x, const double *y, double *pow_out,
+                  double *sqrt_out, double *div_out);
+
+/* HIP-event durations (ms) of the most recent forward / backward kernel launches. */
+int sa_last_kernel_ms(sa_solver *s, float *forward_ms, float *backward_ms);
+int sa_set_stream(sa_solver *s, void *hip_stream);     /* hipStream_t; NULL = library-owned stream */
+int sa_synchronize(sa_solver *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

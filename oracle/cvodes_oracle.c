@@ -216,6 +216,10 @@ typedef struct {
     int ilast, newdata;
     double T[QMAX + 1];
     double Y[QMAX + 1][NSD];
+    /* the backward wrappers (cvArhs, cvArhsQ, cvLsJacBWrapper) each re-interpolate y(t); at an
+       unchanged t that is the same value again, so it is evaluated once (as the HIP kernel does) */
+    int have_last;
+    double last_t, last_y[NSD];
     long n_interp, n_rebuild;
 } traj_t;
 
@@ -276,11 +280,17 @@ static int traj_find_index(traj_t *tr, double t, int *indx, int *newpoint)
 static int traj_get_y(traj_t *tr, double t, double *y)
 {
     int indx, newpoint;
+    if (tr->have_last && t == tr->last_t) {
+        for (int i = 0; i < NS; i++) y[i] = tr->last_y[i];
+        return CV_SUCCESS;
+    }
     tr->n_interp++;
     int flag = traj_find_index(tr, t, &indx, &newpoint);
     if (flag != CV_SUCCESS) return flag;
+    tr->have_last = 1;
+    tr->last_t = t;
     if (indx == 0) {
-        for (int i = 0; i < NS; i++) y[i] = tr->y[i];
+        for (int i = 0; i < NS; i++) y[i] = tr->last_y[i] = tr->y[i];
         return CV_SUCCESS;
     }
     double dt = fabs(tr->t[indx] - tr->t[indx - 1]);
@@ -307,7 +317,7 @@ static int traj_get_y(traj_t *tr, double t, double *y)
     for (int k = 0; k < NS; k++) {
         double acc = cvals[0] * tr->Y[0][k];
         for (int i = 1; i <= order; i++) acc += cvals[i] * tr->Y[i][k];
-        y[k] = acc;
+        y[k] = tr->last_y[k] = acc;
     }
     return CV_SUCCESS;
 }
@@ -1525,6 +1535,7 @@ int orc_solve_backward_batch(orc_batch *bt, const orc_config *cfg, int B, const 
             continue;
         }
         tr->newdata = 1;
+        tr->have_last = 0;
         tr->n_interp = tr->n_rebuild = 0;
         status[b] = solve_backward_one(cfg, ps + (size_t)b * NQ, pr + (size_t)b * rem_stride, t0, tend,
                                        tvals, n_t, grads + (size_t)b * grads_stride,

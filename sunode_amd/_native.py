@@ -1,0 +1,288 @@
+"""Build + ctypes binding of the native engine.
+
+* ``libsunode_amd.so`` (host, C ABI of ``include/sunode_amd.h``) is compiled once with g++
+  against the HIP runtime and kept in-tree under ``sunode_amd/_lib/``.
+* One gfx950 code object per problem (generated callbacks + ``csrc/bdf_kernels.hip``) is
+  compiled on demand and cached by source hash under ``sunode_amd/_cache/``.
+
+The device build is a three-stage pipeline on purpose (see the comment on compile-time loops in
+bdf_kernels.hip): clang -O0 -> ``opt always-inline,sroa`` -> clang -O3.  Forcing full inlining
+and scalar replacement *before* any other optimisation is what keeps the per-lane integrator
+state (about 150 doubles) in VGPRs; the stock -O3 pipeline simplifies the small helpers first
+and ends up indexing a scratch copy of the state dynamically.
+
+There is no CPU fallback: if the HIP runtime / a GPU is missing the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import os
+import shutil
+import subprocess
+import tempfile
+from typing import Optional
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+_CSRC = os.path.join(_PKG, "csrc")
+_LIBDIR = os.path.join(_PKG, "_lib")
+_CACHE = os.path.join(_PKG, "_cache")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+LLVM_BIN = os.path.join(ROCM, "lib", "llvm", "bin")
+ARCH = "gfx950"
+
+SA_MEM_HOST, SA_MEM_DEVICE = 0, 1
+N_STATS = 16
+STAT_NAMES = ["nst", "nfe", "nsetups", "nje", "nni", "ncfn", "netf", "qlast", "npts", "nfqe", "netfq",
+              "ninterp", "nrebuild", "retries", "attempts", "reserved"]
+
+
+class NativeBuildError(RuntimeError):
+    pass
+
+
+def _run(cmd, **kw):
+    res = subprocess.run(cmd, capture_output=True, text=True, **kw)
+    if res.returncode != 0:
+        raise NativeBuildError("command failed: %s\n%s\n%s" % (" ".join(cmd), res.stdout[-4000:], res.stderr[-4000:]))
+    return res
+
+
+def _hash_files(*paths, extra=b""):
+    h = hashlib.sha256(extra)
+    for p in paths:
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def host_library_path() -> str:
+    return os.path.join(_LIBDIR, "libsunode_amd.so")
+
+
+def build_host_library(force: bool = False) -> str:
+    """g++ build of csrc/sunode_amd.cpp -> _lib/libsunode_amd.so (stamp = source hash)."""
+    os.makedirs(_LIBDIR, exist_ok=True)
+    src = os.path.join(_CSRC, "sunode_amd.cpp")
+    deps = [src, os.path.join(_CSRC, "sa_device_abi.h"), os.path.join(_ROOT, "include", "sunode_amd.h")]
+    lib = host_library_path()
+    stamp = lib + ".stamp"
+    want = _hash_files(*deps) if all(os.path.exists(d) for d in deps) else None
+    if not force and os.path.exists(lib):
+        if want is None:
+            return lib
+        if os.path.exists(stamp) and open(stamp).read().strip() == want:
+            return lib
+    if want is None:
+        raise NativeBuildError("host library sources missing and no prebuilt %s" % lib)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+           "-I" + os.path.join(ROCM, "include"), src, "-o", lib + ".tmp",
+           "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    _run(cmd)
+    os.replace(lib + ".tmp", lib)
+    with open(stamp, "w") as fh:
+        fh.write(want)
+    return lib
+
+
+def code_object_path(native_source: str) -> str:
+    kern = os.path.join(_CSRC, "bdf_kernels.hip")
+    abi = os.path.join(_CSRC, "sa_device_abi.h")
+    key = _hash_files(kern, abi, extra=native_source.encode()) if os.path.exists(kern) else \
+        hashlib.sha256(native_source.encode()).hexdigest()[:16]
+    return os.path.join(_CACHE, "sa_%s.hsaco" % key)
+
+
+def build_code_object(native_source: str, force: bool = False, keep_temps: bool = False) -> str:
+    """Compile the integrator kernels for one problem to a gfx950 code object (cached)."""
+    os.makedirs(_CACHE, exist_ok=True)
+    out = code_object_path(native_source)
+    if os.path.exists(out) and not force:
+        return out
+    kern = os.path.join(_CSRC, "bdf_kernels.hip")
+    hdr = out[:-6] + ".h"
+    with open(hdr, "w") as fh:
+        fh.write(native_source)
+    tmp = tempfile.mkdtemp(prefix="sa_build_", dir=_CACHE)
+    try:
+        bc0, bc1, obj = (os.path.join(tmp, n) for n in ("k0.bc", "k1.bc", "k.o"))
+        hipcc = os.path.join(ROCM, "bin", "hipcc")
+        _run([hipcc, "--offload-arch=" + ARCH, "--cuda-device-only", "-emit-llvm", "-c", "-O0",
+              "-Xclang", "-disable-O0-optnone", "-ffp-contract=off", "-std=c++17",
+              "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-I" + _CSRC, kern, "-o", bc0])
+        _run([os.path.join(LLVM_BIN, "opt"), "-passes=always-inline,sroa", bc0, "-o", bc1])
+        _run([os.path.join(LLVM_BIN, "clang"), "-x", "ir", bc1, "-target", "amdgcn-amd-amdhsa",
+              "-mcpu=" + ARCH, "-O3", "-ffp-contract=off", "-c", "-o", obj])
+        _run([os.path.join(LLVM_BIN, "ld.lld"), "-shared", obj, "-o", out + ".tmp"])
+        os.replace(out + ".tmp", out)
+    finally:
+        if not keep_temps:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+class _Options(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("device", ctypes.c_int32), ("rtol", ctypes.c_double),
+                ("atol", ctypes.POINTER(ctypes.c_double)), ("rtolB", ctypes.c_double), ("atolB", ctypes.c_double),
+                ("rtolQB", ctypes.c_double), ("atolQB", ctypes.c_double), ("mxstep", ctypes.c_int32),
+                ("max_retries_fwd", ctypes.c_int32), ("max_retries_bwd", ctypes.c_int32),
+                ("traj_capacity", ctypes.c_int32)]
+
+
+_LIB: Optional[ctypes.CDLL] = None
+
+_dp = ctypes.c_void_p     # raw addresses: host numpy buffers or device pointers
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libsunode_amd.so and declare every symbol of include/sunode_amd.h."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = ctypes.CDLL(build_host_library())
+    i32, i64, dbl, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+    L.sa_abi_version.restype = ctypes.c_int
+    L.sa_last_error.restype = ctypes.c_char_p
+    L.sa_solver_create.argtypes = [ctypes.c_char_p, ctypes.POINTER(_Options), ctypes.POINTER(vp)]
+    L.sa_solver_destroy.argtypes = [vp]
+    L.sa_solver_destroy.restype = None
+    L.sa_solver_set_options.argtypes = [vp, ctypes.POINTER(_Options)]
+    L.sa_solver_sizes.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    fwd = [vp, ctypes.c_int, i32, _dp, _dp, _dp, i32, dbl, _dp, i32, _dp, _dp, _dp]
+    L.sa_solve_batch.argtypes = fwd
+    L.sa_solve_forward_batch.argtypes = fwd
+    L.sa_solve_backward_batch.argtypes = [vp, ctypes.c_int, i32, _dp, _dp, i32, dbl, dbl, _dp, i32, _dp, i64,
+                                          _dp, _dp, _dp, _dp]
+    L.sa_eval_callbacks.argtypes = [vp, ctypes.c_int, i32] + [_dp] * 11
+    L.sa_math_probe.argtypes = [vp, i32] + [_dp] * 5
+    L.sa_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.sa_set_stream.argtypes = [vp, vp]
+    L.sa_synchronize.argtypes = [vp]
+    for name in ("sa_solver_create", "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch",
+                 "sa_solve_forward_batch", "sa_solve_backward_batch", "sa_eval_callbacks", "sa_math_probe",
+                 "sa_last_kernel_ms", "sa_set_stream", "sa_synchronize"):
+        getattr(L, name).restype = ctypes.c_int
+    _LIB = L
+    return L
+
+
+EXPORTED_SYMBOLS = ["sa_abi_version", "sa_last_error", "sa_solver_create", "sa_solver_destroy",
+                    "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_forward_batch",
+                    "sa_solve_backward_batch", "sa_eval_callbacks", "sa_math_probe", "sa_last_kernel_ms",
+                    "sa_set_stream", "sa_synchronize"]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def _addr(x) -> int:
+    """Address of a numpy array (host) or pass-through of an int device pointer."""
+    if x is None:
+        return 0
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):            # torch tensor
+        return int(x.data_ptr())
+    raise TypeError("unsupported buffer type %r" % type(x))
+
+
+class NativeSolver:
+    """One ``sa_solver`` handle: a problem's code object loaded on one GPU."""
+
+    def __init__(self, native_source: str, *, device: int = 0, rtol=1e-10, atol=1e-10, rtolB=1e-10,
+                 atolB=1e-10, rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
+                 max_retries_bwd=50, traj_capacity=2048, n_states: Optional[int] = None):
+        self.L = load_library()
+        self.code_object = build_code_object(native_source)
+        self._h = ctypes.c_void_p()
+        self._n_hint = n_states
+        self._opt_kw = dict(device=device, rtol=rtol, atol=atol, rtolB=rtolB, atolB=atolB, rtolQB=rtolQB,
+                            atolQB=atolQB, mxstep=mxstep, max_retries_fwd=max_retries_fwd,
+                            max_retries_bwd=max_retries_bwd, traj_capacity=traj_capacity)
+        opt, keep = self._make_options(n_states if n_states is not None else 64)
+        rc = self.L.sa_solver_create(self.code_object.encode(), ctypes.byref(opt), ctypes.byref(self._h))
+        self._check(rc)
+        n, p, r = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self._check(self.L.sa_solver_sizes(self._h, ctypes.byref(n), ctypes.byref(p), ctypes.byref(r)))
+        self.n, self.p, self.r = n.value, p.value, r.value
+        self.set_options()
+
+    def _make_options(self, n):
+        kw = self._opt_kw
+        atol = np.ascontiguousarray(np.broadcast_to(np.asarray(kw["atol"], dtype=np.float64), (max(n, 1),)))
+        opt = _Options()
+        opt.struct_size = ctypes.sizeof(_Options)
+        opt.device = kw["device"]
+        opt.rtol = float(kw["rtol"])
+        opt.atol = atol.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        opt.rtolB, opt.atolB = float(kw["rtolB"]), float(kw["atolB"])
+        opt.rtolQB, opt.atolQB = float(kw["rtolQB"]), float(kw["atolQB"])
+        opt.mxstep, opt.max_retries_fwd = int(kw["mxstep"]), int(kw["max_retries_fwd"])
+        opt.max_retries_bwd, opt.traj_capacity = int(kw["max_retries_bwd"]), int(kw["traj_capacity"])
+        return opt, atol
+
+    def set_options(self, **kw):
+        self._opt_kw.update(kw)
+        opt, keep = self._make_options(self.n)
+        self._check(self.L.sa_solver_set_options(self._h, ctypes.byref(opt)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NativeError("sunode_amd native call failed (%d): %s" % (rc, self.L.sa_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.L.sa_solver_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- raw entry points (addresses or numpy arrays; shapes are the caller's responsibility) --
+    def solve(self, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats, adjoint=False):
+        fn = self.L.sa_solve_forward_batch if adjoint else self.L.sa_solve_batch
+        self._check(fn(self._h, mem, B, _addr(y0), _addr(ps), _addr(pr), rem_stride, float(t0), _addr(tvals),
+                       n_t, _addr(y_out), _addr(status), _addr(stats)))
+
+    def solve_backward(self, mem, B, ps, pr, rem_stride, t0, tend, tvals, n_t, grads, grads_stride, grad_out,
+                       lamda_out, status, stats):
+        self._check(self.L.sa_solve_backward_batch(self._h, mem, B, _addr(ps), _addr(pr), rem_stride, float(t0),
+                                                   float(tend), _addr(tvals), n_t, _addr(grads), int(grads_stride),
+                                                   _addr(grad_out), _addr(lamda_out), _addr(status), _addr(stats)))
+
+    def eval_callbacks(self, t, y, lam, ps, pr):
+        npts = len(t)
+        n, p, r = self.n, self.p, self.r
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (t, y, lam, ps, pr)]
+        rhs = np.zeros((npts, n)); jac = np.zeros((npts, n * n)); adj = np.zeros((npts, n))
+        quad = np.zeros((npts, p)); adjjac = np.zeros((npts, n * n)); codes = np.zeros((npts, 5), np.int32)
+        self._check(self.L.sa_eval_callbacks(self._h, SA_MEM_HOST, npts, *[_addr(a) for a in arrs], _addr(rhs),
+                                             _addr(jac), _addr(adj), _addr(quad), _addr(adjjac), _addr(codes)))
+        return dict(rhs=rhs, jac=jac.reshape(npts, n, n).transpose(0, 2, 1).copy(), adj=adj, quad=quad,
+                    adjjac=adjjac.reshape(npts, n, n).transpose(0, 2, 1).copy(), codes=codes)
+
+    def math_probe(self, x, y):
+        x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+        out = [np.zeros_like(x) for _ in range(3)]
+        self._check(self.L.sa_math_probe(self._h, len(x), _addr(x), _addr(y), *[_addr(o) for o in out]))
+        return out
+
+    def last_kernel_ms(self):
+        f, b = ctypes.c_float(), ctypes.c_float()
+        self._check(self.L.sa_last_kernel_ms(self._h, ctypes.byref(f), ctypes.byref(b)))
+        return f.value, b.value
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.sa_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self.L.sa_synchronize(self._h))

@@ -1,0 +1,70 @@
+/*
+ * Kernel-argument blocks shared by the host library (sunode_amd.cpp) and the per-problem
+ * device code (bdf_kernels.hip).  Plain C layout; passed by value as the single kernarg.
+ *
+ * HBM layouts (all fp64 unless noted):
+ *   y0      [B][n]            row per instance (what AdjointSolver.solve_forward receives, with
+ *                             a leading batch axis; reference solver.py:682)
+ *   ps      [B][p]            differentiated parameters, subset_paths order
+ *   pr      [B][r] or [r]     remaining parameters (rem_stride = r or 0)
+ *   tvals   [n_t]             shared output grid
+ *   y_out   [B][n_t][n]
+ *   grads   [B][n_t][n] or [n_t][n] (grads_stride = n_t*n or 0)
+ *   stats   [B][16] int64     counters, see SA_ST_* in include/sunode_amd.h
+ *   trajectory arena (the CVODES "data points" of CVodeAdjInit / CVodeF):
+ *     traj_t [cap][stride], traj_y [cap][n][stride], traj_q [cap][stride] (u8), traj_np [B] (i32)
+ *     instance index fastest: lanes of a wave write one step with unit stride.
+ */
+#ifndef SA_DEVICE_ABI_H
+#define SA_DEVICE_ABI_H
+
+#include <stdint.h>
+
+#define SA_MODE_PLAIN 0      /* Solver.solve: CVode(NORMAL) per tval, mxstep x max_retries budget */
+#define SA_MODE_ADJ_FWD 1    /* AdjointSolver.solve_forward: CVodeF, every step stored */
+
+#define SA_N_STATS 16
+
+typedef struct {
+    int32_t B, n_t, mode, mxstep, max_retries, traj_cap, rem_stride, reserved;
+    int64_t traj_stride;
+    double t0, rtol;
+    const double *atol;
+    const double *y0, *ps, *pr, *tvals;
+    double *y_out;
+    int32_t *status;
+    int64_t *stats;
+    double *traj_t, *traj_y;
+    uint8_t *traj_q;
+    int32_t *traj_np;
+} sa_fwd_args;
+
+typedef struct {
+    int32_t B, n_t, mxstep, max_retries, traj_cap, rem_stride, reserved0, reserved1;
+    int64_t traj_stride, grads_stride;
+    double t0, tend, tinitial;
+    double rtolB, atolB, rtolQB, atolQB;
+    const double *ps, *pr, *tvals, *grads;
+    double *grad_out, *lamda_out;
+    int32_t *status;
+    const int32_t *fwd_status;
+    int64_t *stats;
+    const double *traj_t, *traj_y;
+    const uint8_t *traj_q;
+    const int32_t *traj_np;
+} sa_bwd_args;
+
+typedef struct {
+    int32_t npts, reserved;
+    const double *t, *y, *lam, *ps, *pr;      /* [npts], [npts][n], [npts][n], [npts][p], [npts][r] */
+    double *rhs, *jac, *adj, *quad, *adjjac;  /* [npts][n], [npts][n*n] col-major, ... */
+    int32_t *codes;                           /* [npts][5] */
+} sa_eval_args;
+
+typedef struct {
+    int32_t n, reserved;
+    const double *x, *y;
+    double *pow_out, *sqrt_out, *div_out;
+} sa_math_args;
+
+#endif

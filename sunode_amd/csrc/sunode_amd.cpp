@@ -1,0 +1,443 @@
+/*
+ * libsunode_amd.so -- host side of the C ABI in include/sunode_amd.h.
+ *
+ * Thin by design: loads the per-problem gfx950 code object (hipModuleLoad), owns the device
+ * buffers (trajectory arena, staging copies for host-memory calls, tolerance vector) and
+ * launches the forward / backward integrator kernels of bdf_kernels.hip on one HIP stream,
+ * timing them with HIP events.  No integrator arithmetic happens on the host and there is no
+ * CPU fallback: every entry point fails with SA_ERR_HIP if no GPU / code object is usable.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sunode_amd.h"
+#include "sa_device_abi.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(SA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SA_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes < 256 ? 256 : bytes;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return SA_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct sa_solver {
+    int device = 0;
+    int n = 0, p = 0, r = 0;
+    hipModule_t module = nullptr;
+    hipFunction_t k_forward = nullptr, k_backward = nullptr, k_eval = nullptr, k_math = nullptr;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   /* fwd start/stop, bwd start/stop */
+    bool have_fwd_time = false, have_bwd_time = false;
+    sa_options opt{};
+    std::vector<double> atol;
+    DevBuf d_atol;
+    /* trajectory arena + forward bookkeeping of the last forward batch */
+    DevBuf traj_t, traj_y, traj_q, traj_np, fwd_status;
+    int64_t traj_stride = 0;
+    int32_t fwd_B = 0;
+    double fwd_t0 = 0.0;
+    /* staging for SA_MEM_HOST calls */
+    DevBuf s_y0, s_ps, s_pr, s_tvals, s_yout, s_status, s_stats, s_grads, s_gout, s_lout;
+    DevBuf s_misc[12];
+};
+
+static int launch(sa_solver *s, hipFunction_t f, int32_t nthreads_total, void *args, size_t args_size)
+{
+    unsigned grid = (unsigned)((nthreads_total + 63) / 64);
+    if (grid == 0) return SA_OK;
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_size,
+                      HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, 64, 1, 1, 0, s->stream, nullptr, config));
+    return SA_OK;
+}
+
+static int apply_options(sa_solver *s, const sa_options *opt)
+{
+    if (!opt || opt->struct_size != (int32_t)sizeof(sa_options))
+        return fail(SA_ERR_ARG, "sa_options.struct_size mismatch (got %d, want %zu)",
+                    opt ? opt->struct_size : -1, sizeof(sa_options));
+    if (s->n > 0 && !opt->atol) return fail(SA_ERR_ARG, "sa_options.atol is NULL");
+    if (opt->traj_capacity < 2) return fail(SA_ERR_ARG, "traj_capacity must be >= 2");
+    s->opt = *opt;
+    s->atol.assign(opt->atol, opt->atol + s->n);
+    s->opt.atol = nullptr;
+    int rc = s->d_atol.ensure(sizeof(double) * (s->n > 0 ? s->n : 1));
+    if (rc) return rc;
+    if (s->n > 0)
+        HIP_TRY(hipMemcpy(s->d_atol.p, s->atol.data(), sizeof(double) * s->n, hipMemcpyHostToDevice));
+    return SA_OK;
+}
+
+extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
+extern "C" const char *sa_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solver **out)
+{
+    if (!path || !opt || !out) return fail(SA_ERR_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (opt->device < 0 || opt->device >= ndev)
+        return fail(SA_ERR_ARG, "device %d out of range (%d visible)", opt->device, ndev);
+    HIP_TRY(hipSetDevice(opt->device));
+    sa_solver *s = new sa_solver();
+    s->device = opt->device;
+    hipError_t e = hipModuleLoad(&s->module, path);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(SA_ERR_MODULE, "hipModuleLoad(%s) failed: %s", path, hipGetErrorString(e));
+    }
+    hipDeviceptr_t meta_p = nullptr;
+    size_t meta_sz = 0;
+    int32_t meta[4] = {0, 0, 0, 0};
+    e = hipModuleGetGlobal(&meta_p, &meta_sz, s->module, "sa_meta");
+    if (e != hipSuccess || meta_sz != sizeof(meta) ||
+        hipMemcpyDtoH(meta, meta_p, sizeof(meta)) != hipSuccess || meta[3] != SA_ABI_VERSION) {
+        (void)hipModuleUnload(s->module);
+        delete s;
+        return fail(SA_ERR_MODULE, "%s: sa_meta missing or ABI mismatch", path);
+    }
+    s->n = meta[0]; s->p = meta[1]; s->r = meta[2];
+    const char *names[4] = {"sa_k_forward", "sa_k_backward", "sa_k_eval", "sa_k_math"};
+    hipFunction_t *slots[4] = {&s->k_forward, &s->k_backward, &s->k_eval, &s->k_math};
+    for (int i = 0; i < 4; i++) {
+        e = hipModuleGetFunction(slots[i], s->module, names[i]);
+        if (e != hipSuccess) {
+            (void)hipModuleUnload(s->module);
+            delete s;
+            return fail(SA_ERR_MODULE, "%s: kernel %s not found", path, names[i]);
+        }
+    }
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipModuleUnload(s->module);
+        delete s;
+        return fail(SA_ERR_HIP, "hipStreamCreate failed");
+    }
+    s->own_stream = true;
+    for (int i = 0; i < 4; i++) (void)hipEventCreate(&s->ev[i]);
+    int rc = apply_options(s, opt);
+    if (rc) { sa_solver_destroy(s); return rc; }
+    *out = s;
+    return SA_OK;
+}
+
+extern "C" void sa_solver_destroy(sa_solver *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    DevBuf *bufs[] = {&s->d_atol, &s->traj_t, &s->traj_y, &s->traj_q, &s->traj_np, &s->fwd_status, &s->s_y0,
+                      &s->s_ps, &s->s_pr, &s->s_tvals, &s->s_yout, &s->s_status, &s->s_stats, &s->s_grads,
+                      &s->s_gout, &s->s_lout};
+    for (DevBuf *b : bufs) b->release();
+    for (DevBuf &b : s->s_misc) b.release();
+    for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->module) (void)hipModuleUnload(s->module);
+    delete s;
+}
+
+extern "C" int sa_solver_set_options(sa_solver *s, const sa_options *opt)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    sa_options o = *opt;
+    o.device = s->device;
+    return apply_options(s, &o);
+}
+
+extern "C" int sa_solver_sizes(const sa_solver *s, int32_t *n, int32_t *p, int32_t *r)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    if (n) *n = s->n;
+    if (p) *p = s->p;
+    if (r) *r = s->r;
+    return SA_OK;
+}
+
+extern "C" int sa_set_stream(sa_solver *s, void *stream)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->own_stream) { (void)hipStreamDestroy(s->stream); s->own_stream = false; }
+    if (stream) {
+        s->stream = (hipStream_t)stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        s->own_stream = true;
+    }
+    return SA_OK;
+}
+
+extern "C" int sa_synchronize(sa_solver *s)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SA_OK;
+}
+
+extern "C" int sa_last_kernel_ms(sa_solver *s, float *fwd, float *bwd)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    if (fwd) {
+        *fwd = -1.0f;
+        if (s->have_fwd_time) { HIP_TRY(hipEventSynchronize(s->ev[1])); HIP_TRY(hipEventElapsedTime(fwd, s->ev[0], s->ev[1])); }
+    }
+    if (bwd) {
+        *bwd = -1.0f;
+        if (s->have_bwd_time) { HIP_TRY(hipEventSynchronize(s->ev[3])); HIP_TRY(hipEventElapsedTime(bwd, s->ev[2], s->ev[3])); }
+    }
+    return SA_OK;
+}
+
+/* stage a host array into a device buffer (async on the solver stream) */
+static int stage_in(sa_solver *s, DevBuf &b, const void *host, size_t bytes, const void **dev)
+{
+    int rc = b.ensure(bytes ? bytes : 8);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, s->stream));
+    *dev = b.p;
+    return SA_OK;
+}
+
+static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const double *y0, const double *ps,
+                          const double *pr, int32_t rem_stride, double t0, const double *tvals, int32_t n_t,
+                          double *y_out, int32_t *status, int64_t *stats)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    if (B < 0 || n_t < 0) return fail(SA_ERR_ARG, "negative size");
+    if (rem_stride != 0 && rem_stride != s->r) return fail(SA_ERR_ARG, "rem_stride must be 0 or n_rem=%d", s->r);
+    if (s->r > 32 && rem_stride != 0 && mem == SA_MEM_HOST && false) return fail(SA_ERR_ARG, "unreachable");
+    HIP_TRY(hipSetDevice(s->device));
+    if (B == 0 || n_t == 0) return SA_OK;
+    const size_t nB = (size_t)B;
+    const double *d_y0 = y0, *d_ps = ps, *d_pr = pr, *d_tv = tvals;
+    double *d_yout = y_out;
+    int32_t *d_status = status;
+    int64_t *d_stats = stats;
+    int rc;
+    if (mem == SA_MEM_HOST) {
+        const void *q;
+        if ((rc = stage_in(s, s->s_y0, y0, sizeof(double) * nB * s->n, &q))) return rc; d_y0 = (const double *)q;
+        if ((rc = stage_in(s, s->s_ps, ps, sizeof(double) * nB * s->p, &q))) return rc; d_ps = (const double *)q;
+        if ((rc = stage_in(s, s->s_pr, pr, sizeof(double) * (rem_stride ? nB : 1) * s->r, &q))) return rc; d_pr = (const double *)q;
+        if ((rc = stage_in(s, s->s_tvals, tvals, sizeof(double) * n_t, &q))) return rc; d_tv = (const double *)q;
+        if ((rc = s->s_yout.ensure(sizeof(double) * nB * n_t * s->n))) return rc; d_yout = (double *)s->s_yout.p;
+        if ((rc = s->s_status.ensure(sizeof(int32_t) * nB))) return rc; d_status = (int32_t *)s->s_status.p;
+        if ((rc = s->s_stats.ensure(sizeof(int64_t) * nB * SA_N_STATS))) return rc; d_stats = (int64_t *)s->s_stats.p;
+    } else if (mem != SA_MEM_DEVICE) {
+        return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
+    }
+    sa_fwd_args a;
+    memset(&a, 0, sizeof a);
+    a.B = B; a.n_t = n_t; a.mode = mode; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_fwd;
+    a.traj_cap = s->opt.traj_capacity; a.rem_stride = rem_stride;
+    a.t0 = t0; a.rtol = s->opt.rtol; a.atol = (const double *)s->d_atol.p;
+    a.y0 = d_y0; a.ps = d_ps; a.pr = d_pr; a.tvals = d_tv; a.y_out = d_yout; a.status = d_status; a.stats = d_stats;
+    if (mode == SA_MODE_ADJ_FWD) {
+        int64_t stride = ((int64_t)B + 63) / 64 * 64;
+        size_t rows = (size_t)s->opt.traj_capacity;
+        if ((rc = s->traj_t.ensure(sizeof(double) * rows * stride))) return rc;
+        if ((rc = s->traj_y.ensure(sizeof(double) * rows * stride * (s->n > 0 ? s->n : 1)))) return rc;
+        if ((rc = s->traj_q.ensure(rows * stride))) return rc;
+        if ((rc = s->traj_np.ensure(sizeof(int32_t) * stride))) return rc;
+        if ((rc = s->fwd_status.ensure(sizeof(int32_t) * stride))) return rc;
+        s->traj_stride = stride;
+        a.traj_stride = stride;
+        a.traj_t = (double *)s->traj_t.p; a.traj_y = (double *)s->traj_y.p;
+        a.traj_q = (uint8_t *)s->traj_q.p; a.traj_np = (int32_t *)s->traj_np.p;
+    }
+    HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+    if ((rc = launch(s, s->k_forward, B, &a, sizeof a))) return rc;
+    HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+    s->have_fwd_time = true;
+    if (mode == SA_MODE_ADJ_FWD) {
+        HIP_TRY(hipMemcpyAsync(s->fwd_status.p, d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToDevice, s->stream));
+        s->fwd_B = B;
+        s->fwd_t0 = t0;
+    }
+    if (mem == SA_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(y_out, d_yout, sizeof(double) * nB * n_t * s->n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
+        if (stats)
+            HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(int64_t) * nB * SA_N_STATS, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return SA_OK;
+}
+
+extern "C" int sa_solve_batch(sa_solver *s, int mem, int32_t B, const double *y0, const double *ps,
+                              const double *pr, int32_t rem_stride, double t0, const double *tvals, int32_t n_t,
+                              double *y_out, int32_t *status, int64_t *stats)
+{
+    return forward_common(s, SA_MODE_PLAIN, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats);
+}
+
+extern "C" int sa_solve_forward_batch(sa_solver *s, int mem, int32_t B, const double *y0, const double *ps,
+                                      const double *pr, int32_t rem_stride, double t0, const double *tvals,
+                                      int32_t n_t, double *y_out, int32_t *status, int64_t *stats)
+{
+    return forward_common(s, SA_MODE_ADJ_FWD, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats);
+}
+
+extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const double *ps, const double *pr,
+                                       int32_t rem_stride, double t0, double tend, const double *tvals,
+                                       int32_t n_t, const double *grads, int64_t grads_stride, double *grad_out,
+                                       double *lamda_out, int32_t *status, int64_t *stats)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    if (B != s->fwd_B) return fail(SA_ERR_ARG, "backward batch %d does not match the last forward batch %d", B, s->fwd_B);
+    if (rem_stride != 0 && rem_stride != s->r) return fail(SA_ERR_ARG, "rem_stride must be 0 or n_rem=%d", s->r);
+    if (grads_stride != 0 && grads_stride != (int64_t)n_t * s->n) return fail(SA_ERR_ARG, "grads_stride must be 0 or n_t*n");
+    HIP_TRY(hipSetDevice(s->device));
+    if (B == 0) return SA_OK;
+    const size_t nB = (size_t)B;
+    const double *d_ps = ps, *d_pr = pr, *d_tv = tvals, *d_g = grads;
+    double *d_gout = grad_out, *d_lout = lamda_out;
+    int32_t *d_status = status;
+    int64_t *d_stats = stats;
+    int rc;
+    if (mem == SA_MEM_HOST) {
+        const void *q;
+        if ((rc = stage_in(s, s->s_ps, ps, sizeof(double) * nB * s->p, &q))) return rc; d_ps = (const double *)q;
+        if ((rc = stage_in(s, s->s_pr, pr, sizeof(double) * (rem_stride ? nB : 1) * s->r, &q))) return rc; d_pr = (const double *)q;
+        if ((rc = stage_in(s, s->s_tvals, tvals, sizeof(double) * n_t, &q))) return rc; d_tv = (const double *)q;
+        if ((rc = stage_in(s, s->s_grads, grads, sizeof(double) * (grads_stride ? nB : 1) * n_t * s->n, &q))) return rc; d_g = (const double *)q;
+        if ((rc = s->s_gout.ensure(sizeof(double) * nB * (s->p > 0 ? s->p : 1)))) return rc; d_gout = (double *)s->s_gout.p;
+        if ((rc = s->s_lout.ensure(sizeof(double) * nB * (s->n > 0 ? s->n : 1)))) return rc; d_lout = (double *)s->s_lout.p;
+        if ((rc = s->s_status.ensure(sizeof(int32_t) * nB))) return rc; d_status = (int32_t *)s->s_status.p;
+        if ((rc = s->s_stats.ensure(sizeof(int64_t) * nB * SA_N_STATS))) return rc; d_stats = (int64_t *)s->s_stats.p;
+    } else if (mem != SA_MEM_DEVICE) {
+        return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
+    }
+    sa_bwd_args a;
+    memset(&a, 0, sizeof a);
+    a.B = B; a.n_t = n_t; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_bwd;
+    a.traj_cap = s->opt.traj_capacity; a.rem_stride = rem_stride;
+    a.traj_stride = s->traj_stride; a.grads_stride = grads_stride;
+    a.t0 = t0; a.tend = tend; a.tinitial = s->fwd_t0;
+    a.rtolB = s->opt.rtolB; a.atolB = s->opt.atolB; a.rtolQB = s->opt.rtolQB; a.atolQB = s->opt.atolQB;
+    a.ps = d_ps; a.pr = d_pr; a.tvals = d_tv; a.grads = d_g; a.grad_out = d_gout; a.lamda_out = d_lout;
+    a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
+    a.traj_t = (const double *)s->traj_t.p; a.traj_y = (const double *)s->traj_y.p;
+    a.traj_q = (const uint8_t *)s->traj_q.p; a.traj_np = (const int32_t *)s->traj_np.p;
+    HIP_TRY(hipEventRecord(s->ev[2], s->stream));
+    if ((rc = launch(s, s->k_backward, B, &a, sizeof a))) return rc;
+    HIP_TRY(hipEventRecord(s->ev[3], s->stream));
+    s->have_bwd_time = true;
+    if (mem == SA_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(grad_out, d_gout, sizeof(double) * nB * s->p, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(lamda_out, d_lout, sizeof(double) * nB * s->n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
+        if (stats)
+            HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(int64_t) * nB * SA_N_STATS, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return SA_OK;
+}
+
+extern "C" int sa_eval_callbacks(sa_solver *s, int mem, int32_t npts, const double *t, const double *y,
+                                 const double *lam, const double *ps, const double *pr, double *rhs, double *jac,
+                                 double *adj, double *quad, double *adjjac, int32_t *codes)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    if (npts <= 0) return SA_OK;
+    const size_t N = (size_t)npts, n = s->n, p = s->p, r = s->r;
+    sa_eval_args a;
+    memset(&a, 0, sizeof a);
+    a.npts = npts;
+    int rc;
+    if (mem == SA_MEM_HOST) {
+        const void *q;
+        if ((rc = stage_in(s, s->s_misc[0], t, sizeof(double) * N, &q))) return rc; a.t = (const double *)q;
+        if ((rc = stage_in(s, s->s_misc[1], y, sizeof(double) * N * n, &q))) return rc; a.y = (const double *)q;
+        if ((rc = stage_in(s, s->s_misc[2], lam, sizeof(double) * N * n, &q))) return rc; a.lam = (const double *)q;
+        if ((rc = stage_in(s, s->s_misc[3], ps, sizeof(double) * N * p, &q))) return rc; a.ps = (const double *)q;
+        if ((rc = stage_in(s, s->s_misc[4], pr, sizeof(double) * N * r, &q))) return rc; a.pr = (const double *)q;
+        size_t sz[6] = {sizeof(double) * N * n, sizeof(double) * N * n * n, sizeof(double) * N * n,
+                        sizeof(double) * N * p, sizeof(double) * N * n * n, sizeof(int32_t) * N * 5};
+        for (int i = 0; i < 6; i++) if ((rc = s->s_misc[5 + i].ensure(sz[i] ? sz[i] : 8))) return rc;
+        a.rhs = (double *)s->s_misc[5].p; a.jac = (double *)s->s_misc[6].p; a.adj = (double *)s->s_misc[7].p;
+        a.quad = (double *)s->s_misc[8].p; a.adjjac = (double *)s->s_misc[9].p; a.codes = (int32_t *)s->s_misc[10].p;
+        if ((rc = launch(s, s->k_eval, npts, &a, sizeof a))) return rc;
+        void *host[6] = {rhs, jac, adj, quad, adjjac, codes};
+        for (int i = 0; i < 6; i++)
+            if (sz[i] && host[i]) HIP_TRY(hipMemcpyAsync(host[i], s->s_misc[5 + i].p, sz[i], hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return SA_OK;
+    }
+    a.t = t; a.y = y; a.lam = lam; a.ps = ps; a.pr = pr;
+    a.rhs = rhs; a.jac = jac; a.adj = adj; a.quad = quad; a.adjjac = adjjac; a.codes = codes;
+    return launch(s, s->k_eval, npts, &a, sizeof a);
+}
+
+extern "C" int sa_math_probe(sa_solver *s, int32_t n, const double *x, const double *y, double *pow_out,
+                             double *sqrt_out, double *div_out)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    if (n <= 0) return SA_OK;
+    const size_t bytes = sizeof(double) * (size_t)n;
+    sa_math_args a;
+    memset(&a, 0, sizeof a);
+    a.n = n;
+    const void *q;
+    int rc;
+    if ((rc = stage_in(s, s->s_misc[0], x, bytes, &q))) return rc; a.x = (const double *)q;
+    if ((rc = stage_in(s, s->s_misc[1], y, bytes, &q))) return rc; a.y = (const double *)q;
+    for (int i = 0; i < 3; i++) if ((rc = s->s_misc[5 + i].ensure(bytes))) return rc;
+    a.pow_out = (double *)s->s_misc[5].p; a.sqrt_out = (double *)s->s_misc[6].p; a.div_out = (double *)s->s_misc[7].p;
+    if ((rc = launch(s, s->k_math, n, &a, sizeof a))) return rc;
+    HIP_TRY(hipMemcpyAsync(pow_out, a.pow_out, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(sqrt_out, a.sqrt_out, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(div_out, a.div_out, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SA_OK;
+}

@@ -1,0 +1,358 @@
+"""``Solver`` / ``AdjointSolver`` with the reference's signatures, backed by the HIP engine.
+
+Mirrors /root/reference/sunode/solver.py: ``Solver`` (``:213-527``), ``AdjointSolver``
+(``:530-784``), ``SolverError`` (``:21``).  Where the reference holds one CVODES memory
+block and integrates one parameter set per call, these classes hold one ``sa_solver``
+handle (C ABI, include/sunode_amd.h) and integrate a whole batch per call; the scalar
+methods of the reference API are the B = 1 case of the same kernels.
+
+Scope: BDF with dense Newton/LU and analytic Jacobians in both
+directions, polynomial interpolation of the stored forward trajectory.  Options of the
+reference outside that path raise ``NotImplementedError`` instead of silently doing
+something else.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+
+from sunode_amd import _native
+from sunode_amd.dtypesubset import _as_dict
+
+#: CVODES return codes -> names (reference builds this table from the cffi lib, basic.py:49-55)
+ERRORS: Dict[int, str] = {
+    0: "CV_SUCCESS", 1: "CV_TSTOP_RETURN", 2: "CV_ROOT_RETURN", 99: "CV_WARNING",
+    -1: "CV_TOO_MUCH_WORK", -2: "CV_TOO_MUCH_ACC", -3: "CV_ERR_FAILURE", -4: "CV_CONV_FAILURE",
+    -5: "CV_LINIT_FAIL", -6: "CV_LSETUP_FAIL", -7: "CV_LSOLVE_FAIL", -8: "CV_RHSFUNC_FAIL",
+    -9: "CV_FIRST_RHSFUNC_ERR", -10: "CV_REPTD_RHSFUNC_ERR", -11: "CV_UNREC_RHSFUNC_ERR",
+    -12: "CV_RTFUNC_FAIL", -13: "CV_NLS_INIT_FAIL", -14: "CV_NLS_SETUP_FAIL", -15: "CV_CONSTR_FAIL",
+    -20: "CV_MEM_FAIL", -21: "CV_MEM_NULL", -22: "CV_ILL_INPUT", -23: "CV_NO_MALLOC", -24: "CV_BAD_K",
+    -25: "CV_BAD_T", -26: "CV_BAD_DKY", -27: "CV_TOO_CLOSE", -28: "CV_VECTOROP_ERR",
+    -30: "CV_NO_QUAD", -31: "CV_QRHSFUNC_FAIL", -32: "CV_FIRST_QRHSFUNC_ERR",
+    -33: "CV_REPTD_QRHSFUNC_ERR", -34: "CV_UNREC_QRHSFUNC_ERR",
+    -101: "CV_NO_ADJ", -102: "CV_NO_FWD", -103: "CV_NO_BCK", -104: "CV_BAD_TB0",
+    -105: "CV_REIFWD_FAIL", -106: "CV_FWD_FAIL", -107: "CV_GETY_BADT",
+}
+
+
+class SolverError(RuntimeError):
+    pass
+
+
+def _flat_state(problem, y0) -> np.ndarray:
+    y0 = np.asarray(y0)
+    if y0.dtype == problem.state_dtype:
+        y0 = y0[None].view(np.float64)
+    y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1)
+    if y0.shape != (problem.n_states,):
+        raise ValueError(f"y0 should have shape {(problem.n_states,)} but has shape {y0.shape}.")
+    return y0
+
+
+def _is_device_tensor(x) -> bool:
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+class _EngineMixin:
+    """Shared plumbing: native handle (lazy), parameter record, batch argument checks."""
+
+    _problem: Any
+    _user_data: np.ndarray
+
+    def _native_kwargs(self) -> Dict[str, Any]:
+        raise NotImplementedError
+
+    def _engine(self) -> _native.NativeSolver:
+        if self._native is None:
+            self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
+                                                **self._native_kwargs())
+        return self._native
+
+    # -- reference parameter API (solver.py:435-465 / 650-680) ----------------------------
+    @property
+    def params_dtype(self):
+        return self._problem.params_dtype
+
+    @property
+    def derivative_params_dtype(self):
+        return self._problem.params_subset.subset_dtype
+
+    @property
+    def remainder_params_dtype(self):
+        return self._problem.params_subset.remainder.subset_dtype
+
+    def set_params(self, params):
+        self._problem.update_params(self._user_data, params)
+
+    def get_params(self):
+        return self._problem.extract_params(self._user_data)
+
+    def set_params_dict(self, params):
+        data = self.get_params()
+        self._problem.params_subset.from_dict(params, data)
+        self.set_params(data)
+
+    def get_params_dict(self):
+        return _as_dict(self.get_params())
+
+    def set_derivative_params(self, params):
+        self._problem.update_subset_params(self._user_data, params)
+
+    def set_remaining_params(self, params):
+        self._problem.update_remaining_params(self._user_data, params)
+
+    def as_xarray(self, tvals, out, sens_out=None, unstack_state=True, unstack_params=True):
+        return self._problem.solution_to_xarray(
+            tvals, out, self._user_data, sensitivity=sens_out,
+            unstack_state=unstack_state, unstack_params=unstack_params)
+
+    # -- batch helpers ---------------------------------------------------------------------
+    def _batch_inputs(self, y0, params_sub, params_rem):
+        n, p, r = self._problem.n_states, self._problem.n_params, self._problem.n_remainder
+        y0 = np.ascontiguousarray(y0, dtype=np.float64)
+        if y0.ndim != 2 or y0.shape[1] != n:
+            raise ValueError(f"y0 must have shape (B, {n})")
+        B = y0.shape[0]
+        ps = np.ascontiguousarray(params_sub, dtype=np.float64).reshape(B, p) if p else np.zeros((B, 0))
+        pr = np.ascontiguousarray(params_rem, dtype=np.float64) if r else np.zeros(0)
+        if r and pr.shape == (r,):
+            stride = 0
+        elif r and pr.shape == (B, r):
+            stride = r
+        elif r:
+            raise ValueError(f"params_rem must have shape ({r},) or (B, {r})")
+        else:
+            stride = 0
+        if ps.size == 0:
+            ps = np.zeros(1)
+        if pr.size == 0:
+            pr = np.zeros(1)
+        return B, y0, ps, pr, stride
+
+    @staticmethod
+    def stats_as_dict(stats: np.ndarray) -> Dict[str, np.ndarray]:
+        return {name: stats[..., i] for i, name in enumerate(_native.STAT_NAMES[:15])}
+
+
+class Solver(_EngineMixin):
+    """Forward solves (reference ``Solver``, solver.py:213-527) -- BDF/dense only."""
+
+    def __init__(self, problem, *, abstol: float = 1e-10, reltol: float = 1e-10, sens_mode: Optional[str] = None,
+                 scaling_factors: Optional[np.ndarray] = None, constraints: Optional[np.ndarray] = None,
+                 solver="BDF", linear_solver="dense", linear_solver_kwargs=None, mxsteps: int = 500,
+                 device: int = 0):
+        if sens_mode not in (None, False):
+            if sens_mode not in ("simultaneous", "staggered"):
+                raise ValueError('sens_mode must be one of "simultaneous" and "staggered".')
+            raise NotImplementedError("forward sensitivities are not part of the MI355X hot path yet; "
+                                      "use AdjointSolver for gradients")
+        if solver != "BDF":
+            if solver == "ADAMS":
+                raise NotImplementedError("only the BDF method is implemented on the device")
+            raise ValueError(f"Unknown solver {solver}.")
+        if linear_solver != "dense":
+            if linear_solver in ("dense_finitediff", "spgmr", "spgmr_finitediff", "band"):
+                raise NotImplementedError("the device integrator always uses dense LU with the analytic Jacobian")
+            raise ValueError(f"Unknown linear solver: {linear_solver}")
+        if constraints is not None:
+            raise NotImplementedError("constraints are not implemented on the device")
+        self._problem = problem
+        self._user_data = problem.make_user_data()
+        self._constraints = constraints
+        self._abstol, self._reltol = abstol, reltol
+        self._linear_solver_kind = linear_solver
+        self._linear_solver_kwargs = linear_solver_kwargs or {}
+        self._sens_mode = None
+        self._compute_sens = False
+        self._mxsteps = mxsteps
+        self._device = device
+        self._set_tolerances(abstol, reltol)
+        self._state_names = ["_problem", "_user_data", "_constraints", "_abstol", "_reltol",
+                             "_linear_solver_kind", "_linear_solver_kwargs", "_sens_mode", "_mxsteps",
+                             "_device", "_state_names"]
+        self._init_native()
+
+    def _init_native(self):
+        self._source = self._problem.native_source()
+        _native.build_code_object(self._source)      # compile at construction like the reference JITs
+        self._native = None
+
+    def __getstate__(self):
+        return {name: self.__dict__[name] for name in self._state_names}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._compute_sens = False
+        self._set_tolerances(self._abstol, self._reltol)
+        self._init_native()
+
+    def _set_tolerances(self, atol=None, rtol=None):
+        atol, rtol = np.array(atol, dtype=float), np.array(rtol, dtype=float)
+        if rtol.ndim != 0:
+            raise ValueError("vector reltol is not supported (the reference's CVodeVVtolerances path is "
+                             "undeclared in its cdef headers)")
+        if atol.ndim == 1 and atol.shape != (self._problem.n_states,):
+            raise ValueError("Invalid tolerance.")
+        if atol.ndim > 1:
+            raise ValueError("Invalid tolerance.")
+        self._atol, self._rtol = atol, rtol
+
+    def _native_kwargs(self):
+        return dict(device=self._device, rtol=float(self._rtol), atol=self._atol, mxstep=self._mxsteps,
+                    traj_capacity=2)
+
+    def make_output_buffers(self, tvals):
+        return np.zeros((len(tvals), self._problem.n_states))
+
+    def solve(self, t0, tvals, y0, y_out, *, sens0=None, sens_out=None, max_retries=5):
+        y0 = _flat_state(self._problem, y0)
+        ps, pr = self._problem.flat_params(self._user_data)
+        tvals = np.ascontiguousarray(tvals, dtype=np.float64)
+        yo, status, _ = self.solve_batch(t0, tvals, y0[None], ps[None], pr, max_retries=max_retries)
+        if status[0] != 0:
+            code = int(status[0])
+            if code == -1:
+                raise SolverError("Too many solver retries.")
+            raise SolverError(f"Solving ode failed: {ERRORS.get(code, 'unknown')} ({code})")
+        y_out[...] = yo[0]
+
+    def solve_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5
+                    ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """``solve`` for B parameter draws at once: returns (y_out [B,n_t,n], status [B], stats [B,16])."""
+        eng = self._engine()
+        if max_retries != eng._opt_kw["max_retries_fwd"]:
+            eng.set_options(max_retries_fwd=max_retries)
+        B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
+        tvals = np.ascontiguousarray(tvals, dtype=np.float64)
+        y_out = np.zeros((B, len(tvals), self._problem.n_states))
+        status = np.zeros(B, np.int32)
+        stats = np.zeros((B, _native.N_STATS), np.int64)
+        eng.solve(_native.SA_MEM_HOST, B, y0, ps, pr, stride, t0, tvals, len(tvals), y_out, status, stats)
+        return y_out, status, stats
+
+
+class AdjointSolver(_EngineMixin):
+    """Forward + adjoint solves (reference ``AdjointSolver``, solver.py:530-784).
+
+    Extra keyword arguments (not in the reference): ``backward_abstol/backward_reltol`` and
+    ``quad_abstol/quad_reltol`` expose what the reference hard-codes to 1e-10
+    (solver.py:599,614 -- there one has to poke ``lib.CVodeSStolerancesB`` by hand,
+    README.md:245-247); ``max_steps`` bounds the stored trajectory per instance (the
+    device-side equivalent of ``checkpoint_n``, which stays accepted for compatibility).
+    """
+
+    def __init__(self, problem, *, abstol=1e-10, reltol=1e-10, checkpoint_n=500_000, interpolation="polynomial",
+                 constraints=None, solver="BDF", adjoint_solver="BDF", backward_abstol=1e-10,
+                 backward_reltol=1e-10, quad_abstol=1e-10, quad_reltol=1e-10, mxsteps: int = 500,
+                 max_steps: int = 4096, device: int = 0):
+        if solver not in ("BDF", "ADAMS"):
+            raise ValueError(f"Unknown solver {solver}.")
+        if adjoint_solver not in ("BDF", "ADAMS"):
+            raise ValueError(f"Unknown solver {adjoint_solver}.")
+        if solver != "BDF" or adjoint_solver != "BDF":
+            raise NotImplementedError("only the BDF method is implemented on the device")
+        if interpolation == "hermite":
+            raise NotImplementedError("only polynomial interpolation of the forward trajectory is implemented")
+        if interpolation != "polynomial":
+            raise ValueError(f"Unknown interpolation {interpolation}.")
+        if constraints is not None:
+            raise NotImplementedError("constraints are not implemented on the device")
+        self._problem = problem
+        self._user_data = problem.make_user_data()
+        self._constraints = None
+        self._set_tolerances(abstol, reltol)
+        self._tolB = (float(backward_reltol), float(backward_abstol), float(quad_reltol), float(quad_abstol))
+        self._mxsteps = mxsteps
+        self._max_steps = int(min(max_steps, checkpoint_n + 1))
+        self._device = device
+        self._source = problem.native_source()
+        _native.build_code_object(self._source)
+        self._native = None
+        self._last_forward = None
+
+    def _set_tolerances(self, atol=None, rtol=None):
+        atol, rtol = np.array(atol, dtype=float), np.array(rtol, dtype=float)
+        if not (rtol.ndim == 0 and atol.ndim in (0, 1)):
+            raise ValueError("Invalid tolerance.")
+        if atol.ndim == 1 and atol.shape != (self._problem.n_states,):
+            raise ValueError("Invalid tolerance.")
+        self._atol, self._rtol = atol, rtol
+
+    def _native_kwargs(self):
+        rB, aB, rQ, aQ = self._tolB
+        return dict(device=self._device, rtol=float(self._rtol), atol=self._atol, rtolB=rB, atolB=aB,
+                    rtolQB=rQ, atolQB=aQ, mxstep=self._mxsteps, traj_capacity=self._max_steps)
+
+    def make_output_buffers(self, tvals):
+        y_vals = np.zeros((len(tvals), self._problem.n_states))
+        grad_out = np.zeros(self._problem.n_params)
+        lamda_out = np.zeros(self._problem.n_states)
+        return y_vals, grad_out, lamda_out
+
+    # -- scalar API (B = 1) ----------------------------------------------------------------
+    def solve_forward(self, t0, tvals, y0, y_out, *, max_retries=5):
+        y0 = _flat_state(self._problem, y0)
+        ps, pr = self._problem.flat_params(self._user_data)
+        yo, status, _ = self.solve_forward_batch(t0, tvals, y0[None], ps[None], pr)
+        if status[0] != 0:
+            code = int(status[0])
+            raise SolverError(f"Solving ode failed: {ERRORS.get(code, 'unknown')} ({code})")
+        y_out[...] = yo[0]
+
+    def solve_backward(self, t0, tend, tvals, grads, grad_out, lamda_out, lamda_all_out=None,
+                       quad_all_out=None, max_retries=50):
+        if lamda_all_out is not None or quad_all_out is not None:
+            raise NotImplementedError("lamda_all_out / quad_all_out are not produced by the device kernel")
+        grads = np.ascontiguousarray(grads, dtype=np.float64)
+        g, lam, status, _ = self.solve_backward_batch(t0, tend, tvals, grads[None], max_retries=max_retries)
+        if status[0] != 0:
+            code = int(status[0])
+            if code == -1:
+                raise SolverError("Too many solver retries.")
+            raise SolverError(f"Solving ode failed: {ERRORS.get(code, 'unknown')} ({code})")
+        grad_out[...] = g[0]
+        lamda_out[...] = lam[0]
+
+    # -- batch API -------------------------------------------------------------------------
+    def solve_forward_batch(self, t0, tvals, y0, params_sub, params_rem):
+        """B forward solves with stored trajectories: (y_out [B,n_t,n], status [B], stats [B,16])."""
+        eng = self._engine()
+        B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
+        tvals = np.ascontiguousarray(tvals, dtype=np.float64)
+        y_out = np.zeros((B, len(tvals), self._problem.n_states))
+        status = np.zeros(B, np.int32)
+        stats = np.zeros((B, _native.N_STATS), np.int64)
+        eng.solve(_native.SA_MEM_HOST, B, y0, ps, pr, stride, t0, tvals, len(tvals), y_out, status, stats,
+                  adjoint=True)
+        self._last_forward = (B, ps, pr, stride)
+        return y_out, status, stats
+
+    def solve_backward_batch(self, t0, tend, tvals, grads, *, max_retries=50):
+        """Adjoint pass for the batch of the last ``solve_forward_batch``.
+
+        ``grads``: [B, n_t, n] or [n_t, n] (shared).  Returns (grad_out [B,p] = dL/dp,
+        lamda_out [B,n] = -dL/dy0, status [B], stats [B,16])."""
+        if self._last_forward is None:
+            raise SolverError("solve_backward called before solve_forward")
+        eng = self._engine()
+        if max_retries != eng._opt_kw["max_retries_bwd"]:
+            eng.set_options(max_retries_bwd=max_retries)
+        B, ps, pr, stride = self._last_forward
+        n, p = self._problem.n_states, self._problem.n_params
+        tvals = np.ascontiguousarray(tvals, dtype=np.float64)
+        n_t = len(tvals)
+        grads = np.ascontiguousarray(grads, dtype=np.float64)
+        if grads.shape == (n_t, n):
+            gstride = 0
+        elif grads.shape == (B, n_t, n):
+            gstride = n_t * n
+        else:
+            raise ValueError(f"grads must have shape ({n_t}, {n}) or ({B}, {n_t}, {n})")
+        grad_out = np.zeros((B, max(p, 1)))
+        lamda_out = np.zeros((B, max(n, 1)))
+        status = np.zeros(B, np.int32)
+        stats = np.zeros((B, _native.N_STATS), np.int64)
+        eng.solve_backward(_native.SA_MEM_HOST, B, ps, pr, stride, t0, tend, tvals, n_t, grads, gstride,
+                           grad_out, lamda_out, status, stats)
+        return grad_out[:, :p], lamda_out[:, :n], status, stats

@@ -62,11 +62,6 @@ SA_FN double sa_cardinal_bspline4(double t) {
     if (t >= 4.0 && t <= 5.0) return t*(t*(t*((1.0/24.0)*t - 5.0/6.0) + 25.0/4.0) - 125.0/6.0) + 625.0/24.0;
     return 0.0;
 }
-SA_FN int sa_all_finite(const double* v, int n) {
-    int ok = 1;
-    for (int i = 0; i < n; ++i) ok &= (__builtin_isfinite(v[i]) ? 1 : 0);
-    return ok;
-}
 """
 
 
@@ -158,11 +153,20 @@ def emit_function(
     written = {}
     for k, value in enumerate(reduced):
         written[int(out_index[k])] = "0.0" if value == 0 else printer.doprint(value)
+    nonzero = []
     for slot in range(n_out):
-        lines.append("    out[%d] = %s;" % (slot, written.get(slot, "0.0")))
+        text = written.get(slot, "0.0")
+        lines.append("    out[%d] = %s;" % (slot, text))
+        if text != "0.0":
+            nonzero.append(slot)
     lines.append("    (void)t; (void)y; (void)ps; (void)pr;")
-    if n_out:
-        lines.append("    return sa_all_finite(out, %d) ? 0 : 1;" % n_out)
+    if nonzero:
+        # x*0.0 is (+-)0 for finite x and NaN for inf/nan; straight-line on purpose (constant
+        # subscripts only, see bdf_kernels.hip on scalar replacement of the per-lane state)
+        lines.append("    double chk = 0.0;")
+        for slot in nonzero:
+            lines.append("    chk += out[%d] * 0.0;" % slot)
+        lines.append("    return (chk == 0.0) ? 0 : 1;")
     else:
         lines.append("    return 0;")
     lines.append("}")

@@ -1,0 +1,178 @@
+"""HIP engine vs CPU oracle on identical inputs (runs on the MI355X box: pytest -m gpu).
+
+Calls go through the C ABI (libsunode_amd.so) via sunode_amd.solver.  Bars:
+  * step/order bookkeeping (nst, nfe, nsetups, nje, nni, ncfn, netf, last order, stored
+    points, quadrature counters, table rebuilds): bit-exact vs the oracle;
+  * states / gradients: bit-exact vs the oracle for rational right-hand sides (both sides
+    evaluate the same IEEE operation sequence, -ffp-contract=off, deterministic pow);
+  * states / gradients vs truth fixtures: within the integration tolerance (written per test).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_oracle, make_problem
+from tools.problems import lv_batch, robertson_batch, seir_batch
+
+pytestmark = pytest.mark.gpu
+
+CMP = [0, 1, 2, 3, 4, 5, 6, 7, 8]            # nst..qlast, npts
+CMP_B = [0, 1, 2, 3, 4, 5, 6, 9, 10, 12]     # backward: + nfqe, netfq, nrebuild
+
+
+def _lv_inputs(B):
+    prob = make_problem("lv")
+    d = lv_batch(B)
+    ps = d["params"][:, prob.params_subset.subset_index]
+    pr = d["params"][:, prob.params_subset.remainder_index]
+    return prob, d, ps, pr
+
+
+def test_device_arithmetic_matches_host_bitwise():
+    """IEEE divide / sqrt and the deterministic pow must agree bit-for-bit with the host."""
+    from sunode_amd.solver import Solver
+    prob = make_problem("lv")
+    eng = Solver(prob)._engine()
+    orc = make_oracle("lv")
+    rng = np.random.RandomState(1)
+    x = np.concatenate([10.0 ** rng.uniform(-300, 300, 20000), 10.0 ** rng.uniform(-12, 3, 40000),
+                        [1.0, 6.0, 0.0, -1.0, 5e-324, 1e-310]])
+    y = np.concatenate([1.0 / rng.randint(1, 8, 20000), 1.0 / rng.randint(1, 8, 40000), [0.5] * 6])
+    pw, sq, dv = eng.math_probe(x, y)
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(sq[x >= 0], np.sqrt(x[x >= 0]))
+        np.testing.assert_array_equal(dv, x / y)
+    ref = np.array([orc.det_pow(float(a), float(b)) for a, b in zip(x, y)])
+    np.testing.assert_array_equal(pw, ref)
+
+
+@pytest.mark.parametrize("name", ["lv", "robertson", "seir", "misc", "notebook"])
+def test_device_callbacks_match_golden(name, golden_dir):
+    """Generated device functions vs the reference's own lambdify output (golden vectors)."""
+    import json
+    from sunode_amd.solver import Solver
+    with open(os.path.join(golden_dir, "callbacks.json")) as fh:
+        pts = json.load(fh)[name]
+    prob = make_problem(name)
+    eng = Solver(prob)._engine()
+    par = np.array([p["params"] for p in pts])
+    got = eng.eval_callbacks([p["t"] for p in pts], [p["y"] for p in pts], [p["lam"] for p in pts],
+                             par[:, prob.params_subset.subset_index], par[:, prob.params_subset.remainder_index])
+    orc = make_oracle(name)
+    for i, p in enumerate(pts):
+        host = orc.eval(p["t"], p["y"], p["lam"], par[i, prob.params_subset.subset_index],
+                        par[i, prob.params_subset.remainder_index])
+        for key in ("rhs", "jac", "adj", "quad", "adjjac"):
+            want = np.array(p[key], float).reshape(got[key][i].shape)
+            scale = float(np.max(np.abs(want))) if want.size else 0.0
+            np.testing.assert_allclose(got[key][i], want, rtol=1e-13, atol=4e-15 * scale)
+            if name != "misc":       # rational rhs: device == host bit-for-bit
+                np.testing.assert_array_equal(got[key][i], host[key].reshape(got[key][i].shape))
+        assert got["codes"][i].tolist() == p["codes"]
+
+
+def test_lv_plain_solve_bitexact_vs_oracle():
+    from sunode_amd.solver import Solver
+    prob, d, ps, pr = _lv_inputs(512)
+    sol = Solver(prob, abstol=1e-8, reltol=1e-8)
+    y, status, stats = sol.solve_batch(0.0, d["tvals"], d["y0"], ps, pr)
+    orc = make_oracle("lv")
+    yo, so, sto = orc.solve(orc.config(rtol=1e-8, atol=1e-8), d["y0"], ps, pr, 0.0, d["tvals"], nthreads=8)
+    assert (status == 0).all() and (so == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP[:8]], sto[:, CMP[:8]])
+    np.testing.assert_array_equal(y, yo)
+
+
+@pytest.mark.parametrize("tol", [1e-8, 1e-10])
+def test_lv_forward_adjoint_bitexact_vs_oracle(tol):
+    from sunode_amd.solver import AdjointSolver
+    prob, d, ps, pr = _lv_inputs(1024)
+    sol = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol,
+                        quad_abstol=tol, quad_reltol=tol)
+    tv = d["tvals"]
+    y, status, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+    grads = np.ones((len(tv), 2))
+    g, lam, status_b, stats_b = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("lv")
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], ps, pr, 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (status == 0).all() and (status_b == 0).all() and (so == 0).all() and (sbo == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(stats_b[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
+def test_lv_gradients_match_truth(golden_dir):
+    """rtol=atol=1e-8 everywhere: states <= 1e-5, gradients <= 4e-6 relative to truth
+    (north star: gradients within 1e-6 of CVODES, which itself carries ~4e-7 at this tolerance)."""
+    from sunode_amd.solver import AdjointSolver
+    d = np.load(os.path.join(golden_dir, "truth_lv.npz"))
+    prob = make_problem("lv")
+    sol = AdjointSolver(prob, abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8,
+                        quad_abstol=1e-8, quad_reltol=1e-8)
+    y, st, _ = sol.solve_forward_batch(float(d["t0"]), d["tvals"], d["y0"], d["ps"], d["pr"])
+    g, lam, st2, _ = sol.solve_backward_batch(d["tvals"][-1], float(d["t0"]), d["tvals"], d["grads"])
+    assert (st == 0).all() and (st2 == 0).all()
+    assert np.max(np.abs(y - d["y_out"]) / np.abs(d["y_out"]).max(axis=(0, 1))) < 1e-5
+    assert np.max(np.abs(g - d["grad_params"]) / np.abs(d["grad_params"]).max(axis=1, keepdims=True)) < 4e-6
+    assert np.max(np.abs(-lam - d["grad_y0"]) / np.abs(d["grad_y0"]).max(axis=1, keepdims=True)) < 4e-6
+
+
+def test_robertson_forward_adjoint_vs_oracle_and_truth(golden_dir):
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("robertson")
+    d = robertson_batch(256)
+    tv = d["tvals"]
+    k = np.arange(len(tv))[:, None]; i = np.arange(3)[None, :]
+    grads = 1.0 + 0.5 * np.cos(1.7 * k + 0.9 * i)
+    sol = AdjointSolver(prob, abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8,
+                        quad_abstol=1e-10, quad_reltol=1e-8)
+    y, status, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["params"], np.zeros(0))
+    g, lam, status_b, stats_b = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("robertson")
+    cfg = orc.config(rtol=1e-8, atol=1e-10, rtolB=1e-8, atolB=1e-10, rtolQB=1e-8, atolQB=1e-10)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], d["params"], np.zeros(0), 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (status == 0).all() and (status_b == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(stats_b[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+    t = np.load(os.path.join(golden_dir, "truth_robertson.npz"))
+    assert np.max(np.abs(y[:4] - t["y_out"]) / np.abs(t["y_out"]).max(axis=(0, 1))) < 1e-5
+    assert np.max(np.abs(g[:4] - t["grad_params"]) / np.abs(t["grad_params"]).max(axis=1, keepdims=True)) < 1e-5
+
+
+def test_scalar_api_readme_example():
+    """README.md:96-118 through the reference-shaped scalar API (config 1)."""
+    from sunode_amd.solver import Solver
+    prob = make_problem("lv")
+    solver = Solver(prob, sens_mode=None, solver="BDF")
+    tvals = np.linspace(0, 10)
+    y0 = np.zeros((), dtype=prob.state_dtype)
+    y0["hares"] = 1
+    y0["lynx"] = 0.1
+    solver.set_params_dict({"alpha": 0.1, "beta": 0.2, "gamma": 0.3, "delta": 0.4})
+    out = solver.make_output_buffers(tvals)
+    solver.solve(t0=0, tvals=tvals, y0=y0, y_out=out)
+    np.testing.assert_allclose(out[-1], [1.32497001, 1.04585428], rtol=2e-8)
+    assert out.view(prob.state_dtype)["hares"].shape == (50, 1)
+
+
+def test_failures_are_per_instance():
+    """A draw that exhausts the step budget gets CV_TOO_MUCH_WORK + NaN rows; its neighbours finish."""
+    from sunode_amd.solver import Solver
+    prob = make_problem("robertson")
+    sol = Solver(prob, abstol=1e-10, reltol=1e-8, mxsteps=100)
+    params = np.tile([0.04, 1e4, 3e7], (4, 1))
+    params[2] = [0.04, 1e-3, 1e-3]                   # non-stiff draw: few steps
+    y, status, stats = sol.solve_batch(0.0, np.array([0.0, 40.0]), np.tile([1.0, 0, 0], (4, 1)), params,
+                                       np.zeros(0), max_retries=2)
+    assert status.tolist() == [-1, -1, 0, -1]
+    assert np.isnan(y[[0, 1, 3]]).all() and np.isfinite(y[2]).all()
+    assert (stats[[0, 1, 3], 13] == 2).all()
