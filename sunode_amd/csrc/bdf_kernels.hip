@@ -252,6 +252,7 @@ struct Cv {
     double tfinal;
     int ilast, newdata, have_last, tb_order;
     double last_t, tb_dt;
+    double tlo, thi;                  /* t[ilast-1], t[ilast]: bracketing times kept in registers */
     double T[QMAX + 1];
     double Y[QMAX + 1][NSD];
     int n_interp, n_rebuild;
@@ -269,10 +270,13 @@ DEV int interp_y(Cv<BWD> &m, double t)
     if (m.have_last && t == m.last_t) return CV_SUCCESS;
     m.n_interp++;
     int newpoint = 0, indx;
-    if (m.newdata) { m.ilast = m.np - 1; newpoint = 1; m.newdata = 0; }
+    if (m.newdata) {
+        m.ilast = m.np - 1; newpoint = 1; m.newdata = 0;
+        m.tlo = trj_t(m, m.ilast - 1); m.thi = trj_t(m, m.ilast);
+    }
     int ilast = m.ilast;
-    bool to_left = (t - trj_t(m, ilast - 1)) < 0.0;
-    bool to_right = (t - trj_t(m, ilast)) > 0.0;
+    bool to_left = (t - m.tlo) < 0.0;
+    bool to_right = (t - m.thi) > 0.0;
     indx = ilast;
     if (to_left) {
         newpoint = 1;
@@ -282,8 +286,9 @@ DEV int interp_y(Cv<BWD> &m, double t)
             else break;
         }
         m.ilast = (indx == 0) ? 1 : indx;
+        m.tlo = trj_t(m, m.ilast - 1); m.thi = trj_t(m, m.ilast);
         if (indx == 0) {
-            if (fabs(t - trj_t(m, 0)) > FUZZ_FACTOR_ADJ * UROUND) return CV_GETY_BADT;
+            if (fabs(t - m.tlo) > FUZZ_FACTOR_ADJ * UROUND) return CV_GETY_BADT;
         }
     } else if (to_right) {
         newpoint = 1;
@@ -292,8 +297,9 @@ DEV int interp_y(Cv<BWD> &m, double t)
             if ((t - trj_t(m, indx)) > 0.0) indx++;
             else break;
         }
-        if ((t - trj_t(m, indx)) > FUZZ_FACTOR_ADJ * UROUND * (fabs(m.tfinal) + 1.0)) return CV_GETY_BADT;
         m.ilast = indx;
+        m.tlo = trj_t(m, indx - 1); m.thi = trj_t(m, indx);
+        if ((t - m.thi) > FUZZ_FACTOR_ADJ * UROUND * (fabs(m.tfinal) + 1.0)) return CV_GETY_BADT;
     }
     m.have_last = 1;
     m.last_t = t;
@@ -303,7 +309,7 @@ DEV int interp_y(Cv<BWD> &m, double t)
     }
     if (newpoint) {
         m.n_rebuild++;
-        double dt = fabs(trj_t(m, indx) - trj_t(m, indx - 1));
+        double dt = fabs(m.thi - m.tlo);         /* indx == ilast here */
         int order = (int)m.traj_q[(int64_t)indx * m.tstride];
         int base = indx;
         if (indx < order) base += order - indx;
@@ -1276,7 +1282,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     SFOR(i, 0, NS) m.atol[i] = a.atol[i]; SEND
     m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.tb_order = 0;
-    m.last_t = 0.0; m.tb_dt = 0.0; m.n_interp = 0; m.n_rebuild = 0;
+    m.last_t = 0.0; m.tb_dt = 0.0; m.n_interp = 0; m.n_rebuild = 0; m.tlo = 0.0; m.thi = 0.0;
     m.traj_t = nullptr; m.traj_y = nullptr; m.traj_q = nullptr; m.tstride = 0;
 
     double y0[NSD];
@@ -1387,6 +1393,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     m.np = np;
     m.tfinal = (status == CV_SUCCESS) ? m.traj_t[(int64_t)(np - 1) * a.traj_stride] : a.tinitial;
     m.ilast = 0; m.newdata = 1; m.have_last = 0; m.tb_order = 0; m.last_t = 0.0; m.tb_dt = 1.0;
+    m.tlo = 0.0; m.thi = 0.0;
     m.n_interp = 0; m.n_rebuild = 0;
     SFOR(j, 0, (QMAX) + 1) { m.T[j] = 0.0; SFOR(i, 0, NS) m.Y[j][i] = 0.0; SEND } SEND
     SFOR(i, 0, NS) m.ytmp[i] = 0.0; SEND
@@ -1396,7 +1403,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     SFOR(i, 0, NQ) { quad[i] = 0.0; quad_out[i] = 0.0; } SEND
     const double *g = a.grads + (int64_t)inst * a.grads_stride;
     bool first_call = true;
-    int total_retries = 0, attempts = 0;
+    int total_retries = 0, attempts = 0, wave_iters = 0;
     cv_reinit(m, a.t0, lam, quad);
 
     /* ts = [t0] + reversed(tvals) + [tend]; interval iv = (ts[iv+1], ts[iv]) */
@@ -1419,7 +1426,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
                     if (flag != CV_SUCCESS) status = flag;
                 }
             }
-            int nstloc = 0, retries = 0;
+            int nstloc = 0, retries = 0, lane_iters = 0;
             StepCtl c;
             c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0;
             c.saved_t = t_upper;
@@ -1436,7 +1443,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
                     if (!idone && ier != CV_SUCCESS) { status = ier; idone = true; }
                 }
                 if (!idone) {
-                    attempts++;
+                    attempts++; lane_iters++;
                     int r = cv_attempt(m, c);
                     if (r < 0) { status = r; idone = true; }
                     else if (r == 1) {
@@ -1457,6 +1464,11 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
                     }
                 }
             }
+            {   /* diagnostic: iterations the whole wave spent in this interval = max over its lanes */
+                int wi = lane_iters;
+                for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(wi, off); wi = wi > o ? wi : o; }
+                wave_iters += wi;
+            }
             if (status == CV_SUCCESS || m.nst > 0) accumulate_stats(m, st);
             if (status == CV_SUCCESS) { SFOR(i, 0, NQ) quad[i] = quad_out[i]; SEND }
         }
@@ -1473,7 +1485,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     SFOR(i, 0, NS) a.lamda_out[(int64_t)inst * NS + i] = lam[i]; SEND
     a.status[inst] = status;
     st[ST_NPTS] = np; st[ST_NINTERP] = m.n_interp; st[ST_NREBUILD] = m.n_rebuild;
-    st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+    st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts; st[ST_RESERVED1] = wave_iters;
     SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
 }
 
