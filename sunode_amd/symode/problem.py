@@ -30,6 +30,10 @@ Shape = Tuple[int, ...]
 data_dtype = np.dtype(np.float64)
 
 
+def _identity(expr):
+    return expr
+
+
 def _scalarize(item: np.ndarray) -> Any:
     if hasattr(item, "shape") and item.shape == ():
         return item.item()
@@ -54,8 +58,8 @@ class SympyProblem:
             states, [], fixed_dtype=data_dtype, coords=self.coords)
         self.state_dtype = self.state_subset.dtype
         self._rhs_sympy_func = rhs_sympy
-        self._simplify = np.vectorize(simplify if simplify is not None else (lambda e: e),
-                                      otypes=[object])
+        self._simplify_func = simplify if simplify is not None else _identity
+        self._simplify = np.vectorize(self._simplify_func, otypes=[object])
 
         self._sym_time = sym.Symbol("time", real=True)
 
@@ -123,6 +127,18 @@ class SympyProblem:
         self._host_funcs: Dict[str, Any] = {}
 
     # ------------------------------------------------------------------
+    def __getstate__(self):
+        # dynamic dataclasses / lambdified host functions are rebuilt on demand, not pickled
+        state = dict(self.__dict__)
+        for key in ("_sym_params", "_sym_states", "_host_funcs", "_simplify"):
+            state.pop(key, None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._host_funcs = {}
+        self._simplify = np.vectorize(self._simplify_func, otypes=[object])
+
     def _declare(self, subset: dtypesubset.DTypeSubset, kind: str, **assumptions) -> Dict[Path, np.ndarray]:
         out: Dict[Path, np.ndarray] = {}
         for path, shape in subset.flat_shapes.items():
