@@ -105,7 +105,10 @@ def main():
     stats_f = torch.empty((B, 16), dtype=torch.int64, device=dev)
     stats_b = torch.empty((B, 16), dtype=torch.int64, device=dev)
 
-    eng = _native.NativeSolver(prob.native_source(), device=local_rank, rtol=tol, atol=tol, rtolB=tol, atolB=tol,
+    source = prob.native_source()
+    if os.environ.get("SA_ABLATE"):          # timing experiments only (kernel results are then wrong)
+        source += "".join("\n#define SA_ABLATE_%s 1\n" % k for k in os.environ["SA_ABLATE"].split(","))
+    eng = _native.NativeSolver(source, device=local_rank, rtol=tol, atol=tol, rtolB=tol, atolB=tol,
                                rtolQB=tol, atolQB=tol, traj_capacity=512, n_states=n)
     torch.cuda.synchronize()
 

@@ -311,9 +311,12 @@ static int traj_get_y(traj_t *tr, double t, double *y)
             }
         }
     }
+    /* CVODES divides by dt per term; one reciprocal per call (as the HIP kernel does) differs
+       from that only in the last bits of an interpolated y(t) */
     double cvals[QMAX + 1];
+    const double inv_dt = 1.0 / dt;
     cvals[0] = 1.0;
-    for (int i = 0; i < order; i++) cvals[i + 1] = cvals[i] * (t - tr->T[i]) / dt;
+    for (int i = 0; i < order; i++) cvals[i + 1] = cvals[i] * (t - tr->T[i]) * inv_dt;
     for (int k = 0; k < NS; k++) {
         double acc = cvals[0] * tr->Y[0][k];
         for (int i = 1; i <= order; i++) acc += cvals[i] * tr->Y[i][k];

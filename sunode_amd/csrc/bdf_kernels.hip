@@ -219,6 +219,14 @@ DEV double pick(const double (&a)[N], int idx)
     return r;
 }
 
+/* divided-difference table of one stored trajectory index (see "stored forward trajectory") */
+struct TrajTable {
+    int order;
+    double dt;
+    double T[QMAX + 1];
+    double Y[QMAX + 1][NSD];
+};
+
 /* ------------------------------------------------------------------------------------ */
 /* per-lane integrator state                                                              */
 /* ------------------------------------------------------------------------------------ */
@@ -245,22 +253,55 @@ struct Cv {
     double prl[NR <= 32 ? NRD : 1];   /* remaining parameters held per lane (small NR) */
     const double *prg;            /* or read through a (typically shared) global pointer (large NR) */
     /* trajectory interpolation (backward) */
-    const double *traj_t, *traj_y;
-    const uint8_t *traj_q;
-    int64_t tstride;
+    const double *traj;               /* lane's first record; see "stored forward trajectory" */
+    int64_t trow;                     /* step pitch in doubles */
+    TrajTable cur, nxt;               /* tables of index cur_idx and cur_idx - 1 */
+    int cur_idx;
     int np;
     double tfinal;
-    int ilast, newdata, have_last, tb_order;
-    double last_t, tb_dt;
+    int ilast, newdata, have_last;
+    double last_t;
     double tlo, thi;                  /* t[ilast-1], t[ilast]: bracketing times kept in registers */
-    double T[QMAX + 1];
-    double Y[QMAX + 1][NSD];
     int n_interp, n_rebuild;
 };
 
-/* ---- trajectory access: [step][instance], instance index already folded into the base ---- */
+/* ---- stored forward trajectory ------------------------------------------------------------
+ * CVODES (CV_POLYNOMIAL) stores (t_n, y_n, q_n) after every forward step and, in the backward
+ * wrappers, rebuilds a Newton divided-difference table through the q+1 points ending at the bracketing
+ * index whenever that index changes (CVApolynomialGetY).  Doing that rebuild inside the backward
+ * kernel is the worst case for a thread-per-instance mapping: ~88 rebuilds per instance against
+ * ~1500 loop iterations per wave means SOME lane rebuilds in nearly every iteration, so the whole wave
+ * pays 15 divides + dependent loads every time.  Instead the FORWARD kernel, whose lanes all store
+ * a point in the same iteration, builds the table of every index once and stores it:
+ *
+ *   record (step s, instance) = TREC = 8 + 6n doubles: {order, dt, T[0..5], Y[0..5][n]}
+ *     T[j] = t_{s-j},  Y = scaled divided differences through points s..s-order,  dt = |t_s - t_{s-1}|
+ *   traj[(s * stride + inst) * TREC + f], instance index fastest.
+ *
+ * The backward kernel keeps the table of the current index (`cur`) and the already-fetched table
+ * of the next index to the left (`nxt`) in registers; the common move (one index to the left)
+ * is a register copy plus ONE asynchronous prefetch whose data is first needed at the next move,
+ * at least one loop iteration later.  Same values as CVODES computes on demand, hence bit-identical
+ * to the CPU oracle.
+ */
+#define TREC (8 + 6 * NS)
+
+/* unconditional load from a clamped index (a guarded load would be merged with a default at the
+   join, i.e. waited for on the spot); out-of-range tables are never consumed */
 template <bool BWD>
-DEV double trj_t(const Cv<BWD> &m, int s) { return m.traj_t[(int64_t)s * m.tstride]; }
+DEV void load_table(const Cv<BWD> &m, int s, TrajTable &tb)
+{
+    int sc = s < 0 ? 0 : s;
+    sc = sc > m.np - 1 ? m.np - 1 : sc;
+    const double *r = m.traj + (int64_t)sc * m.trow;
+    tb.order = (int)r[0];
+    tb.dt = r[1];
+    SFOR(j, 0, (QMAX) + 1) tb.T[j] = r[2 + j]; SEND
+    SFOR(j, 0, (QMAX) + 1) { SFOR(i, 0, NS) tb.Y[j][i] = r[8 + j * NS + i]; SEND } SEND
+}
+
+template <bool BWD>
+DEV double point_time(const Cv<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + 2]; }
 
 /* CVAfindIndex + CVApolynomialGetY (forward integration direction), with the wrappers'
    repeated interpolation at an unchanged t evaluated once. */
@@ -268,80 +309,89 @@ template <bool BWD>
 DEV int interp_y(Cv<BWD> &m, double t)
 {
     if (m.have_last && t == m.last_t) return CV_SUCCESS;
+#ifdef SA_ABLATE_INTERP          /* timing experiment: no trajectory access at all */
+    m.have_last = 1; m.last_t = t;
+    SFOR(i, 0, NS) m.ytmp[i] = 1.0 + 0.001 * t; SEND
+    return CV_SUCCESS;
+#endif
     m.n_interp++;
     int newpoint = 0, indx;
     if (m.newdata) {
         m.ilast = m.np - 1; newpoint = 1; m.newdata = 0;
-        m.tlo = trj_t(m, m.ilast - 1); m.thi = trj_t(m, m.ilast);
+        load_table(m, m.ilast, m.cur);
+        load_table(m, m.ilast - 1, m.nxt);
+        m.cur_idx = m.ilast;
+        m.tlo = m.cur.T[1]; m.thi = m.cur.T[0];
     }
-    int ilast = m.ilast;
+    const int ilast = m.ilast;
     bool to_left = (t - m.tlo) < 0.0;
     bool to_right = (t - m.thi) > 0.0;
     indx = ilast;
     if (to_left) {
         newpoint = 1;
+        double tprev = m.tlo;                 /* t[indx-1] */
+        double tcur = m.thi;                  /* t[indx]   */
         for (;;) {
             if (indx == 0) break;
-            if ((t - trj_t(m, indx - 1)) <= 0.0) indx--;
-            else break;
+            if ((t - tprev) <= 0.0) {
+                indx--;
+                tcur = tprev;
+                if (indx > 0)
+                    tprev = (indx == m.cur_idx - 1) ? m.nxt.T[1] : point_time(m, indx - 1);
+            } else break;
         }
         m.ilast = (indx == 0) ? 1 : indx;
-        m.tlo = trj_t(m, m.ilast - 1); m.thi = trj_t(m, m.ilast);
         if (indx == 0) {
+            /* tcur = t[0]; CVODES leaves ilast = 1 here */
+            m.tlo = tcur; m.thi = point_time(m, 1);
             if (fabs(t - m.tlo) > FUZZ_FACTOR_ADJ * UROUND) return CV_GETY_BADT;
+        } else {
+            m.tlo = tprev; m.thi = tcur;
         }
     } else if (to_right) {
         newpoint = 1;
+        double tcur = m.thi;                  /* t[indx] */
+        double tprev = m.tlo;
         for (;;) {
             if (indx >= m.np - 1) break;
-            if ((t - trj_t(m, indx)) > 0.0) indx++;
-            else break;
+            if ((t - tcur) > 0.0) {
+                indx++;
+                tprev = tcur;
+                tcur = point_time(m, indx);
+            } else break;
         }
         m.ilast = indx;
-        m.tlo = trj_t(m, indx - 1); m.thi = trj_t(m, indx);
+        m.tlo = tprev; m.thi = tcur;
         if ((t - m.thi) > FUZZ_FACTOR_ADJ * UROUND * (fabs(m.tfinal) + 1.0)) return CV_GETY_BADT;
     }
     m.have_last = 1;
     m.last_t = t;
     if (indx == 0) {
-        SFOR(i, 0, NS) m.ytmp[i] = m.traj_y[(int64_t)i * m.tstride]; SEND
+        SFOR(i, 0, NS) m.ytmp[i] = m.traj[8 + i]; SEND        /* record 0: Y[0] = y(t0) */
         return CV_SUCCESS;
+    }
+    if (newpoint && indx != m.cur_idx) {
+        if (indx == m.cur_idx - 1) {
+            m.cur = m.nxt;                               /* common move: one index to the left */
+        } else {
+            load_table(m, indx, m.cur);                  /* back-step or multi-index move (rare) */
+        }
+        m.cur_idx = indx;
+        load_table(m, indx - 1, m.nxt);                  /* prefetch; consumed at a later move */
     }
     if (newpoint) {
         m.n_rebuild++;
-        double dt = fabs(m.thi - m.tlo);         /* indx == ilast here */
-        int order = (int)m.traj_q[(int64_t)indx * m.tstride];
-        int base = indx;
-        if (indx < order) base += order - indx;
-        m.tb_dt = dt;
-        m.tb_order = order;
-        SFOR(j, 0, (QMAX) + 1) {
-            if (j <= order) {
-                int s = base - j;
-                m.T[j] = trj_t(m, s);
-                SFOR(i, 0, NS) m.Y[j][i] = m.traj_y[((int64_t)s * NS + i) * m.tstride]; SEND
-            }
-        } SEND
-        SFOR(i, 1, (QMAX) + 1) {
-            SFOR_DOWN(j, QMAX, 1) {
-                if constexpr (j >= i) {
-                    if (j <= order) {
-                        double factor = dt / (m.T[j] - m.T[j - i]);
-                        SFOR(k, 0, NS) m.Y[j][k] = factor * m.Y[j][k] + (-factor) * m.Y[j - 1][k]; SEND
-                    }
-                }
-            } SEND
-        } SEND
+        if (m.cur.order > m.cur_idx) return CV_GETY_BADT;    /* CVODES would shift the base; cannot occur */
     }
     {
-        const int order = m.tb_order;
-        const double dt = m.tb_dt;
+        const int order = m.cur.order;
+        const double inv_dt = 1.0 / m.cur.dt;
         double cvals[QMAX + 1];
         cvals[0] = 1.0;
-        SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - m.T[i]) / dt : 0.0; SEND
+        SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - m.cur.T[i]) * inv_dt : 0.0; SEND
         SFOR(k, 0, NS) {
-            double acc = cvals[0] * m.Y[0][k];
-            SFOR(i, 1, (QMAX) + 1) if (i <= order) acc += cvals[i] * m.Y[i][k]; SEND
+            double acc = cvals[0] * m.cur.Y[0][k];
+            SFOR(i, 1, (QMAX) + 1) if (i <= order) acc += cvals[i] * m.cur.Y[i][k]; SEND
             m.ytmp[k] = acc;
         } SEND
     }
@@ -1269,6 +1319,29 @@ DEV void accumulate_stats(const Cv<BWD> &m, int64_t *acc)
 
 #define SA_NAN __longlong_as_double(0x7ff8000000000000LL)
 
+/* Build the CVApolynomialGetY divided-difference table of the newest stored point from the point
+   history (T[j], Y[j] = point s-j) and write the trajectory record.  Same operation order as the
+   on-demand rebuild in CVODES / the oracle: factor = dt / (T[j] - T[j-i]), Y[j] = f*Y[j] - f*Y[j-1]. */
+DEV void store_table(double *r, int order, double dt, const double (&hT)[QMAX + 1], const double (&hY)[QMAX + 1][NSD])
+{
+    double Y[QMAX + 1][NSD];
+    SFOR(j, 0, (QMAX) + 1) { SFOR(i, 0, NS) Y[j][i] = hY[j][i]; SEND } SEND
+    SFOR(i, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, 1) {
+            if constexpr (j >= i) {
+                if (j <= order) {
+                    double factor = dt / (hT[j] - hT[j - i]);
+                    SFOR(k, 0, NS) Y[j][k] = factor * Y[j][k] + (-factor) * Y[j - 1][k]; SEND
+                }
+            }
+        } SEND
+    } SEND
+    r[0] = (double)order;
+    r[1] = dt;
+    SFOR(j, 0, (QMAX) + 1) r[2 + j] = hT[j]; SEND
+    SFOR(j, 0, (QMAX) + 1) { SFOR(i, 0, NS) r[8 + j * NS + i] = Y[j][i]; SEND } SEND
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* forward kernel: Solver.solve (mode PLAIN) / AdjointSolver.solve_forward (mode ADJ_FWD)   */
 /* ------------------------------------------------------------------------------------ */
@@ -1281,9 +1354,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     m.rtol = a.rtol;
     SFOR(i, 0, NS) m.atol[i] = a.atol[i]; SEND
     m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
-    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.tb_order = 0;
-    m.last_t = 0.0; m.tb_dt = 0.0; m.n_interp = 0; m.n_rebuild = 0; m.tlo = 0.0; m.thi = 0.0;
-    m.traj_t = nullptr; m.traj_y = nullptr; m.traj_q = nullptr; m.tstride = 0;
+    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0;
+    m.last_t = 0.0; m.n_interp = 0; m.n_rebuild = 0; m.tlo = 0.0; m.thi = 0.0;
+    m.traj = nullptr; m.trow = 0; m.cur_idx = 0;
 
     double y0[NSD];
     SFOR(i, 0, NS) y0[i] = a.y0[(int64_t)inst * NS + i]; SEND
@@ -1291,10 +1364,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
 
     const bool store = (a.mode == SA_MODE_ADJ_FWD);
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
-    double *tt = a.traj_t + inst;
-    double *ty = a.traj_y + inst;
-    uint8_t *tqo = a.traj_q + inst;
-    const int64_t ts = a.traj_stride;
+    double *trec = a.traj + (int64_t)inst * TREC;     /* records {order, dt, T[6], Y[6][n]} */
+    const int64_t trow = a.traj_stride * TREC;
+    double hT[QMAX + 1], hY[QMAX + 1][NSD];           /* the last six stored points, newest first */
+    SFOR(j, 0, (QMAX) + 1) { hT[j] = 0.0; SFOR(i, 0, NS) hY[j][i] = 0.0; SEND } SEND
 
     int status = CV_SUCCESS, k = 0, np = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
     while (k < a.n_t && a.tvals[k] == a.t0) {       /* solver.py:505,707: row 0 <- y0 */
@@ -1308,9 +1381,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         int flag = cv_first_call(m, a.tvals[k]);
         if (flag != CV_SUCCESS) { status = flag; done = true; }
         else if (store) {
-            tt[0] = m.tn;
-            SFOR(i, 0, NS) ty[(int64_t)i * ts] = m.zn[0][i]; SEND
-            tqo[0] = 0;
+            hT[0] = m.tn;
+            SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
+            store_table(trec, 0, 1.0, hT, hY);
             np = 1;
         }
     }
@@ -1334,9 +1407,13 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                 if (store) {
                     if (np >= a.traj_cap) { status = CV_TOO_MUCH_WORK; done = true; }
                     else {
-                        tt[(int64_t)np * ts] = m.tn;
-                        SFOR(i, 0, NS) ty[((int64_t)np * NS + i) * ts] = m.zn[0][i]; SEND
-                        tqo[(int64_t)np * ts] = (uint8_t)m.qu;
+                        SFOR_DOWN(j, QMAX, 1) {
+                            hT[j] = hT[j - 1];
+                            SFOR(i, 0, NS) hY[j][i] = hY[j - 1][i]; SEND
+                        } SEND
+                        hT[0] = m.tn;
+                        SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
+                        store_table(trec + (int64_t)np * trow, m.qu, fabs(hT[0] - hT[1]), hT, hY);
                         np++;
                     }
                 }
@@ -1388,14 +1465,19 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     SFOR(i, 0, NS) m.atol[i] = a.atolB; SEND
     m.rtolQ = a.rtolQB; m.atolQ = a.atolQB;
     m.tstop = a.tinitial;
-    m.traj_t = a.traj_t + inst; m.traj_y = a.traj_y + inst; m.traj_q = a.traj_q + inst;
-    m.tstride = a.traj_stride;
+    m.traj = a.traj + (int64_t)inst * TREC;
+    m.trow = a.traj_stride * TREC;
     m.np = np;
-    m.tfinal = (status == CV_SUCCESS) ? m.traj_t[(int64_t)(np - 1) * a.traj_stride] : a.tinitial;
-    m.ilast = 0; m.newdata = 1; m.have_last = 0; m.tb_order = 0; m.last_t = 0.0; m.tb_dt = 1.0;
+    m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + 2] : a.tinitial;
+    m.cur_idx = 0;
+    m.cur.order = 0; m.cur.dt = 1.0; m.nxt.order = 0; m.nxt.dt = 1.0;
+    SFOR(j, 0, (QMAX) + 1) {
+        m.cur.T[j] = 0.0; m.nxt.T[j] = 0.0;
+        SFOR(i, 0, NS) { m.cur.Y[j][i] = 0.0; m.nxt.Y[j][i] = 0.0; } SEND
+    } SEND
+    m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
     m.tlo = 0.0; m.thi = 0.0;
     m.n_interp = 0; m.n_rebuild = 0;
-    SFOR(j, 0, (QMAX) + 1) { m.T[j] = 0.0; SFOR(i, 0, NS) m.Y[j][i] = 0.0; SEND } SEND
     SFOR(i, 0, NS) m.ytmp[i] = 0.0; SEND
 
     double lam[NSD], quad[NQD], quad_out[NQD];

@@ -12,8 +12,9 @@
  *   grads   [B][n_t][n] or [n_t][n] (grads_stride = n_t*n or 0)
  *   stats   [B][16] int64     counters, see SA_ST_* in include/sunode_amd.h
  *   trajectory arena (the CVODES "data points" of CVodeAdjInit / CVodeF):
- *     traj_t [cap][stride], traj_y [cap][n][stride], traj_q [cap][stride] (u8), traj_np [B] (i32)
- *     instance index fastest: lanes of a wave write one step with unit stride.
+ *     traj [cap][stride][8+6n] records {order, dt, T[6], Y[6][n]} = the divided-difference table
+ *     CVApolynomialGetY needs at that index, built once by the forward kernel; traj_np [B] (i32);
+ *     instance index fastest: the lanes of a wave write one step as one contiguous block.
  */
 #ifndef SA_DEVICE_ABI_H
 #define SA_DEVICE_ABI_H
@@ -34,8 +35,7 @@ typedef struct {
     double *y_out;
     int32_t *status;
     int64_t *stats;
-    double *traj_t, *traj_y;
-    uint8_t *traj_q;
+    double *traj;
     int32_t *traj_np;
 } sa_fwd_args;
 
@@ -49,8 +49,7 @@ typedef struct {
     int32_t *status;
     const int32_t *fwd_status;
     int64_t *stats;
-    const double *traj_t, *traj_y;
-    const uint8_t *traj_q;
+    const double *traj;
     const int32_t *traj_np;
 } sa_bwd_args;
 

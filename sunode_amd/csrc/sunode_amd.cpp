@@ -74,7 +74,7 @@ struct sa_solver {
     std::vector<double> atol;
     DevBuf d_atol;
     /* trajectory arena + forward bookkeeping of the last forward batch */
-    DevBuf traj_t, traj_y, traj_q, traj_np, fwd_status;
+    DevBuf traj, traj_np, fwd_status;
     int64_t traj_stride = 0;
     int32_t fwd_B = 0;
     double fwd_t0 = 0.0;
@@ -168,7 +168,7 @@ extern "C" void sa_solver_destroy(sa_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    DevBuf *bufs[] = {&s->d_atol, &s->traj_t, &s->traj_y, &s->traj_q, &s->traj_np, &s->fwd_status, &s->s_y0,
+    DevBuf *bufs[] = {&s->d_atol, &s->traj, &s->traj_np, &s->fwd_status, &s->s_y0,
                       &s->s_ps, &s->s_pr, &s->s_tvals, &s->s_yout, &s->s_status, &s->s_stats, &s->s_grads,
                       &s->s_gout, &s->s_lout};
     for (DevBuf *b : bufs) b->release();
@@ -283,15 +283,12 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
     if (mode == SA_MODE_ADJ_FWD) {
         int64_t stride = ((int64_t)B + 63) / 64 * 64;
         size_t rows = (size_t)s->opt.traj_capacity;
-        if ((rc = s->traj_t.ensure(sizeof(double) * rows * stride))) return rc;
-        if ((rc = s->traj_y.ensure(sizeof(double) * rows * stride * (s->n > 0 ? s->n : 1)))) return rc;
-        if ((rc = s->traj_q.ensure(rows * stride))) return rc;
+        if ((rc = s->traj.ensure(sizeof(double) * rows * stride * (size_t)(8 + 6 * s->n)))) return rc;
         if ((rc = s->traj_np.ensure(sizeof(int32_t) * stride))) return rc;
         if ((rc = s->fwd_status.ensure(sizeof(int32_t) * stride))) return rc;
         s->traj_stride = stride;
         a.traj_stride = stride;
-        a.traj_t = (double *)s->traj_t.p; a.traj_y = (double *)s->traj_y.p;
-        a.traj_q = (uint8_t *)s->traj_q.p; a.traj_np = (int32_t *)s->traj_np.p;
+        a.traj = (double *)s->traj.p; a.traj_np = (int32_t *)s->traj_np.p;
     }
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if ((rc = launch(s, s->k_forward, B, &a, sizeof a))) return rc;
@@ -365,8 +362,7 @@ extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const d
     a.rtolB = s->opt.rtolB; a.atolB = s->opt.atolB; a.rtolQB = s->opt.rtolQB; a.atolQB = s->opt.atolQB;
     a.ps = d_ps; a.pr = d_pr; a.tvals = d_tv; a.grads = d_g; a.grad_out = d_gout; a.lamda_out = d_lout;
     a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
-    a.traj_t = (const double *)s->traj_t.p; a.traj_y = (const double *)s->traj_y.p;
-    a.traj_q = (const uint8_t *)s->traj_q.p; a.traj_np = (const int32_t *)s->traj_np.p;
+    a.traj = (const double *)s->traj.p; a.traj_np = (const int32_t *)s->traj_np.p;
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     if ((rc = launch(s, s->k_backward, B, &a, sizeof a))) return rc;
     HIP_TRY(hipEventRecord(s->ev[3], s->stream));
