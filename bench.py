@@ -173,6 +173,11 @@ def main():
                      "bdf_steps_per_s": world * B * float(sf[0] + sb[0]) * args.steps / elapsed,
                      "rhs_evals_per_s": world * B * float(sf[1] + sb[1] + sb[9]) * args.steps / elapsed},
         }
+        if "PROFILE" in os.environ.get("SA_ABLATE", ""):
+            names = ["pre_step+post", "predict+set", "interp", "newton", "errtest+quad", "complete+prepare",
+                     "post_step", "interval_setup"]
+            tot = float(sb[8:16].sum())
+            out["phase_cycles_per_lane"] = {k: [float(v), round(float(v) / tot, 4)] for k, v in zip(names, sb[8:16])}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, tol)
         print(json.dumps(out), flush=True)

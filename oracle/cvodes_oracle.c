@@ -41,6 +41,11 @@
 #define SA_FN static inline
 #include SA_PROBLEM_HEADER
 
+/* Fused multiply-add is used explicitly (never by compiler contraction: -ffp-contract=off) at the
+   same places as in the HIP kernel, so both sides round identically.  CVODES itself evaluates these
+   a*b+c forms with two roundings; the difference is one ulp per operation. */
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+
 #define NS SA_N_STATES
 #define NQ SA_N_SUB
 #define NR SA_N_REM
@@ -145,40 +150,40 @@ static double det_log(double x)
     double s = f / (2.0 + f);
     double z = s * s;
     double p = 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
-    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+    p = FMA(p, z, 1.0 / 21.0);
+    p = FMA(p, z, 1.0 / 19.0);
+    p = FMA(p, z, 1.0 / 17.0);
+    p = FMA(p, z, 1.0 / 15.0);
+    p = FMA(p, z, 1.0 / 13.0);
+    p = FMA(p, z, 1.0 / 11.0);
+    p = FMA(p, z, 1.0 / 9.0);
+    p = FMA(p, z, 1.0 / 7.0);
+    p = FMA(p, z, 1.0 / 5.0);
+    p = FMA(p, z, 1.0 / 3.0);
+    p = FMA(p, z, 1.0);
+    return FMA((double)e, 0.6931471805599453, 2.0 * s * p);
 }
 
 static double det_exp(double w)
 {
     if (w > 700.0) w = 700.0;
     if (w < -700.0) w = -700.0;
-    double kf = floor(w * 1.4426950408889634 + 0.5);
-    double r = (w - kf * 0.693147180369123816490) - kf * 1.90821492927058770002e-10;
+    double kf = floor(FMA(w, 1.4426950408889634, 0.5));
+    double r = FMA(-kf, 1.90821492927058770002e-10, FMA(-kf, 0.693147180369123816490, w));
     double p = 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    p = FMA(p, r, 1.0 / 479001600.0);
+    p = FMA(p, r, 1.0 / 39916800.0);
+    p = FMA(p, r, 1.0 / 3628800.0);
+    p = FMA(p, r, 1.0 / 362880.0);
+    p = FMA(p, r, 1.0 / 40320.0);
+    p = FMA(p, r, 1.0 / 5040.0);
+    p = FMA(p, r, 1.0 / 720.0);
+    p = FMA(p, r, 1.0 / 120.0);
+    p = FMA(p, r, 1.0 / 24.0);
+    p = FMA(p, r, 1.0 / 6.0);
+    p = FMA(p, r, 0.5);
+    p = FMA(p, r, 1.0);
+    p = FMA(p, r, 1.0);
     union { double d; uint64_t u; } v;
     v.u = (uint64_t)((int64_t)kf + 1023) << 52;
     return p * v.d;
@@ -307,7 +312,7 @@ static int traj_get_y(traj_t *tr, double t, double *y)
             for (int j = order; j >= i; j--) {
                 double factor = dt / (tr->T[j] - tr->T[j - i]);
                 for (int k = 0; k < NS; k++)
-                    tr->Y[j][k] = factor * tr->Y[j][k] + (-factor) * tr->Y[j - 1][k];
+                    tr->Y[j][k] = factor * (tr->Y[j][k] - tr->Y[j - 1][k]);
             }
         }
     }
@@ -319,7 +324,7 @@ static int traj_get_y(traj_t *tr, double t, double *y)
     for (int i = 0; i < order; i++) cvals[i + 1] = cvals[i] * (t - tr->T[i]) * inv_dt;
     for (int k = 0; k < NS; k++) {
         double acc = cvals[0] * tr->Y[0][k];
-        for (int i = 1; i <= order; i++) acc += cvals[i] * tr->Y[i][k];
+        for (int i = 1; i <= order; i++) acc = FMA(cvals[i], tr->Y[i][k], acc);
         y[k] = tr->last_y[k] = acc;
     }
     return CV_SUCCESS;
@@ -355,6 +360,7 @@ typedef struct {
     /* linear solver */
     double A[NSD * NSD], savedJ[NSD * NSD];
     int piv[NSD];
+    double inv_piv[NSD];
     int jcur, nls_jcur;
 } cvmem;
 
@@ -386,7 +392,7 @@ static double wrms(const double *x, const double *w, int n)
 {
     if (n == 0) return 0.0;
     double sum = 0.0;
-    for (int i = 0; i < n; i++) { double prod = x[i] * w[i]; sum += prod * prod; }
+    for (int i = 0; i < n; i++) { double prod = x[i] * w[i]; sum = FMA(prod, prod, sum); }
     return sqrt(sum / n);
 }
 
@@ -399,7 +405,7 @@ static double quad_update_norm(cvmem *m, double old_nrm, const double *xQ, const
 static int ewt_set(cvmem *m, const double *ycur, double *w)
 {
     for (int i = 0; i < NS; i++) {
-        double v = m->rtol * fabs(ycur[i]) + m->atol[i];
+        double v = FMA(m->rtol, fabs(ycur[i]), m->atol[i]);
         if (v <= 0.0) return -1;
         w[i] = 1.0 / v;
     }
@@ -409,7 +415,7 @@ static int ewt_set(cvmem *m, const double *ycur, double *w)
 static int ewtQ_set(cvmem *m, const double *qcur, double *w)
 {
     for (int i = 0; i < NQ; i++) {
-        double v = m->rtolQ * fabs(qcur[i]) + m->atolQ;
+        double v = FMA(m->rtolQ, fabs(qcur[i]), m->atolQ);
         if (v <= 0.0) return -1;
         w[i] = 1.0 / v;
     }
@@ -417,7 +423,7 @@ static int ewtQ_set(cvmem *m, const double *qcur, double *w)
 }
 
 /* ---- dense LU (SUNDIALS denseGETRF / denseGETRS, column-major) ---- */
-static int dense_getrf(double *a, int n, int *p)
+static int dense_getrf(double *a, int n, int *p, double *inv_piv)
 {
     for (int k = 0; k < n; k++) {
         double *col_k = a + (size_t)k * n;
@@ -434,18 +440,19 @@ static int dense_getrf(double *a, int n, int *p)
             }
         }
         double mult = 1.0 / col_k[k];
+        inv_piv[k] = mult;           /* reused by the solves instead of dividing by the pivot again */
         for (int i = k + 1; i < n; i++) col_k[i] *= mult;
         for (int j = k + 1; j < n; j++) {
             double *col_j = a + (size_t)j * n;
             double a_kj = col_j[k];
             if (a_kj != 0.0)
-                for (int i = k + 1; i < n; i++) col_j[i] -= a_kj * col_k[i];
+                for (int i = k + 1; i < n; i++) col_j[i] = FMA(-a_kj, col_k[i], col_j[i]);
         }
     }
     return 0;
 }
 
-static void dense_getrs(const double *a, int n, const int *p, double *b)
+static void dense_getrs(const double *a, int n, const int *p, const double *inv_piv, double *b)
 {
     for (int k = 0; k < n; k++) {
         int pk = p[k];
@@ -453,14 +460,14 @@ static void dense_getrs(const double *a, int n, const int *p, double *b)
     }
     for (int k = 0; k < n - 1; k++) {
         const double *col_k = a + (size_t)k * n;
-        for (int i = k + 1; i < n; i++) b[i] -= col_k[i] * b[k];
+        for (int i = k + 1; i < n; i++) b[i] = FMA(-col_k[i], b[k], b[i]);
     }
     for (int k = n - 1; k > 0; k--) {
         const double *col_k = a + (size_t)k * n;
-        b[k] /= col_k[k];
-        for (int i = 0; i < k; i++) b[i] -= col_k[i] * b[k];
+        b[k] *= inv_piv[k];
+        for (int i = 0; i < k; i++) b[i] = FMA(-col_k[i], b[k], b[i]);
     }
-    if (n > 0) b[0] /= a[0];
+    if (n > 0) b[0] *= inv_piv[0];
 }
 
 /* ------------------------------------------------------------------------- */
@@ -498,7 +505,7 @@ static double cv_upper_bound_h0(cvmem *m, double tdist)
         for (int i = 0; i < NS; i++) {
             double t2 = fabs(m->zn[0][i]);
             double t1 = 1.0 / temp1[i];
-            t1 = HUB_FACTOR * t2 + t1;
+            t1 = FMA(HUB_FACTOR, t2, t1);
             double v = fabs(m->zn[1][i]) / t1;
             if (v > hub_inv) hub_inv = v;
         }
@@ -510,7 +517,7 @@ static double cv_upper_bound_h0(cvmem *m, double tdist)
         for (int i = 0; i < NQ; i++) {
             double t2 = fabs(m->znQ[0][i]);
             double t1 = 1.0 / tempQ[i];
-            t1 = HUB_FACTOR * t2 + t1;
+            t1 = FMA(HUB_FACTOR, t2, t1);
             double v = fabs(m->znQ[1][i]) / t1;
             if (v > hubQ_inv) hubQ_inv = v;
         }
@@ -523,7 +530,7 @@ static double cv_upper_bound_h0(cvmem *m, double tdist)
 
 static int cv_ydd_norm(cvmem *m, double hg, double *yddnrm)
 {
-    for (int i = 0; i < NS; i++) m->y[i] = hg * m->zn[1][i] + m->zn[0][i];
+    for (int i = 0; i < NS; i++) m->y[i] = FMA(hg, m->zn[1][i], m->zn[0][i]);
     int retval = cv_f(m, m->tn + hg, m->y, m->tempv);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return RHSFUNC_RECVR;
@@ -624,7 +631,7 @@ static void cv_increase_bdf(cvmem *m)
             prod *= xi;
             alpha0 -= 1.0 / (j + 1);
             alpha1 += 1.0 / xi;
-            for (int i = j + 2; i >= 2; i--) m->l[i] = m->l[i] * xiold + m->l[i - 1];
+            for (int i = j + 2; i >= 2; i--) m->l[i] = FMA(m->l[i], xiold, m->l[i - 1]);
             xiold = xi;
         }
     }
@@ -632,11 +639,11 @@ static void cv_increase_bdf(cvmem *m)
     int L = m->L;
     for (int i = 0; i < NS; i++) m->zn[L][i] = A1 * m->zn[QMAX][i];
     for (int j = 2; j <= m->q; j++)
-        for (int i = 0; i < NS; i++) m->zn[j][i] = m->l[j] * m->zn[L][i] + m->zn[j][i];
+        for (int i = 0; i < NS; i++) m->zn[j][i] = FMA(m->l[j], m->zn[L][i], m->zn[j][i]);
     if (m->quadr) {
         for (int i = 0; i < NQ; i++) m->znQ[L][i] = A1 * m->znQ[QMAX][i];
         for (int j = 2; j <= m->q; j++)
-            for (int i = 0; i < NQ; i++) m->znQ[j][i] = m->l[j] * m->znQ[L][i] + m->znQ[j][i];
+            for (int i = 0; i < NQ; i++) m->znQ[j][i] = FMA(m->l[j], m->znQ[L][i], m->znQ[j][i]);
     }
 }
 
@@ -648,13 +655,13 @@ static void cv_decrease_bdf(cvmem *m)
     for (int j = 1; j <= m->q - 2; j++) {
         hsum += m->tau[j];
         double xi = hsum / m->hscale;
-        for (int i = j + 2; i >= 2; i--) m->l[i] = m->l[i] * xi + m->l[i - 1];
+        for (int i = j + 2; i >= 2; i--) m->l[i] = FMA(m->l[i], xi, m->l[i - 1]);
     }
     for (int j = 2; j < m->q; j++)
-        for (int i = 0; i < NS; i++) m->zn[j][i] = -m->l[j] * m->zn[m->q][i] + m->zn[j][i];
+        for (int i = 0; i < NS; i++) m->zn[j][i] = FMA(-m->l[j], m->zn[m->q][i], m->zn[j][i]);
     if (m->quadr)
         for (int j = 2; j < m->q; j++)
-            for (int i = 0; i < NQ; i++) m->znQ[j][i] = -m->l[j] * m->znQ[m->q][i] + m->znQ[j][i];
+            for (int i = 0; i < NQ; i++) m->znQ[j][i] = FMA(-m->l[j], m->znQ[m->q][i], m->znQ[j][i]);
 }
 
 static void cv_adjust_order(cvmem *m, int deltaq)
@@ -703,7 +710,7 @@ static void cv_set_tq_bdf(cvmem *m, double hsum, double alpha0, double alpha0_ha
 {
     int q = m->q;
     double A1 = 1.0 - alpha0_hat + alpha0;
-    double A2 = 1.0 + q * A1;
+    double A2 = FMA((double)q, A1, 1.0);
     m->tq[2] = fabs(A1 / (alpha0 * A2));
     m->tq[5] = fabs(A2 * xistar_inv / (m->l[q] * xi_inv));
     if (m->qwait == 1) {
@@ -721,7 +728,7 @@ static void cv_set_tq_bdf(cvmem *m, double hsum, double alpha0, double alpha0_ha
         double Cppinv = (1.0 - A6 + A5) / A2;
         m->tq[3] = fabs(Cppinv / (xi_inv * (q + 2) * A5));
     }
-    m->tq[4] = NLSCOEF / m->tq[2];
+    m->tq[4] = m->tq[2] * 10.0;       /* 1/tq[4] of CVODES (= tq[2]/nlscoef): the test multiplies */
 }
 
 static void cv_set_bdf(cvmem *m)
@@ -737,14 +744,14 @@ static void cv_set_bdf(cvmem *m)
             hsum += m->tau[j - 1];
             xi_inv = m->h / hsum;
             alpha0 -= 1.0 / j;
-            for (int i = j; i >= 1; i--) m->l[i] += m->l[i - 1] * xi_inv;
+            for (int i = j; i >= 1; i--) m->l[i] = FMA(m->l[i - 1], xi_inv, m->l[i]);
         }
         alpha0 -= 1.0 / q;
         xistar_inv = -m->l[1] - alpha0;
         hsum += m->tau[q - 1];
         xi_inv = m->h / hsum;
         alpha0_hat = -m->l[1] - xi_inv;
-        for (int i = q; i >= 1; i--) m->l[i] += m->l[i - 1] * xistar_inv;
+        for (int i = q; i >= 1; i--) m->l[i] = FMA(m->l[i - 1], xistar_inv, m->l[i]);
     }
     cv_set_tq_bdf(m, hsum, alpha0, alpha0_hat, xi_inv, xistar_inv);
 }
@@ -781,10 +788,12 @@ static int cv_lsetup(cvmem *m, int convfail, const double *ypred)
     /* SUNMatScaleAddI(-gamma, A) */
     double c = -m->gamma;
     for (int j = 0; j < NS; j++) {
-        for (int i = 0; i < NS; i++) m->A[(size_t)j * NS + i] *= c;
-        m->A[(size_t)j * NS + j] += 1.0;
+        for (int i = 0; i < NS; i++) {
+            if (i == j) m->A[(size_t)j * NS + i] = FMA(c, m->A[(size_t)j * NS + i], 1.0);
+            else m->A[(size_t)j * NS + i] *= c;
+        }
     }
-    int ier = dense_getrf(m->A, NS, m->piv);
+    int ier = dense_getrf(m->A, NS, m->piv, m->inv_piv);
     return ier > 0 ? 1 : 0;
 }
 
@@ -805,7 +814,7 @@ static int cv_nls_lsetup(cvmem *m, int jbad, int *convfail)
 
 static void cv_lsolve(cvmem *m, double *b)
 {
-    dense_getrs(m->A, NS, m->piv, b);
+    dense_getrs(m->A, NS, m->piv, m->inv_piv, b);
     if (m->gamrat != 1.0) {
         double s = 2.0 / (1.0 + m->gamrat);
         for (int i = 0; i < NS; i++) b[i] *= s;
@@ -819,8 +828,8 @@ static int cv_nls_residual(cvmem *m, const double *ycor, double *res)
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return RHSFUNC_RECVR;
     for (int i = 0; i < NS; i++) {
-        res[i] = m->rl1 * m->zn[1][i] + ycor[i];
-        res[i] = -m->gamma * m->ftemp[i] + res[i];
+        res[i] = FMA(m->rl1, m->zn[1][i], ycor[i]);
+        res[i] = FMA(-m->gamma, m->ftemp[i], res[i]);
     }
     return CV_SUCCESS;
 }
@@ -829,7 +838,7 @@ static int cv_nls_conv_test(cvmem *m, int curiter, const double *delta, const do
 {
     double del = wrms(delta, m->ewt, NS);
     if (curiter > 0) m->crate = fmax(CRDOWN * m->crate, del / m->delp);
-    double dcon = del * fmin(1.0, m->crate) / m->tq[4];
+    double dcon = del * fmin(1.0, m->crate) * m->tq[4];
     if (dcon <= 1.0) {
         m->acnrm = (curiter == 0) ? del : wrms(ycor, m->ewt, NS);
         return CV_SUCCESS;
@@ -955,7 +964,7 @@ static int cv_quad_nls(cvmem *m)
     if (retval < 0) return CV_QRHSFUNC_FAIL;
     if (retval > 0) return QRHSFUNC_RECVR;
     for (int i = 0; i < NQ; i++) {
-        m->acorQ[i] = m->h * m->acorQ[i] - m->znQ[1][i];
+        m->acorQ[i] = FMA(m->h, m->acorQ[i], -m->znQ[1][i]);
         m->acorQ[i] = m->rl1 * m->acorQ[i];
         m->yQ[i] = m->znQ[0][i] + m->acorQ[i];
     }
@@ -971,10 +980,10 @@ static void cv_complete_step(cvmem *m)
     if ((m->q == 1) && (m->nst > 1)) m->tau[2] = m->tau[1];
     m->tau[1] = m->h;
     for (int j = 0; j <= m->q; j++)
-        for (int i = 0; i < NS; i++) m->zn[j][i] = m->l[j] * m->acor[i] + m->zn[j][i];
+        for (int i = 0; i < NS; i++) m->zn[j][i] = FMA(m->l[j], m->acor[i], m->zn[j][i]);
     if (m->quadr)
         for (int j = 0; j <= m->q; j++)
-            for (int i = 0; i < NQ; i++) m->znQ[j][i] = m->l[j] * m->acorQ[i] + m->znQ[j][i];
+            for (int i = 0; i < NQ; i++) m->znQ[j][i] = FMA(m->l[j], m->acorQ[i], m->znQ[j][i]);
     m->qwait--;
     if ((m->qwait == 1) && (m->q != QMAX)) {
         for (int i = 0; i < NS; i++) m->zn[QMAX][i] = m->acor[i];
@@ -1014,10 +1023,10 @@ static double cv_compute_etaqp1(cvmem *m)
     if (m->q != QMAX) {
         if (m->saved_tq5 == 0.0) return m->etaqp1;
         double cquot = (m->tq[5] / m->saved_tq5) * rpower_i(m->h / m->tau[2], m->L);
-        for (int i = 0; i < NS; i++) m->tempv[i] = -cquot * m->zn[QMAX][i] + m->acor[i];
+        for (int i = 0; i < NS; i++) m->tempv[i] = FMA(-cquot, m->zn[QMAX][i], m->acor[i]);
         double dup = wrms(m->tempv, m->ewt, NS);
         if (m->quadr && m->errconQ) {
-            for (int i = 0; i < NQ; i++) m->tempvQ[i] = -cquot * m->znQ[QMAX][i] + m->acorQ[i];
+            for (int i = 0; i < NQ; i++) m->tempvQ[i] = FMA(-cquot, m->znQ[QMAX][i], m->acorQ[i]);
             dup = quad_update_norm(m, dup, m->tempvQ, m->ewtQ);
         }
         dup = dup * m->tq[3];
@@ -1129,13 +1138,13 @@ static int cv_get_dky0(cvmem *m, double t, double *dky, double *dkyQ)
     }
     for (int i = 0; i < NS; i++) {
         double acc = cvals[0] * m->zn[m->q][i];
-        for (int v = 1; v < nvec; v++) acc += cvals[v] * m->zn[m->q - v][i];
+        for (int v = 1; v < nvec; v++) acc = FMA(cvals[v], m->zn[m->q - v][i], acc);
         dky[i] = acc;
     }
     if (dkyQ) {
         for (int i = 0; i < NQ; i++) {
             double acc = cvals[0] * m->znQ[m->q][i];
-            for (int v = 1; v < nvec; v++) acc += cvals[v] * m->znQ[m->q - v][i];
+            for (int v = 1; v < nvec; v++) acc = FMA(cvals[v], m->znQ[m->q - v][i], acc);
             dkyQ[i] = acc;
         }
     }

@@ -39,14 +39,22 @@ def build_oracle_library(native_source: str, tag: Optional[str] = None, opt: str
     os.makedirs(_BUILD, exist_ok=True)
     with open(_SRC, "rb") as fh:
         src = fh.read()
-    key = hashlib.sha256(native_source.encode() + b"\0" + src + opt.encode()).hexdigest()[:16]
+    fma_flag = []
+    try:
+        with open("/proc/cpuinfo") as fh:
+            if " fma " in fh.read():
+                fma_flag = ["-mfma"]          # __builtin_fma -> vfmadd instead of a libm call
+    except OSError:
+        pass
+    key = hashlib.sha256(native_source.encode() + b"\0" + src + opt.encode() +
+                         " ".join(fma_flag).encode()).hexdigest()[:16]
     stem = "orc_%s_%s" % (tag or "p", key)
     hdr = os.path.join(_BUILD, stem + ".h")
     lib = os.path.join(_BUILD, stem + ".so")
     if not os.path.exists(lib):
         with open(hdr, "w") as fh:
             fh.write(native_source)
-        cmd = ["gcc", opt, "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-std=gnu11",
+        cmd = ["gcc", opt, "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-std=gnu11"] + fma_flag + [
                "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, _SRC, "-o", lib + ".tmp", "-lm"]
         subprocess.run(cmd, check=True, capture_output=True, text=True)
         os.replace(lib + ".tmp", lib)

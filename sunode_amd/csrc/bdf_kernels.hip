@@ -40,6 +40,8 @@
 #define NQD (NQ > 0 ? NQ : 1)
 #define NRD (NR > 0 ? NR : 1)
 #define DEV static __device__ __forceinline__
+/* explicit fused multiply-add at the same places as the CPU oracle (no compiler contraction) */
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
 
 /*
  * Compile-time loops.  Every per-lane array (Nordsieck columns, LU, coefficient vectors...) must
@@ -139,56 +141,56 @@ enum { ST_NST, ST_NFE, ST_NSETUPS, ST_NJE, ST_NNI, ST_NCFN, ST_NETF, ST_QLAST,
 /* ------------------------------------------------------------------------------------ */
 DEV double det_log(double x)
 {
-    uint64_t u = (uint64_t)__double_as_longlong(x);
+    uint64_t u = __builtin_bit_cast(uint64_t, x);
     int e = (int)((u >> 52) & 0x7ff);
     if (e == 0) {
-        u = (uint64_t)__double_as_longlong(x * 18014398509481984.0);
+        u = __builtin_bit_cast(uint64_t, x * 18014398509481984.0);
         e = (int)((u >> 52) & 0x7ff) - 54;
     }
     e -= 1023;
     u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
-    double m = __longlong_as_double((long long)u);
+    double m = __builtin_bit_cast(double, u);
     if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
     double f = m - 1.0;
     double s = f / (2.0 + f);
     double z = s * s;
     double p = 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
-    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+    p = FMA(p, z, 1.0 / 21.0);
+    p = FMA(p, z, 1.0 / 19.0);
+    p = FMA(p, z, 1.0 / 17.0);
+    p = FMA(p, z, 1.0 / 15.0);
+    p = FMA(p, z, 1.0 / 13.0);
+    p = FMA(p, z, 1.0 / 11.0);
+    p = FMA(p, z, 1.0 / 9.0);
+    p = FMA(p, z, 1.0 / 7.0);
+    p = FMA(p, z, 1.0 / 5.0);
+    p = FMA(p, z, 1.0 / 3.0);
+    p = FMA(p, z, 1.0);
+    return FMA((double)e, 0.6931471805599453, 2.0 * s * p);
 }
 
 DEV double det_exp(double w)
 {
     if (w > 700.0) w = 700.0;
     if (w < -700.0) w = -700.0;
-    double kf = floor(w * 1.4426950408889634 + 0.5);
-    double r = (w - kf * 0.693147180369123816490) - kf * 1.90821492927058770002e-10;
+    double kf = floor(FMA(w, 1.4426950408889634, 0.5));
+    double r = FMA(-kf, 1.90821492927058770002e-10, FMA(-kf, 0.693147180369123816490, w));
     double p = 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    p = FMA(p, r, 1.0 / 479001600.0);
+    p = FMA(p, r, 1.0 / 39916800.0);
+    p = FMA(p, r, 1.0 / 3628800.0);
+    p = FMA(p, r, 1.0 / 362880.0);
+    p = FMA(p, r, 1.0 / 40320.0);
+    p = FMA(p, r, 1.0 / 5040.0);
+    p = FMA(p, r, 1.0 / 720.0);
+    p = FMA(p, r, 1.0 / 120.0);
+    p = FMA(p, r, 1.0 / 24.0);
+    p = FMA(p, r, 1.0 / 6.0);
+    p = FMA(p, r, 0.5);
+    p = FMA(p, r, 1.0);
+    p = FMA(p, r, 1.0);
     uint64_t bits = (uint64_t)((int64_t)kf + 1023) << 52;
-    return p * __longlong_as_double((long long)bits);
+    return p * __builtin_bit_cast(double, bits);
 }
 
 DEV double rpower_r(double base, double expo)
@@ -219,21 +221,29 @@ DEV double pick(const double (&a)[N], int idx)
     return r;
 }
 
-/* divided-difference table of one stored trajectory index (see "stored forward trajectory") */
-struct TrajTable {
-    int order;
-    double dt;
-    double T[QMAX + 1];
-    double Y[QMAX + 1][NSD];
-};
+/* Optional phase timing (build with SA_PROFILE; bench.py SA_ABLATE=PROFILE): s_memtime deltas per
+   phase of the attempt loop, written over stats slots 8..15 of the backward kernel. */
+#ifdef SA_ABLATE_PROFILE
+#define PROF_DECL long long prof[8]; long long prof_last; int prof_cur;
+#define PHASE(m, k) do { long long now_ = clock64(); (m).prof[(m).prof_cur] += now_ - (m).prof_last; \
+                         (m).prof_last = now_; (m).prof_cur = (k); } while (0)
+#else
+#define PROF_DECL
+#define PHASE(m, k) do { } while (0)
+#endif
 
 /* ------------------------------------------------------------------------------------ */
 /* per-lane integrator state                                                              */
 /* ------------------------------------------------------------------------------------ */
 template <bool BWD>
 struct Cv {
+    /* Invariant: columns j > q of zn / znQ are exactly zero (CVODES leaves stale data there and
+       parks the saved correction Delta_n in zn[qmax]; here that lives in zsave / zsaveQ).  With
+       zero columns above the order, predict / restore / rescale / correct / interpolate run over all
+       six columns without per-lane predicates: adding or scaling a zero column is exact. */
     double zn[QMAX + 1][NSD];
     double znQ[QMAX + 1][NQD];
+    double zsave[NSD], zsaveQ[NQD];
     double ewt[NSD], acor[NSD], tempv[NSD], ftemp[NSD], y[NSD];
     double ewtQ[NQD], acorQ[NQD], tempvQ[NQD];
     double ytmp[NSD];                 /* interpolated forward state (backward only) */
@@ -248,6 +258,7 @@ struct Cv {
     int nst, nfe, nje, nsetups, nni, ncfn, netf, nfQe, netfQ, nstlp, nstlj;
     double A[NSD * NSD], savedJ[NSD * NSD];
     int piv[NSD];
+    double inv_piv[NSD];
     int jcur, nls_jcur;
     double ps[NQD];
     double prl[NR <= 32 ? NRD : 1];   /* remaining parameters held per lane (small NR) */
@@ -255,14 +266,17 @@ struct Cv {
     /* trajectory interpolation (backward) */
     const double *traj;               /* lane's first record; see "stored forward trajectory" */
     int64_t trow;                     /* step pitch in doubles */
-    TrajTable cur, nxt;               /* tables of index cur_idx and cur_idx - 1 */
-    int cur_idx;
+    int cur_idx;                      /* index whose divided-difference table is in use */
+    double pf[4];                     /* in-flight prefetch touches (never consumed as data) */
+    double *ltab;                     /* this lane's column of the LDS table copy: ltab[field * 64] */
+    double tlo2;                      /* t[ilast-2] */
     int np;
     double tfinal;
     int ilast, newdata, have_last;
     double last_t;
     double tlo, thi;                  /* t[ilast-1], t[ilast]: bracketing times kept in registers */
     int n_interp, n_rebuild;
+    PROF_DECL
 };
 
 /* ---- stored forward trajectory ------------------------------------------------------------
@@ -278,27 +292,15 @@ struct Cv {
  *     T[j] = t_{s-j},  Y = scaled divided differences through points s..s-order,  dt = |t_s - t_{s-1}|
  *   traj[(s * stride + inst) * TREC + f], instance index fastest.
  *
- * The backward kernel keeps the table of the current index (`cur`) and the already-fetched table
- * of the next index to the left (`nxt`) in registers; the common move (one index to the left)
- * is a register copy plus ONE asynchronous prefetch whose data is first needed at the next move,
- * at least one loop iteration later.  Same values as CVODES computes on demand, hence bit-identical
- * to the CPU oracle.
+ * The backward kernel then only COPIES a table: when a lane's table index moves (~every 13th
+ * attempt) it copies the 8 + 6n doubles of the new record from HBM/L2 into its private column of an
+ * LDS array ltab[field][lane] (10 KB per wave, conflict-free: the bank depends on the lane only), and
+ * every interpolation evaluates the polynomial from LDS.  No table occupies VGPRs across
+ * iterations, nothing is rebuilt in the divergent part of the loop, and the index search of the
+ * common move (one index to the left) needs no load at all (t[idx-1], t[idx-2] ride along in
+ * registers).  Same values as CVODES computes on demand, hence bit-identical to the oracle.
  */
 #define TREC (8 + 6 * NS)
-
-/* unconditional load from a clamped index (a guarded load would be merged with a default at the
-   join, i.e. waited for on the spot); out-of-range tables are never consumed */
-template <bool BWD>
-DEV void load_table(const Cv<BWD> &m, int s, TrajTable &tb)
-{
-    int sc = s < 0 ? 0 : s;
-    sc = sc > m.np - 1 ? m.np - 1 : sc;
-    const double *r = m.traj + (int64_t)sc * m.trow;
-    tb.order = (int)r[0];
-    tb.dt = r[1];
-    SFOR(j, 0, (QMAX) + 1) tb.T[j] = r[2 + j]; SEND
-    SFOR(j, 0, (QMAX) + 1) { SFOR(i, 0, NS) tb.Y[j][i] = r[8 + j * NS + i]; SEND } SEND
-}
 
 template <bool BWD>
 DEV double point_time(const Cv<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + 2]; }
@@ -318,10 +320,8 @@ DEV int interp_y(Cv<BWD> &m, double t)
     int newpoint = 0, indx;
     if (m.newdata) {
         m.ilast = m.np - 1; newpoint = 1; m.newdata = 0;
-        load_table(m, m.ilast, m.cur);
-        load_table(m, m.ilast - 1, m.nxt);
-        m.cur_idx = m.ilast;
-        m.tlo = m.cur.T[1]; m.thi = m.cur.T[0];
+        m.tlo = point_time(m, m.ilast - 1); m.thi = point_time(m, m.ilast);
+        m.tlo2 = (m.ilast >= 2) ? point_time(m, m.ilast - 2) : m.tlo;
     }
     const int ilast = m.ilast;
     bool to_left = (t - m.tlo) < 0.0;
@@ -336,8 +336,7 @@ DEV int interp_y(Cv<BWD> &m, double t)
             if ((t - tprev) <= 0.0) {
                 indx--;
                 tcur = tprev;
-                if (indx > 0)
-                    tprev = (indx == m.cur_idx - 1) ? m.nxt.T[1] : point_time(m, indx - 1);
+                if (indx > 0) tprev = (indx == ilast - 1) ? m.tlo2 : point_time(m, indx - 1);
             } else break;
         }
         m.ilast = (indx == 0) ? 1 : indx;
@@ -370,28 +369,31 @@ DEV int interp_y(Cv<BWD> &m, double t)
         SFOR(i, 0, NS) m.ytmp[i] = m.traj[8 + i]; SEND        /* record 0: Y[0] = y(t0) */
         return CV_SUCCESS;
     }
-    if (newpoint && indx != m.cur_idx) {
-        if (indx == m.cur_idx - 1) {
-            m.cur = m.nxt;                               /* common move: one index to the left */
-        } else {
-            load_table(m, indx, m.cur);                  /* back-step or multi-index move (rare) */
-        }
-        m.cur_idx = indx;
-        load_table(m, indx - 1, m.nxt);                  /* prefetch; consumed at a later move */
-    }
     if (newpoint) {
         m.n_rebuild++;
-        if (m.cur.order > m.cur_idx) return CV_GETY_BADT;    /* CVODES would shift the base; cannot occur */
+        m.cur_idx = indx;                     /* the table CVODES would rebuild now */
+        const double *r = m.traj + (int64_t)indx * m.trow;
+        /* the touches issued at the previous move have long landed: retire them (keeps their
+           destination registers reserved until now, i.e. the loads were never waited for early) */
+        asm volatile("" :: "v"(m.pf[0]), "v"(m.pf[1]), "v"(m.pf[2]), "v"(m.pf[3]));
+        SFOR(f, 0, TREC) m.ltab[f * 64] = r[f]; SEND
+        {   /* touch the record of the next index to the left so that it is L2-resident when needed */
+            const double *rn = r - (indx > 0 ? m.trow : 0);
+            m.pf[0] = rn[0]; m.pf[1] = rn[TREC / 3]; m.pf[2] = rn[2 * TREC / 3]; m.pf[3] = rn[TREC - 1];
+        }
+        if (m.ltab[0] > (double)indx) return CV_GETY_BADT;   /* CVODES would shift the base; cannot occur */
+        if (indx == m.ilast) m.tlo2 = m.ltab[4 * 64];        /* T[2] = t[ilast-2] for the next move */
     }
     {
-        const int order = m.cur.order;
-        const double inv_dt = 1.0 / m.cur.dt;
+        const double *lt = m.ltab;
+        const int order = (int)lt[0];
+        const double inv_dt = 1.0 / lt[64];
         double cvals[QMAX + 1];
         cvals[0] = 1.0;
-        SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - m.cur.T[i]) * inv_dt : 0.0; SEND
+        SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - lt[(2 + i) * 64]) * inv_dt : 0.0; SEND
         SFOR(k, 0, NS) {
-            double acc = cvals[0] * m.cur.Y[0][k];
-            SFOR(i, 1, (QMAX) + 1) if (i <= order) acc += cvals[i] * m.cur.Y[i][k]; SEND
+            double acc = cvals[0] * lt[(8 + k) * 64];
+            SFOR(i, 1, (QMAX) + 1) acc = FMA(cvals[i], lt[(8 + i * NS + k) * 64], acc); SEND
             m.ytmp[k] = acc;
         } SEND
     }
@@ -437,7 +439,7 @@ DEV double wrms(const double *x, const double *w)
 {
     if constexpr (N == 0) return 0.0;
     double sum = 0.0;
-    SFOR(i, 0, N) { double prod = x[i] * w[i]; sum += prod * prod; } SEND
+    SFOR(i, 0, N) { double prod = x[i] * w[i]; sum = FMA(prod, prod, sum); } SEND
     return sqrt(sum / N);
 }
 
@@ -453,7 +455,7 @@ DEV int ewt_set(const Cv<BWD> &m, const double *ycur, double *w)
 {
     int bad = 0;
     SFOR(i, 0, NS) {
-        double v = m.rtol * fabs(ycur[i]) + m.atol[i];
+        double v = FMA(m.rtol, fabs(ycur[i]), m.atol[i]);
         bad |= (v <= 0.0);
         w[i] = 1.0 / v;
     } SEND
@@ -465,7 +467,7 @@ DEV int ewtQ_set(const Cv<BWD> &m, const double *qcur, double *w)
 {
     int bad = 0;
     SFOR(i, 0, NQ) {
-        double v = m.rtolQ * fabs(qcur[i]) + m.atolQ;
+        double v = FMA(m.rtolQ, fabs(qcur[i]), m.atolQ);
         bad |= (v <= 0.0);
         w[i] = 1.0 / v;
     } SEND
@@ -473,7 +475,7 @@ DEV int ewtQ_set(const Cv<BWD> &m, const double *qcur, double *w)
 }
 
 /* ---- dense LU with partial pivoting, column-major, fully unrolled (denseGETRF/GETRS) ---- */
-DEV int dense_getrf(double *a, int *p)
+DEV int dense_getrf(double *a, int *p, double *inv_piv)
 {
     int ier = 0;
     SFOR(k, 0, NS) {
@@ -498,11 +500,12 @@ DEV int dense_getrf(double *a, int *p)
                 } SEND
             }
             double mult = 1.0 / a[k * NS + k];
+            inv_piv[k] = mult;
             SFOR(i, k + 1, NS) a[k * NS + i] *= mult; SEND
             SFOR(j, k + 1, NS) {
                 double a_kj = a[j * NS + k];
                 if (a_kj != 0.0) {
-                    SFOR(i, k + 1, NS) a[j * NS + i] -= a_kj * a[k * NS + i]; SEND
+                    SFOR(i, k + 1, NS) a[j * NS + i] = FMA(-a_kj, a[k * NS + i], a[j * NS + i]); SEND
                 }
             } SEND
         }
@@ -510,7 +513,7 @@ DEV int dense_getrf(double *a, int *p)
     return ier;
 }
 
-DEV void dense_getrs(const double *a, const int *p, double *b)
+DEV void dense_getrs(const double *a, const int *p, const double *inv_piv, double *b)
 {
     SFOR(k, 0, NS) {
         int pk = p[k];
@@ -523,13 +526,13 @@ DEV void dense_getrs(const double *a, const int *p, double *b)
         }
     } SEND
     SFOR(k, 0, NS - 1) {
-        SFOR(i, k + 1, NS) b[i] -= a[k * NS + i] * b[k]; SEND
+        SFOR(i, k + 1, NS) b[i] = FMA(-a[k * NS + i], b[k], b[i]); SEND
     } SEND
     SFOR_DOWN(k, NS - 1, (0) + 1) {
-        b[k] /= a[k * NS + k];
-        SFOR(i, 0, k) b[i] -= a[k * NS + i] * b[k]; SEND
+        b[k] *= inv_piv[k];
+        SFOR(i, 0, k) b[i] = FMA(-a[k * NS + i], b[k], b[i]); SEND
     } SEND
-    if (NS > 0) b[0] /= a[0];
+    if (NS > 0) b[0] *= inv_piv[0];
 }
 
 /* ---- CVodeInit / CVodeReInit ---- */
@@ -554,8 +557,8 @@ DEV void cv_reinit(Cv<BWD> &m, double t0, const double *y0, const double *q0)
     m.jcur = 0; m.nls_jcur = 0;
     SFOR(i, 0, 7) { m.tau[i] = 0.0; m.l[i] = 0.0; } SEND
     SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
-    SFOR(i, 0, NS) { m.acor[i] = 0.0; m.tempv[i] = 0.0; m.ftemp[i] = 0.0; m.y[i] = 0.0; } SEND
-    SFOR(i, 0, NQ) { m.acorQ[i] = 0.0; m.tempvQ[i] = 0.0; } SEND
+    SFOR(i, 0, NS) { m.acor[i] = 0.0; m.tempv[i] = 0.0; m.ftemp[i] = 0.0; m.y[i] = 0.0; m.zsave[i] = 0.0; } SEND
+    SFOR(i, 0, NQ) { m.acorQ[i] = 0.0; m.tempvQ[i] = 0.0; m.zsaveQ[i] = 0.0; } SEND
 }
 
 /* ---- cvHin ---- */
@@ -569,7 +572,7 @@ DEV double cv_upper_bound_h0(Cv<BWD> &m, double tdist)
         SFOR(i, 0, NS) {
             double t2 = fabs(m.zn[0][i]);
             double t1 = 1.0 / temp1[i];
-            t1 = HUB_FACTOR * t2 + t1;
+            t1 = FMA(HUB_FACTOR, t2, t1);
             double v = fabs(m.zn[1][i]) / t1;
             if (v > hub_inv) hub_inv = v;
         } SEND
@@ -581,7 +584,7 @@ DEV double cv_upper_bound_h0(Cv<BWD> &m, double tdist)
         SFOR(i, 0, NQ) {
             double t2 = fabs(m.znQ[0][i]);
             double t1 = 1.0 / tempQ[i];
-            t1 = HUB_FACTOR * t2 + t1;
+            t1 = FMA(HUB_FACTOR, t2, t1);
             double v = fabs(m.znQ[1][i]) / t1;
             if (v > hubQ_inv) hubQ_inv = v;
         } SEND
@@ -595,7 +598,7 @@ DEV double cv_upper_bound_h0(Cv<BWD> &m, double tdist)
 template <bool BWD>
 DEV int cv_ydd_norm(Cv<BWD> &m, double hg, double *yddnrm)
 {
-    SFOR(i, 0, NS) m.y[i] = hg * m.zn[1][i] + m.zn[0][i]; SEND
+    SFOR(i, 0, NS) m.y[i] = FMA(hg, m.zn[1][i], m.zn[0][i]); SEND
     if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
     int retval = cv_f(m, m.tn + hg, m.y, m.tempv);
     if (retval < 0) return CV_RHSFUNC_FAIL;
@@ -677,11 +680,9 @@ DEV void cv_rescale(Cv<BWD> &m)
 {
     double factor = m.eta;
     SFOR(j, 1, (QMAX) + 1) {
-        if (j <= m.q) {
-            SFOR(i, 0, NS) m.zn[j][i] *= factor; SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] *= factor; SEND }
-            factor *= m.eta;
-        }
+        SFOR(i, 0, NS) m.zn[j][i] *= factor; SEND
+        if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] *= factor; SEND }
+        factor *= m.eta;
     } SEND
     m.h = m.hscale * m.eta;
     m.hscale = m.h;
@@ -700,15 +701,15 @@ DEV void cv_increase_bdf(Cv<BWD> &m)
             prod *= xi;
             alpha0 -= 1.0 / (j + 1);
             alpha1 += 1.0 / xi;
-            SFOR_DOWN(i, j + 2, 2) m.l[i] = m.l[i] * xiold + m.l[i - 1]; SEND
+            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xiold, m.l[i - 1]); SEND
             xiold = xi;
         }
     } SEND
     double A1 = (-alpha0 - alpha1) / prod;
     const int L = m.L;
     double znL[NSD], znQL[NQD];
-    SFOR(i, 0, NS) znL[i] = A1 * m.zn[QMAX][i]; SEND
-    SFOR(i, 0, NQ) znQL[i] = BWD ? A1 * m.znQ[QMAX][i] : 0.0; SEND
+    SFOR(i, 0, NS) znL[i] = A1 * m.zsave[i]; SEND
+    SFOR(i, 0, NQ) znQL[i] = BWD ? A1 * m.zsaveQ[i] : 0.0; SEND
     SFOR(j, 2, (QMAX) + 1) {
         if (j == L) {
             SFOR(i, 0, NS) m.zn[j][i] = znL[i]; SEND
@@ -717,8 +718,8 @@ DEV void cv_increase_bdf(Cv<BWD> &m)
     } SEND
     SFOR(j, 2, QMAX) {
         if (j <= m.q) {
-            SFOR(i, 0, NS) m.zn[j][i] = m.l[j] * znL[i] + m.zn[j][i]; SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = m.l[j] * znQL[i] + m.znQ[j][i]; SEND }
+            SFOR(i, 0, NS) m.zn[j][i] = FMA(m.l[j], znL[i], m.zn[j][i]); SEND
+            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(m.l[j], znQL[i], m.znQ[j][i]); SEND }
         }
     } SEND
 }
@@ -733,7 +734,7 @@ DEV void cv_decrease_bdf(Cv<BWD> &m)
         if (j <= m.q - 2) {
             hsum += m.tau[j];
             double xi = hsum / m.hscale;
-            SFOR_DOWN(i, j + 2, 2) m.l[i] = m.l[i] * xi + m.l[i - 1]; SEND
+            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xi, m.l[i - 1]); SEND
         }
     } SEND
     double znq[NSD], znQq[NQD];
@@ -749,8 +750,20 @@ DEV void cv_decrease_bdf(Cv<BWD> &m)
     } SEND
     SFOR(j, 2, QMAX) {
         if (j < m.q) {
-            SFOR(i, 0, NS) m.zn[j][i] = -m.l[j] * znq[i] + m.zn[j][i]; SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = -m.l[j] * znQq[i] + m.znQ[j][i]; SEND }
+            SFOR(i, 0, NS) m.zn[j][i] = FMA(-m.l[j], znq[i], m.zn[j][i]); SEND
+            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(-m.l[j], znQq[i], m.znQ[j][i]); SEND }
+        }
+    } SEND
+}
+
+/* restore the zero-column invariant after the order dropped from q_old to q_old - 1 */
+template <bool BWD>
+DEV void cv_clear_column(Cv<BWD> &m, int q_old)
+{
+    SFOR(j, 2, (QMAX) + 1) {
+        if (j == q_old) {
+            SFOR(i, 0, NS) m.zn[j][i] = 0.0; SEND
+            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = 0.0; SEND }
         }
     } SEND
 }
@@ -768,6 +781,7 @@ DEV void cv_adjust_params(Cv<BWD> &m)
 {
     if (m.qprime != m.q) {
         cv_adjust_order(m, m.qprime - m.q);
+        if (m.qprime < m.q) cv_clear_column(m, m.q);
         m.q = m.qprime;
         m.L = m.q + 1;
         m.qwait = m.L;
@@ -784,10 +798,8 @@ DEV void cv_predict(Cv<BWD> &m)
     }
     SFOR(k, 1, (QMAX) + 1) {
         SFOR_DOWN(j, QMAX, k) {
-            if (j <= m.q) {
-                SFOR(i, 0, NS) m.zn[j - 1][i] = m.zn[j - 1][i] + m.zn[j][i]; SEND
-                if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] + m.znQ[j][i]; SEND }
-            }
+            SFOR(i, 0, NS) m.zn[j - 1][i] = m.zn[j - 1][i] + m.zn[j][i]; SEND
+            if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] + m.znQ[j][i]; SEND }
         } SEND
     } SEND
 }
@@ -798,10 +810,8 @@ DEV void cv_restore(Cv<BWD> &m, double saved_t)
     m.tn = saved_t;
     SFOR(k, 1, (QMAX) + 1) {
         SFOR_DOWN(j, QMAX, k) {
-            if (j <= m.q) {
-                SFOR(i, 0, NS) m.zn[j - 1][i] = m.zn[j - 1][i] - m.zn[j][i]; SEND
-                if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] - m.znQ[j][i]; SEND }
-            }
+            SFOR(i, 0, NS) m.zn[j - 1][i] = m.zn[j - 1][i] - m.zn[j][i]; SEND
+            if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] - m.znQ[j][i]; SEND }
         } SEND
     } SEND
 }
@@ -822,7 +832,7 @@ DEV void cv_set(Cv<BWD> &m)
                 hsum += m.tau[j - 1];
                 xi_inv = m.h / hsum;
                 alpha0 -= 1.0 / j;
-                SFOR_DOWN(i, j, 1) m.l[i] += m.l[i - 1] * xi_inv; SEND
+                SFOR_DOWN(i, j, 1) m.l[i] = FMA(m.l[i - 1], xi_inv, m.l[i]); SEND
             }
         } SEND
         alpha0 -= inv_int(q);
@@ -831,13 +841,13 @@ DEV void cv_set(Cv<BWD> &m)
         xi_inv = m.h / hsum;
         alpha0_hat = -m.l[1] - xi_inv;
         SFOR_DOWN(i, QMAX, 1) {
-            if (i <= q) m.l[i] += m.l[i - 1] * xistar_inv;
+            if (i <= q) m.l[i] = FMA(m.l[i - 1], xistar_inv, m.l[i]);
         } SEND
     }
     {
         double lq = pick(m.l, q);
         double A1 = 1.0 - alpha0_hat + alpha0;
-        double A2 = 1.0 + q * A1;
+        double A2 = FMA((double)q, A1, 1.0);
         m.tq[2] = fabs(A1 / (alpha0 * A2));
         m.tq[5] = fabs(A2 * xistar_inv / (lq * xi_inv));
         if (m.qwait == 1) {
@@ -855,7 +865,7 @@ DEV void cv_set(Cv<BWD> &m)
             double Cppinv = (1.0 - A6 + A5) / A2;
             m.tq[3] = fabs(Cppinv / (xi_inv * (q + 2) * A5));
         }
-        m.tq[4] = NLSCOEF / m.tq[2];
+        m.tq[4] = m.tq[2] * 10.0;       /* 1/tq[4] of CVODES (= tq[2]/nlscoef): the test multiplies */
     }
     m.rl1 = 1.0 / m.l[1];
     m.gamma = m.h * m.rl1;
@@ -886,10 +896,12 @@ DEV int cv_lsetup(Cv<BWD> &m, int convfail)
     if (jret > 0) return 1;
     double c = -m.gamma;
     SFOR(j, 0, NS) {
-        SFOR(i, 0, NS) m.A[j * NS + i] *= c; SEND
-        m.A[j * NS + j] += 1.0;
+        SFOR(i, 0, NS) {
+            if constexpr (i == j) m.A[j * NS + i] = FMA(c, m.A[j * NS + i], 1.0);
+            else m.A[j * NS + i] *= c;
+        } SEND
     } SEND
-    int ier = dense_getrf(m.A, m.piv);
+    int ier = dense_getrf(m.A, m.piv, m.inv_piv);
     return ier > 0 ? 1 : 0;
 }
 
@@ -917,8 +929,8 @@ DEV int cv_nls_residual(Cv<BWD> &m, double *res)
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return RHSFUNC_RECVR;
     SFOR(i, 0, NS) {
-        res[i] = m.rl1 * m.zn[1][i] + m.acor[i];
-        res[i] = -m.gamma * m.ftemp[i] + res[i];
+        res[i] = FMA(m.rl1, m.zn[1][i], m.acor[i]);
+        res[i] = FMA(-m.gamma, m.ftemp[i], res[i]);
     } SEND
     return CV_SUCCESS;
 }
@@ -942,7 +954,7 @@ DEV int cv_newton_pass(Cv<BWD> &m, int callSetup, int jbad, int &convfail, int &
     for (;;) {
         m.nni++;
         SFOR(i, 0, NS) delta[i] = -1.0 * delta[i]; SEND
-        dense_getrs(m.A, m.piv, delta);
+        dense_getrs(m.A, m.piv, m.inv_piv, delta);
         if (m.gamrat != 1.0) {
             double s = 2.0 / (1.0 + m.gamrat);
             SFOR(i, 0, NS) delta[i] *= s; SEND
@@ -951,7 +963,7 @@ DEV int cv_newton_pass(Cv<BWD> &m, int callSetup, int jbad, int &convfail, int &
         /* cvNlsConvTest */
         double del = wrms<NS>(delta, m.ewt);
         if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
-        double dcon = del * fmin(1.0, m.crate) / m.tq[4];
+        double dcon = del * fmin(1.0, m.crate) * m.tq[4];
         if (dcon <= 1.0) {
             m.acnrm = (curiter == 0) ? del : wrms<NS>(m.acor, m.ewt);
             m.nls_jcur = 0;
@@ -985,6 +997,7 @@ DEV int cv_error_test_failed(Cv<BWD> &m, double saved_t, double dsm, int &nef, i
     if (m.q > 1) {
         m.eta = ETAMIN;
         cv_adjust_order(m, -1);
+        cv_clear_column(m, m.q);
         m.L = m.q;
         m.q--;
         m.qwait = m.L;
@@ -1018,16 +1031,14 @@ DEV void cv_complete_step(Cv<BWD> &m)
     SFOR_DOWN(i, QMAX, 2) { if (i <= m.q) m.tau[i] = m.tau[i - 1]; } SEND
     if ((m.q == 1) && (m.nst > 1)) m.tau[2] = m.tau[1];
     m.tau[1] = m.h;
-    SFOR(j, 0, (QMAX) + 1) {
-        if (j <= m.q) {
-            SFOR(i, 0, NS) m.zn[j][i] = m.l[j] * m.acor[i] + m.zn[j][i]; SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = m.l[j] * m.acorQ[i] + m.znQ[j][i]; SEND }
-        }
+    SFOR(j, 0, (QMAX) + 1) {                 /* l[j] == 0 for j > q */
+        SFOR(i, 0, NS) m.zn[j][i] = FMA(m.l[j], m.acor[i], m.zn[j][i]); SEND
+        if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(m.l[j], m.acorQ[i], m.znQ[j][i]); SEND }
     } SEND
     m.qwait--;
     if ((m.qwait == 1) && (m.q != QMAX)) {
-        SFOR(i, 0, NS) m.zn[QMAX][i] = m.acor[i]; SEND
-        if (BWD) { SFOR(i, 0, NQ) m.znQ[QMAX][i] = m.acorQ[i]; SEND }
+        SFOR(i, 0, NS) m.zsave[i] = m.acor[i]; SEND
+        if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = m.acorQ[i]; SEND }
         m.saved_tq5 = m.tq[5];
     }
 }
@@ -1091,10 +1102,10 @@ DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
             double pw = 1.0;
             SFOR(i, 1, (QMAX + 1) + 1) { if (i <= m.L) pw *= base; } SEND
             double cquot = (m.tq[5] / m.saved_tq5) * pw;
-            SFOR(i, 0, NS) m.tempv[i] = -cquot * m.zn[QMAX][i] + m.acor[i]; SEND
+            SFOR(i, 0, NS) m.tempv[i] = FMA(-cquot, m.zsave[i], m.acor[i]); SEND
             double dup = wrms<NS>(m.tempv, m.ewt);
             if (BWD) {
-                SFOR(i, 0, NQ) m.tempvQ[i] = -cquot * m.znQ[QMAX][i] + m.acorQ[i]; SEND
+                SFOR(i, 0, NQ) m.tempvQ[i] = FMA(-cquot, m.zsaveQ[i], m.acorQ[i]); SEND
                 dup = quad_update_norm(m, dup, m.tempvQ);
             }
             dup = dup * m.tq[3];
@@ -1115,8 +1126,8 @@ DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
     } else {
         m.eta = m.etaqp1;
         m.qprime = m.q + 1;
-        SFOR(i, 0, NS) m.zn[QMAX][i] = m.acor[i]; SEND
-        if (BWD) { SFOR(i, 0, NQ) m.znQ[QMAX][i] = m.acorQ[i]; SEND }
+        SFOR(i, 0, NS) m.zsave[i] = m.acor[i]; SEND
+        if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = m.acorQ[i]; SEND }
     }
     cv_set_eta(m);
 }
@@ -1135,18 +1146,14 @@ DEV int cv_get_dky0(const Cv<BWD> &m, double t, double *dky, double *dkyQ)
     pw[0] = 1.0;
     SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
     SFOR(i, 0, NS) {
-        double acc = 0.0;
-        SFOR_DOWN(j, QMAX, 0) {
-            if (j <= m.q) acc = (j == m.q) ? pw[j] * m.zn[j][i] : acc + pw[j] * m.zn[j][i];
-        } SEND
+        double acc = pw[QMAX] * m.zn[QMAX][i];
+        SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.zn[j][i], acc); SEND
         dky[i] = acc;
     } SEND
     if (BWD) {
         SFOR(i, 0, NQ) {
-            double acc = 0.0;
-            SFOR_DOWN(j, QMAX, 0) {
-                if (j <= m.q) acc = (j == m.q) ? pw[j] * m.znQ[j][i] : acc + pw[j] * m.znQ[j][i];
-            } SEND
+            double acc = pw[QMAX] * m.znQ[QMAX][i];
+            SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.znQ[j][i], acc); SEND
             dkyQ[i] = acc;
         } SEND
     }
@@ -1244,8 +1251,10 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
     }
     int callSetup, jbad;
     if (!c.redo) {
+        PHASE(m, 1);
         cv_predict(m);
         cv_set(m);
+        PHASE(m, 2);
         if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
         c.convfail = ((c.nflag == FIRST_CALL) || (c.nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
         callSetup = (c.nflag == PREV_CONV_FAIL) || (c.nflag == PREV_ERR_FAIL) || (m.nst == 0) ||
@@ -1256,7 +1265,9 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
         jbad = 1;
     }
     int in_loop;
+    PHASE(m, 3);
     int nls = cv_newton_pass(m, callSetup, jbad, c.convfail, in_loop);
+    PHASE(m, 4);
     if ((nls > 0) && in_loop && !m.nls_jcur) {
         /* SUNNonlinSol_Newton: recoverable failure with stale Jacobian data -> redo with jbad */
         c.redo = 1;
@@ -1276,7 +1287,7 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
         int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
         if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR);
         SFOR(i, 0, NQ) {
-            m.acorQ[i] = m.h * m.acorQ[i] - m.znQ[1][i];
+            m.acorQ[i] = FMA(m.h, m.acorQ[i], -m.znQ[1][i]);
             m.acorQ[i] = m.rl1 * m.acorQ[i];
         } SEND
         double acnrmQ = wrms<NQ>(m.acorQ, m.ewtQ);
@@ -1287,8 +1298,10 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
         }
         if (dsmQ > dsm) dsm = dsmQ;
     }
+    PHASE(m, 5);
     cv_complete_step(m);
     cv_prepare_next_step(m, dsm);
+    PHASE(m, 6);
     m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
     SFOR(i, 0, NS) m.acor[i] = m.tq[2] * m.acor[i]; SEND
     if (BWD) { SFOR(i, 0, NQ) m.acorQ[i] = m.tq[2] * m.acorQ[i]; SEND }
@@ -1317,11 +1330,11 @@ DEV void accumulate_stats(const Cv<BWD> &m, int64_t *acc)
     acc[ST_NFQE] += m.nfQe; acc[ST_NETFQ] += m.netfQ;
 }
 
-#define SA_NAN __longlong_as_double(0x7ff8000000000000LL)
+#define SA_NAN __builtin_bit_cast(double, (uint64_t)0x7ff8000000000000ULL)
 
 /* Build the CVApolynomialGetY divided-difference table of the newest stored point from the point
    history (T[j], Y[j] = point s-j) and write the trajectory record.  Same operation order as the
-   on-demand rebuild in CVODES / the oracle: factor = dt / (T[j] - T[j-i]), Y[j] = f*Y[j] - f*Y[j-1]. */
+   on-demand rebuild in the oracle: factor = dt / (T[j] - T[j-i]), Y[j] = factor * (Y[j] - Y[j-1]). */
 DEV void store_table(double *r, int order, double dt, const double (&hT)[QMAX + 1], const double (&hY)[QMAX + 1][NSD])
 {
     double Y[QMAX + 1][NSD];
@@ -1331,7 +1344,7 @@ DEV void store_table(double *r, int order, double dt, const double (&hT)[QMAX + 
             if constexpr (j >= i) {
                 if (j <= order) {
                     double factor = dt / (hT[j] - hT[j - i]);
-                    SFOR(k, 0, NS) Y[j][k] = factor * Y[j][k] + (-factor) * Y[j - 1][k]; SEND
+                    SFOR(k, 0, NS) Y[j][k] = factor * (Y[j][k] - Y[j - 1][k]); SEND
                 }
             }
         } SEND
@@ -1356,7 +1369,8 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0;
     m.last_t = 0.0; m.n_interp = 0; m.n_rebuild = 0; m.tlo = 0.0; m.thi = 0.0;
-    m.traj = nullptr; m.trow = 0; m.cur_idx = 0;
+    m.traj = nullptr; m.trow = 0; m.cur_idx = 0; m.tlo2 = 0.0; m.ltab = nullptr;
+    m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
 
     double y0[NSD];
     SFOR(i, 0, NS) y0[i] = a.y0[(int64_t)inst * NS + i]; SEND
@@ -1451,6 +1465,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
 /* ------------------------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
 {
+    __shared__ double ltab[TREC * 64];        /* per-lane copy of the current divided-difference table */
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
     int64_t st[SA_N_STATS];
@@ -1469,12 +1484,15 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     m.trow = a.traj_stride * TREC;
     m.np = np;
     m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + 2] : a.tinitial;
-    m.cur_idx = 0;
-    m.cur.order = 0; m.cur.dt = 1.0; m.nxt.order = 0; m.nxt.dt = 1.0;
-    SFOR(j, 0, (QMAX) + 1) {
-        m.cur.T[j] = 0.0; m.nxt.T[j] = 0.0;
-        SFOR(i, 0, NS) { m.cur.Y[j][i] = 0.0; m.nxt.Y[j][i] = 0.0; } SEND
-    } SEND
+    m.cur_idx = 0; m.tlo2 = 0.0;
+    m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
+#ifdef SA_ABLATE_PROFILE
+    SFOR(k, 0, 8) m.prof[k] = 0; SEND
+    m.prof_last = clock64(); m.prof_cur = 7;
+#endif
+    m.ltab = ltab + threadIdx.x;
+    SFOR(f, 0, TREC) m.ltab[f * 64] = 0.0; SEND
+    m.ltab[64] = 1.0;
     m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
     m.tlo = 0.0; m.thi = 0.0;
     m.n_interp = 0; m.n_rebuild = 0;
@@ -1514,6 +1532,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
             c.saved_t = t_upper;
             bool idone = (status != CV_SUCCESS);
             while (!idone) {
+                PHASE(m, 0);
                 if (!c.in_step) {
                     int ier = cv_pre_step(m);
                     if (ier == CV_ILL_INPUT) { status = ier; idone = true; }
@@ -1546,9 +1565,14 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
                     }
                 }
             }
+            PHASE(m, 7);
             {   /* diagnostic: iterations the whole wave spent in this interval = max over its lanes */
                 int wi = lane_iters;
-                for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(wi, off); wi = wi > o ? wi : o; }
+                const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                SFOR(b, 0, 6) {        /* butterfly max over the 64 lanes (builtins only: no call ABI) */
+                    int o = __builtin_amdgcn_ds_bpermute((lane ^ (1 << b)) << 2, wi);
+                    wi = wi > o ? wi : o;
+                } SEND
                 wave_iters += wi;
             }
             if (status == CV_SUCCESS || m.nst > 0) accumulate_stats(m, st);
@@ -1568,6 +1592,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     a.status[inst] = status;
     st[ST_NPTS] = np; st[ST_NINTERP] = m.n_interp; st[ST_NREBUILD] = m.n_rebuild;
     st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts; st[ST_RESERVED1] = wave_iters;
+#ifdef SA_ABLATE_PROFILE
+    PHASE(m, 7);
+    SFOR(k, 0, 8) st[8 + k] = m.prof[k]; SEND
+#endif
     SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
 }
 
