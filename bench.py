@@ -35,11 +35,23 @@ def make_problem():
     return SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(prob, tol, target_seconds=12.0):
     """Oracle (CPU restatement of the CVODES path) on all host cores, bounded sample."""
     from oracle.harness import Oracle
     from tools.problems import lv_batch
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     orc = Oracle(prob, "lv", opt="-O2")
     cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
 
@@ -55,12 +67,13 @@ def cpu_baseline(prob, tol, target_seconds=12.0):
         assert (st == 0).all() and (st2 == 0).all()
         return dt
 
-    probe = 64 * cores
+    probe = 256 * cores
     dt = run(probe)
-    B = int(min(65536, max(probe, probe * target_seconds / max(dt, 1e-6))))
+    B = int(min(4 * 65536, max(probe, probe * target_seconds / max(dt, 1e-6))))
     dt = run(B)
     return {"value": B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": "%d of the 65536 config-2 draws, fwd+adjoint, OpenMP over instances, gcc -O2" % B}
+            "sample": "%d config-2 draws (same generator), fwd+adjoint, OpenMP over instances, gcc -O2, "
+                      "threads = cgroup CPU quota" % B}
 
 
 def main():

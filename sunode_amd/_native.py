@@ -88,11 +88,23 @@ def build_host_library(force: bool = False) -> str:
     return lib
 
 
+#: measured on MI355X (LV, B=65536): the iterative ILP scheduler is ~5 % faster than the default
+#: for this latency-bound single-wave-per-SIMD kernel (profiles/ notes)
+DEFAULT_CODEGEN_FLAGS = "-mllvm -amdgpu-sched-strategy=iterative-ilp"
+
+
+def _extra_codegen_flags():
+    """Extra flags for the final clang -O3 stage (tuning experiments), e.g.
+    SA_CLANG_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"; part of the cache key."""
+    return os.environ.get("SA_CLANG_FLAGS", DEFAULT_CODEGEN_FLAGS).split()
+
+
 def code_object_path(native_source: str) -> str:
     kern = os.path.join(_CSRC, "bdf_kernels.hip")
     abi = os.path.join(_CSRC, "sa_device_abi.h")
-    key = _hash_files(kern, abi, extra=native_source.encode()) if os.path.exists(kern) else \
-        hashlib.sha256(native_source.encode()).hexdigest()[:16]
+    extra = native_source.encode() + " ".join(_extra_codegen_flags()).encode()
+    key = _hash_files(kern, abi, extra=extra) if os.path.exists(kern) else \
+        hashlib.sha256(extra).hexdigest()[:16]
     return os.path.join(_CACHE, "sa_%s.hsaco" % key)
 
 
@@ -114,8 +126,15 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
               "-Xclang", "-disable-O0-optnone", "-ffp-contract=off", "-std=c++17",
               "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-I" + _CSRC, kern, "-o", bc0])
         _run([os.path.join(LLVM_BIN, "opt"), "-passes=always-inline,sroa", bc0, "-o", bc1])
-        _run([os.path.join(LLVM_BIN, "clang"), "-x", "ir", bc1, "-target", "amdgcn-amd-amdhsa",
-              "-mcpu=" + ARCH, "-O3", "-ffp-contract=off", "-c", "-o", obj])
+        base = [os.path.join(LLVM_BIN, "clang"), "-x", "ir", bc1, "-target", "amdgcn-amd-amdhsa",
+                "-mcpu=" + ARCH, "-O3", "-ffp-contract=off"]
+        try:
+            _run(base + _extra_codegen_flags() + ["-c", "-o", obj])
+        except NativeBuildError:
+            if not _extra_codegen_flags():
+                raise
+            # the non-default scheduler strategies crash clang on very large kernels: plain -O3 then
+            _run(base + ["-c", "-o", obj])
         _run([os.path.join(LLVM_BIN, "ld.lld"), "-shared", obj, "-o", out + ".tmp"])
         os.replace(out + ".tmp", out)
     finally:

@@ -820,57 +820,67 @@ DEV void cv_restore(Cv<BWD> &m, double saved_t)
 template <bool BWD>
 DEV void cv_set(Cv<BWD> &m)
 {
+    /* Straight-line (select-based) form of cvSetBDF/cvSetTqBDF: a lone wavefront per SIMD is bound by
+       dependent-instruction latency, so one long basic block the scheduler can interleave beats a
+       chain of short per-lane predicated blocks.  Values are identical to the branching form. */
     const int q = m.q;
-    double alpha0, alpha0_hat, xi_inv, xistar_inv, hsum;
-    m.l[0] = m.l[1] = xi_inv = xistar_inv = 1.0;
+    const bool gt1 = q > 1;
+    double alpha0 = -1.0, alpha0_hat = -1.0, xi_inv = 1.0, xistar_inv = 1.0, hsum = m.h;
+    m.l[0] = m.l[1] = 1.0;
     SFOR(i, 2, (QMAX) + 1) m.l[i] = 0.0; SEND
-    alpha0 = alpha0_hat = -1.0;
-    hsum = m.h;
-    if (q > 1) {
-        SFOR(j, 2, QMAX) {
-            if (j < q) {
-                hsum += m.tau[j - 1];
-                xi_inv = m.h / hsum;
-                alpha0 -= 1.0 / j;
-                SFOR_DOWN(i, j, 1) m.l[i] = FMA(m.l[i - 1], xi_inv, m.l[i]); SEND
-            }
-        } SEND
-        alpha0 -= inv_int(q);
-        xistar_inv = -m.l[1] - alpha0;
-        hsum += pick(m.tau, q - 1);
-        xi_inv = m.h / hsum;
-        alpha0_hat = -m.l[1] - xi_inv;
+    SFOR(j, 2, QMAX) {
+        const bool on = j < q;
+        hsum = on ? hsum + m.tau[j - 1] : hsum;
+        const double xi = m.h / hsum;
+        xi_inv = on ? xi : xi_inv;
+        alpha0 = on ? alpha0 - 1.0 / j : alpha0;
+        SFOR_DOWN(i, j, 1) { const double v = FMA(m.l[i - 1], xi_inv, m.l[i]); m.l[i] = on ? v : m.l[i]; } SEND
+    } SEND
+    {
+        const double a0 = alpha0 - inv_int(q);
+        alpha0 = gt1 ? a0 : alpha0;
+        const double xs = -m.l[1] - alpha0;
+        xistar_inv = gt1 ? xs : xistar_inv;
+        const double hs = hsum + pick(m.tau, q - 1);
+        hsum = gt1 ? hs : hsum;
+        const double xi = m.h / hsum;
+        xi_inv = gt1 ? xi : xi_inv;
+        const double ah = -m.l[1] - xi_inv;
+        alpha0_hat = gt1 ? ah : alpha0_hat;
         SFOR_DOWN(i, QMAX, 1) {
-            if (i <= q) m.l[i] = FMA(m.l[i - 1], xistar_inv, m.l[i]);
+            const double v = FMA(m.l[i - 1], xistar_inv, m.l[i]);
+            m.l[i] = (gt1 && i <= q) ? v : m.l[i];
         } SEND
     }
     {
-        double lq = pick(m.l, q);
-        double A1 = 1.0 - alpha0_hat + alpha0;
-        double A2 = FMA((double)q, A1, 1.0);
+        const double lq = pick(m.l, q);
+        const double A1 = 1.0 - alpha0_hat + alpha0;
+        const double A2 = FMA((double)q, A1, 1.0);
         m.tq[2] = fabs(A1 / (alpha0 * A2));
         m.tq[5] = fabs(A2 * xistar_inv / (lq * xi_inv));
-        if (m.qwait == 1) {
-            if (q > 1) {
-                double C = xistar_inv / lq;
-                double A3 = alpha0 + inv_int(q);
-                double A4 = alpha0_hat + xi_inv;
-                double Cpinv = (1.0 - A4 + A3) / A3;
-                m.tq[1] = fabs(C * Cpinv);
-            } else m.tq[1] = 1.0;
-            hsum += pick(m.tau, q);
-            xi_inv = m.h / hsum;
-            double A5 = alpha0 - inv_int(q + 1);
-            double A6 = alpha0_hat - xi_inv;
-            double Cppinv = (1.0 - A6 + A5) / A2;
-            m.tq[3] = fabs(Cppinv / (xi_inv * (q + 2) * A5));
+        {
+            const bool w1 = (m.qwait == 1);
+            const double C = xistar_inv / lq;
+            const double A3 = alpha0 + inv_int(q);
+            const double A4 = alpha0_hat + xi_inv;
+            const double Cpinv = (1.0 - A4 + A3) / A3;
+            const double tq1 = gt1 ? fabs(C * Cpinv) : 1.0;
+            m.tq[1] = w1 ? tq1 : m.tq[1];
+            const double hs = hsum + pick(m.tau, q);
+            const double xi3 = m.h / hs;
+            const double A5 = alpha0 - inv_int(q + 1);
+            const double A6 = alpha0_hat - xi3;
+            const double Cppinv = (1.0 - A6 + A5) / A2;
+            const double tq3 = fabs(Cppinv / (xi3 * (q + 2) * A5));
+            m.tq[3] = w1 ? tq3 : m.tq[3];
         }
         m.tq[4] = m.tq[2] * 10.0;       /* 1/tq[4] of CVODES (= tq[2]/nlscoef): the test multiplies */
     }
     m.rl1 = 1.0 / m.l[1];
     m.gamma = m.h * m.rl1;
-    if (m.nst == 0) m.gammap = m.gamma;
-    m.gamrat = (m.nst > 0) ? m.gamma / m.gammap : 1.0;
+    m.gammap = (m.nst == 0) ? m.gamma : m.gammap;
+    const double gr = m.gamma / m.gammap;
+    m.gamrat = (m.nst > 0) ? gr : 1.0;
 }
 
 /* ---- linear solver interface (cvLsSetup / cvLsSolve on SUNLinSol_Dense) ---- */
@@ -1028,18 +1038,19 @@ DEV void cv_complete_step(Cv<BWD> &m)
     m.nst++;
     m.hu = m.h;
     m.qu = m.q;
-    SFOR_DOWN(i, QMAX, 2) { if (i <= m.q) m.tau[i] = m.tau[i - 1]; } SEND
-    if ((m.q == 1) && (m.nst > 1)) m.tau[2] = m.tau[1];
+    SFOR_DOWN(i, QMAX, 2) m.tau[i] = (i <= m.q) ? m.tau[i - 1] : m.tau[i]; SEND
+    m.tau[2] = ((m.q == 1) && (m.nst > 1)) ? m.tau[1] : m.tau[2];
     m.tau[1] = m.h;
     SFOR(j, 0, (QMAX) + 1) {                 /* l[j] == 0 for j > q */
         SFOR(i, 0, NS) m.zn[j][i] = FMA(m.l[j], m.acor[i], m.zn[j][i]); SEND
         if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(m.l[j], m.acorQ[i], m.znQ[j][i]); SEND }
     } SEND
     m.qwait--;
-    if ((m.qwait == 1) && (m.q != QMAX)) {
-        SFOR(i, 0, NS) m.zsave[i] = m.acor[i]; SEND
-        if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = m.acorQ[i]; SEND }
-        m.saved_tq5 = m.tq[5];
+    {
+        const bool sv = (m.qwait == 1) && (m.q != QMAX);
+        SFOR(i, 0, NS) m.zsave[i] = sv ? m.acor[i] : m.zsave[i]; SEND
+        if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = sv ? m.acorQ[i] : m.zsaveQ[i]; SEND }
+        m.saved_tq5 = sv ? m.tq[5] : m.saved_tq5;
     }
 }
 
@@ -1196,10 +1207,10 @@ DEV int cv_first_call(Cv<BWD> &m, double tout)
 template <bool BWD>
 DEV int cv_pre_step(Cv<BWD> &m)
 {
-    if (m.nst > 0) {
-        if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
-        if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
-    }
+    /* CVODES refreshes the weights only for nst > 0; at nst == 0 they were just computed from the
+       same zn[0], so doing it always gives identical values without a per-lane branch */
+    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
+    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
     double nrm = wrms<NS>(m.zn[0], m.ewt);
     if (BWD) nrm = quad_update_norm(m, nrm, m.znQ[0]);
     if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
@@ -1246,7 +1257,28 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
         c.ncf = c.nef = c.nefQ = 0;
         c.nflag = FIRST_CALL;
         c.redo = 0;
-        if ((m.nst > 0) && (m.hprime != m.h)) cv_adjust_params(m);
+        /* cvAdjustParams: the (rare) order change stays a branch, the rescale runs always with
+           eta = 1 (exact no-op) for lanes whose step size does not change */
+        const bool adj = (m.nst > 0) && (m.hprime != m.h);
+        if (adj && (m.qprime != m.q)) {
+            cv_adjust_order(m, m.qprime - m.q);
+            if (m.qprime < m.q) cv_clear_column(m, m.q);
+            m.q = m.qprime;
+            m.L = m.q + 1;
+            m.qwait = m.L;
+        }
+        {
+            const double eta = adj ? m.eta : 1.0;
+            double factor = eta;
+            SFOR(j, 1, (QMAX) + 1) {
+                SFOR(i, 0, NS) m.zn[j][i] *= factor; SEND
+                if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] *= factor; SEND }
+                factor *= eta;
+            } SEND
+            const double hnew = m.hscale * m.eta;
+            m.h = adj ? hnew : m.h;
+            m.hscale = adj ? hnew : m.hscale;
+        }
         c.in_step = 1;
     }
     int callSetup, jbad;
