@@ -157,12 +157,16 @@ def main():
     sb = stats_b.double().mean(dim=0).cpu().numpy()
     if rank == 0:
         value = world * B * args.steps / elapsed
-        # algorithmic HBM bytes of the dominant kernel (backward), per launch:
-        #   per instance: params 8*(p+r), stored trajectory read once npts*(8*(n+1)+1), npts+fwd status 8,
-        #   outputs 8*(p+n) + status 4 + stats 128; shared: grads 8*n_t*n, tvals 8*n_t
+        # algorithmic HBM bytes per launch:
+        #   trajectory record per stored point: 8*(8+6n) B = {order, dt, T[6], Y[6][n]} (built by the forward
+        #   kernel, read once by the backward kernel when the lane's table index moves onto it)
+        #   backward, per instance: params 8*(p+r) + npts*rec + npts/fwd-status 8 + outputs 8*(p+n) + status 4
+        #     + stats 128; shared: grads 8*n_t*n + tvals 8*n_t
+        #   forward, per instance: y0+params 8*(n+p+r) + npts*rec + y_out 8*n_t*n + status 4 + np 4 + stats 128
         npts = float(sf[8])
-        bwd_bytes = B * (8 * 4 + npts * (8 * (n + 1) + 1) + 8 + 8 * (p + n) + 4 + 128) + 8 * n_t * n + 8 * n_t
-        fwd_bytes = B * (8 * (n + 4) + npts * (8 * (n + 1) + 1) + 8 * n_t * n + 4 + 4 + 128) + 8 * n_t
+        rec = 8 * (8 + 6 * n)
+        bwd_bytes = B * (8 * 4 + npts * rec + 8 + 8 * (p + n) + 4 + 128) + 8 * n_t * n + 8 * n_t
+        fwd_bytes = B * (8 * (n + 4) + npts * rec + 8 * n_t * n + 4 + 4 + 128) + 8 * n_t
         bwd_s = float(np.mean(bwd_ms)) * 1e-3
         fwd_s = float(np.mean(fwd_ms)) * 1e-3
         achieved = bwd_bytes / bwd_s / 1e9
