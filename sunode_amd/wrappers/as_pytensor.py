@@ -1,0 +1,206 @@
+"""pytensor front-end: ``solve_ivp`` + Ops with the reference's names and wiring.
+
+Counterpart of /root/reference/sunode/wrappers/as_pytensor.py (``solve_ivp`` ``:20-137``,
+``EvalRhs`` ``:140-183``, ``SolveODEAdjoint`` ``:266-308``, ``SolveODEAdjointBackward``
+``:311-344``) on top of the HIP engine.  Only the adjoint path (the hot path of this build) is
+provided; ``derivatives='forward'`` raises ``NotImplementedError``.  On top of the reference's
+per-draw Ops there is a batched pair (``SolveODEAdjointBatch`` / ``...BatchBackward``) whose
+leading axis is the parameter draw, which is what actually feeds a GPU.
+
+pytensor is an optional dependency: importing this module without it raises ``ImportError``.
+Gradient wiring (reference ``:294-308``): d/dy0 = -lamda, d/dparams = grad_out,
+d/dtvals = (rhs(y(t_i)) * g_i).sum(-1); fixed parameters and t0 are not differentiable.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Optional
+
+import numpy as np
+
+try:
+    import pytensor.tensor as pt
+    from pytensor.gradient import grad_not_implemented
+    from pytensor.graph.basic import Constant, Variable
+    from pytensor.graph.op import Op
+except ImportError as exc:  # pragma: no cover - depends on the environment
+    raise ImportError("sunode_amd.wrappers.as_pytensor needs pytensor, which is not installed") from exc
+
+from sunode_amd.dtypesubset import as_flattened
+from sunode_amd.solver import AdjointSolver, SolverError
+from sunode_amd.symode.problem import SympyProblem
+
+
+def _static_dims(vals: Any, label: Optional[str] = None) -> Any:
+    """Replace every tensor leaf of a nested dict by its (static) shape / dim names."""
+    if isinstance(vals, dict):
+        return {key: _static_dims(item, key) for key, item in vals.items()}
+    if isinstance(vals, tuple):
+        tensor, dims = vals
+    else:
+        tensor, dims = vals, pt.as_tensor_variable(vals, dtype="float64").type.shape
+        if any(d is None for d in dims):
+            raise ValueError("Shapes of tensors need to be statically known or given explicitly.")
+    if isinstance(dims, (str, int)):
+        dims = (dims,)
+    tensor = pt.as_tensor_variable(tensor, dtype="float64")
+    if tensor.ndim != len(dims):
+        raise ValueError(f"Dimension mismatch for {label}: Value has rank {tensor.ndim}, "
+                         f"but {len(dims)} was specified.")
+    return dims
+
+
+def _concat_flat(flat: Dict[Any, Any], paths) -> Any:
+    pieces = []
+    for path in paths:
+        item = flat[path]
+        if isinstance(item, tuple):
+            item = item[0]
+        pieces.append(pt.as_tensor_variable(item, dtype="float64").reshape((-1,)))
+    if not pieces:
+        return pt.as_tensor_variable(np.zeros(0), dtype="float64")
+    return pt.concatenate(pieces)
+
+
+def solve_ivp(t0, y0, params, tvals, rhs: Callable, derivatives: str = "adjoint", coords=None,
+              make_solver=None, derivative_subset=None, solver_kwargs=None, simplify=None):
+    """Build the pytensor graph of an ODE solution (reference ``solve_ivp``).
+
+    Returns ``(solution_dict, flat_solution, problem, solver, y0_flat, params_subs_flat)``."""
+    solver_kwargs = dict(solver_kwargs or {})
+    if derivatives == "forward":
+        raise NotImplementedError("forward sensitivities are not implemented by the HIP engine; "
+                                  "use derivatives='adjoint'")
+    if derivatives != "adjoint":
+        raise ValueError("derivatives must be 'adjoint'")
+
+    y0_dims = _static_dims(y0)
+    params_dims = _static_dims(params)
+    flat_params = as_flattened(params)
+    if derivative_subset is None:
+        # differentiate w.r.t. every parameter that is a non-constant graph variable (reference :72-81)
+        derivative_subset = []
+        for path, item in flat_params.items():
+            tensor = item[0] if isinstance(item, tuple) else item
+            if isinstance(tensor, Variable) and not isinstance(tensor, Constant):
+                derivative_subset.append(path)
+
+    problem = SympyProblem(params_dims, y0_dims, rhs, derivative_subset, coords=coords, simplify=simplify)
+    params_subs_flat = _concat_flat(flat_params, problem.params_subset.subset_paths)
+    params_rem_flat = _concat_flat(flat_params, problem.params_subset.remainder.subset_paths)
+    y0_flat = _concat_flat(as_flattened(y0), problem.state_subset.paths)
+    t0 = pt.as_tensor_variable(t0, dtype="float64")
+    tvals = pt.as_tensor_variable(tvals, dtype="float64")
+
+    solver = make_solver(problem, **solver_kwargs) if make_solver else AdjointSolver(problem, **solver_kwargs)
+    flat_solution = SolveODEAdjoint(solver)(y0_flat, params_subs_flat, params_rem_flat, t0, tvals)
+    solution = problem.flat_solution_as_dict(flat_solution)
+    return solution, flat_solution, problem, solver, y0_flat, params_subs_flat
+
+
+class EvalRhs(Op):
+    """rhs(t_i, y_i) for every output time (needed only for d/dtvals)."""
+    itypes = [pt.dvector, pt.dvector, pt.dmatrix, pt.dvector]      # params, params_fixed, y, tvals
+    otypes = [pt.dmatrix]
+    __props__ = ("_solver_id",)
+
+    def __init__(self, solver):
+        self._solver = solver
+        self._solver_id = id(solver)
+
+    def perform(self, node, inputs, outputs):
+        params, params_fixed, y, tvals = inputs
+        eng = self._solver._engine()
+        n_t = len(tvals)
+        res = eng.eval_callbacks(tvals, y, np.zeros_like(y), np.tile(params, (n_t, 1)),
+                                 np.tile(params_fixed, (n_t, 1)))
+        if res["codes"][:, 0].any():
+            raise ValueError("Bad ode rhs return code: 1")
+        outputs[0][0] = res["rhs"]
+
+
+class SolveODEAdjoint(Op):
+    itypes = [pt.dvector, pt.dvector, pt.dvector, pt.dscalar, pt.dvector]   # y0, params, fixed, t0, tvals
+    otypes = [pt.dmatrix]
+    __props__ = ("_solver_id",)
+
+    def __init__(self, solver):
+        self._solver = solver
+        self._solver_id = id(solver)
+
+    def perform(self, node, inputs, outputs):
+        y0, params, params_fixed, t0, tvals = inputs
+        y, status, _ = self._solver.solve_forward_batch(float(t0), tvals, y0[None], params[None], params_fixed)
+        outputs[0][0] = y[0]            # failed solves are NaN-filled by the engine (reference :289-290)
+
+    def grad(self, inputs, g):
+        g, = g
+        y0, params, params_fixed, t0, tvals = inputs
+        solution = self(*inputs)
+        lamda, gradient = SolveODEAdjointBackward(self._solver)(y0, params, params_fixed, g, t0, tvals)
+        return [
+            -lamda,
+            gradient,
+            grad_not_implemented(self, 2, params_fixed),
+            grad_not_implemented(self, 3, t0),
+            (EvalRhs(self._solver)(params, params_fixed, solution, tvals) * g).sum(-1),
+        ]
+
+
+class SolveODEAdjointBackward(Op):
+    itypes = [pt.dvector, pt.dvector, pt.dvector, pt.dmatrix, pt.dscalar, pt.dvector]
+    otypes = [pt.dvector, pt.dvector]                                 # lamda, gradient
+    __props__ = ("_solver_id",)
+
+    def __init__(self, solver):
+        self._solver = solver
+        self._solver_id = id(solver)
+
+    def perform(self, node, inputs, outputs):
+        y0, params, params_fixed, grads, t0, tvals = inputs
+        # like the reference (:332-336) the forward pass is repeated: the trajectory arena belongs to it
+        self._solver.solve_forward_batch(float(t0), tvals, y0[None], params[None], params_fixed)
+        grad_out, lamda_out, status, _ = self._solver.solve_backward_batch(
+            float(tvals[-1]), float(t0), tvals, np.ascontiguousarray(grads)[None])
+        outputs[0][0] = lamda_out[0]
+        outputs[1][0] = grad_out[0]
+
+
+class SolveODEAdjointBatch(Op):
+    """Batched forward solve: y0 [B,n], params [B,p], params_fixed [r] (shared), t0, tvals -> [B,n_t,n]."""
+    itypes = [pt.dmatrix, pt.dmatrix, pt.dvector, pt.dscalar, pt.dvector]
+    otypes = [pt.dtensor3]
+    __props__ = ("_solver_id",)
+
+    def __init__(self, solver):
+        self._solver = solver
+        self._solver_id = id(solver)
+
+    def perform(self, node, inputs, outputs):
+        y0, params, params_fixed, t0, tvals = inputs
+        y, _, _ = self._solver.solve_forward_batch(float(t0), tvals, y0, params, params_fixed)
+        outputs[0][0] = y
+
+    def grad(self, inputs, g):
+        g, = g
+        y0, params, params_fixed, t0, tvals = inputs
+        lamda, gradient = SolveODEAdjointBatchBackward(self._solver)(y0, params, params_fixed, g, t0, tvals)
+        return [-lamda, gradient, grad_not_implemented(self, 2, params_fixed),
+                grad_not_implemented(self, 3, t0), grad_not_implemented(self, 4, tvals)]
+
+
+class SolveODEAdjointBatchBackward(Op):
+    itypes = [pt.dmatrix, pt.dmatrix, pt.dvector, pt.dtensor3, pt.dscalar, pt.dvector]
+    otypes = [pt.dmatrix, pt.dmatrix]
+    __props__ = ("_solver_id",)
+
+    def __init__(self, solver):
+        self._solver = solver
+        self._solver_id = id(solver)
+
+    def perform(self, node, inputs, outputs):
+        y0, params, params_fixed, grads, t0, tvals = inputs
+        self._solver.solve_forward_batch(float(t0), tvals, y0, params, params_fixed)
+        grad_out, lamda_out, _, _ = self._solver.solve_backward_batch(
+            float(tvals[-1]), float(t0), tvals, np.ascontiguousarray(grads))
+        outputs[0][0] = lamda_out
+        outputs[1][0] = grad_out

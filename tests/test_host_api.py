@@ -124,3 +124,21 @@ def test_solver_pickles_like_the_reference():
     # SympyProblem holds the user's rhs function; module-level functions pickle fine
     s2 = pickle.loads(pickle.dumps(s))
     assert float(s2._rtol) == 1e-6 and s2.get_params_dict()["delta"] == 0.4
+
+
+def test_pytensor_wrapper_is_import_guarded():
+    """pytensor is optional (absent in this image): the wrapper must fail with a clear ImportError,
+    and importing the package itself must not pull it in."""
+    import importlib
+    import sunode_amd  # noqa: F401
+    try:
+        import pytensor  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    if have:
+        mod = importlib.import_module("sunode_amd.wrappers.as_pytensor")
+        assert hasattr(mod, "solve_ivp") and hasattr(mod, "SolveODEAdjoint")
+    else:
+        with pytest.raises(ImportError, match="pytensor"):
+            importlib.import_module("sunode_amd.wrappers.as_pytensor")
