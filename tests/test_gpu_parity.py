@@ -176,3 +176,32 @@ def test_failures_are_per_instance():
     assert status.tolist() == [-1, -1, 0, -1]
     assert np.isnan(y[[0, 1, 3]]).all() and np.isfinite(y[2]).all()
     assert (stats[[0, 1, 3], 13] == 2).all()
+
+
+def test_seir_forward_adjoint_vs_oracle_and_truth(golden_dir):
+    """Config 4 problem (16 states, 8 differentiated + 16 shared fixed parameters)."""
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("seir")
+    d = seir_batch(128)
+    tv = d["tvals"]
+    k = np.arange(len(tv))[:, None]; i = np.arange(16)[None, :]
+    grads = 1.0 + 0.5 * np.cos(1.7 * k + 0.9 * i)
+    tol = 1e-8
+    sol = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol,
+                        quad_abstol=tol, quad_reltol=tol, max_steps=1024)
+    y, status, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], d["pr"])
+    g, lam, status_b, stats_b = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("seir")
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (status == 0).all() and (status_b == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(stats_b[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+    t = np.load(os.path.join(golden_dir, "truth_seir.npz"))
+    assert np.max(np.abs(y[:2] - t["y_out"]) / np.abs(t["y_out"]).max(axis=(0, 1))) < 1e-5
+    scale = np.abs(t["grad_params"]).max(axis=1, keepdims=True)
+    assert np.max(np.abs(g[:2] - t["grad_params"]) / scale) < 3e-5

@@ -1,0 +1,55 @@
+"""Throughput of the other BASELINE configs (parity-test cases, not the headline bench line).
+
+python tools/bench_configs.py robertson 262144 | seir 16384 | lv 65536
+Host-memory API (solve_forward_batch / solve_backward_batch); prints kernel times from HIP events.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sunode_amd import SympyProblem  # noqa: E402
+from sunode_amd.solver import AdjointSolver  # noqa: E402
+from tools.problems import PROBLEMS, lv_batch, robertson_batch, seir_batch  # noqa: E402
+
+
+def main():
+    name = sys.argv[1]
+    B = int(sys.argv[2])
+    s = PROBLEMS[name]
+    prob = SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
+    if name == "lv":
+        d = lv_batch(B)
+        ps, pr = d["params"][:, :2], d["params"][:, 2:]
+        rt, at, cap = 1e-8, 1e-8, 512
+    elif name == "robertson":
+        d = robertson_batch(B)
+        ps, pr = d["params"], np.zeros(0)
+        rt, at, cap = 1e-8, 1e-10, 2048
+    else:
+        d = seir_batch(B)
+        ps, pr = d["ps"], d["pr"]
+        rt, at, cap = 1e-8, 1e-8, 1024
+    tv = d["tvals"]
+    n = prob.n_states
+    k = np.arange(len(tv))[:, None]; i = np.arange(n)[None, :]
+    grads = np.ones((len(tv), n)) if name == "lv" else 1.0 + 0.5 * np.cos(1.7 * k + 0.9 * i)
+    sol = AdjointSolver(prob, abstol=at, reltol=rt, backward_abstol=at, backward_reltol=rt, quad_abstol=at,
+                        quad_reltol=rt, max_steps=cap)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+        g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+        wall = time.perf_counter() - t0
+        f, b = sol._engine().last_kernel_ms()
+    print("%s B=%d: fwd kernel %.2f ms, bwd kernel %.2f ms, wall (host arrays) %.1f ms -> %.3g solves/s (kernels), "
+          "failed %d/%d, fwd steps %.0f, bwd steps %.0f, bwd wave-iters %.0f"
+          % (name, B, f, b, 1e3 * wall, B / ((f + b) * 1e-3), int((st != 0).sum()), int((stb != 0).sum()),
+             stats[:, 0].mean(), statsb[:, 0].mean(), statsb[:, 15].mean()))
+
+
+if __name__ == "__main__":
+    main()
