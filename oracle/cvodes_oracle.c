@@ -388,12 +388,23 @@ static int cv_jac(cvmem *m, double t, const double *y, double *J)
 }
 
 /* ---- vector kernels ---- */
+/* WRMS norm.  The sum of squares is taken as a balanced binary tree over the components padded with
+   zeros to the next power of two (leaf i = (x_i w_i)^2) instead of CVODES' left-to-right loop: that
+   is the association a cross-lane butterfly reduction produces, so the cooperative HIP kernel (one
+   lane per component) and the thread-per-instance kernel round identically to this oracle. */
 static double wrms(const double *x, const double *w, int n)
 {
     if (n == 0) return 0.0;
-    double sum = 0.0;
-    for (int i = 0; i < n; i++) { double prod = x[i] * w[i]; sum = FMA(prod, prod, sum); }
-    return sqrt(sum / n);
+    int P = 1;
+    while (P < n) P <<= 1;
+    double buf[P];
+    for (int i = 0; i < P; i++) {
+        double prod = (i < n) ? x[i] * w[i] : 0.0;
+        buf[i] = prod * prod;
+    }
+    for (int m = 1; m < P; m <<= 1)
+        for (int i = 0; i < P; i += 2 * m) buf[i] = buf[i] + buf[i + m];
+    return sqrt(buf[0] / n);
 }
 
 static double quad_update_norm(cvmem *m, double old_nrm, const double *xQ, const double *wQ)

@@ -434,13 +434,34 @@ DEV int cv_jac(Cv<BWD> &m, double t, const double *y, double *J)
 }
 
 /* ---- vector kernels ---- */
+/* balanced-tree sum over P = 2^k leaves (the association of a cross-lane butterfly; see the oracle) */
+template <int P>
+DEV double tree_sum(double (&buf)[P])
+{
+    if constexpr (P > 1) {
+        double half[P / 2];
+        SFOR(i, 0, P / 2) half[i] = buf[2 * i] + buf[2 * i + 1]; SEND
+        return tree_sum<P / 2>(half);
+    } else {
+        return buf[0];
+    }
+}
+
+constexpr int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
 template <int N>
 DEV double wrms(const double *x, const double *w)
 {
     if constexpr (N == 0) return 0.0;
-    double sum = 0.0;
-    SFOR(i, 0, N) { double prod = x[i] * w[i]; sum = FMA(prod, prod, sum); } SEND
-    return sqrt(sum / N);
+    else {
+        constexpr int P = next_pow2(N);
+        double leaf[P];
+        SFOR(i, 0, P) {
+            if constexpr (i < N) { double prod = x[i] * w[i]; leaf[i] = prod * prod; }
+            else leaf[i] = 0.0;
+        } SEND
+        return sqrt(tree_sum<P>(leaf) / N);
+    }
 }
 
 template <bool BWD>

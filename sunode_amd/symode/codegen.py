@@ -48,6 +48,9 @@ HELPERS_C = r"""
 #ifndef SA_FN
 #error "SA_FN must be defined (e.g. 'static inline' or '__device__ __forceinline__')"
 #endif
+#ifndef SA_STORE
+#define SA_STORE(slot, value) out[slot] = (value)
+#endif
 SA_FN double sa_logaddexp(double a, double b) {
     double lo = fmin(a, b), hi = fmax(a, b);
     return hi + log1p(exp(lo - hi));
@@ -153,22 +156,19 @@ def emit_function(
     written = {}
     for k, value in enumerate(reduced):
         written[int(out_index[k])] = "0.0" if value == 0 else printer.doprint(value)
-    nonzero = []
+    # Outputs go through SA_STORE(slot, value): plain kernels / the oracle define it as
+    # `out[slot] = value`; the cooperative kernel (one lane per state component) keeps only the
+    # slots a lane owns.  x*0.0 is (+-)0 for finite x and NaN for inf/nan: the finiteness check is
+    # straight-line on purpose (constant subscripts only, see bdf_kernels.hip on scalar replacement).
+    lines.append("    double chk = 0.0;")
     for slot in range(n_out):
         text = written.get(slot, "0.0")
-        lines.append("    out[%d] = %s;" % (slot, text))
-        if text != "0.0":
-            nonzero.append(slot)
-    lines.append("    (void)t; (void)y; (void)ps; (void)pr;")
-    if nonzero:
-        # x*0.0 is (+-)0 for finite x and NaN for inf/nan; straight-line on purpose (constant
-        # subscripts only, see bdf_kernels.hip on scalar replacement of the per-lane state)
-        lines.append("    double chk = 0.0;")
-        for slot in nonzero:
-            lines.append("    chk += out[%d] * 0.0;" % slot)
-        lines.append("    return (chk == 0.0) ? 0 : 1;")
-    else:
-        lines.append("    return 0;")
+        if text == "0.0":
+            lines.append("    SA_STORE(%d, 0.0);" % slot)
+        else:
+            lines.append("    { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; }" % (text, slot))
+    lines.append("    (void)t; (void)y; (void)ps; (void)pr; (void)out;")
+    lines.append("    return (chk == 0.0) ? 0 : 1;")
     lines.append("}")
     return "\n".join(lines)
 
