@@ -99,11 +99,44 @@ def _extra_codegen_flags():
     return os.environ.get("SA_CLANG_FLAGS", DEFAULT_CODEGEN_FLAGS).split()
 
 
+#: systems with more states than this use the cooperative kernels (bdf_coop.hip): G lanes per instance
+REGISTER_KERNEL_MAX_STATES = 5
+
+
+def kernel_variant(native_source: str):
+    """(source file, lanes per instance) for a generated problem header.
+
+    n <= 5 states: thread-per-instance, the whole integrator in one lane's registers.
+    larger: cooperative, G = next power of two >= max(n_states, n_sub, 8) lanes per instance.
+    SA_FORCE_GROUP=<G> forces the cooperative build with that group size (tests run small
+    problems through both mappings); SA_FORCE_GROUP=1 forces thread-per-instance."""
+    import re
+    n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
+    p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
+    forced = os.environ.get("SA_FORCE_GROUP")
+    if forced:
+        g = int(forced)
+    elif n <= REGISTER_KERNEL_MAX_STATES:
+        g = 1
+    else:
+        g = 8
+        while g < max(n, p):
+            g *= 2
+    if g == 1:
+        return "bdf_kernels.hip", 1
+    if g < max(n, p) or g > 64 or g & (g - 1):
+        raise NativeBuildError("cooperative kernels need max(n_states, n_sub) = %d <= group size %d <= 64 "
+                               "(larger systems need the workgroup mapping, not built yet)" % (max(n, p), g))
+    return "bdf_coop.hip", g
+
+
 def code_object_path(native_source: str) -> str:
-    kern = os.path.join(_CSRC, "bdf_kernels.hip")
-    abi = os.path.join(_CSRC, "sa_device_abi.h")
-    extra = native_source.encode() + " ".join(_extra_codegen_flags()).encode()
-    key = _hash_files(kern, abi, extra=extra) if os.path.exists(kern) else \
+    fname, group = kernel_variant(native_source)
+    kern = os.path.join(_CSRC, fname)
+    deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h")]
+    deps = [d for d in deps if os.path.exists(d)]
+    extra = native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group
+    key = _hash_files(*deps, extra=extra) if os.path.exists(kern) else \
         hashlib.sha256(extra).hexdigest()[:16]
     return os.path.join(_CACHE, "sa_%s.hsaco" % key)
 
@@ -114,7 +147,8 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
     out = code_object_path(native_source)
     if os.path.exists(out) and not force:
         return out
-    kern = os.path.join(_CSRC, "bdf_kernels.hip")
+    fname, group = kernel_variant(native_source)
+    kern = os.path.join(_CSRC, fname)
     hdr = out[:-6] + ".h"
     with open(hdr, "w") as fh:
         fh.write(native_source)
@@ -124,7 +158,7 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
         hipcc = os.path.join(ROCM, "bin", "hipcc")
         _run([hipcc, "--offload-arch=" + ARCH, "--cuda-device-only", "-emit-llvm", "-c", "-O0",
               "-Xclang", "-disable-O0-optnone", "-ffp-contract=off", "-std=c++17",
-              "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-I" + _CSRC, kern, "-o", bc0])
+              "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-DSA_GROUP=%d" % group, "-I" + _CSRC, kern, "-o", bc0])
         _run([os.path.join(LLVM_BIN, "opt"), "-passes=always-inline,sroa", bc0, "-o", bc1])
         base = [os.path.join(LLVM_BIN, "clang"), "-x", "ir", bc1, "-target", "amdgcn-amd-amdhsa",
                 "-mcpu=" + ARCH, "-O3", "-ffp-contract=off"]

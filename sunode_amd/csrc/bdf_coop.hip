@@ -1,0 +1,1317 @@
+/*
+ * bdf_coop.hip -- cooperative mapping of the batched BDF(1-5)/Newton integrator + adjoint (gfx950).
+ *
+ * For systems too large to keep one integrator per lane in registers (n > ~5) a group of G = 2^k
+ * lanes (G >= max(n_states, n_sub), G <= 64) integrates ONE instance; a wavefront carries 64/G
+ * instances.  Lane i of a group owns component i of every vector (Nordsieck columns, weights,
+ * corrections, quadrature components) and ROW i of the Newton matrix I - gamma*J / of the saved
+ * Jacobian, so:
+ *   - vector updates (predict, rescale, correct, residual) are one instruction per column per lane;
+ *   - WRMS norms are butterfly all-reductions over the group (ds_bpermute), whose association is
+ *     the balanced tree the CPU oracle uses -> bit-identical norms in every lane;
+ *   - the dense LU with partial pivoting is row-distributed: pivot search = group arg-max, row
+ *     exchange = one shuffle per column, elimination = broadcast of the pivot row (n^2/2 shuffle+FMA
+ *     pairs instead of n^3/3 serial flops); the triangular solves broadcast one entry per step;
+ *   - step-size / order control scalars are recomputed redundantly by every lane of the group
+ *     from the same inputs, so group-uniform control flow needs no vote instructions;
+ *   - the sympy-generated callbacks are scalar straight-line code without exploitable structure:
+ *     every lane gathers the full state (n shuffles), evaluates the whole callback and keeps the
+ *     entries it owns through an output sink (SA_STORE) -- redundant work, but divergence-free.
+ * Only 64/G instances diverge inside a wavefront (vs 64 in the thread-per-instance kernels), a
+ * batch of B instances fills B*G/64 wavefronts (latency hiding for mid-size batches), and the
+ * per-lane state is a few dozen registers.
+ *
+ * Same algorithm, operation order and rounding as bdf_kernels.hip / the CPU oracle (restated
+ * CVODES 5.x; reference call sites /root/reference/sunode/solver.py:467-527, 682-784).
+ * Kernel entry points and argument blocks are identical to the thread-per-instance build; the host
+ * library reads the group size from sa_meta and sizes the grid accordingly.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SA_FN static __device__ __forceinline__
+#define SA_TEMPLATE template <class SinkT>
+#define SA_OUT_T SinkT &
+#define SA_STORE(slot, value) out.template put<(slot)>(value)
+#include SA_PROBLEM_HEADER
+#include "sa_device_abi.h"
+#include "sa_common.h"
+
+#ifndef SA_GROUP
+#error "SA_GROUP (lanes per instance) must be defined"
+#endif
+#define G SA_GROUP
+#define KPW (64 / G)
+static_assert(G >= NS && G >= NQ && G <= 64 && (G & (G - 1)) == 0, "bad SA_GROUP");
+constexpr int ilog2(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
+#define LOG2G ilog2(G)
+#define TREC (8 + 6 * NS)
+#define SA_REM_IN_REGS (NR <= 32)
+#define SA_NAN __builtin_bit_cast(double, (uint64_t)0x7ff8000000000000ULL)
+
+/* ---- cross-lane primitives (all lanes of a group are always converged when these run) ---- */
+DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+DEV double shfl_d(double v, int src_lane)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
+DEV int shfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+/* output sinks for the generated callbacks */
+struct VecSink {            /* keep entry `li` of a vector-valued callback */
+    int li;
+    double v;
+    template <int S> __device__ __forceinline__ void put(double x) { v = (S == li) ? x : v; }
+};
+struct RowSink {            /* keep row `li` of a column-major n x n callback: slot = col * n + row */
+    int li;
+    double *row;
+    template <int S> __device__ __forceinline__ void put(double x)
+    {
+        constexpr int col = S / (NS > 0 ? NS : 1), r = S % (NS > 0 ? NS : 1);
+        row[col] = (r == li) ? x : row[col];
+    }
+};
+
+/* ------------------------------------------------------------------------------------ */
+/* per-lane state: one component of every vector + replicated control scalars            */
+/* ------------------------------------------------------------------------------------ */
+template <bool BWD>
+struct Cc {
+    int lane, li, gbase;              /* lane in wave, index in group, first lane of the group */
+    /* component li of the vectors (zero for padding lanes li >= n / li >= p) */
+    double zn[QMAX + 1], znQ[QMAX + 1], zsave, zsaveQ;
+    double ewt, acor, tempv, ftemp, y, ewtQ, acorQ, tempvQ, ytmp, atol;
+    double Arow[NSD], Srow[NSD];      /* row li of I - gamma*J (LU in place) and of the saved Jacobian */
+    double inv_piv;                   /* 1/pivot of row li */
+    int piv[NSD];                     /* pivot rows (replicated) */
+    /* replicated scalars */
+    double rtol, rtolQ, atolQ;
+    double tn, h, hprime, hscale, eta, etamax, hu;
+    int q, qprime, L, qwait, qu;
+    double tau[7], tq[6], l[7];
+    double rl1, gamma, gammap, gamrat, crate, delp, acnrm, saved_tq5;
+    double etaq, etaqm1, etaqp1, tstop;
+    int nst, nfe, nje, nsetups, nni, ncfn, netf, nfQe, netfQ, nstlp, nstlj;
+    int jcur, nls_jcur;
+    double ps[NQD];
+    double prl[NR <= 32 ? NRD : 1];
+    const double *prg;
+    /* stored trajectory (backward) */
+    const double *traj;               /* instance's first record */
+    int64_t trow;
+    int np;
+    double tfinal;
+    int ilast, newdata, have_last, cur_idx;
+    double last_t, tlo, thi, tlo2;
+    double *ltab;                     /* LDS copy of the current divided-difference table (per instance) */
+    int n_interp, n_rebuild;
+};
+
+template <bool BWD>
+DEV const double *pr_of(const Cc<BWD> &m)
+{
+    if constexpr (SA_REM_IN_REGS) return m.prl;
+    else return m.prg;
+}
+
+template <bool BWD> DEV double bcast(const Cc<BWD> &m, double v, int k) { return shfl_d(v, m.gbase + k); }
+
+template <bool BWD>
+DEV double gsum(const Cc<BWD> &m, double v)
+{
+    SFOR(b, 0, LOG2G) v = v + shfl_d(v, m.lane ^ (1 << b)); SEND
+    return v;
+}
+
+template <bool BWD>
+DEV double gmax(const Cc<BWD> &m, double v)
+{
+    SFOR(b, 0, LOG2G) { const double o = shfl_d(v, m.lane ^ (1 << b)); v = v > o ? v : o; } SEND
+    return v;
+}
+
+template <bool BWD>
+DEV void gather(const Cc<BWD> &m, double mine, double (&full)[NSD])
+{
+    SFOR(i, 0, NS) full[i] = bcast(m, mine, i); SEND
+}
+
+/* ---- norms ---- */
+template <bool BWD>
+DEV double wrms_n(const Cc<BWD> &m, double x, double w)      /* over the n state components */
+{
+    if constexpr (NS == 0) return 0.0;
+    const double prod = (m.li < NS) ? x * w : 0.0;
+    return sqrt(gsum(m, prod * prod) / NS);
+}
+
+template <bool BWD>
+DEV double wrms_q(const Cc<BWD> &m, double x, double w)      /* over the p quadrature components */
+{
+    if constexpr (NQ == 0) return 0.0;
+    const double prod = (m.li < NQ) ? x * w : 0.0;
+    return sqrt(gsum(m, prod * prod) / NQ);
+}
+
+template <bool BWD>
+DEV double quad_update_norm(const Cc<BWD> &m, double old_nrm, double xQ)
+{
+    const double qnrm = wrms_q(m, xQ, m.ewtQ);
+    return old_nrm > qnrm ? old_nrm : qnrm;
+}
+
+template <bool BWD>
+DEV int ewt_set(const Cc<BWD> &m, double ycur, double &w)
+{
+    const double v = FMA(m.rtol, fabs(ycur), m.atol);
+    const double bad = gmax(m, (m.li < NS && v <= 0.0) ? 1.0 : 0.0);
+    w = 1.0 / v;
+    return bad > 0.0 ? -1 : 0;
+}
+
+template <bool BWD>
+DEV int ewtQ_set(const Cc<BWD> &m, double qcur, double &w)
+{
+    const double v = FMA(m.rtolQ, fabs(qcur), m.atolQ);
+    const double bad = gmax(m, (m.li < NQ && v <= 0.0) ? 1.0 : 0.0);
+    w = 1.0 / v;
+    return bad > 0.0 ? -1 : 0;
+}
+
+/* ---- stored trajectory: same records as the thread-per-instance build ---- */
+template <bool BWD>
+DEV double point_time(const Cc<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + 2]; }
+
+template <bool BWD>
+DEV int interp_y(Cc<BWD> &m, double t)
+{
+    if (m.have_last && t == m.last_t) return CV_SUCCESS;
+    m.n_interp++;
+    int newpoint = 0, indx;
+    if (m.newdata) {
+        m.ilast = m.np - 1; newpoint = 1; m.newdata = 0;
+        m.tlo = point_time(m, m.ilast - 1); m.thi = point_time(m, m.ilast);
+        m.tlo2 = (m.ilast >= 2) ? point_time(m, m.ilast - 2) : m.tlo;
+    }
+    const int ilast = m.ilast;
+    const bool to_left = (t - m.tlo) < 0.0;
+    const bool to_right = (t - m.thi) > 0.0;
+    indx = ilast;
+    if (to_left) {
+        newpoint = 1;
+        double tprev = m.tlo, tcur = m.thi;
+        for (;;) {
+            if (indx == 0) break;
+            if ((t - tprev) <= 0.0) {
+                indx--;
+                tcur = tprev;
+                if (indx > 0) tprev = (indx == ilast - 1) ? m.tlo2 : point_time(m, indx - 1);
+            } else break;
+        }
+        m.ilast = (indx == 0) ? 1 : indx;
+        if (indx == 0) {
+            m.tlo = tcur; m.thi = point_time(m, 1);
+            if (fabs(t - m.tlo) > FUZZ_FACTOR_ADJ * UROUND) return CV_GETY_BADT;
+        } else {
+            m.tlo = tprev; m.thi = tcur;
+        }
+    } else if (to_right) {
+        newpoint = 1;
+        double tcur = m.thi, tprev = m.tlo;
+        for (;;) {
+            if (indx >= m.np - 1) break;
+            if ((t - tcur) > 0.0) {
+                indx++;
+                tprev = tcur;
+                tcur = point_time(m, indx);
+            } else break;
+        }
+        m.ilast = indx;
+        m.tlo = tprev; m.thi = tcur;
+        if ((t - m.thi) > FUZZ_FACTOR_ADJ * UROUND * (fabs(m.tfinal) + 1.0)) return CV_GETY_BADT;
+    }
+    m.have_last = 1;
+    m.last_t = t;
+    if (indx == 0) {
+        m.ytmp = (m.li < NS) ? m.traj[8 + (m.li < NS ? m.li : 0)] : 0.0;      /* record 0: Y[0] = y(t0) */
+        return CV_SUCCESS;
+    }
+    if (newpoint) {
+        m.n_rebuild++;
+        m.cur_idx = indx;
+        const double *r = m.traj + (int64_t)indx * m.trow;
+        /* the group copies the record cooperatively: lane li moves entries li, li+G, ... */
+        __builtin_amdgcn_wave_barrier();
+        for (int f = m.li; f < TREC; f += G) m.ltab[f] = r[f];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (m.ltab[0] > (double)indx) return CV_GETY_BADT;
+        if (indx == m.ilast) m.tlo2 = m.ltab[4];
+    }
+    {
+        const double *lt = m.ltab;
+        const int order = (int)lt[0];
+        const double inv_dt = 1.0 / lt[1];
+        double cvals[QMAX + 1];
+        cvals[0] = 1.0;
+        SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - lt[2 + i]) * inv_dt : 0.0; SEND
+        const int c = (m.li < NS) ? m.li : 0;
+        double acc = cvals[0] * lt[8 + c];
+        SFOR(i, 1, (QMAX) + 1) acc = FMA(cvals[i], lt[8 + i * NS + c], acc); SEND
+        m.ytmp = (m.li < NS) ? acc : 0.0;
+    }
+    return CV_SUCCESS;
+}
+
+/* ---- callbacks: gather the full vectors, evaluate redundantly, keep the owned entries ---- */
+template <bool BWD>
+DEV int cv_f(Cc<BWD> &m, double t, double ymine, double &out)
+{
+    m.nfe++;
+    VecSink sink{m.li, 0.0};
+    int rc;
+    if constexpr (BWD) {
+        double yfull[NSD], lfull[NSD];
+        gather(m, m.ytmp, yfull);
+        gather(m, ymine, lfull);
+        rc = sa_adj_rhs(t, yfull, lfull, m.ps, pr_of(m), sink);
+    } else {
+        double yfull[NSD];
+        gather(m, ymine, yfull);
+        rc = sa_rhs(t, yfull, m.ps, pr_of(m), sink);
+    }
+    out = sink.v;
+    return rc;
+}
+
+template <bool BWD>
+DEV int cv_fQ(Cc<BWD> &m, double t, double ymine, double &out)
+{
+    m.nfQe++;
+    VecSink sink{m.li, 0.0};
+    double yfull[NSD], lfull[NSD];
+    gather(m, m.ytmp, yfull);
+    gather(m, ymine, lfull);
+    const int rc = sa_quad_rhs(t, yfull, lfull, m.ps, pr_of(m), sink);
+    out = sink.v;
+    return rc;
+}
+
+template <bool BWD>
+DEV int cv_jac(Cc<BWD> &m, double t, double ymine)            /* row li of the Jacobian -> m.Arow */
+{
+    SFOR(j, 0, NS) m.Arow[j] = 0.0; SEND
+    RowSink sink{m.li, m.Arow};
+    double yfull[NSD];
+    if constexpr (BWD) {
+        gather(m, m.ytmp, yfull);
+        return sa_adj_jac(t, yfull, m.ps, pr_of(m), sink);
+    } else {
+        gather(m, ymine, yfull);
+        return sa_jac(t, yfull, m.ps, pr_of(m), sink);
+    }
+}
+
+/* ---- row-distributed dense LU with partial pivoting (denseGETRF / denseGETRS semantics) ---- */
+template <bool BWD>
+DEV int dense_getrf(Cc<BWD> &m)
+{
+    int ier = 0;
+    SFOR(k, 0, NS) {
+        /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF) */
+        double best = (m.li >= k && m.li < NS) ? fabs(m.Arow[k]) : -1.0;
+        int bi = m.li;
+        SFOR(b, 0, LOG2G) {
+            const double ov = shfl_d(best, m.lane ^ (1 << b));
+            const int oi = shfl_i(bi, m.lane ^ (1 << b));
+            const bool take = (ov > best) || (ov == best && oi < bi);
+            best = take ? ov : best;
+            bi = take ? oi : bi;
+        } SEND
+        const int l = bi;
+        m.piv[k] = l;
+        if (best == 0.0 && ier == 0) ier = k + 1;
+        if (ier == 0) {
+            if (l != k) {        /* exchange rows k and l */
+                const int src = m.gbase + ((m.li == k) ? l : ((m.li == l) ? k : m.li));
+                SFOR(c, 0, NS) m.Arow[c] = shfl_d(m.Arow[c], src); SEND
+            }
+            const double akk = bcast(m, m.Arow[k], k);
+            const double mult = 1.0 / akk;
+            if (m.li == k) m.inv_piv = mult;
+            if (m.li > k) m.Arow[k] *= mult;
+            SFOR(j, k + 1, NS) {
+                const double a_kj = bcast(m, m.Arow[j], k);
+                if (a_kj != 0.0) {
+                    if (m.li > k) m.Arow[j] = FMA(-a_kj, m.Arow[k], m.Arow[j]);
+                }
+            } SEND
+        }
+    } SEND
+    return ier;
+}
+
+template <bool BWD>
+DEV double dense_getrs(const Cc<BWD> &m, double b)            /* b: component li of the right-hand side */
+{
+    SFOR(k, 0, NS) {
+        const int pk = m.piv[k];
+        if (pk != k) {
+            const int src = m.gbase + ((m.li == k) ? pk : ((m.li == pk) ? k : m.li));
+            b = shfl_d(b, src);
+        }
+    } SEND
+    SFOR(k, 0, NS - 1) {
+        const double bk = bcast(m, b, k);
+        if (m.li > k && m.li < NS) b = FMA(-m.Arow[k], bk, b);
+    } SEND
+    SFOR_DOWN(k, NS - 1, 1) {
+        if (m.li == k) b *= m.inv_piv;
+        const double bk = bcast(m, b, k);
+        if (m.li < k) b = FMA(-m.Arow[k], bk, b);
+    } SEND
+    if (NS > 0) { if (m.li == 0) b *= m.inv_piv; }
+    return b;
+}
+
+/* ---- CVodeInit / CVodeReInit ---- */
+template <bool BWD>
+DEV void cv_reinit(Cc<BWD> &m, double t0, double y0, double q0)
+{
+    m.tn = t0;
+    m.q = 1; m.L = 2; m.qwait = 2; m.etamax = ETAMX1;
+    m.qu = 0; m.hu = 0.0;
+    SFOR(j, 0, (QMAX) + 1) { m.zn[j] = 0.0; m.znQ[j] = 0.0; } SEND
+    m.zn[0] = y0;
+    if (BWD) m.znQ[0] = q0;
+    m.nst = m.nfe = m.ncfn = m.netf = m.nni = m.nsetups = 0;
+    m.nje = 0; m.nstlp = 0; m.nstlj = 0; m.nfQe = m.netfQ = 0;
+    m.h = 0.0; m.hprime = 0.0; m.hscale = 0.0; m.eta = 1.0;
+    m.qprime = 1;
+    m.gamma = m.gammap = 0.0; m.gamrat = 1.0; m.crate = 1.0; m.delp = 0.0;
+    m.acnrm = 0.0; m.saved_tq5 = 0.0;
+    m.jcur = 0; m.nls_jcur = 0;
+    SFOR(i, 0, 7) { m.tau[i] = 0.0; m.l[i] = 0.0; } SEND
+    SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
+    m.acor = m.tempv = m.ftemp = m.y = m.zsave = 0.0;
+    m.acorQ = m.tempvQ = m.zsaveQ = 0.0;
+}
+
+/* ---- cvHin ---- */
+template <bool BWD>
+DEV double cv_upper_bound_h0(Cc<BWD> &m, double tdist)
+{
+    double w;
+    ewt_set(m, m.zn[0], w);
+    double t1 = FMA(HUB_FACTOR, fabs(m.zn[0]), 1.0 / w);
+    double hub_inv = gmax(m, (m.li < NS) ? fabs(m.zn[1]) / t1 : 0.0);
+    if (BWD) {
+        double wq;
+        ewtQ_set(m, m.znQ[0], wq);
+        double t1q = FMA(HUB_FACTOR, fabs(m.znQ[0]), 1.0 / wq);
+        const double hubQ_inv = gmax(m, (m.li < NQ) ? fabs(m.znQ[1]) / t1q : 0.0);
+        if (hubQ_inv > hub_inv) hub_inv = hubQ_inv;
+    }
+    double hub = HUB_FACTOR * tdist;
+    if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
+    return hub;
+}
+
+template <bool BWD>
+DEV int cv_ydd_norm(Cc<BWD> &m, double hg, double *yddnrm)
+{
+    m.y = FMA(hg, m.zn[1], m.zn[0]);
+    if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+    int retval = cv_f(m, m.tn + hg, m.y, m.tempv);
+    if (retval < 0) return CV_RHSFUNC_FAIL;
+    if (retval > 0) return RHSFUNC_RECVR;
+    if (BWD) {
+        retval = cv_fQ(m, m.tn + hg, m.y, m.tempvQ);
+        if (retval < 0) return CV_QRHSFUNC_FAIL;
+        if (retval > 0) return QRHSFUNC_RECVR;
+    }
+    m.tempv = m.tempv - m.zn[1];
+    m.tempv = (1.0 / hg) * m.tempv;
+    *yddnrm = wrms_n(m, m.tempv, m.ewt);
+    if (BWD) {
+        m.tempvQ = m.tempvQ - m.znQ[1];
+        m.tempvQ = (1.0 / hg) * m.tempvQ;
+        *yddnrm = quad_update_norm(m, *yddnrm, m.tempvQ);
+    }
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_hin(Cc<BWD> &m, double tout)
+{
+    double tdiff = tout - m.tn;
+    if (tdiff == 0.0) return CV_TOO_CLOSE;
+    double sign = (tdiff > 0.0) ? 1.0 : -1.0;
+    double tdist = fabs(tdiff);
+    double tround = UROUND * fmax(fabs(m.tn), fabs(tout));
+    if (tdist < 2.0 * tround) return CV_TOO_CLOSE;
+    double hlb = HLB_FACTOR * tround;
+    double hub = cv_upper_bound_h0(m, tdist);
+    double hg = sqrt(hlb * hub);
+    if (hub < hlb) {
+        m.h = (sign < 0.0) ? -hg : hg;
+        return CV_SUCCESS;
+    }
+    double hs = hg, hnew = hg, yddnrm = 0.0;
+    int result = 1;
+    for (int count1 = 1; count1 <= HIN_MAX_ITERS && result == 1; count1++) {
+        int hgOK = 0;
+        for (int count2 = 1; count2 <= HIN_MAX_ITERS; count2++) {
+            double hgs = hg * sign;
+            int retval = cv_ydd_norm(m, hgs, &yddnrm);
+            if (retval < 0) { result = CV_RHSFUNC_FAIL; break; }
+            if (retval == CV_SUCCESS) { hgOK = 1; break; }
+            hg *= 0.2;
+        }
+        if (result != 1) break;
+        if (!hgOK) {
+            if (count1 <= 2) { result = CV_REPTD_RHSFUNC_ERR; break; }
+            hnew = hs;
+            result = 0;
+            break;
+        }
+        hs = hg;
+        hnew = (yddnrm * hub * hub > 2.0) ? sqrt(2.0 / yddnrm) : sqrt(hg * hub);
+        if (count1 == HIN_MAX_ITERS) { result = 0; break; }
+        double hrat = hnew / hg;
+        if ((hrat > 0.5) && (hrat < 2.0)) { result = 0; break; }
+        if ((count1 > 1) && (hrat > 2.0)) { hnew = hg; result = 0; break; }
+        hg = hnew;
+    }
+    if (result < 0) return result;
+    double h0 = H_BIAS * hnew;
+    if (h0 < hlb) h0 = hlb;
+    if (h0 > hub) h0 = hub;
+    if (sign < 0.0) h0 = -h0;
+    m.h = h0;
+    return CV_SUCCESS;
+}
+
+/* ---- Nordsieck array manipulation (columns j > q are kept at zero, see bdf_kernels.hip) ---- */
+template <bool BWD>
+DEV void cv_rescale(Cc<BWD> &m)
+{
+    double factor = m.eta;
+    SFOR(j, 1, (QMAX) + 1) {
+        m.zn[j] *= factor;
+        if (BWD) m.znQ[j] *= factor;
+        factor *= m.eta;
+    } SEND
+    m.h = m.hscale * m.eta;
+    m.hscale = m.h;
+}
+
+template <bool BWD>
+DEV void cv_increase_bdf(Cc<BWD> &m)
+{
+    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
+    double alpha1 = 1.0, prod = 1.0, xiold = 1.0, alpha0 = -1.0, hsum = m.hscale;
+    m.l[2] = 1.0;
+    SFOR(j, 1, QMAX - 1) {
+        if (j < m.q) {
+            hsum += m.tau[j + 1];
+            double xi = hsum / m.hscale;
+            prod *= xi;
+            alpha0 -= 1.0 / (j + 1);
+            alpha1 += 1.0 / xi;
+            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xiold, m.l[i - 1]); SEND
+            xiold = xi;
+        }
+    } SEND
+    const double A1 = (-alpha0 - alpha1) / prod;
+    const int L = m.L;
+    const double znL = A1 * m.zsave;
+    const double znQL = BWD ? A1 * m.zsaveQ : 0.0;
+    SFOR(j, 2, (QMAX) + 1) {
+        if (j == L) { m.zn[j] = znL; if (BWD) m.znQ[j] = znQL; }
+    } SEND
+    SFOR(j, 2, QMAX) {
+        if (j <= m.q) {
+            m.zn[j] = FMA(m.l[j], znL, m.zn[j]);
+            if (BWD) m.znQ[j] = FMA(m.l[j], znQL, m.znQ[j]);
+        }
+    } SEND
+}
+
+template <bool BWD>
+DEV void cv_decrease_bdf(Cc<BWD> &m)
+{
+    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
+    m.l[2] = 1.0;
+    double hsum = 0.0;
+    SFOR(j, 1, (QMAX - 2) + 1) {
+        if (j <= m.q - 2) {
+            hsum += m.tau[j];
+            double xi = hsum / m.hscale;
+            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xi, m.l[i - 1]); SEND
+        }
+    } SEND
+    const double znq = pick(m.zn, m.q);
+    const double znQq = pick(m.znQ, m.q);
+    SFOR(j, 2, QMAX) {
+        if (j < m.q) {
+            m.zn[j] = FMA(-m.l[j], znq, m.zn[j]);
+            if (BWD) m.znQ[j] = FMA(-m.l[j], znQq, m.znQ[j]);
+        }
+    } SEND
+}
+
+template <bool BWD>
+DEV void cv_clear_column(Cc<BWD> &m, int q_old)
+{
+    SFOR(j, 2, (QMAX) + 1) {
+        if (j == q_old) { m.zn[j] = 0.0; if (BWD) m.znQ[j] = 0.0; }
+    } SEND
+}
+
+template <bool BWD>
+DEV void cv_adjust_order(Cc<BWD> &m, int deltaq)
+{
+    if ((m.q == 2) && (deltaq != 1)) return;
+    if (deltaq == 1) cv_increase_bdf(m);
+    else if (deltaq == -1) cv_decrease_bdf(m);
+}
+
+template <bool BWD>
+DEV void cv_predict(Cc<BWD> &m)
+{
+    m.tn += m.h;
+    if (BWD) {
+        if ((m.tn - m.tstop) * m.h > 0.0) m.tn = m.tstop;
+    }
+    SFOR(k, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, k) {
+            m.zn[j - 1] = m.zn[j - 1] + m.zn[j];
+            if (BWD) m.znQ[j - 1] = m.znQ[j - 1] + m.znQ[j];
+        } SEND
+    } SEND
+}
+
+template <bool BWD>
+DEV void cv_restore(Cc<BWD> &m, double saved_t)
+{
+    m.tn = saved_t;
+    SFOR(k, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, k) {
+            m.zn[j - 1] = m.zn[j - 1] - m.zn[j];
+            if (BWD) m.znQ[j - 1] = m.znQ[j - 1] - m.znQ[j];
+        } SEND
+    } SEND
+}
+
+/* ---- linear solver interface ---- */
+template <bool BWD>
+DEV int cv_lsetup(Cc<BWD> &m, int convfail)
+{
+    double dgamma = fabs((m.gamma / m.gammap) - 1.0);
+    int jbad = (m.nst == 0) || (m.nst > m.nstlj + MSBJ) ||
+               ((convfail == CV_FAIL_BAD_J) && (dgamma < CVLS_DGMAX)) ||
+               (convfail == CV_FAIL_OTHER);
+    int jret = 0;
+    if (!jbad) {
+        m.jcur = 0;
+        SFOR(j, 0, NS) m.Arow[j] = m.Srow[j]; SEND
+    } else {
+        m.nje++;
+        m.nstlj = m.nst;
+        m.jcur = 1;
+        jret = cv_jac(m, m.tn, m.y);
+        if (jret == 0) { SFOR(j, 0, NS) m.Srow[j] = m.Arow[j]; SEND }
+    }
+    if (jret < 0) return -1;
+    if (jret > 0) return 1;
+    const double c = -m.gamma;
+    SFOR(j, 0, NS) {            /* entry (li, j): diagonal gets the fused c*J + 1 */
+        const double d = FMA(c, m.Arow[j], 1.0);
+        const double o = m.Arow[j] * c;
+        m.Arow[j] = (m.li == j) ? d : o;
+    } SEND
+    int ier = dense_getrf(m);
+    return ier > 0 ? 1 : 0;
+}
+
+template <bool BWD>
+DEV int cv_nls_lsetup(Cc<BWD> &m, int jbad, int &convfail)
+{
+    if (jbad) convfail = CV_FAIL_BAD_J;
+    int retval = cv_lsetup(m, convfail);
+    m.nsetups++;
+    m.nls_jcur = m.jcur;
+    m.gamrat = 1.0;
+    m.gammap = m.gamma;
+    m.crate = 1.0;
+    m.nstlp = m.nst;
+    if (retval < 0) return CV_LSETUP_FAIL;
+    if (retval > 0) return NLS_CONV_RECVR;
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_nls_residual(Cc<BWD> &m, double &res)
+{
+    m.y = m.zn[0] + m.acor;
+    int retval = cv_f(m, m.tn, m.y, m.ftemp);
+    if (retval < 0) return CV_RHSFUNC_FAIL;
+    if (retval > 0) return RHSFUNC_RECVR;
+    res = FMA(m.rl1, m.zn[1], m.acor);
+    res = FMA(-m.gamma, m.ftemp, res);
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_newton_pass(Cc<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
+{
+    double delta;
+    in_loop = 0;
+    m.acor = 0.0;
+    int retval = cv_nls_residual(m, delta);
+    if (retval != CV_SUCCESS) return retval;
+    if (callSetup) {
+        retval = cv_nls_lsetup(m, jbad, convfail);
+        if (retval != CV_SUCCESS) return retval;
+    }
+    int curiter = 0;
+    in_loop = 1;
+    for (;;) {
+        m.nni++;
+        delta = -1.0 * delta;
+        delta = dense_getrs(m, delta);
+        if (m.gamrat != 1.0) {
+            double s = 2.0 / (1.0 + m.gamrat);
+            delta *= s;
+        }
+        m.acor = m.acor + delta;
+        double del = wrms_n(m, delta, m.ewt);
+        if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
+        double dcon = del * fmin(1.0, m.crate) * m.tq[4];
+        if (dcon <= 1.0) {
+            m.acnrm = (curiter == 0) ? del : wrms_n(m, m.acor, m.ewt);
+            m.nls_jcur = 0;
+            return CV_SUCCESS;
+        }
+        if ((curiter >= 1) && (del > RDIV * m.delp)) return NLS_CONV_RECVR;
+        m.delp = del;
+        curiter++;
+        if (curiter >= NLS_MAXCOR) return NLS_CONV_RECVR;
+        retval = cv_nls_residual(m, delta);
+        if (retval != CV_SUCCESS) return retval;
+    }
+}
+
+template <bool BWD>
+DEV int cv_error_test_failed(Cc<BWD> &m, double saved_t, double dsm, int &nef, int &netf_counter)
+{
+    nef++;
+    netf_counter++;
+    cv_restore(m, saved_t);
+    if (nef == MXNEF) return CV_ERR_FAILURE;
+    m.etamax = 1.0;
+    if (nef <= MXNEF1) {
+        m.eta = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
+        m.eta = fmax(ETAMIN, m.eta);
+        if (nef >= SMALL_NEF) m.eta = fmin(m.eta, ETAMXF);
+        cv_rescale(m);
+        return 0;
+    }
+    if (m.q > 1) {
+        m.eta = ETAMIN;
+        cv_adjust_order(m, -1);
+        cv_clear_column(m, m.q);
+        m.L = m.q;
+        m.q--;
+        m.qwait = m.L;
+        cv_rescale(m);
+        return 0;
+    }
+    m.eta = ETAMIN;
+    m.h *= m.eta;
+    m.hscale = m.h;
+    m.qwait = LONG_WAIT;
+    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+    int retval = cv_f(m, m.tn, m.zn[0], m.tempv);
+    if (retval < 0) return CV_RHSFUNC_FAIL;
+    if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
+    m.zn[1] = m.h * m.tempv;
+    if (BWD) {
+        retval = cv_fQ(m, m.tn, m.zn[0], m.tempvQ);
+        if (retval < 0) return CV_QRHSFUNC_FAIL;
+        if (retval > 0) return CV_UNREC_QRHSFUNC_ERR;
+        m.znQ[1] = m.h * m.tempvQ;
+    }
+    return 0;
+}
+
+template <bool BWD>
+DEV void cv_complete_step(Cc<BWD> &m)
+{
+    m.nst++;
+    m.hu = m.h;
+    m.qu = m.q;
+    SFOR_DOWN(i, QMAX, 2) m.tau[i] = (i <= m.q) ? m.tau[i - 1] : m.tau[i]; SEND
+    m.tau[2] = ((m.q == 1) && (m.nst > 1)) ? m.tau[1] : m.tau[2];
+    m.tau[1] = m.h;
+    SFOR(j, 0, (QMAX) + 1) {
+        m.zn[j] = FMA(m.l[j], m.acor, m.zn[j]);
+        if (BWD) m.znQ[j] = FMA(m.l[j], m.acorQ, m.znQ[j]);
+    } SEND
+    m.qwait--;
+    {
+        const bool sv = (m.qwait == 1) && (m.q != QMAX);
+        m.zsave = sv ? m.acor : m.zsave;
+        if (BWD) m.zsaveQ = sv ? m.acorQ : m.zsaveQ;
+        m.saved_tq5 = sv ? m.tq[5] : m.saved_tq5;
+    }
+}
+
+template <bool BWD>
+DEV void cv_set_eta(Cc<BWD> &m)
+{
+    if (m.eta < THRESH) {
+        m.eta = 1.0;
+        m.hprime = m.h;
+    } else {
+        m.eta = fmin(m.eta, m.etamax);
+        m.hprime = m.h * m.eta;
+    }
+}
+
+template <bool BWD>
+DEV void cv_prepare_next_step(Cc<BWD> &m, double dsm)
+{
+    if (m.etamax == 1.0) {
+        m.qwait = m.qwait > 2 ? m.qwait : 2;
+        m.qprime = m.q;
+        m.hprime = m.h;
+        m.eta = 1.0;
+        return;
+    }
+    m.etaq = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
+    if (m.qwait != 0) {
+        m.eta = m.etaq;
+        m.qprime = m.q;
+        cv_set_eta(m);
+        return;
+    }
+    m.qwait = 2;
+    m.etaqm1 = 0.0;
+    if (m.q > 1) {
+        double ddn = wrms_n(m, pick(m.zn, m.q), m.ewt);
+        if (BWD) ddn = quad_update_norm(m, ddn, pick(m.znQ, m.q));
+        ddn = ddn * m.tq[1];
+        m.etaqm1 = 1.0 / (rpower_r(BIAS1 * ddn, inv_int(m.q)) + ADDON);
+    }
+    m.etaqp1 = 0.0;
+    if (m.q != QMAX) {
+        if (m.saved_tq5 != 0.0) {
+            double base = m.h / m.tau[2];
+            double pw = 1.0;
+            SFOR(i, 1, (QMAX + 1) + 1) { if (i <= m.L) pw *= base; } SEND
+            double cquot = (m.tq[5] / m.saved_tq5) * pw;
+            m.tempv = FMA(-cquot, m.zsave, m.acor);
+            double dup = wrms_n(m, m.tempv, m.ewt);
+            if (BWD) {
+                m.tempvQ = FMA(-cquot, m.zsaveQ, m.acorQ);
+                dup = quad_update_norm(m, dup, m.tempvQ);
+            }
+            dup = dup * m.tq[3];
+            m.etaqp1 = 1.0 / (rpower_r(BIAS3 * dup, inv_int(m.L + 1)) + ADDON);
+        }
+    }
+    double etam = fmax(m.etaqm1, fmax(m.etaq, m.etaqp1));
+    if (etam < THRESH) {
+        m.eta = 1.0;
+        m.qprime = m.q;
+    } else if (etam == m.etaq) {
+        m.eta = m.etaq;
+        m.qprime = m.q;
+    } else if (etam == m.etaqm1) {
+        m.eta = m.etaqm1;
+        m.qprime = m.q - 1;
+    } else {
+        m.eta = m.etaqp1;
+        m.qprime = m.q + 1;
+        m.zsave = m.acor;
+        if (BWD) m.zsaveQ = m.acorQ;
+    }
+    cv_set_eta(m);
+}
+
+template <bool BWD>
+DEV int cv_get_dky0(const Cc<BWD> &m, double t, double &dky, double &dkyQ)
+{
+    double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.hu));
+    if (m.hu < 0.0) tfuzz = -tfuzz;
+    double tp = m.tn - m.hu - tfuzz;
+    double tn1 = m.tn + tfuzz;
+    if ((t - tp) * (t - tn1) > 0.0) return CV_BAD_T;
+    double s = (t - m.tn) / m.h;
+    double pw[QMAX + 1];
+    pw[0] = 1.0;
+    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
+    {
+        double acc = pw[QMAX] * m.zn[QMAX];
+        SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.zn[j], acc); SEND
+        dky = acc;
+    }
+    if (BWD) {
+        double acc = pw[QMAX] * m.znQ[QMAX];
+        SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.znQ[j], acc); SEND
+        dkyQ = acc;
+    }
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_first_call(Cc<BWD> &m, double tout)
+{
+    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
+    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
+    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+    int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
+    if (retval < 0) return CV_RHSFUNC_FAIL;
+    if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+    if (BWD) {
+        retval = cv_fQ(m, m.tn, m.zn[0], m.znQ[1]);
+        if (retval < 0) return CV_QRHSFUNC_FAIL;
+        if (retval > 0) return CV_FIRST_QRHSFUNC_ERR;
+    }
+    double tout_hin = tout;
+    if (BWD) {
+        if ((m.tstop - m.tn) * (tout - m.tn) <= 0.0) return CV_ILL_INPUT;
+        if ((tout - m.tn) * (tout - m.tstop) > 0.0) tout_hin = m.tstop;
+    }
+    int hflag = cv_hin(m, tout_hin);
+    if (hflag != CV_SUCCESS) return hflag;
+    if (BWD) {
+        if ((m.tn + m.h - m.tstop) * m.h > 0.0) m.h = (m.tstop - m.tn) * (1.0 - 4.0 * UROUND);
+    }
+    m.hscale = m.h;
+    m.hprime = m.h;
+    m.zn[1] = m.h * m.zn[1];
+    if (BWD) m.znQ[1] = m.h * m.znQ[1];
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_pre_step(Cc<BWD> &m)
+{
+    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
+    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
+    double nrm = wrms_n(m, m.zn[0], m.ewt);
+    if (BWD) nrm = quad_update_norm(m, nrm, m.znQ[0]);
+    if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
+    return CV_SUCCESS;
+}
+
+struct StepCtl {
+    int in_step, redo, nflag, ncf, nef, nefQ, convfail;
+    double saved_t;
+};
+
+template <bool BWD>
+DEV int cv_handle_nflag_failed(Cc<BWD> &m, StepCtl &c, int nflag)
+{
+    m.ncfn++;
+    cv_restore(m, c.saved_t);
+    if (nflag < 0) return nflag;
+    c.ncf++;
+    m.etamax = 1.0;
+    if (c.ncf == MXNCF) {
+        if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
+        if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
+        return CV_REPTD_QRHSFUNC_ERR;
+    }
+    m.eta = ETACF;
+    c.nflag = PREV_CONV_FAIL;
+    cv_rescale(m);
+    return 0;
+}
+
+/* one step ATTEMPT; 1 = step completed, 0 = call again, <0 = unrecoverable (see bdf_kernels.hip) */
+template <bool BWD>
+DEV int cv_attempt(Cc<BWD> &m, StepCtl &c)
+{
+    if (!c.in_step) {
+        c.saved_t = m.tn;
+        c.ncf = c.nef = c.nefQ = 0;
+        c.nflag = FIRST_CALL;
+        c.redo = 0;
+        if ((m.nst > 0) && (m.hprime != m.h)) {
+            if (m.qprime != m.q) {
+                cv_adjust_order(m, m.qprime - m.q);
+                if (m.qprime < m.q) cv_clear_column(m, m.q);
+                m.q = m.qprime;
+                m.L = m.q + 1;
+                m.qwait = m.L;
+            }
+            cv_rescale(m);
+        }
+        c.in_step = 1;
+    }
+    int callSetup, jbad;
+    if (!c.redo) {
+        cv_predict(m);
+        cv_set(m);
+        if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+        c.convfail = ((c.nflag == FIRST_CALL) || (c.nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
+        callSetup = (c.nflag == PREV_CONV_FAIL) || (c.nflag == PREV_ERR_FAIL) || (m.nst == 0) ||
+                    (m.nst >= m.nstlp + MSBP) || (fabs(m.gamrat - 1.0) > DGMAX);
+        jbad = 0;
+    } else {
+        callSetup = 1;
+        jbad = 1;
+    }
+    int in_loop;
+    int nls = cv_newton_pass(m, callSetup, jbad, c.convfail, in_loop);
+    if ((nls > 0) && in_loop && !m.nls_jcur) {
+        c.redo = 1;
+        return 0;
+    }
+    c.redo = 0;
+    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls);
+
+    m.y = m.zn[0] + m.acor;
+    double dsm = m.acnrm * m.tq[2];
+    if (dsm > 1.0) {
+        c.nflag = PREV_ERR_FAIL;
+        return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
+    }
+    if (BWD) {
+        c.ncf = c.nef = 0;
+        int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
+        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR);
+        m.acorQ = FMA(m.h, m.acorQ, -m.znQ[1]);
+        m.acorQ = m.rl1 * m.acorQ;
+        double acnrmQ = wrms_q(m, m.acorQ, m.ewtQ);
+        double dsmQ = acnrmQ * m.tq[2];
+        if (dsmQ > 1.0) {
+            c.nflag = PREV_ERR_FAIL;
+            return cv_error_test_failed(m, c.saved_t, dsmQ, c.nefQ, m.netfQ);
+        }
+        if (dsmQ > dsm) dsm = dsmQ;
+    }
+    cv_complete_step(m);
+    cv_prepare_next_step(m, dsm);
+    m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
+    m.acor = m.tq[2] * m.acor;
+    if (BWD) m.acorQ = m.tq[2] * m.acorQ;
+    c.in_step = 0;
+    return 1;
+}
+
+template <bool BWD>
+DEV void setup_lane(Cc<BWD> &m)
+{
+    m.lane = lane_id();
+    m.li = m.lane & (G - 1);
+    m.gbase = m.lane & ~(G - 1);
+}
+
+template <bool BWD>
+DEV void load_params(Cc<BWD> &m, const double *ps, const double *pr, int rem_stride, int inst)
+{
+    SFOR(i, 0, NQ) m.ps[i] = ps[(int64_t)inst * NQ + i]; SEND
+    if constexpr (SA_REM_IN_REGS) {
+        SFOR(i, 0, NR) m.prl[i] = pr[(int64_t)inst * rem_stride + i]; SEND
+        m.prg = nullptr;
+    } else {
+        m.prl[0] = 0.0;
+        m.prg = pr + (int64_t)inst * rem_stride;
+    }
+}
+
+template <bool BWD>
+DEV void accumulate_stats(const Cc<BWD> &m, int64_t *acc)
+{
+    acc[ST_NST] += m.nst; acc[ST_NFE] += m.nfe; acc[ST_NSETUPS] += m.nsetups; acc[ST_NJE] += m.nje;
+    acc[ST_NNI] += m.nni; acc[ST_NCFN] += m.ncfn; acc[ST_NETF] += m.netf; acc[ST_QLAST] = m.qu;
+    acc[ST_NFQE] += m.nfQe; acc[ST_NETFQ] += m.netfQ;
+}
+
+/* forward: trajectory record of the newest point (see bdf_kernels.hip::store_table) */
+DEV void store_table(double *r, int li, int order, double dt, const double (&hT)[QMAX + 1], const double (&hY)[QMAX + 1])
+{
+    double Y[QMAX + 1];
+    SFOR(j, 0, (QMAX) + 1) Y[j] = hY[j]; SEND
+    SFOR(i, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, 1) {
+            if constexpr (j >= i) {
+                if (j <= order) {
+                    double factor = dt / (hT[j] - hT[j - i]);
+                    Y[j] = factor * (Y[j] - Y[j - 1]);
+                }
+            }
+        } SEND
+    } SEND
+    if (li == 0) {
+        r[0] = (double)order;
+        r[1] = dt;
+        SFOR(j, 0, (QMAX) + 1) r[2 + j] = hT[j]; SEND
+    }
+    if (li < NS) { SFOR(j, 0, (QMAX) + 1) r[8 + j * NS + li] = Y[j]; SEND }
+}
+
+/* ------------------------------------------------------------------------------------ */
+extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
+{
+    Cc<false> m;
+    setup_lane(m);
+    const int inst = blockIdx.x * KPW + (m.lane / G);
+    if (inst >= a.B) return;
+    load_params(m, a.ps, a.pr, a.rem_stride, inst);
+    m.rtol = a.rtol;
+    m.atol = (m.li < NS) ? a.atol[m.li < NS ? m.li : 0] : 1.0;
+    m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0; m.ewtQ = 0.0;
+    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
+    m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
+    m.traj = nullptr; m.trow = 0; m.ltab = nullptr; m.ytmp = 0.0; m.inv_piv = 0.0;
+    SFOR(j, 0, NS) { m.Arow[j] = 0.0; m.Srow[j] = 0.0; m.piv[j] = 0; } SEND
+
+    const double y0 = (m.li < NS) ? a.y0[(int64_t)inst * NS + (m.li < NS ? m.li : 0)] : 0.0;
+    cv_reinit(m, a.t0, y0, 0.0);
+
+    const bool store = (a.mode == SA_MODE_ADJ_FWD);
+    double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
+    double *trec = a.traj + (int64_t)inst * TREC;
+    const int64_t trow = a.traj_stride * TREC;
+    double hT[QMAX + 1], hY[QMAX + 1];
+    SFOR(j, 0, (QMAX) + 1) { hT[j] = 0.0; hY[j] = 0.0; } SEND
+
+    int status = CV_SUCCESS, k = 0, np = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
+    while (k < a.n_t && a.tvals[k] == a.t0) {
+        if (m.li < NS) yo[m.li] = y0;
+        k++;
+    }
+    bool done = (k >= a.n_t);
+    StepCtl c;
+    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0; c.saved_t = a.t0;
+    if (!done) {
+        int flag = cv_first_call(m, a.tvals[k]);
+        if (flag != CV_SUCCESS) { status = flag; done = true; }
+        else if (store) {
+            hT[0] = m.tn;
+            hY[0] = m.zn[0];
+            store_table(trec, m.li, 0, 1.0, hT, hY);
+            np = 1;
+        }
+    }
+    while (!done) {
+        if (!c.in_step) {
+            int ier = cv_pre_step(m);
+            if (ier == CV_ILL_INPUT) { status = ier; done = true; }
+            else if (!store && a.mxstep > 0 && nstloc >= a.mxstep) {
+                retries++; total_retries++;
+                if (retries >= a.max_retries) { status = CV_TOO_MUCH_WORK; done = true; }
+                else nstloc = 0;
+            }
+            if (!done && ier != CV_SUCCESS) { status = ier; done = true; }
+        }
+        if (!done) {
+            attempts++;
+            int r = cv_attempt(m, c);
+            if (r < 0) { status = r; done = true; }
+            else if (r == 1) {
+                nstloc++;
+                if (store) {
+                    if (np >= a.traj_cap) { status = CV_TOO_MUCH_WORK; done = true; }
+                    else {
+                        SFOR_DOWN(j, QMAX, 1) { hT[j] = hT[j - 1]; hY[j] = hY[j - 1]; } SEND
+                        hT[0] = m.tn;
+                        hY[0] = m.zn[0];
+                        store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+                        np++;
+                    }
+                }
+                while (!done && k < a.n_t) {
+                    double tout = a.tvals[k];
+                    if (tout == a.t0) {
+                        if (m.li < NS) yo[m.li] = y0;
+                        k++;
+                    } else if ((m.tn - tout) * m.h >= 0.0) {
+                        double dky, dq;
+                        cv_get_dky0(m, tout, dky, dq);
+                        if (m.li < NS) yo[(int64_t)k * NS + m.li] = dky;
+                        k++;
+                        nstloc = 0; retries = 0;
+                    } else break;
+                }
+                if (k >= a.n_t) done = true;
+            }
+        }
+    }
+    if (status != CV_SUCCESS) {
+        for (int j = m.li; j < a.n_t * NS; j += G) yo[j] = SA_NAN;
+    }
+    if (m.li == 0) {
+        a.status[inst] = status;
+        if (store) a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
+        int64_t st[SA_N_STATS];
+        SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
+        accumulate_stats(m, st);
+        st[ST_NPTS] = np; st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+        SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
+{
+    __shared__ double ltab_all[KPW * TREC];
+    Cc<true> m;
+    setup_lane(m);
+    const int grp = m.lane / G;
+    const int inst = blockIdx.x * KPW + grp;
+    if (inst >= a.B) return;
+    int64_t st[SA_N_STATS];
+    SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
+    int status = CV_SUCCESS;
+    const int np = a.traj_np[inst];
+    if (a.fwd_status[inst] != CV_SUCCESS || np < 2) status = CV_NO_FWD;
+
+    load_params(m, a.ps, a.pr, a.rem_stride, inst);
+    m.rtol = a.rtolB;
+    m.atol = a.atolB;
+    m.rtolQ = a.rtolQB; m.atolQ = a.atolQB;
+    m.tstop = a.tinitial;
+    m.traj = a.traj + (int64_t)inst * TREC;
+    m.trow = a.traj_stride * TREC;
+    m.np = np;
+    m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + 2] : a.tinitial;
+    m.cur_idx = 0; m.tlo2 = 0.0; m.tlo = m.thi = 0.0;
+    m.ltab = ltab_all + grp * TREC;
+    for (int f = m.li; f < TREC; f += G) m.ltab[f] = (f == 1) ? 1.0 : 0.0;
+    m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
+    m.n_interp = 0; m.n_rebuild = 0;
+    m.ytmp = 0.0; m.inv_piv = 0.0; m.ewtQ = 0.0; m.ewt = 0.0;
+    SFOR(j, 0, NS) { m.Arow[j] = 0.0; m.Srow[j] = 0.0; m.piv[j] = 0; } SEND
+
+    double lam = 0.0, quad = 0.0, quad_out = 0.0;
+    const double *g = a.grads + (int64_t)inst * a.grads_stride;
+    bool first_call = true;
+    int total_retries = 0, attempts = 0;
+    cv_reinit(m, a.t0, lam, quad);
+
+    for (int iv = 0; iv <= a.n_t; iv++) {
+        const double t_upper = (iv == 0) ? a.t0 : a.tvals[a.n_t - iv];
+        const double t_lower = (iv == a.n_t) ? a.tend : a.tvals[a.n_t - 1 - iv];
+        if (t_lower < t_upper) {
+            if (status == CV_SUCCESS) {
+                cv_reinit(m, t_upper, lam, quad);
+                if (first_call) {
+                    if ((t_upper - a.tinitial) < 0.0 || (m.tfinal - t_upper) < 0.0) status = CV_BAD_TB0;
+                    first_call = false;
+                }
+                if (status == CV_SUCCESS && ((t_lower - a.tinitial) < 0.0 || (m.tfinal - t_lower) < 0.0)) {
+                    double tfuzz = 100.0 * UROUND * (fabs(a.tinitial) + fabs(m.tfinal));
+                    if ((t_lower - a.tinitial) < -tfuzz || (m.tfinal - t_lower) < -tfuzz) status = CV_ILL_INPUT;
+                }
+                if (status == CV_SUCCESS) {
+                    int flag = cv_first_call(m, t_lower);
+                    if (flag != CV_SUCCESS) status = flag;
+                }
+            }
+            int nstloc = 0, retries = 0;
+            StepCtl c;
+            c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0;
+            c.saved_t = t_upper;
+            bool idone = (status != CV_SUCCESS);
+            while (!idone) {
+                if (!c.in_step) {
+                    int ier = cv_pre_step(m);
+                    if (ier == CV_ILL_INPUT) { status = ier; idone = true; }
+                    else if (a.mxstep > 0 && nstloc >= a.mxstep) {
+                        retries++; total_retries++;
+                        if (retries >= a.max_retries) { status = CV_TOO_MUCH_WORK; idone = true; }
+                        else nstloc = 0;
+                    }
+                    if (!idone && ier != CV_SUCCESS) { status = ier; idone = true; }
+                }
+                if (!idone) {
+                    attempts++;
+                    int r = cv_attempt(m, c);
+                    if (r < 0) { status = r; idone = true; }
+                    else if (r == 1) {
+                        nstloc++;
+                        double troundoff = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.h));
+                        if (fabs(m.tn - m.tstop) <= troundoff) m.tn = m.tstop;
+                        if ((m.tn - t_lower) * m.h >= 0.0) {
+                            cv_get_dky0(m, t_lower, lam, quad_out);
+                            idone = true;
+                        } else {
+                            troundoff = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.h));
+                            if (fabs(m.tn - m.tstop) <= troundoff) { status = CV_TSTOP_RETURN; idone = true; }
+                            else if ((m.tn + m.hprime - m.tstop) * m.h > 0.0) {
+                                m.hprime = (m.tstop - m.tn) * (1.0 - 4.0 * UROUND);
+                                m.eta = m.hprime / m.h;
+                            }
+                        }
+                    }
+                }
+            }
+            if (status == CV_SUCCESS || m.nst > 0) accumulate_stats(m, st);
+            if (status == CV_SUCCESS) quad = quad_out;
+        }
+        if (iv < a.n_t && status == CV_SUCCESS) {
+            const double *gi = g + (int64_t)(a.n_t - 1 - iv) * NS;
+            if (m.li < NS) lam -= gi[m.li < NS ? m.li : 0];
+        }
+    }
+    if (status != CV_SUCCESS) { quad_out = SA_NAN; lam = SA_NAN; }
+    if (m.li < NQ) a.grad_out[(int64_t)inst * NQ + m.li] = quad_out;
+    if (m.li < NS) a.lamda_out[(int64_t)inst * NS + m.li] = lam;
+    if (m.li == 0) {
+        a.status[inst] = status;
+        st[ST_NPTS] = np; st[ST_NINTERP] = m.n_interp; st[ST_NREBUILD] = m.n_rebuild;
+        st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+        SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
+    }
+}
+
+/* callback evaluation + arithmetic probe: one lane per point, plain array outputs */
+struct ArraySink {
+    double *p;
+    template <int S> __device__ __forceinline__ void put(double x) { p[S] = x; }
+};
+
+extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.npts) return;
+    double y[NSD], lam[NSD], ps[NQD], pr[SA_REM_IN_REGS ? NRD : 1];
+    SFOR(k, 0, NS) { y[k] = a.y[(int64_t)i * NS + k]; lam[k] = a.lam[(int64_t)i * NS + k]; } SEND
+    SFOR(k, 0, NQ) ps[k] = a.ps[(int64_t)i * NQ + k]; SEND
+    const double *prp = pr;
+    if constexpr (SA_REM_IN_REGS) { SFOR(k, 0, NR) pr[k] = a.pr[(int64_t)i * NR + k]; SEND }
+    else { pr[0] = 0.0; prp = a.pr + (int64_t)i * NR; }
+    const double t = a.t[i];
+    ArraySink s_rhs{a.rhs + (int64_t)i * NS}, s_jac{a.jac + (int64_t)i * NS * NS}, s_adj{a.adj + (int64_t)i * NS},
+        s_quad{a.quad + (int64_t)i * NQ}, s_ajac{a.adjjac + (int64_t)i * NS * NS};
+    a.codes[i * 5 + 0] = sa_rhs(t, y, ps, prp, s_rhs);
+    a.codes[i * 5 + 1] = sa_jac(t, y, ps, prp, s_jac);
+    a.codes[i * 5 + 2] = sa_adj_rhs(t, y, lam, ps, prp, s_adj);
+    a.codes[i * 5 + 3] = sa_quad_rhs(t, y, lam, ps, prp, s_quad);
+    a.codes[i * 5 + 4] = sa_adj_jac(t, y, ps, prp, s_ajac);
+}
+
+extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n) return;
+    a.pow_out[i] = rpower_r(a.x[i], a.y[i]);
+    a.sqrt_out[i] = sqrt(a.x[i]);
+    a.div_out[i] = a.x[i] / a.y[i];
+}
+
+/* {n_states, n_sub, n_rem, ABI version, lanes per instance} read back by sa_solver_create() */
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[5] = {NS, NQ, NR, 1, G};

@@ -33,193 +33,7 @@
 #include SA_PROBLEM_HEADER
 #include "sa_device_abi.h"
 
-#define NS SA_N_STATES
-#define NQ SA_N_SUB
-#define NR SA_N_REM
-#define NSD (NS > 0 ? NS : 1)
-#define NQD (NQ > 0 ? NQ : 1)
-#define NRD (NR > 0 ? NR : 1)
-#define DEV static __device__ __forceinline__
-/* explicit fused multiply-add at the same places as the CPU oracle (no compiler contraction) */
-#define FMA(a, b, c) __builtin_fma((a), (b), (c))
-
-/*
- * Compile-time loops.  Every per-lane array (Nordsieck columns, LU, coefficient vectors...) must
- * be scalar-replaced into VGPRs by the FIRST SROA pass, i.e. before instcombine gets a chance to
- * turn a select chain over array elements into a dynamically indexed scratch load.  `#pragma
- * unroll` unrolls too late for that, so loops over array indices are expanded by template
- * recursion (always-inlined lambdas): no loop and no variable subscript ever reaches the IR.
- */
-template <int I> struct IC { static constexpr int value = I; };
-template <int B, int E, class F>
-DEV void sfor(F &&f)
-{
-    if constexpr (B < E) { f(IC<B>{}); sfor<B + 1, E>(f); }
-}
-template <int B, int E, class F>
-DEV void sfor_down(F &&f)          /* B, B-1, ..., E (inclusive) */
-{
-    if constexpr (B >= E) { f(IC<B>{}); sfor_down<B - 1, E>(f); }
-}
-#define SFOR(var, B, E) sfor<(B), (E)>([&](auto var##_ic) __attribute__((always_inline)) { constexpr int var = decltype(var##_ic)::value;
-#define SFOR_DOWN(var, B, E) sfor_down<(B), (E)>([&](auto var##_ic) __attribute__((always_inline)) { constexpr int var = decltype(var##_ic)::value;
-#define SEND });
-
-/* CVODES return codes (16_cvodes.h:45-106) */
-#define CV_SUCCESS 0
-#define CV_TSTOP_RETURN 1
-#define CV_TOO_MUCH_WORK (-1)
-#define CV_TOO_MUCH_ACC (-2)
-#define CV_ERR_FAILURE (-3)
-#define CV_CONV_FAILURE (-4)
-#define CV_LSETUP_FAIL (-6)
-#define CV_RHSFUNC_FAIL (-8)
-#define CV_FIRST_RHSFUNC_ERR (-9)
-#define CV_REPTD_RHSFUNC_ERR (-10)
-#define CV_UNREC_RHSFUNC_ERR (-11)
-#define CV_ILL_INPUT (-22)
-#define CV_BAD_T (-25)
-#define CV_TOO_CLOSE (-27)
-#define CV_QRHSFUNC_FAIL (-31)
-#define CV_FIRST_QRHSFUNC_ERR (-32)
-#define CV_REPTD_QRHSFUNC_ERR (-33)
-#define CV_UNREC_QRHSFUNC_ERR (-34)
-#define CV_NO_FWD (-102)
-#define CV_BAD_TB0 (-104)
-#define CV_GETY_BADT (-107)
-
-/* CVODES constants */
-#define QMAX 5
-#define UROUND 2.220446049250313e-16
-#define ETAMX1 10000.0
-#define ETAMX2 10.0
-#define ETAMX3 10.0
-#define ETAMXF 0.2
-#define ETAMIN 0.1
-#define ETACF 0.25
-#define ADDON 0.000001
-#define BIAS1 6.0
-#define BIAS2 6.0
-#define BIAS3 10.0
-#define THRESH 1.5
-#define MXNCF 10
-#define MXNEF 7
-#define MXNEF1 3
-#define SMALL_NEF 2
-#define LONG_WAIT 10
-#define SMALL_NST 10
-#define NLS_MAXCOR 3
-#define CRDOWN 0.3
-#define DGMAX 0.3
-#define RDIV 2.0
-#define MSBP 20
-#define NLSCOEF 0.1
-#define MSBJ 50
-#define CVLS_DGMAX 0.2
-#define HLB_FACTOR 100.0
-#define HUB_FACTOR 0.1
-#define H_BIAS 0.5
-#define HIN_MAX_ITERS 4
-#define FUZZ_FACTOR 100.0
-#define FUZZ_FACTOR_ADJ 1000000.0
-
-#define FIRST_CALL 101
-#define PREV_CONV_FAIL 102
-#define PREV_ERR_FAIL 103
-#define RHSFUNC_RECVR 9
-#define QRHSFUNC_RECVR 11
-#define NLS_CONV_RECVR 902
-#define CV_NO_FAILURES 0
-#define CV_FAIL_BAD_J 1
-#define CV_FAIL_OTHER 2
-
-enum { ST_NST, ST_NFE, ST_NSETUPS, ST_NJE, ST_NNI, ST_NCFN, ST_NETF, ST_QLAST,
-       ST_NPTS, ST_NFQE, ST_NETFQ, ST_NINTERP, ST_NREBUILD, ST_RETRIES, ST_ATTEMPTS, ST_RESERVED1 };
-
-/* ------------------------------------------------------------------------------------ */
-/* deterministic pow (pure +,-,*,/): same operation sequence as the CPU restatement       */
-/* ------------------------------------------------------------------------------------ */
-DEV double det_log(double x)
-{
-    uint64_t u = __builtin_bit_cast(uint64_t, x);
-    int e = (int)((u >> 52) & 0x7ff);
-    if (e == 0) {
-        u = __builtin_bit_cast(uint64_t, x * 18014398509481984.0);
-        e = (int)((u >> 52) & 0x7ff) - 54;
-    }
-    e -= 1023;
-    u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
-    double m = __builtin_bit_cast(double, u);
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double p = 1.0 / 23.0;
-    p = FMA(p, z, 1.0 / 21.0);
-    p = FMA(p, z, 1.0 / 19.0);
-    p = FMA(p, z, 1.0 / 17.0);
-    p = FMA(p, z, 1.0 / 15.0);
-    p = FMA(p, z, 1.0 / 13.0);
-    p = FMA(p, z, 1.0 / 11.0);
-    p = FMA(p, z, 1.0 / 9.0);
-    p = FMA(p, z, 1.0 / 7.0);
-    p = FMA(p, z, 1.0 / 5.0);
-    p = FMA(p, z, 1.0 / 3.0);
-    p = FMA(p, z, 1.0);
-    return FMA((double)e, 0.6931471805599453, 2.0 * s * p);
-}
-
-DEV double det_exp(double w)
-{
-    if (w > 700.0) w = 700.0;
-    if (w < -700.0) w = -700.0;
-    double kf = floor(FMA(w, 1.4426950408889634, 0.5));
-    double r = FMA(-kf, 1.90821492927058770002e-10, FMA(-kf, 0.693147180369123816490, w));
-    double p = 1.0 / 6227020800.0;
-    p = FMA(p, r, 1.0 / 479001600.0);
-    p = FMA(p, r, 1.0 / 39916800.0);
-    p = FMA(p, r, 1.0 / 3628800.0);
-    p = FMA(p, r, 1.0 / 362880.0);
-    p = FMA(p, r, 1.0 / 40320.0);
-    p = FMA(p, r, 1.0 / 5040.0);
-    p = FMA(p, r, 1.0 / 720.0);
-    p = FMA(p, r, 1.0 / 120.0);
-    p = FMA(p, r, 1.0 / 24.0);
-    p = FMA(p, r, 1.0 / 6.0);
-    p = FMA(p, r, 0.5);
-    p = FMA(p, r, 1.0);
-    p = FMA(p, r, 1.0);
-    uint64_t bits = (uint64_t)((int64_t)kf + 1023) << 52;
-    return p * __builtin_bit_cast(double, bits);
-}
-
-DEV double rpower_r(double base, double expo)
-{
-    if (base <= 0.0) return 0.0;
-    return det_exp(expo * det_log(base));
-}
-
-/* 1/k for k = 1..7, identical to the correctly rounded quotient 1.0/k */
-DEV double inv_int(int k)
-{
-    double r = 1.0;
-    r = (k == 2) ? 1.0 / 2.0 : r;
-    r = (k == 3) ? 1.0 / 3.0 : r;
-    r = (k == 4) ? 1.0 / 4.0 : r;
-    r = (k == 5) ? 1.0 / 5.0 : r;
-    r = (k == 6) ? 1.0 / 6.0 : r;
-    r = (k == 7) ? 1.0 / 7.0 : r;
-    return r;
-}
-
-/* dynamic pick from a small register array without dynamic indexing */
-template <int N>
-DEV double pick(const double (&a)[N], int idx)
-{
-    double r = a[0];
-    SFOR(k, 1, N) r = (idx == k) ? a[k] : r; SEND
-    return r;
-}
+#include "sa_common.h"
 
 /* Optional phase timing (build with SA_PROFILE; bench.py SA_ABLATE=PROFILE): s_memtime deltas per
    phase of the attempt loop, written over stats slots 8..15 of the backward kernel. */
@@ -835,73 +649,6 @@ DEV void cv_restore(Cv<BWD> &m, double saved_t)
             if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] - m.znQ[j][i]; SEND }
         } SEND
     } SEND
-}
-
-/* cvSetBDF + cvSetTqBDF + the tail of cvSet */
-template <bool BWD>
-DEV void cv_set(Cv<BWD> &m)
-{
-    /* Straight-line (select-based) form of cvSetBDF/cvSetTqBDF: a lone wavefront per SIMD is bound by
-       dependent-instruction latency, so one long basic block the scheduler can interleave beats a
-       chain of short per-lane predicated blocks.  Values are identical to the branching form. */
-    const int q = m.q;
-    const bool gt1 = q > 1;
-    double alpha0 = -1.0, alpha0_hat = -1.0, xi_inv = 1.0, xistar_inv = 1.0, hsum = m.h;
-    m.l[0] = m.l[1] = 1.0;
-    SFOR(i, 2, (QMAX) + 1) m.l[i] = 0.0; SEND
-    SFOR(j, 2, QMAX) {
-        const bool on = j < q;
-        hsum = on ? hsum + m.tau[j - 1] : hsum;
-        const double xi = m.h / hsum;
-        xi_inv = on ? xi : xi_inv;
-        alpha0 = on ? alpha0 - 1.0 / j : alpha0;
-        SFOR_DOWN(i, j, 1) { const double v = FMA(m.l[i - 1], xi_inv, m.l[i]); m.l[i] = on ? v : m.l[i]; } SEND
-    } SEND
-    {
-        const double a0 = alpha0 - inv_int(q);
-        alpha0 = gt1 ? a0 : alpha0;
-        const double xs = -m.l[1] - alpha0;
-        xistar_inv = gt1 ? xs : xistar_inv;
-        const double hs = hsum + pick(m.tau, q - 1);
-        hsum = gt1 ? hs : hsum;
-        const double xi = m.h / hsum;
-        xi_inv = gt1 ? xi : xi_inv;
-        const double ah = -m.l[1] - xi_inv;
-        alpha0_hat = gt1 ? ah : alpha0_hat;
-        SFOR_DOWN(i, QMAX, 1) {
-            const double v = FMA(m.l[i - 1], xistar_inv, m.l[i]);
-            m.l[i] = (gt1 && i <= q) ? v : m.l[i];
-        } SEND
-    }
-    {
-        const double lq = pick(m.l, q);
-        const double A1 = 1.0 - alpha0_hat + alpha0;
-        const double A2 = FMA((double)q, A1, 1.0);
-        m.tq[2] = fabs(A1 / (alpha0 * A2));
-        m.tq[5] = fabs(A2 * xistar_inv / (lq * xi_inv));
-        {
-            const bool w1 = (m.qwait == 1);
-            const double C = xistar_inv / lq;
-            const double A3 = alpha0 + inv_int(q);
-            const double A4 = alpha0_hat + xi_inv;
-            const double Cpinv = (1.0 - A4 + A3) / A3;
-            const double tq1 = gt1 ? fabs(C * Cpinv) : 1.0;
-            m.tq[1] = w1 ? tq1 : m.tq[1];
-            const double hs = hsum + pick(m.tau, q);
-            const double xi3 = m.h / hs;
-            const double A5 = alpha0 - inv_int(q + 1);
-            const double A6 = alpha0_hat - xi3;
-            const double Cppinv = (1.0 - A6 + A5) / A2;
-            const double tq3 = fabs(Cppinv / (xi3 * (q + 2) * A5));
-            m.tq[3] = w1 ? tq3 : m.tq[3];
-        }
-        m.tq[4] = m.tq[2] * 10.0;       /* 1/tq[4] of CVODES (= tq[2]/nlscoef): the test multiplies */
-    }
-    m.rl1 = 1.0 / m.l[1];
-    m.gamma = m.h * m.rl1;
-    m.gammap = (m.nst == 0) ? m.gamma : m.gammap;
-    const double gr = m.gamma / m.gammap;
-    m.gamrat = (m.nst > 0) ? gr : 1.0;
 }
 
 /* ---- linear solver interface (cvLsSetup / cvLsSolve on SUNLinSol_Dense) ---- */
@@ -1690,5 +1437,5 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
     a.div_out[i] = a.x[i] / a.y[i];
 }
 
-/* problem sizes + ABI version, read back by sa_solver_create() */
-extern "C" __device__ __attribute__((used)) const int32_t sa_meta[4] = {NS, NQ, NR, 1};
+/* {n_states, n_sub, n_rem, ABI version, lanes per instance} read back by sa_solver_create() */
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[5] = {NS, NQ, NR, 1, 1};

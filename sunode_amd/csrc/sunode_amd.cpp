@@ -64,6 +64,7 @@ struct DevBuf {
 struct sa_solver {
     int device = 0;
     int n = 0, p = 0, r = 0;
+    int group = 1;                 /* lanes per instance: 1 = thread-per-instance, 2^k = cooperative build */
     hipModule_t module = nullptr;
     hipFunction_t k_forward = nullptr, k_backward = nullptr, k_eval = nullptr, k_math = nullptr;
     hipStream_t stream = nullptr;
@@ -83,9 +84,10 @@ struct sa_solver {
     DevBuf s_misc[12];
 };
 
-static int launch(sa_solver *s, hipFunction_t f, int32_t nthreads_total, void *args, size_t args_size)
+static int launch(sa_solver *s, hipFunction_t f, int32_t n_items, void *args, size_t args_size, int lanes_per_item = 1)
 {
-    unsigned grid = (unsigned)((nthreads_total + 63) / 64);
+    const int per_block = 64 / lanes_per_item;
+    unsigned grid = (unsigned)((n_items + per_block - 1) / per_block);
     if (grid == 0) return SA_OK;
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_size,
                       HIP_LAUNCH_PARAM_END};
@@ -131,15 +133,16 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
     }
     hipDeviceptr_t meta_p = nullptr;
     size_t meta_sz = 0;
-    int32_t meta[4] = {0, 0, 0, 0};
+    int32_t meta[5] = {0, 0, 0, 0, 0};
     e = hipModuleGetGlobal(&meta_p, &meta_sz, s->module, "sa_meta");
     if (e != hipSuccess || meta_sz != sizeof(meta) ||
-        hipMemcpyDtoH(meta, meta_p, sizeof(meta)) != hipSuccess || meta[3] != SA_ABI_VERSION) {
+        hipMemcpyDtoH(meta, meta_p, sizeof(meta)) != hipSuccess || meta[3] != SA_ABI_VERSION ||
+        meta[4] < 1 || meta[4] > 64 || (meta[4] & (meta[4] - 1)) != 0) {
         (void)hipModuleUnload(s->module);
         delete s;
         return fail(SA_ERR_MODULE, "%s: sa_meta missing or ABI mismatch", path);
     }
-    s->n = meta[0]; s->p = meta[1]; s->r = meta[2];
+    s->n = meta[0]; s->p = meta[1]; s->r = meta[2]; s->group = meta[4];
     const char *names[4] = {"sa_k_forward", "sa_k_backward", "sa_k_eval", "sa_k_math"};
     hipFunction_t *slots[4] = {&s->k_forward, &s->k_backward, &s->k_eval, &s->k_math};
     for (int i = 0; i < 4; i++) {
@@ -291,7 +294,7 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
         a.traj = (double *)s->traj.p; a.traj_np = (int32_t *)s->traj_np.p;
     }
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    if ((rc = launch(s, s->k_forward, B, &a, sizeof a))) return rc;
+    if ((rc = launch(s, s->k_forward, B, &a, sizeof a, s->group))) return rc;
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     s->have_fwd_time = true;
     if (mode == SA_MODE_ADJ_FWD) {
@@ -364,7 +367,7 @@ extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const d
     a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
     a.traj = (const double *)s->traj.p; a.traj_np = (const int32_t *)s->traj_np.p;
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
-    if ((rc = launch(s, s->k_backward, B, &a, sizeof a))) return rc;
+    if ((rc = launch(s, s->k_backward, B, &a, sizeof a, s->group))) return rc;
     HIP_TRY(hipEventRecord(s->ev[3], s->stream));
     s->have_bwd_time = true;
     if (mem == SA_MEM_HOST) {

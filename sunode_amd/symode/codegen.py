@@ -48,8 +48,16 @@ HELPERS_C = r"""
 #ifndef SA_FN
 #error "SA_FN must be defined (e.g. 'static inline' or '__device__ __forceinline__')"
 #endif
+/* Output plumbing: by default the callbacks write a flat array.  A kernel may instead pass a sink
+   object (SA_TEMPLATE / SA_OUT_T) and redefine SA_STORE to keep only the slots a lane owns. */
 #ifndef SA_STORE
 #define SA_STORE(slot, value) out[slot] = (value)
+#endif
+#ifndef SA_OUT_T
+#define SA_OUT_T double*
+#endif
+#ifndef SA_TEMPLATE
+#define SA_TEMPLATE
 #endif
 SA_FN double sa_logaddexp(double a, double b) {
     double lo = fmin(a, b), hi = fmax(a, b);
@@ -150,7 +158,7 @@ def emit_function(
     else:
         assigns, reduced = [], []
     printer = HipExprPrinter(symbol_map)
-    lines: List[str] = ["SA_FN int %s(%s) {" % (name, signature)]
+    lines: List[str] = ["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature)]
     for var, value in assigns:
         lines.append("    const double %s = %s;" % (var.name, printer.doprint(value)))
     written = {}
@@ -191,8 +199,8 @@ def generate_problem_source(
     col_major = [j * n + i for i in range(n) for j in range(n)]
     jac = np.asarray(jac, dtype=object).reshape(n, n) if n else np.zeros((0, 0), object)
     adj_jac = np.array([[-jac[j, i] for j in range(n)] for i in range(n)], dtype=object).reshape(n, n)
-    base = "double t, const double* y, const double* ps, const double* pr, double* out"
-    adj = "double t, const double* y, const double* lam, const double* ps, const double* pr, double* out"
+    base = "double t, const double* y, const double* ps, const double* pr, SA_OUT_T out"
+    adj = "double t, const double* y, const double* lam, const double* ps, const double* pr, SA_OUT_T out"
     parts = [
         "/* generated by sunode_amd.symode.codegen -- do not edit */",
         "/* %s */" % description.replace("*/", "* /"),

@@ -205,3 +205,43 @@ def test_seir_forward_adjoint_vs_oracle_and_truth(golden_dir):
     assert np.max(np.abs(y[:2] - t["y_out"]) / np.abs(t["y_out"]).max(axis=(0, 1))) < 1e-5
     scale = np.abs(t["grad_params"]).max(axis=1, keepdims=True)
     assert np.max(np.abs(g[:2] - t["grad_params"]) / scale) < 3e-5
+
+
+@pytest.mark.parametrize("name,group", [("lv", 8), ("notebook", 8), ("robertson", 16)])
+def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch):
+    """The same problem through both kernel families (SA_FORCE_GROUP): G lanes per instance with
+    butterfly norms and row-distributed LU must reproduce the one-lane-per-instance result
+    bit for bit (and therefore the oracle)."""
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem(name)
+    rng = np.random.RandomState(3)
+    B = 100                                            # ragged vs 64/G instances per wavefront
+    if name == "lv":
+        d = lv_batch(B)
+        y0, ps, pr, tv = d["y0"], d["params"][:, :2], d["params"][:, 2:], d["tvals"]
+        kw = dict(abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8, quad_abstol=1e-8,
+                  quad_reltol=1e-8)
+    elif name == "robertson":
+        d = robertson_batch(B)
+        y0, ps, pr, tv = d["y0"], d["params"], np.zeros(0), d["tvals"]
+        kw = dict(abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8, quad_abstol=1e-10,
+                  quad_reltol=1e-8)
+    else:
+        y0 = np.abs(rng.randn(B, 5)) + 0.5
+        ps = rng.randn(B, 3)
+        pr = np.linspace(0, 1, 50)
+        tv = np.arange(20) / 100
+        kw = {}
+    n = prob.n_states
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(n)[None, :])
+    results = []
+    for g in ("1", str(group)):
+        monkeypatch.setenv("SA_FORCE_GROUP", g)
+        sol = AdjointSolver(prob, **kw)
+        y, st, stats = sol.solve_forward_batch(float(tv[0]), tv, y0, ps, pr)
+        gr, lam, stb, statsb = sol.solve_backward_batch(tv[-1], float(tv[0]), tv, grads)
+        assert (st == 0).all() and (stb == 0).all()
+        results.append((y, stats[:, CMP], gr, lam, statsb[:, CMP_B]))
+        sol._engine().close()
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)
