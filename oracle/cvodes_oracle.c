@@ -1342,7 +1342,9 @@ static int solve_plain_one(const orc_config *cfg, const double *y0, const double
     double ybuf[NSD], tret;
     for (int k = 0; k < n_t && status == CV_SUCCESS; k++) {
         double t = tvals[k];
-        if (t == t0) { for (int i = 0; i < NS; i++) y_out[i] = y0[i]; continue; }   /* row 0, solver.py:505 */
+        /* solver.py:505 writes row 0 here (it assumes tvals[0] == t0); row k is the sane reading of a
+           repeated t0 and identical in the only case the reference supports */
+        if (t == t0) { for (int i = 0; i < NS; i++) y_out[(size_t)k * NS + i] = y0[i]; continue; }
         int retval = CV_TOO_MUCH_WORK, retry;
         for (retry = 0; retry < cfg->max_retries_fwd; retry++) {
             retval = cv_cvode_normal(m, t, ybuf, NULL, &tret);
@@ -1371,7 +1373,7 @@ static int solve_forward_one(const orc_config *cfg, const double *y0, const doub
     int status = CV_SUCCESS, first = 1;
     for (int k = 0; k < n_t && status == CV_SUCCESS; k++) {
         double tout = tvals[k];
-        if (tout == t0) { for (int i = 0; i < NS; i++) y_out[i] = y0[i]; continue; }   /* solver.py:707 */
+        if (tout == t0) { for (int i = 0; i < NS; i++) y_out[(size_t)k * NS + i] = y0[i]; continue; }   /* solver.py:707, row k */
         if (first) {
             tr->tinitial = m->tn;
             traj_push(tr, m->tn, m->zn[0], 0, 0);

@@ -1091,7 +1091,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
 
     int status = CV_SUCCESS, k = 0, np = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
     while (k < a.n_t && a.tvals[k] == a.t0) {
-        if (m.li < NS) yo[m.li] = y0;
+        if (m.li < NS) yo[(int64_t)k * NS + m.li] = y0;
         k++;
     }
     bool done = (k >= a.n_t);
@@ -1137,7 +1137,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                 while (!done && k < a.n_t) {
                     double tout = a.tvals[k];
                     if (tout == a.t0) {
-                        if (m.li < NS) yo[m.li] = y0;
+                        if (m.li < NS) yo[(int64_t)k * NS + m.li] = y0;
                         k++;
                     } else if ((m.tn - tout) * m.h >= 0.0) {
                         double dky, dq;

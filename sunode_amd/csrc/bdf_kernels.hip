@@ -1184,8 +1184,8 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     SFOR(j, 0, (QMAX) + 1) { hT[j] = 0.0; SFOR(i, 0, NS) hY[j][i] = 0.0; SEND } SEND
 
     int status = CV_SUCCESS, k = 0, np = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
-    while (k < a.n_t && a.tvals[k] == a.t0) {       /* solver.py:505,707: row 0 <- y0 */
-        SFOR(i, 0, NS) yo[i] = y0[i]; SEND
+    while (k < a.n_t && a.tvals[k] == a.t0) {       /* solver.py:505,707 (row k; the reference writes row 0) */
+        SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = y0[i]; SEND
         k++;
     }
     bool done = (k >= a.n_t);
@@ -1234,7 +1234,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                 while (!done && k < a.n_t) {
                     double tout = a.tvals[k];
                     if (tout == a.t0) {
-                        SFOR(i, 0, NS) yo[i] = y0[i]; SEND
+                        SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = y0[i]; SEND
                         k++;
                     } else if ((m.tn - tout) * m.h >= 0.0) {
                         double dky[NSD];

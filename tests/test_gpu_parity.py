@@ -245,3 +245,73 @@ def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch
         sol._engine().close()
     for a, b in zip(*results):
         np.testing.assert_array_equal(a, b)
+
+
+def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
+    orc = make_oracle(name)
+    cfg = orc.config(**cfg_kw)
+    y, st, stats = orc.solve_forward(cfg, y0, ps, pr, t0, tv)
+    g, lam, stb, statsb = orc.solve_backward(cfg, tv[-1] if t_start is None else t_start,
+                                             t0 if t_end is None else t_end, tv, grads)
+    return y, st, g, lam, stb
+
+
+def test_edge_cases_match_oracle():
+    """Ragged / degenerate inputs (reference semantics, solver.py:705-708, 750-776):
+    tvals[0] > t0 (extra interval down to tend), a single output time, B = 1, B not a multiple of 64,
+    per-instance cotangents, tvals containing t0 twice."""
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("lv")
+    tol = dict(abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8, quad_abstol=1e-8, quad_reltol=1e-8)
+    okw = dict(rtol=1e-8, atol=1e-8, rtolB=1e-8, atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
+    rng = np.random.RandomState(5)
+    for B, tv, t0 in [(1, np.linspace(0, 10), 0.0), (67, np.array([2.5]), 0.0), (3, np.linspace(1.0, 4.0, 7), 0.5),
+                      (5, np.array([0.0, 0.0, 1.0, 3.0]), 0.0)]:
+        d = lv_batch(B)
+        ps, pr = d["params"][:, :2], d["params"][:, 2:]
+        grads = rng.randn(B, len(tv), 2)
+        sol = AdjointSolver(prob, **tol)
+        y, st, _ = sol.solve_forward_batch(t0, tv, d["y0"], ps, pr)
+        g, lam, stb, _ = sol.solve_backward_batch(tv[-1], t0, tv, grads)
+        yo, so, go, lo, sbo = _oracle_adjoint("lv", okw, d["y0"], ps, pr, t0, tv, grads)
+        np.testing.assert_array_equal(st, so)
+        np.testing.assert_array_equal(stb, sbo)
+        np.testing.assert_array_equal(y, yo)
+        np.testing.assert_array_equal(g, go)
+        np.testing.assert_array_equal(lam, lo)
+
+
+def test_empty_batch_and_no_derivative_params():
+    from sunode_amd import SympyProblem
+    from sunode_amd.solver import AdjointSolver, Solver
+    prob = make_problem("lv")
+    sol = Solver(prob, abstol=1e-8, reltol=1e-8)
+    y, st, stats = sol.solve_batch(0.0, np.linspace(0, 1, 5), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros((0, 2)))
+    assert y.shape == (0, 5, 2) and st.shape == (0,)
+    # a problem without differentiated parameters: quadrature length 0 (reference test_solve.py:7-78)
+    p0 = SympyProblem({"b": ()}, {"x": ()}, lambda t, y, p: {"x": -p.b * y.x}, derivative_params=[])
+    adj = AdjointSolver(p0, abstol=1e-10, reltol=1e-10)
+    tv = np.linspace(0, 1, 11)
+    y, st, _ = adj.solve_forward_batch(0.0, tv, np.ones((4, 1)), np.zeros((4, 0)), np.array([2.0]))
+    g, lam, stb, _ = adj.solve_backward_batch(tv[-1], 0.0, tv, np.ones((11, 1)))
+    assert (st == 0).all() and (stb == 0).all() and g.shape == (4, 0)
+    np.testing.assert_allclose(y[0, :, 0], np.exp(-2.0 * tv), rtol=2e-8)
+    np.testing.assert_allclose(-lam[:, 0], np.exp(-2.0 * tv).sum(), rtol=1e-7)      # dL/dy0, L = sum_k y(t_k)
+
+
+def test_backward_reports_failed_forward_and_budget():
+    """Instances whose forward pass failed come back CV_NO_FWD (-102) with NaN gradients; a backward
+    step budget that is too small gives CV_TOO_MUCH_WORK for that instance only."""
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("robertson")
+    d = robertson_batch(8)
+    tv = d["tvals"]
+    params = d["params"].copy()
+    sol = AdjointSolver(prob, abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8,
+                        quad_abstol=1e-10, quad_reltol=1e-8, max_steps=600)     # arena too small for most
+    y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], params, np.zeros(0))
+    g, lam, stb, _ = sol.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 3)))
+    assert set(st.tolist()) <= {0, -1} and (st == -1).any()
+    assert ((stb == -102) == (st == -1)).all()
+    assert np.isnan(g[st == -1]).all() and np.isnan(y[st == -1]).all()
+    assert np.isfinite(g[st == 0]).all()
