@@ -46,7 +46,7 @@ static_assert(G >= NS && G >= NQ && G <= 64 && (G & (G - 1)) == 0, "bad SA_GROUP
 constexpr int ilog2(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
 #define LOG2G ilog2(G)
 #define TREC (8 + 6 * NS)
-#define SA_REM_IN_REGS (NR <= 32)
+#define SA_REM_IN_REGS (NR <= 8)      /* larger (typically shared) blocks are read through scalar loads */
 #define SA_NAN __builtin_bit_cast(double, (uint64_t)0x7ff8000000000000ULL)
 
 /* ---- cross-lane primitives (all lanes of a group are always converged when these run) ---- */
@@ -100,7 +100,7 @@ struct Cc {
     int nst, nfe, nje, nsetups, nni, ncfn, netf, nfQe, netfQ, nstlp, nstlj;
     int jcur, nls_jcur;
     double ps[NQD];
-    double prl[NR <= 32 ? NRD : 1];
+    double prl[SA_REM_IN_REGS ? NRD : 1];
     const double *prg;
     /* stored trajectory (backward) */
     const double *traj;               /* instance's first record */
