@@ -107,13 +107,17 @@ def kernel_variant(native_source: str):
     """(source file, lanes per instance) for a generated problem header.
 
     n <= 5 states: thread-per-instance, the whole integrator in one lane's registers.
-    larger: cooperative, G = next power of two >= max(n_states, n_sub, 8) lanes per instance.
+    up to 64: cooperative, G = next power of two >= max(n_states, n_sub, 8) lanes per instance.
+    larger: memory-resident thread-per-instance kernel (state in an HBM workspace, [element][instance]).
     SA_FORCE_GROUP=<G> forces the cooperative build with that group size (tests run small
-    problems through both mappings); SA_FORCE_GROUP=1 forces thread-per-instance."""
+    problems through every mapping); SA_FORCE_GROUP=1 forces the register kernel and
+    SA_FORCE_GROUP=mem the memory-resident one."""
     import re
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
     forced = os.environ.get("SA_FORCE_GROUP")
+    if forced == "mem" or (not forced and max(n, p) > 64):
+        return "bdf_mem.hip", 1
     if forced:
         g = int(forced)
     elif n <= REGISTER_KERNEL_MAX_STATES:
@@ -125,8 +129,8 @@ def kernel_variant(native_source: str):
     if g == 1:
         return "bdf_kernels.hip", 1
     if g < max(n, p) or g > 64 or g & (g - 1):
-        raise NativeBuildError("cooperative kernels need max(n_states, n_sub) = %d <= group size %d <= 64 "
-                               "(larger systems need the workgroup mapping, not built yet)" % (max(n, p), g))
+        raise NativeBuildError("cooperative kernels need max(n_states, n_sub) = %d <= group size %d <= 64"
+                               % (max(n, p), g))
     return "bdf_coop.hip", g
 
 
@@ -135,7 +139,7 @@ def code_object_path(native_source: str) -> str:
     kern = os.path.join(_CSRC, fname)
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h")]
     deps = [d for d in deps if os.path.exists(d)]
-    extra = native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group
+    extra = native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group + fname.encode()
     key = _hash_files(*deps, extra=extra) if os.path.exists(kern) else \
         hashlib.sha256(extra).hexdigest()[:16]
     return os.path.join(_CACHE, "sa_%s.hsaco" % key)

@@ -1314,4 +1314,4 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 }
 
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance} read back by sa_solver_create() */
-extern "C" __device__ __attribute__((used)) const int32_t sa_meta[5] = {NS, NQ, NR, 1, G};
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, G, 0};

@@ -15,6 +15,8 @@
  *     traj [cap][stride][8+6n] records {order, dt, T[6], Y[6][n]} = the divided-difference table
  *     CVApolynomialGetY needs at that index, built once by the forward kernel; traj_np [B] (i32);
  *     instance index fastest: the lanes of a wave write one step as one contiguous block.
+ *   ws      [W][ws_stride]    integrator workspace of the memory-resident kernels (bdf_mem.hip):
+ *                             element e of instance i at ws[e*ws_stride + i]; W = sa_meta[5]
  */
 #ifndef SA_DEVICE_ABI_H
 #define SA_DEVICE_ABI_H
@@ -37,6 +39,8 @@ typedef struct {
     int64_t *stats;
     double *traj;
     int32_t *traj_np;
+    double *ws;               /* memory-resident kernels only: [sa_meta[5]][ws_stride] doubles */
+    int64_t ws_stride;
 } sa_fwd_args;
 
 typedef struct {
@@ -51,6 +55,8 @@ typedef struct {
     int64_t *stats;
     const double *traj;
     const int32_t *traj_np;
+    double *ws;
+    int64_t ws_stride;
 } sa_bwd_args;
 
 typedef struct {

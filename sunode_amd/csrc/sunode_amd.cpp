@@ -65,6 +65,8 @@ struct sa_solver {
     int device = 0;
     int n = 0, p = 0, r = 0;
     int group = 1;                 /* lanes per instance: 1 = thread-per-instance, 2^k = cooperative build */
+    int64_t ws_doubles = 0;        /* per-instance workspace of the memory-resident build (0: register builds) */
+    DevBuf ws;
     hipModule_t module = nullptr;
     hipFunction_t k_forward = nullptr, k_backward = nullptr, k_eval = nullptr, k_math = nullptr;
     hipStream_t stream = nullptr;
@@ -133,16 +135,16 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
     }
     hipDeviceptr_t meta_p = nullptr;
     size_t meta_sz = 0;
-    int32_t meta[5] = {0, 0, 0, 0, 0};
+    int32_t meta[6] = {0, 0, 0, 0, 0, 0};
     e = hipModuleGetGlobal(&meta_p, &meta_sz, s->module, "sa_meta");
     if (e != hipSuccess || meta_sz != sizeof(meta) ||
         hipMemcpyDtoH(meta, meta_p, sizeof(meta)) != hipSuccess || meta[3] != SA_ABI_VERSION ||
-        meta[4] < 1 || meta[4] > 64 || (meta[4] & (meta[4] - 1)) != 0) {
+        meta[4] < 1 || meta[4] > 64 || (meta[4] & (meta[4] - 1)) != 0 || meta[5] < 0) {
         (void)hipModuleUnload(s->module);
         delete s;
         return fail(SA_ERR_MODULE, "%s: sa_meta missing or ABI mismatch", path);
     }
-    s->n = meta[0]; s->p = meta[1]; s->r = meta[2]; s->group = meta[4];
+    s->n = meta[0]; s->p = meta[1]; s->r = meta[2]; s->group = meta[4]; s->ws_doubles = meta[5];
     const char *names[4] = {"sa_k_forward", "sa_k_backward", "sa_k_eval", "sa_k_math"};
     hipFunction_t *slots[4] = {&s->k_forward, &s->k_backward, &s->k_eval, &s->k_math};
     for (int i = 0; i < 4; i++) {
@@ -249,6 +251,20 @@ static int stage_in(sa_solver *s, DevBuf &b, const void *host, size_t bytes, con
     return SA_OK;
 }
 
+/* memory-resident builds: one [ws_doubles][stride] block, reused by forward and backward */
+static int bind_workspace(sa_solver *s, int32_t B, double **ws, int64_t *stride)
+{
+    *ws = nullptr;
+    *stride = 0;
+    if (s->ws_doubles == 0) return SA_OK;
+    const int64_t st = ((int64_t)B + 63) / 64 * 64;
+    int rc = s->ws.ensure(sizeof(double) * (size_t)s->ws_doubles * (size_t)st);
+    if (rc) return rc;
+    *ws = (double *)s->ws.p;
+    *stride = st;
+    return SA_OK;
+}
+
 static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const double *y0, const double *ps,
                           const double *pr, int32_t rem_stride, double t0, const double *tvals, int32_t n_t,
                           double *y_out, int32_t *status, int64_t *stats)
@@ -293,6 +309,7 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
         a.traj_stride = stride;
         a.traj = (double *)s->traj.p; a.traj_np = (int32_t *)s->traj_np.p;
     }
+    if ((rc = bind_workspace(s, B, &a.ws, &a.ws_stride))) return rc;
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     if ((rc = launch(s, s->k_forward, B, &a, sizeof a, s->group))) return rc;
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
@@ -366,6 +383,7 @@ extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const d
     a.ps = d_ps; a.pr = d_pr; a.tvals = d_tv; a.grads = d_g; a.grad_out = d_gout; a.lamda_out = d_lout;
     a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
     a.traj = (const double *)s->traj.p; a.traj_np = (const int32_t *)s->traj_np.p;
+    if ((rc = bind_workspace(s, B, &a.ws, &a.ws_stride))) return rc;
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     if ((rc = launch(s, s->k_backward, B, &a, sizeof a, s->group))) return rc;
     HIP_TRY(hipEventRecord(s->ev[3], s->stream));

@@ -56,6 +56,13 @@ HELPERS_C = r"""
 #ifndef SA_OUT_T
 #define SA_OUT_T double*
 #endif
+/* input element access: flat arrays by default; the memory-resident kernels stride them */
+#ifndef SA_Y
+#define SA_Y(i) y[i]
+#endif
+#ifndef SA_LAM
+#define SA_LAM(i) lam[i]
+#endif
 #ifndef SA_TEMPLATE
 #define SA_TEMPLATE
 #endif

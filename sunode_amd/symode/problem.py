@@ -84,7 +84,7 @@ class SympyProblem:
         for j, s in enumerate(self._sym_fixed_paramsvec):
             self._c_slots[s.name] = "pr[%d]" % j
         for i, s in enumerate(self._sym_statevec):
-            self._c_slots[s.name] = "y[%d]" % i
+            self._c_slots[s.name] = "SA_Y(%d)" % i
 
         self._sym_params = self.params_subset.as_dataclass(
             "Params", self._sym_deriv_paramsvec, self._sym_fixed_paramsvec, item_map=_scalarize)
@@ -99,7 +99,7 @@ class SympyProblem:
         self._sym_lamda = sym.symarray("lamda", n)
         for i in range(n):
             self._varmap[self._sym_lamda[i].name] = ("lamda", (i,))
-            self._c_slots[self._sym_lamda[i].name] = "lam[%d]" % i
+            self._c_slots[self._sym_lamda[i].name] = "SA_LAM(%d)" % i
         for idx in product(range(p), range(n)):
             self._varmap[self._sym_sens[idx].name] = ("sens", idx)
 

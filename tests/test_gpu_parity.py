@@ -207,11 +207,13 @@ def test_seir_forward_adjoint_vs_oracle_and_truth(golden_dir):
     assert np.max(np.abs(g[:2] - t["grad_params"]) / scale) < 3e-5
 
 
-@pytest.mark.parametrize("name,group", [("lv", 8), ("notebook", 8), ("robertson", 16)])
+@pytest.mark.parametrize("name,group", [("lv", 8), ("notebook", 8), ("robertson", 16),
+                                        ("lv", "mem"), ("notebook", "mem"), ("robertson", "mem")])
 def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch):
-    """The same problem through both kernel families (SA_FORCE_GROUP): G lanes per instance with
-    butterfly norms and row-distributed LU must reproduce the one-lane-per-instance result
-    bit for bit (and therefore the oracle)."""
+    """The same problem through the kernel families (SA_FORCE_GROUP): G lanes per instance with
+    butterfly norms and row-distributed LU, or the memory-resident generic kernel ("mem", the
+    mapping of systems with more than 64 states), must reproduce the one-lane-per-instance
+    register kernel bit for bit (and therefore the oracle)."""
     from sunode_amd.solver import AdjointSolver
     prob = make_problem(name)
     rng = np.random.RandomState(3)
@@ -241,10 +243,40 @@ def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch
         y, st, stats = sol.solve_forward_batch(float(tv[0]), tv, y0, ps, pr)
         gr, lam, stb, statsb = sol.solve_backward_batch(tv[-1], float(tv[0]), tv, grads)
         assert (st == 0).all() and (stb == 0).all()
-        results.append((y, stats[:, CMP], gr, lam, statsb[:, CMP_B]))
+        from sunode_amd.solver import Solver
+        plain = Solver(prob, **{k: v for k, v in kw.items() if k in ("abstol", "reltol")})
+        yp, stp, _ = plain.solve_batch(float(tv[0]), tv, y0, ps, pr)
+        results.append((y, stats[:, CMP], gr, lam, statsb[:, CMP_B], yp, stp))
         sol._engine().close()
+        plain._engine().close()
     for a, b in zip(*results):
         np.testing.assert_array_equal(a, b)
+
+
+def test_seir_memory_resident_mapping_vs_oracle(monkeypatch):
+    """SEIR (n = 16, 16 shared fixed parameters read through the global pointer) through the
+    memory-resident kernel: bit-exact against the oracle like the cooperative build."""
+    from sunode_amd.solver import AdjointSolver
+    monkeypatch.setenv("SA_FORCE_GROUP", "mem")
+    prob = make_problem("seir")
+    d = seir_batch(70)
+    tv = d["tvals"]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(16)[None, :])
+    tol = 1e-8
+    sol = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol,
+                        quad_abstol=tol, quad_reltol=tol, max_steps=1024)
+    y, status, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], d["pr"])
+    g, lam, status_b, stats_b = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("seir")
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (status == 0).all() and (status_b == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(stats_b[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
 
 
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):

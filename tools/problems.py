@@ -183,3 +183,15 @@ def seir_batch(B: int, seed: int = SEED):
     y0 = np.concatenate([pop - I0, np.zeros(4), I0, np.zeros(4)])
     return dict(ps=sub, pr=C.ravel(), y0=np.tile(y0, (B, 1)), tvals=np.linspace(0, 100, 51), t0=0.0,
                 rtol=1e-8, atol=1e-8)
+
+
+def network_batch(B: int, n: int = 100, seed: int = SEED):
+    """Config 5: dense mass-action network, K (n x n) shared fixed, scale(4) differentiated per draw."""
+    u = np.abs(std_normal(seed, 64, n * n)).reshape(n, n)
+    K = u / n
+    scale0 = np.array([1.0, 0.5, 10.0, 0.1])
+    z = np.stack([std_normal(seed, 65 + s, B) for s in range(4)], axis=1)
+    ps = scale0 * np.exp(0.1 * z)
+    zx = std_normal(seed, 70, n)
+    y0 = np.tile(np.exp(0.3 * zx), (B, 1))
+    return dict(ps=ps, pr=K.ravel(), y0=y0, tvals=np.linspace(0, 10, 11), t0=0.0, rtol=1e-8, atol=1e-8)
