@@ -108,16 +108,21 @@ def kernel_variant(native_source: str):
 
     n <= 5 states: thread-per-instance, the whole integrator in one lane's registers.
     up to 64: cooperative, G = next power of two >= max(n_states, n_sub, 8) lanes per instance.
+    up to 128: one wavefront per instance, Newton matrix / LU resident in LDS (bdf_wave.hip).
     larger: memory-resident thread-per-instance kernel (state in an HBM workspace, [element][instance]).
     SA_FORCE_GROUP=<G> forces the cooperative build with that group size (tests run small
-    problems through every mapping); SA_FORCE_GROUP=1 forces the register kernel and
-    SA_FORCE_GROUP=mem the memory-resident one."""
+    problems through every mapping); SA_FORCE_GROUP=1 forces the register kernel,
+    SA_FORCE_GROUP=wave the wavefront-per-instance one and SA_FORCE_GROUP=mem the memory-resident one."""
     import re
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
     forced = os.environ.get("SA_FORCE_GROUP")
-    if forced == "mem" or (not forced and max(n, p) > 64):
+    if forced == "mem" or (not forced and max(n, p) > 128):
         return "bdf_mem.hip", 1
+    if forced == "wave" or (not forced and max(n, p) > 64):
+        if max(n, p) > 128 or n < 1:
+            raise NativeBuildError("the wavefront-per-instance kernel covers 1 <= n_states <= 128, n_sub <= 128")
+        return "bdf_wave.hip", 64
     if forced:
         g = int(forced)
     elif n <= REGISTER_KERNEL_MAX_STATES:
@@ -132,6 +137,13 @@ def kernel_variant(native_source: str):
         raise NativeBuildError("cooperative kernels need max(n_states, n_sub) = %d <= group size %d <= 64"
                                % (max(n, p), g))
     return "bdf_coop.hip", g
+
+
+def _size_defines(native_source: str):
+    import re
+    n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
+    p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
+    return ["-DSA_BUILD_NS=%d" % n, "-DSA_BUILD_NQ=%d" % p]
 
 
 def code_object_path(native_source: str) -> str:
@@ -162,14 +174,18 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
         hipcc = os.path.join(ROCM, "bin", "hipcc")
         _run([hipcc, "--offload-arch=" + ARCH, "--cuda-device-only", "-emit-llvm", "-c", "-O0",
               "-Xclang", "-disable-O0-optnone", "-ffp-contract=off", "-std=c++17",
-              "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-DSA_GROUP=%d" % group, "-I" + _CSRC, kern, "-o", bc0])
+              "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-DSA_GROUP=%d" % group] + _size_defines(native_source)
+             + ["-I" + _CSRC, kern, "-o", bc0])
         _run([os.path.join(LLVM_BIN, "opt"), "-passes=always-inline,sroa", bc0, "-o", bc1])
         base = [os.path.join(LLVM_BIN, "clang"), "-x", "ir", bc1, "-target", "amdgcn-amd-amdhsa",
                 "-mcpu=" + ARCH, "-O3", "-ffp-contract=off"]
+        # the memory-resident build is dominated by the generated callbacks (10^4 statements at
+        # n = 100): default scheduler there, the ILP strategies take several times longer
+        extra = [] if fname in ("bdf_mem.hip", "bdf_wave.hip") else _extra_codegen_flags()
         try:
-            _run(base + _extra_codegen_flags() + ["-c", "-o", obj])
+            _run(base + extra + ["-c", "-o", obj])
         except NativeBuildError:
-            if not _extra_codegen_flags():
+            if not extra:
                 raise
             # the non-default scheduler strategies crash clang on very large kernels: plain -O3 then
             _run(base + ["-c", "-o", obj])

@@ -1,0 +1,1480 @@
+/*
+ * bdf_wave.hip -- one wavefront per instance, LDS-resident dense LU (64 < max(n, p) <= 128; gfx950).
+ *
+ * The mapping for mid-size systems whose batches are small (BASELINE config 5: 100 states, 1024
+ * instances per GPU): a whole wavefront integrates ONE instance.
+ *   - component c of every vector lives in lane c % 64, slot c / 64 (RS = ceil(n/64) slots), so the
+ *     Nordsieck array, weights and corrections are a few dozen VGPRs and every vector update is
+ *     pure register arithmetic;
+ *   - WRMS norms are xor-butterflies over the wave per slot followed by a pairwise sum of the slot
+ *     totals: exactly the balanced tree of the CPU oracle over next_pow2(n) leaves;
+ *   - the Newton matrix I - gamma*J lives in LDS, column-major (n^2 doubles: 80 000 B at n = 100,
+ *     two workgroups per CU).  The LU with partial pivoting is row-distributed (lane owns rows):
+ *     pivot search = wave arg-max, pivot row / pivot entries are LDS broadcast reads, elimination
+ *     is n^2/2 conflict-free ds_read/FMA/ds_write triples per lane slot instead of n^3/3 serial
+ *     flops; the triangular solves broadcast one entry per step with v_readlane;
+ *   - the saved Jacobian and the callback output vector are in an HBM workspace (per instance
+ *     contiguous, coalesced);
+ *   - the sympy-generated callbacks are straight-line scalar code without exploitable structure:
+ *     the wave stages the state in LDS (broadcast reads), every lane evaluates the whole callback
+ *     (chunked noinline functions, shared rate constants through scalar loads) and the results go
+ *     to LDS (Jacobian) or the workspace vector -- redundant but divergence-free work.
+ * Control scalars are recomputed redundantly by all lanes from identical inputs (uniform control
+ * flow without votes).
+ *
+ * Same algorithm, operation order and rounding as the other builds / the CPU oracle (restated
+ * CVODES 5.x; reference call sites /root/reference/sunode/solver.py:467-527, 682-784).
+ * Kernel entry points and argument blocks are those of bdf_kernels.hip; sa_meta = {n, p, r, ABI,
+ * 64 lanes per instance, workspace doubles per instance}.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+/* the build passes the sizes (parsed from the generated header) because the LDS arrays the
+   generated code reads must be declared before that header is included */
+#if !defined(SA_BUILD_NS) || !defined(SA_BUILD_NQ)
+#error "SA_BUILD_NS / SA_BUILD_NQ must be defined"
+#endif
+#define W_NS SA_BUILD_NS
+#define W_NQ SA_BUILD_NQ
+
+__shared__ double s_A[W_NS * W_NS];                 /* Newton matrix / its LU, column-major */
+__shared__ double s_y[W_NS > 0 ? W_NS : 1];         /* callback input: state (backward: interpolated forward state) */
+__shared__ double s_lam[W_NS > 0 ? W_NS : 1];       /* callback input: adjoint state; scratch for the LU solves */
+__shared__ double s_ps[W_NQ > 0 ? W_NQ : 1];        /* differentiated parameters of the instance */
+__shared__ uint8_t s_piv[(W_NS + 15) / 16 * 16];    /* pivot rows (n <= 128 fits a byte) */
+
+#define SA_FN static __device__ __attribute__((noinline))
+#define SA_TEMPLATE template <class SinkT>
+#define SA_OUT_T SinkT
+#define SA_STORE(slot, value) out.template put<(slot)>(value)
+#define SA_Y(i) s_y[i]
+#define SA_LAM(i) s_lam[i]
+#define SA_PS(j) s_ps[j]
+#define SA_PR(j) prc[j]
+#define SA_CONST_AS __attribute__((address_space(4)))
+#define SA_PROLOGUE const SA_CONST_AS double *prc = sa_uniform_const(pr);
+
+/* remaining parameters are read-only for the whole launch and identical for all lanes of the
+   wave: a wave-uniform constant-address-space view turns every pr[j] into a scalar load */
+static __device__ __forceinline__ const SA_CONST_AS double *sa_uniform_const(const double *p)
+{
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (const SA_CONST_AS double *)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
+#include SA_PROBLEM_HEADER
+#include "sa_device_abi.h"
+#include "sa_common.h"
+
+static_assert(NS == W_NS && NQ == W_NQ, "SA_BUILD_NS / SA_BUILD_NQ do not match the generated header");
+static_assert(NS <= 128 && NQ <= 128 && NS >= 1, "the wave kernel covers 1 <= n <= 128, p <= 128");
+
+#define RS ((NS + 63) / 64)                    /* register slots of a state vector */
+#define RQ (NQ > 0 ? (NQ + 63) / 64 : 1)       /* register slots of a quadrature vector */
+#define TREC (8 + 6 * NS)
+#define SA_NAN __builtin_bit_cast(double, (uint64_t)0x7ff8000000000000ULL)
+constexpr int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+/* workspace (doubles per instance): saved Jacobian + callback output vector */
+#define WS_SJ 0
+#define WS_OUT (NS * NS)
+#define WS_DOUBLES (NS * NS + ((NS > NQ ? NS : NQ) + 7) / 8 * 8)
+
+/* ---- cross-lane primitives (the wave is always converged when these run) ---- */
+DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+DEV double shfl_d(double v, int src_lane)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
+DEV int shfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+/* value of lane `src` (wave-uniform index) */
+DEV double readlane_d(double v, int src)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, src);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), src);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
+DEV void lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* output sinks of the generated callbacks (all lanes hold the same value) */
+struct VecOut {             /* vector-valued callbacks -> workspace vector */
+    double *p;
+    template <int S> __device__ __forceinline__ void put(double x) const { p[S] = x; }
+};
+struct MatOut {             /* n x n callbacks -> the LDS matrix (slot = col * n + row) */
+    template <int S> __device__ __forceinline__ void put(double x) const { s_A[S] = x; }
+};
+
+/* ------------------------------------------------------------------------------------ */
+template <bool BWD>
+struct Cw {
+    int lane;
+    double zn[QMAX + 1][RS], znQ[QMAX + 1][RQ], zsave[RS], zsaveQ[RQ];
+    double ewt[RS], acor[RS], tempv[RS], ftemp[RS], y[RS], ytmp[RS], atol[RS];
+    double ewtQ[RQ], acorQ[RQ], tempvQ[RQ];
+    double inv_piv[RS];               /* 1/pivot of the rows the lane owns */
+    int nswaps;                       /* row exchanges of the current factorisation */
+    double *sj, *obuf;                /* workspace: saved Jacobian, callback output vector */
+    const double *pr;
+    double rtol, rtolQ, atolQ;
+    double tn, h, hprime, hscale, eta, etamax, hu;
+    int q, qprime, L, qwait, qu;
+    double tau[7], tq[6], l[7];
+    double rl1, gamma, gammap, gamrat, crate, delp, acnrm, saved_tq5;
+    double etaq, etaqm1, etaqp1, tstop;
+    int nst, nfe, nje, nsetups, nni, ncfn, netf, nfQe, netfQ, nstlp, nstlj;
+    int jcur, nls_jcur;
+    /* stored trajectory (backward): current divided-difference record, own components */
+    const double *traj;
+    int64_t trow;
+    int np;
+    double tfinal;
+    int ilast, newdata, have_last, cur_idx;
+    double last_t, tlo, thi, tlo2;
+    double tab_hdr[8];                /* order, dt, T[6] */
+    double tabY[QMAX + 1][RS];
+    int n_interp, n_rebuild;
+};
+
+#define IDX(m, r) ((r) * 64 + (m).lane)
+
+/* sum over all lanes and slots: xor-butterfly per slot, then the slot totals pairwise */
+template <int NSLOT>
+DEV double wave_sum(int lane, const double (&v)[NSLOT])
+{
+    constexpr int P = pow2_ge(NSLOT);
+    double s[P];
+    SFOR(r, 0, P) {
+        if constexpr (r < NSLOT) {
+            double x = v[r];
+            SFOR(b, 0, 6) x = x + shfl_d(x, lane ^ (1 << b)); SEND
+            s[r] = x;
+        } else {
+            s[r] = 0.0;
+        }
+    } SEND
+    if constexpr (P == 1) return s[0];
+    else if constexpr (P == 2) return s[0] + s[1];
+    else { static_assert(P <= 2, "more than two slots: extend the slot tree"); return 0.0; }
+}
+
+DEV double wave_max(int lane, double x)
+{
+    SFOR(b, 0, 6) { const double o = shfl_d(x, lane ^ (1 << b)); x = x > o ? x : o; } SEND
+    return x;
+}
+
+template <bool BWD>
+DEV double wrms_n(const Cw<BWD> &m, const double (&x)[RS], const double (&w)[RS])
+{
+    double sq[RS];
+    SFOR(r, 0, RS) { const double prod = (IDX(m, r) < NS) ? x[r] * w[r] : 0.0; sq[r] = prod * prod; } SEND
+    return sqrt(wave_sum<RS>(m.lane, sq) / NS);
+}
+
+template <bool BWD>
+DEV double wrms_q(const Cw<BWD> &m, const double (&x)[RQ], const double (&w)[RQ])
+{
+    if constexpr (NQ == 0) return 0.0;
+    double sq[RQ];
+    SFOR(r, 0, RQ) { const double prod = (IDX(m, r) < NQ) ? x[r] * w[r] : 0.0; sq[r] = prod * prod; } SEND
+    return sqrt(wave_sum<RQ>(m.lane, sq) / (NQ > 0 ? NQ : 1));
+}
+
+template <bool BWD>
+DEV double quad_update_norm(const Cw<BWD> &m, double old_nrm, const double (&xQ)[RQ])
+{
+    const double qnrm = wrms_q(m, xQ, m.ewtQ);
+    return old_nrm > qnrm ? old_nrm : qnrm;
+}
+
+template <bool BWD>
+DEV int ewt_set(const Cw<BWD> &m, const double (&ycur)[RS], double (&w)[RS])
+{
+    double bad = 0.0;
+    SFOR(r, 0, RS) {
+        const double v = FMA(m.rtol, fabs(ycur[r]), m.atol[r]);
+        bad = (IDX(m, r) < NS && v <= 0.0) ? 1.0 : bad;
+        w[r] = 1.0 / v;
+    } SEND
+    return wave_max(m.lane, bad) > 0.0 ? -1 : 0;
+}
+
+template <bool BWD>
+DEV int ewtQ_set(const Cw<BWD> &m, const double (&qcur)[RQ], double (&w)[RQ])
+{
+    double bad = 0.0;
+    SFOR(r, 0, RQ) {
+        const double v = FMA(m.rtolQ, fabs(qcur[r]), m.atolQ);
+        bad = (IDX(m, r) < NQ && v <= 0.0) ? 1.0 : bad;
+        w[r] = 1.0 / v;
+    } SEND
+    return wave_max(m.lane, bad) > 0.0 ? -1 : 0;
+}
+
+/* ---- stored trajectory: records as in bdf_kernels.hip ({order, dt, T[6], Y[6][n]} per point) ---- */
+template <bool BWD>
+DEV double point_time(const Cw<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + 2]; }
+
+template <bool BWD>
+DEV int interp_y(Cw<BWD> &m, double t)
+{
+    if (m.have_last && t == m.last_t) return CV_SUCCESS;
+    m.n_interp++;
+    int newpoint = 0, indx;
+    if (m.newdata) {
+        m.ilast = m.np - 1; newpoint = 1; m.newdata = 0;
+        m.tlo = point_time(m, m.ilast - 1); m.thi = point_time(m, m.ilast);
+        m.tlo2 = (m.ilast >= 2) ? point_time(m, m.ilast - 2) : m.tlo;
+    }
+    const int ilast = m.ilast;
+    const bool to_left = (t - m.tlo) < 0.0;
+    const bool to_right = (t - m.thi) > 0.0;
+    indx = ilast;
+    if (to_left) {
+        newpoint = 1;
+        double tprev = m.tlo, tcur = m.thi;
+        for (;;) {
+            if (indx == 0) break;
+            if ((t - tprev) <= 0.0) {
+                indx--;
+                tcur = tprev;
+                if (indx > 0) tprev = (indx == ilast - 1) ? m.tlo2 : point_time(m, indx - 1);
+            } else break;
+        }
+        m.ilast = (indx == 0) ? 1 : indx;
+        if (indx == 0) {
+            m.tlo = tcur; m.thi = point_time(m, 1);
+            if (fabs(t - m.tlo) > FUZZ_FACTOR_ADJ * UROUND) return CV_GETY_BADT;
+        } else {
+            m.tlo = tprev; m.thi = tcur;
+        }
+    } else if (to_right) {
+        newpoint = 1;
+        double tcur = m.thi, tprev = m.tlo;
+        for (;;) {
+            if (indx >= m.np - 1) break;
+            if ((t - tcur) > 0.0) {
+                indx++;
+                tprev = tcur;
+                tcur = point_time(m, indx);
+            } else break;
+        }
+        m.ilast = indx;
+        m.tlo = tprev; m.thi = tcur;
+        if ((t - m.thi) > FUZZ_FACTOR_ADJ * UROUND * (fabs(m.tfinal) + 1.0)) return CV_GETY_BADT;
+    }
+    m.have_last = 1;
+    m.last_t = t;
+    if (indx == 0) {
+        SFOR(r, 0, RS) m.ytmp[r] = (IDX(m, r) < NS) ? m.traj[8 + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND
+        return CV_SUCCESS;
+    }
+    if (newpoint) {
+        m.n_rebuild++;
+        m.cur_idx = indx;
+        const double *r = m.traj + (int64_t)indx * m.trow;
+        SFOR(f, 0, 8) m.tab_hdr[f] = r[f]; SEND
+        SFOR(j, 0, (QMAX) + 1) {
+            SFOR(s, 0, RS) {
+                const int c = IDX(m, s) < NS ? IDX(m, s) : 0;
+                m.tabY[j][s] = r[8 + j * NS + c];
+            } SEND
+        } SEND
+        if (m.tab_hdr[0] > (double)indx) return CV_GETY_BADT;
+        if (indx == m.ilast) m.tlo2 = m.tab_hdr[4];
+    }
+    {
+        const int order = (int)m.tab_hdr[0];
+        const double inv_dt = 1.0 / m.tab_hdr[1];
+        double cvals[QMAX + 1];
+        cvals[0] = 1.0;
+        SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - m.tab_hdr[2 + i]) * inv_dt : 0.0; SEND
+        SFOR(s, 0, RS) {
+            double acc = cvals[0] * m.tabY[0][s];
+            SFOR(i, 1, (QMAX) + 1) acc = FMA(cvals[i], m.tabY[i][s], acc); SEND
+            m.ytmp[s] = (IDX(m, s) < NS) ? acc : 0.0;
+        } SEND
+    }
+    return CV_SUCCESS;
+}
+
+/* ---- callbacks: stage the inputs in LDS, evaluate, fetch the owned outputs ---- */
+template <bool BWD>
+DEV void stage_inputs(const Cw<BWD> &m, const double (&ymine)[RS])
+{
+    lds_sync();
+    SFOR(r, 0, RS) {
+        if (IDX(m, r) < NS) {
+            if constexpr (BWD) { s_y[IDX(m, r)] = m.ytmp[r]; s_lam[IDX(m, r)] = ymine[r]; }
+            else s_y[IDX(m, r)] = ymine[r];
+        }
+    } SEND
+    lds_sync();
+}
+
+template <bool BWD, int NSLOT, int N>
+DEV void fetch_output(const Cw<BWD> &m, double (&out)[NSLOT])
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    SFOR(r, 0, NSLOT) out[r] = (IDX(m, r) < N) ? m.obuf[IDX(m, r) < N ? IDX(m, r) : 0] : 0.0; SEND
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+template <bool BWD>
+DEV int cv_f(Cw<BWD> &m, double t, const double (&ymine)[RS], double (&out)[RS])
+{
+    m.nfe++;
+    stage_inputs(m, ymine);
+    int rc;
+    if constexpr (BWD) rc = sa_adj_rhs(t, nullptr, nullptr, nullptr, m.pr, VecOut{m.obuf});
+    else rc = sa_rhs(t, nullptr, nullptr, m.pr, VecOut{m.obuf});
+    fetch_output<BWD, RS, NS>(m, out);
+    return rc;
+}
+
+template <bool BWD>
+DEV int cv_fQ(Cw<BWD> &m, double t, const double (&ymine)[RS], double (&out)[RQ])
+{
+    m.nfQe++;
+    stage_inputs(m, ymine);
+    const int rc = sa_quad_rhs(t, nullptr, nullptr, nullptr, m.pr, VecOut{m.obuf});
+    fetch_output<BWD, RQ, (NQ > 0 ? NQ : 1)>(m, out);
+    return rc;
+}
+
+template <bool BWD>
+DEV int cv_jac(Cw<BWD> &m, double t, const double (&ymine)[RS])        /* Jacobian -> s_A */
+{
+    stage_inputs(m, ymine);
+    int rc;
+    if constexpr (BWD) rc = sa_adj_jac(t, nullptr, nullptr, m.pr, MatOut{});
+    else rc = sa_jac(t, nullptr, nullptr, m.pr, MatOut{});
+    lds_sync();
+    return rc;
+}
+
+/* ---- row-distributed dense LU in LDS (denseGETRF / denseGETRS semantics) ---- */
+#define AL(i, j) s_A[(j) * NS + (i)]
+#define LU_BATCH 4
+
+template <bool BWD>
+DEV int dense_getrf(Cw<BWD> &m)
+{
+    m.nswaps = 0;
+    for (int k = 0; k < NS; k++) {
+        /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF) */
+        double best = -1.0;
+        int bi = 1 << 20;
+        SFOR(r, 0, RS) {
+            const int i = IDX(m, r);
+            if (i >= k && i < NS) {
+                const double v = fabs(AL(i, k));
+                if (v > best) { best = v; bi = i; }
+            }
+        } SEND
+        SFOR(b, 0, 6) {
+            const double ov = shfl_d(best, m.lane ^ (1 << b));
+            const int oi = shfl_i(bi, m.lane ^ (1 << b));
+            const bool take = (ov > best) || (ov == best && oi < bi);
+            best = take ? ov : best;
+            bi = take ? oi : bi;
+        } SEND
+        const int l = __builtin_amdgcn_readfirstlane(bi);
+        if (m.lane == 0) s_piv[k] = (uint8_t)l;
+        if (best == 0.0) return k + 1;
+        if (l != k) {                   /* exchange rows k and l, one column per lane */
+            m.nswaps++;
+            lds_sync();
+            for (int c = m.lane; c < NS; c += 64) {
+                const double x = AL(k, c), y = AL(l, c);
+                AL(k, c) = y;
+                AL(l, c) = x;
+            }
+            lds_sync();
+        }
+        const double mult = 1.0 / AL(k, k);
+        double lcol[RS];
+        SFOR(r, 0, RS) {
+            const int i = IDX(m, r);
+            m.inv_piv[r] = (i == k) ? mult : m.inv_piv[r];
+            lcol[r] = 0.0;
+            if (i > k && i < NS) { lcol[r] = AL(i, k) * mult; AL(i, k) = lcol[r]; }
+        } SEND
+        /* elimination, LU_BATCH columns at a time: all reads of a batch before its writes */
+        int j = k + 1;
+        for (; j + LU_BATCH <= NS; j += LU_BATCH) {
+            double akj[LU_BATCH], x[LU_BATCH][RS];
+            SFOR(u, 0, LU_BATCH) {
+                akj[u] = AL(k, j + u);
+                SFOR(r, 0, RS) { const int i = IDX(m, r); x[u][r] = (i > k && i < NS) ? AL(i, j + u) : 0.0; } SEND
+            } SEND
+            SFOR(u, 0, LU_BATCH) {
+                if (akj[u] != 0.0) {
+                    SFOR(r, 0, RS) {
+                        const int i = IDX(m, r);
+                        if (i > k && i < NS) AL(i, j + u) = FMA(-akj[u], lcol[r], x[u][r]);
+                    } SEND
+                }
+            } SEND
+        }
+        for (; j < NS; j++) {
+            const double a_kj = AL(k, j);
+            if (a_kj != 0.0) {
+                SFOR(r, 0, RS) {
+                    const int i = IDX(m, r);
+                    if (i > k && i < NS) AL(i, j) = FMA(-a_kj, lcol[r], AL(i, j));
+                } SEND
+            }
+        }
+        lds_sync();
+    }
+    return 0;
+}
+
+/* component k (wave-uniform k) of a lane-distributed vector */
+DEV double bcast_vec(const double (&b)[RS], int k)
+{
+    double v = b[0];
+    SFOR(r, 1, RS) v = ((k >> 6) == r) ? b[r] : v; SEND
+    return readlane_d(v, k & 63);
+}
+
+template <bool BWD>
+DEV void dense_getrs(const Cw<BWD> &m, double (&b)[RS])
+{
+    if (m.nswaps != 0) {               /* row permutation through the LDS scratch vector */
+        lds_sync();
+        SFOR(r, 0, RS) { if (IDX(m, r) < NS) s_lam[IDX(m, r)] = b[r]; } SEND
+        lds_sync();
+        for (int k = 0; k < NS; k++) {
+            const int pk = s_piv[k];
+            if (pk != k) {
+                const double bk = s_lam[k], bp = s_lam[pk];
+                lds_sync();
+                if (m.lane == 0) { s_lam[k] = bp; s_lam[pk] = bk; }
+                lds_sync();
+            }
+        }
+        SFOR(r, 0, RS) { if (IDX(m, r) < NS) b[r] = s_lam[IDX(m, r)]; } SEND
+        lds_sync();
+    }
+    for (int k = 0; k < NS - 1; k++) {
+        const double bk = bcast_vec(b, k);
+        SFOR(r, 0, RS) {
+            const int i = IDX(m, r);
+            if (i > k && i < NS) b[r] = FMA(-AL(i, k), bk, b[r]);
+        } SEND
+    }
+    for (int k = NS - 1; k > 0; k--) {
+        SFOR(r, 0, RS) { if (IDX(m, r) == k) b[r] *= m.inv_piv[r]; } SEND
+        const double bk = bcast_vec(b, k);
+        SFOR(r, 0, RS) {
+            const int i = IDX(m, r);
+            if (i < k) b[r] = FMA(-AL(i, k), bk, b[r]);
+        } SEND
+    }
+    if (m.lane == 0) b[0] *= m.inv_piv[0];
+}
+
+/* ---- CVodeInit / CVodeReInit ---- */
+template <bool BWD>
+DEV void cv_reinit(Cw<BWD> &m, double t0, const double (&y0)[RS], const double (&q0)[RQ])
+{
+    m.tn = t0;
+    m.q = 1; m.L = 2; m.qwait = 2; m.etamax = ETAMX1;
+    m.qu = 0; m.hu = 0.0;
+    SFOR(j, 0, (QMAX) + 1) {
+        SFOR(r, 0, RS) m.zn[j][r] = 0.0; SEND
+        SFOR(r, 0, RQ) m.znQ[j][r] = 0.0; SEND
+    } SEND
+    SFOR(r, 0, RS) m.zn[0][r] = y0[r]; SEND
+    if (BWD) { SFOR(r, 0, RQ) m.znQ[0][r] = q0[r]; SEND }
+    m.nst = m.nfe = m.ncfn = m.netf = m.nni = m.nsetups = 0;
+    m.nje = 0; m.nstlp = 0; m.nstlj = 0; m.nfQe = m.netfQ = 0;
+    m.h = 0.0; m.hprime = 0.0; m.hscale = 0.0; m.eta = 1.0;
+    m.qprime = 1;
+    m.gamma = m.gammap = 0.0; m.gamrat = 1.0; m.crate = 1.0; m.delp = 0.0;
+    m.acnrm = 0.0; m.saved_tq5 = 0.0;
+    m.jcur = 0; m.nls_jcur = 0;
+    SFOR(i, 0, 7) { m.tau[i] = 0.0; m.l[i] = 0.0; } SEND
+    SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
+    SFOR(r, 0, RS) { m.acor[r] = m.tempv[r] = m.ftemp[r] = m.y[r] = m.zsave[r] = 0.0; } SEND
+    SFOR(r, 0, RQ) { m.acorQ[r] = m.tempvQ[r] = m.zsaveQ[r] = 0.0; } SEND
+}
+
+/* ---- cvHin ---- */
+template <bool BWD>
+DEV double cv_upper_bound_h0(Cw<BWD> &m, double tdist)
+{
+    double w[RS];
+    ewt_set(m, m.zn[0], w);
+    double loc = 0.0;
+    SFOR(r, 0, RS) {
+        const double t1 = FMA(HUB_FACTOR, fabs(m.zn[0][r]), 1.0 / w[r]);
+        const double v = (IDX(m, r) < NS) ? fabs(m.zn[1][r]) / t1 : 0.0;
+        loc = v > loc ? v : loc;
+    } SEND
+    double hub_inv = wave_max(m.lane, loc);
+    if (BWD) {
+        double wq[RQ];
+        ewtQ_set(m, m.znQ[0], wq);
+        double locq = 0.0;
+        SFOR(r, 0, RQ) {
+            const double t1q = FMA(HUB_FACTOR, fabs(m.znQ[0][r]), 1.0 / wq[r]);
+            const double v = (IDX(m, r) < NQ) ? fabs(m.znQ[1][r]) / t1q : 0.0;
+            locq = v > locq ? v : locq;
+        } SEND
+        const double hubQ_inv = wave_max(m.lane, locq);
+        if (hubQ_inv > hub_inv) hub_inv = hubQ_inv;
+    }
+    double hub = HUB_FACTOR * tdist;
+    if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
+    return hub;
+}
+
+template <bool BWD>
+DEV int cv_ydd_norm(Cw<BWD> &m, double hg, double *yddnrm)
+{
+    SFOR(r, 0, RS) m.y[r] = FMA(hg, m.zn[1][r], m.zn[0][r]); SEND
+    if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+    int retval = cv_f(m, m.tn + hg, m.y, m.tempv);
+    if (retval < 0) return CV_RHSFUNC_FAIL;
+    if (retval > 0) return RHSFUNC_RECVR;
+    if (BWD) {
+        retval = cv_fQ(m, m.tn + hg, m.y, m.tempvQ);
+        if (retval < 0) return CV_QRHSFUNC_FAIL;
+        if (retval > 0) return QRHSFUNC_RECVR;
+    }
+    SFOR(r, 0, RS) {
+        m.tempv[r] = m.tempv[r] - m.zn[1][r];
+        m.tempv[r] = (1.0 / hg) * m.tempv[r];
+    } SEND
+    *yddnrm = wrms_n(m, m.tempv, m.ewt);
+    if (BWD) {
+        SFOR(r, 0, RQ) {
+            m.tempvQ[r] = m.tempvQ[r] - m.znQ[1][r];
+            m.tempvQ[r] = (1.0 / hg) * m.tempvQ[r];
+        } SEND
+        *yddnrm = quad_update_norm(m, *yddnrm, m.tempvQ);
+    }
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_hin(Cw<BWD> &m, double tout)
+{
+    double tdiff = tout - m.tn;
+    if (tdiff == 0.0) return CV_TOO_CLOSE;
+    double sign = (tdiff > 0.0) ? 1.0 : -1.0;
+    double tdist = fabs(tdiff);
+    double tround = UROUND * fmax(fabs(m.tn), fabs(tout));
+    if (tdist < 2.0 * tround) return CV_TOO_CLOSE;
+    double hlb = HLB_FACTOR * tround;
+    double hub = cv_upper_bound_h0(m, tdist);
+    double hg = sqrt(hlb * hub);
+    if (hub < hlb) {
+        m.h = (sign < 0.0) ? -hg : hg;
+        return CV_SUCCESS;
+    }
+    double hs = hg, hnew = hg, yddnrm = 0.0;
+    int result = 1;
+    for (int count1 = 1; count1 <= HIN_MAX_ITERS && result == 1; count1++) {
+        int hgOK = 0;
+        for (int count2 = 1; count2 <= HIN_MAX_ITERS; count2++) {
+            double hgs = hg * sign;
+            int retval = cv_ydd_norm(m, hgs, &yddnrm);
+            if (retval < 0) { result = CV_RHSFUNC_FAIL; break; }
+            if (retval == CV_SUCCESS) { hgOK = 1; break; }
+            hg *= 0.2;
+        }
+        if (result != 1) break;
+        if (!hgOK) {
+            if (count1 <= 2) { result = CV_REPTD_RHSFUNC_ERR; break; }
+            hnew = hs;
+            result = 0;
+            break;
+        }
+        hs = hg;
+        hnew = (yddnrm * hub * hub > 2.0) ? sqrt(2.0 / yddnrm) : sqrt(hg * hub);
+        if (count1 == HIN_MAX_ITERS) { result = 0; break; }
+        double hrat = hnew / hg;
+        if ((hrat > 0.5) && (hrat < 2.0)) { result = 0; break; }
+        if ((count1 > 1) && (hrat > 2.0)) { hnew = hg; result = 0; break; }
+        hg = hnew;
+    }
+    if (result < 0) return result;
+    double h0 = H_BIAS * hnew;
+    if (h0 < hlb) h0 = hlb;
+    if (h0 > hub) h0 = hub;
+    if (sign < 0.0) h0 = -h0;
+    m.h = h0;
+    return CV_SUCCESS;
+}
+
+/* ---- Nordsieck array manipulation (columns j > q are kept at zero, see bdf_kernels.hip) ---- */
+template <bool BWD>
+DEV void cv_rescale(Cw<BWD> &m)
+{
+    double factor = m.eta;
+    SFOR(j, 1, (QMAX) + 1) {
+        SFOR(r, 0, RS) m.zn[j][r] *= factor; SEND
+        if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] *= factor; SEND }
+        factor *= m.eta;
+    } SEND
+    m.h = m.hscale * m.eta;
+    m.hscale = m.h;
+}
+
+template <bool BWD>
+DEV void cv_increase_bdf(Cw<BWD> &m)
+{
+    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
+    double alpha1 = 1.0, prod = 1.0, xiold = 1.0, alpha0 = -1.0, hsum = m.hscale;
+    m.l[2] = 1.0;
+    SFOR(j, 1, QMAX - 1) {
+        if (j < m.q) {
+            hsum += m.tau[j + 1];
+            double xi = hsum / m.hscale;
+            prod *= xi;
+            alpha0 -= 1.0 / (j + 1);
+            alpha1 += 1.0 / xi;
+            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xiold, m.l[i - 1]); SEND
+            xiold = xi;
+        }
+    } SEND
+    const double A1 = (-alpha0 - alpha1) / prod;
+    const int L = m.L;
+    double znL[RS], znQL[RQ];
+    SFOR(r, 0, RS) znL[r] = A1 * m.zsave[r]; SEND
+    SFOR(r, 0, RQ) znQL[r] = BWD ? A1 * m.zsaveQ[r] : 0.0; SEND
+    SFOR(j, 2, (QMAX) + 1) {
+        if (j == L) {
+            SFOR(r, 0, RS) m.zn[j][r] = znL[r]; SEND
+            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = znQL[r]; SEND }
+        }
+    } SEND
+    SFOR(j, 2, QMAX) {
+        if (j <= m.q) {
+            SFOR(r, 0, RS) m.zn[j][r] = FMA(m.l[j], znL[r], m.zn[j][r]); SEND
+            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(m.l[j], znQL[r], m.znQ[j][r]); SEND }
+        }
+    } SEND
+}
+
+template <bool BWD>
+DEV void cv_decrease_bdf(Cw<BWD> &m)
+{
+    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
+    m.l[2] = 1.0;
+    double hsum = 0.0;
+    SFOR(j, 1, (QMAX - 2) + 1) {
+        if (j <= m.q - 2) {
+            hsum += m.tau[j];
+            double xi = hsum / m.hscale;
+            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xi, m.l[i - 1]); SEND
+        }
+    } SEND
+    double znq[RS], znQq[RQ];
+    SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
+    SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
+    SFOR(j, 2, QMAX) {
+        if (j < m.q) {
+            SFOR(r, 0, RS) m.zn[j][r] = FMA(-m.l[j], znq[r], m.zn[j][r]); SEND
+            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(-m.l[j], znQq[r], m.znQ[j][r]); SEND }
+        }
+    } SEND
+}
+
+template <bool BWD>
+DEV void cv_clear_column(Cw<BWD> &m, int q_old)
+{
+    SFOR(j, 2, (QMAX) + 1) {
+        if (j == q_old) {
+            SFOR(r, 0, RS) m.zn[j][r] = 0.0; SEND
+            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = 0.0; SEND }
+        }
+    } SEND
+}
+
+template <bool BWD>
+DEV void cv_adjust_order(Cw<BWD> &m, int deltaq)
+{
+    if ((m.q == 2) && (deltaq != 1)) return;
+    if (deltaq == 1) cv_increase_bdf(m);
+    else if (deltaq == -1) cv_decrease_bdf(m);
+}
+
+template <bool BWD>
+DEV void cv_predict(Cw<BWD> &m)
+{
+    m.tn += m.h;
+    if (BWD) {
+        if ((m.tn - m.tstop) * m.h > 0.0) m.tn = m.tstop;
+    }
+    SFOR(k, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, k) {
+            SFOR(r, 0, RS) m.zn[j - 1][r] = m.zn[j - 1][r] + m.zn[j][r]; SEND
+            if (BWD) { SFOR(r, 0, RQ) m.znQ[j - 1][r] = m.znQ[j - 1][r] + m.znQ[j][r]; SEND }
+        } SEND
+    } SEND
+}
+
+template <bool BWD>
+DEV void cv_restore(Cw<BWD> &m, double saved_t)
+{
+    m.tn = saved_t;
+    SFOR(k, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, k) {
+            SFOR(r, 0, RS) m.zn[j - 1][r] = m.zn[j - 1][r] - m.zn[j][r]; SEND
+            if (BWD) { SFOR(r, 0, RQ) m.znQ[j - 1][r] = m.znQ[j - 1][r] - m.znQ[j][r]; SEND }
+        } SEND
+    } SEND
+}
+
+/* ---- linear solver interface ---- */
+#define COPY_BATCH 8
+template <bool BWD>
+DEV int cv_lsetup(Cw<BWD> &m, int convfail)
+{
+    double dgamma = fabs((m.gamma / m.gammap) - 1.0);
+    int jbad = (m.nst == 0) || (m.nst > m.nstlj + MSBJ) ||
+               ((convfail == CV_FAIL_BAD_J) && (dgamma < CVLS_DGMAX)) ||
+               (convfail == CV_FAIL_OTHER);
+    int jret = 0;
+    const double c = -m.gamma;
+    lds_sync();
+    if (!jbad) {
+        m.jcur = 0;
+        /* A = I - gamma * savedJ, streamed from the workspace (COPY_BATCH loads in flight per lane) */
+        int base = 0;
+        for (; base + COPY_BATCH * 64 <= NS * NS; base += COPY_BATCH * 64) {
+            double v[COPY_BATCH];
+            SFOR(u, 0, COPY_BATCH) v[u] = m.sj[base + u * 64 + m.lane]; SEND
+            SFOR(u, 0, COPY_BATCH) {
+                const int idx = base + u * 64 + m.lane;
+                s_A[idx] = (idx % NS == idx / NS) ? FMA(c, v[u], 1.0) : v[u] * c;
+            } SEND
+        }
+        for (int idx = base + m.lane; idx < NS * NS; idx += 64) {
+            const double v = m.sj[idx];
+            s_A[idx] = (idx % NS == idx / NS) ? FMA(c, v, 1.0) : v * c;
+        }
+    } else {
+        m.nje++;
+        m.nstlj = m.nst;
+        m.jcur = 1;
+        jret = cv_jac(m, m.tn, m.y);
+        if (jret == 0) {
+            for (int idx = m.lane; idx < NS * NS; idx += 64) {
+                const double v = s_A[idx];
+                m.sj[idx] = v;
+                s_A[idx] = (idx % NS == idx / NS) ? FMA(c, v, 1.0) : v * c;
+            }
+        }
+    }
+    lds_sync();
+    if (jret < 0) return -1;
+    if (jret > 0) return 1;
+    int ier = dense_getrf(m);
+    return ier > 0 ? 1 : 0;
+}
+
+template <bool BWD>
+DEV int cv_nls_lsetup(Cw<BWD> &m, int jbad, int &convfail)
+{
+    if (jbad) convfail = CV_FAIL_BAD_J;
+    int retval = cv_lsetup(m, convfail);
+    m.nsetups++;
+    m.nls_jcur = m.jcur;
+    m.gamrat = 1.0;
+    m.gammap = m.gamma;
+    m.crate = 1.0;
+    m.nstlp = m.nst;
+    if (retval < 0) return CV_LSETUP_FAIL;
+    if (retval > 0) return NLS_CONV_RECVR;
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_nls_residual(Cw<BWD> &m, double (&res)[RS])
+{
+    SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
+    int retval = cv_f(m, m.tn, m.y, m.ftemp);
+    if (retval < 0) return CV_RHSFUNC_FAIL;
+    if (retval > 0) return RHSFUNC_RECVR;
+    SFOR(r, 0, RS) {
+        res[r] = FMA(m.rl1, m.zn[1][r], m.acor[r]);
+        res[r] = FMA(-m.gamma, m.ftemp[r], res[r]);
+    } SEND
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_newton_pass(Cw<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
+{
+    double delta[RS];
+    in_loop = 0;
+    SFOR(r, 0, RS) m.acor[r] = 0.0; SEND
+    int retval = cv_nls_residual(m, delta);
+    if (retval != CV_SUCCESS) return retval;
+    if (callSetup) {
+        retval = cv_nls_lsetup(m, jbad, convfail);
+        if (retval != CV_SUCCESS) return retval;
+    }
+    int curiter = 0;
+    in_loop = 1;
+    for (;;) {
+        m.nni++;
+        SFOR(r, 0, RS) delta[r] = -1.0 * delta[r]; SEND
+        dense_getrs(m, delta);
+        if (m.gamrat != 1.0) {
+            double s = 2.0 / (1.0 + m.gamrat);
+            SFOR(r, 0, RS) delta[r] *= s; SEND
+        }
+        SFOR(r, 0, RS) m.acor[r] = m.acor[r] + delta[r]; SEND
+        double del = wrms_n(m, delta, m.ewt);
+        if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
+        double dcon = del * fmin(1.0, m.crate) * m.tq[4];
+        if (dcon <= 1.0) {
+            m.acnrm = (curiter == 0) ? del : wrms_n(m, m.acor, m.ewt);
+            m.nls_jcur = 0;
+            return CV_SUCCESS;
+        }
+        if ((curiter >= 1) && (del > RDIV * m.delp)) return NLS_CONV_RECVR;
+        m.delp = del;
+        curiter++;
+        if (curiter >= NLS_MAXCOR) return NLS_CONV_RECVR;
+        retval = cv_nls_residual(m, delta);
+        if (retval != CV_SUCCESS) return retval;
+    }
+}
+
+template <bool BWD>
+DEV int cv_error_test_failed(Cw<BWD> &m, double saved_t, double dsm, int &nef, int &netf_counter)
+{
+    nef++;
+    netf_counter++;
+    cv_restore(m, saved_t);
+    if (nef == MXNEF) return CV_ERR_FAILURE;
+    m.etamax = 1.0;
+    if (nef <= MXNEF1) {
+        m.eta = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
+        m.eta = fmax(ETAMIN, m.eta);
+        if (nef >= SMALL_NEF) m.eta = fmin(m.eta, ETAMXF);
+        cv_rescale(m);
+        return 0;
+    }
+    if (m.q > 1) {
+        m.eta = ETAMIN;
+        cv_adjust_order(m, -1);
+        cv_clear_column(m, m.q);
+        m.L = m.q;
+        m.q--;
+        m.qwait = m.L;
+        cv_rescale(m);
+        return 0;
+    }
+    m.eta = ETAMIN;
+    m.h *= m.eta;
+    m.hscale = m.h;
+    m.qwait = LONG_WAIT;
+    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+    int retval = cv_f(m, m.tn, m.zn[0], m.tempv);
+    if (retval < 0) return CV_RHSFUNC_FAIL;
+    if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
+    SFOR(r, 0, RS) m.zn[1][r] = m.h * m.tempv[r]; SEND
+    if (BWD) {
+        retval = cv_fQ(m, m.tn, m.zn[0], m.tempvQ);
+        if (retval < 0) return CV_QRHSFUNC_FAIL;
+        if (retval > 0) return CV_UNREC_QRHSFUNC_ERR;
+        SFOR(r, 0, RQ) m.znQ[1][r] = m.h * m.tempvQ[r]; SEND
+    }
+    return 0;
+}
+
+template <bool BWD>
+DEV void cv_complete_step(Cw<BWD> &m)
+{
+    m.nst++;
+    m.hu = m.h;
+    m.qu = m.q;
+    SFOR_DOWN(i, QMAX, 2) m.tau[i] = (i <= m.q) ? m.tau[i - 1] : m.tau[i]; SEND
+    m.tau[2] = ((m.q == 1) && (m.nst > 1)) ? m.tau[1] : m.tau[2];
+    m.tau[1] = m.h;
+    SFOR(j, 0, (QMAX) + 1) {
+        SFOR(r, 0, RS) m.zn[j][r] = FMA(m.l[j], m.acor[r], m.zn[j][r]); SEND
+        if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(m.l[j], m.acorQ[r], m.znQ[j][r]); SEND }
+    } SEND
+    m.qwait--;
+    {
+        const bool sv = (m.qwait == 1) && (m.q != QMAX);
+        SFOR(r, 0, RS) m.zsave[r] = sv ? m.acor[r] : m.zsave[r]; SEND
+        if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = sv ? m.acorQ[r] : m.zsaveQ[r]; SEND }
+        m.saved_tq5 = sv ? m.tq[5] : m.saved_tq5;
+    }
+}
+
+template <bool BWD>
+DEV void cv_set_eta(Cw<BWD> &m)
+{
+    if (m.eta < THRESH) {
+        m.eta = 1.0;
+        m.hprime = m.h;
+    } else {
+        m.eta = fmin(m.eta, m.etamax);
+        m.hprime = m.h * m.eta;
+    }
+}
+
+template <bool BWD>
+DEV void cv_prepare_next_step(Cw<BWD> &m, double dsm)
+{
+    if (m.etamax == 1.0) {
+        m.qwait = m.qwait > 2 ? m.qwait : 2;
+        m.qprime = m.q;
+        m.hprime = m.h;
+        m.eta = 1.0;
+        return;
+    }
+    m.etaq = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
+    if (m.qwait != 0) {
+        m.eta = m.etaq;
+        m.qprime = m.q;
+        cv_set_eta(m);
+        return;
+    }
+    m.qwait = 2;
+    m.etaqm1 = 0.0;
+    if (m.q > 1) {
+        double znq[RS], znQq[RQ];
+        SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
+        SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
+        double ddn = wrms_n(m, znq, m.ewt);
+        if (BWD) ddn = quad_update_norm(m, ddn, znQq);
+        ddn = ddn * m.tq[1];
+        m.etaqm1 = 1.0 / (rpower_r(BIAS1 * ddn, inv_int(m.q)) + ADDON);
+    }
+    m.etaqp1 = 0.0;
+    if (m.q != QMAX) {
+        if (m.saved_tq5 != 0.0) {
+            double base = m.h / m.tau[2];
+            double pw = 1.0;
+            SFOR(i, 1, (QMAX + 1) + 1) { if (i <= m.L) pw *= base; } SEND
+            double cquot = (m.tq[5] / m.saved_tq5) * pw;
+            SFOR(r, 0, RS) m.tempv[r] = FMA(-cquot, m.zsave[r], m.acor[r]); SEND
+            double dup = wrms_n(m, m.tempv, m.ewt);
+            if (BWD) {
+                SFOR(r, 0, RQ) m.tempvQ[r] = FMA(-cquot, m.zsaveQ[r], m.acorQ[r]); SEND
+                dup = quad_update_norm(m, dup, m.tempvQ);
+            }
+            dup = dup * m.tq[3];
+            m.etaqp1 = 1.0 / (rpower_r(BIAS3 * dup, inv_int(m.L + 1)) + ADDON);
+        }
+    }
+    double etam = fmax(m.etaqm1, fmax(m.etaq, m.etaqp1));
+    if (etam < THRESH) {
+        m.eta = 1.0;
+        m.qprime = m.q;
+    } else if (etam == m.etaq) {
+        m.eta = m.etaq;
+        m.qprime = m.q;
+    } else if (etam == m.etaqm1) {
+        m.eta = m.etaqm1;
+        m.qprime = m.q - 1;
+    } else {
+        m.eta = m.etaqp1;
+        m.qprime = m.q + 1;
+        SFOR(r, 0, RS) m.zsave[r] = m.acor[r]; SEND
+        if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = m.acorQ[r]; SEND }
+    }
+    cv_set_eta(m);
+}
+
+template <bool BWD>
+DEV int cv_get_dky0(const Cw<BWD> &m, double t, double (&dky)[RS], double (&dkyQ)[RQ])
+{
+    double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.hu));
+    if (m.hu < 0.0) tfuzz = -tfuzz;
+    double tp = m.tn - m.hu - tfuzz;
+    double tn1 = m.tn + tfuzz;
+    if ((t - tp) * (t - tn1) > 0.0) return CV_BAD_T;
+    double s = (t - m.tn) / m.h;
+    double pw[QMAX + 1];
+    pw[0] = 1.0;
+    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
+    SFOR(r, 0, RS) {
+        double acc = pw[QMAX] * m.zn[QMAX][r];
+        SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.zn[j][r], acc); SEND
+        dky[r] = acc;
+    } SEND
+    if (BWD) {
+        SFOR(r, 0, RQ) {
+            double acc = pw[QMAX] * m.znQ[QMAX][r];
+            SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.znQ[j][r], acc); SEND
+            dkyQ[r] = acc;
+        } SEND
+    }
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_first_call(Cw<BWD> &m, double tout)
+{
+    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
+    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
+    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+    int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
+    if (retval < 0) return CV_RHSFUNC_FAIL;
+    if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+    if (BWD) {
+        retval = cv_fQ(m, m.tn, m.zn[0], m.znQ[1]);
+        if (retval < 0) return CV_QRHSFUNC_FAIL;
+        if (retval > 0) return CV_FIRST_QRHSFUNC_ERR;
+    }
+    double tout_hin = tout;
+    if (BWD) {
+        if ((m.tstop - m.tn) * (tout - m.tn) <= 0.0) return CV_ILL_INPUT;
+        if ((tout - m.tn) * (tout - m.tstop) > 0.0) tout_hin = m.tstop;
+    }
+    int hflag = cv_hin(m, tout_hin);
+    if (hflag != CV_SUCCESS) return hflag;
+    if (BWD) {
+        if ((m.tn + m.h - m.tstop) * m.h > 0.0) m.h = (m.tstop - m.tn) * (1.0 - 4.0 * UROUND);
+    }
+    m.hscale = m.h;
+    m.hprime = m.h;
+    SFOR(r, 0, RS) m.zn[1][r] = m.h * m.zn[1][r]; SEND
+    if (BWD) { SFOR(r, 0, RQ) m.znQ[1][r] = m.h * m.znQ[1][r]; SEND }
+    return CV_SUCCESS;
+}
+
+template <bool BWD>
+DEV int cv_pre_step(Cw<BWD> &m)
+{
+    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
+    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
+    double nrm = wrms_n(m, m.zn[0], m.ewt);
+    if (BWD) nrm = quad_update_norm(m, nrm, m.znQ[0]);
+    if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
+    return CV_SUCCESS;
+}
+
+struct StepCtl {
+    int in_step, redo, nflag, ncf, nef, nefQ, convfail;
+    double saved_t;
+};
+
+template <bool BWD>
+DEV int cv_handle_nflag_failed(Cw<BWD> &m, StepCtl &c, int nflag)
+{
+    m.ncfn++;
+    cv_restore(m, c.saved_t);
+    if (nflag < 0) return nflag;
+    c.ncf++;
+    m.etamax = 1.0;
+    if (c.ncf == MXNCF) {
+        if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
+        if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
+        return CV_REPTD_QRHSFUNC_ERR;
+    }
+    m.eta = ETACF;
+    c.nflag = PREV_CONV_FAIL;
+    cv_rescale(m);
+    return 0;
+}
+
+/* one step ATTEMPT; 1 = step completed, 0 = call again, <0 = unrecoverable (see bdf_kernels.hip) */
+template <bool BWD>
+DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
+{
+    if (!c.in_step) {
+        c.saved_t = m.tn;
+        c.ncf = c.nef = c.nefQ = 0;
+        c.nflag = FIRST_CALL;
+        c.redo = 0;
+        if ((m.nst > 0) && (m.hprime != m.h)) {
+            if (m.qprime != m.q) {
+                cv_adjust_order(m, m.qprime - m.q);
+                if (m.qprime < m.q) cv_clear_column(m, m.q);
+                m.q = m.qprime;
+                m.L = m.q + 1;
+                m.qwait = m.L;
+            }
+            cv_rescale(m);
+        }
+        c.in_step = 1;
+    }
+    int callSetup, jbad;
+    if (!c.redo) {
+        cv_predict(m);
+        cv_set(m);
+        if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+        c.convfail = ((c.nflag == FIRST_CALL) || (c.nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
+        callSetup = (c.nflag == PREV_CONV_FAIL) || (c.nflag == PREV_ERR_FAIL) || (m.nst == 0) ||
+                    (m.nst >= m.nstlp + MSBP) || (fabs(m.gamrat - 1.0) > DGMAX);
+        jbad = 0;
+    } else {
+        callSetup = 1;
+        jbad = 1;
+    }
+    int in_loop;
+    int nls = cv_newton_pass(m, callSetup, jbad, c.convfail, in_loop);
+    if ((nls > 0) && in_loop && !m.nls_jcur) {
+        c.redo = 1;
+        return 0;
+    }
+    c.redo = 0;
+    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls);
+
+    SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
+    double dsm = m.acnrm * m.tq[2];
+    if (dsm > 1.0) {
+        c.nflag = PREV_ERR_FAIL;
+        return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
+    }
+    if (BWD) {
+        c.ncf = c.nef = 0;
+        int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
+        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR);
+        SFOR(r, 0, RQ) {
+            m.acorQ[r] = FMA(m.h, m.acorQ[r], -m.znQ[1][r]);
+            m.acorQ[r] = m.rl1 * m.acorQ[r];
+        } SEND
+        double acnrmQ = wrms_q(m, m.acorQ, m.ewtQ);
+        double dsmQ = acnrmQ * m.tq[2];
+        if (dsmQ > 1.0) {
+            c.nflag = PREV_ERR_FAIL;
+            return cv_error_test_failed(m, c.saved_t, dsmQ, c.nefQ, m.netfQ);
+        }
+        if (dsmQ > dsm) dsm = dsmQ;
+    }
+    cv_complete_step(m);
+    cv_prepare_next_step(m, dsm);
+    m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
+    SFOR(r, 0, RS) m.acor[r] = m.tq[2] * m.acor[r]; SEND
+    if (BWD) { SFOR(r, 0, RQ) m.acorQ[r] = m.tq[2] * m.acorQ[r]; SEND }
+    c.in_step = 0;
+    return 1;
+}
+
+template <bool BWD>
+DEV void accumulate_stats(const Cw<BWD> &m, int64_t *acc)
+{
+    acc[ST_NST] += m.nst; acc[ST_NFE] += m.nfe; acc[ST_NSETUPS] += m.nsetups; acc[ST_NJE] += m.nje;
+    acc[ST_NNI] += m.nni; acc[ST_NCFN] += m.ncfn; acc[ST_NETF] += m.netf; acc[ST_QLAST] = m.qu;
+    acc[ST_NFQE] += m.nfQe; acc[ST_NETFQ] += m.netfQ;
+}
+
+template <bool BWD>
+DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_stride, int inst, double *ws)
+{
+    m.lane = lane_id();
+    m.pr = pr + (int64_t)inst * rem_stride;
+    m.sj = ws + (int64_t)inst * WS_DOUBLES + WS_SJ;
+    m.obuf = ws + (int64_t)inst * WS_DOUBLES + WS_OUT;
+    for (int j = m.lane; j < NQ; j += 64) s_ps[j] = ps[(int64_t)inst * NQ + j];
+    m.nswaps = 0;
+    SFOR(r, 0, RS) { m.inv_piv[r] = 0.0; m.ytmp[r] = 0.0; m.ewt[r] = 0.0; } SEND
+    SFOR(r, 0, RQ) m.ewtQ[r] = 0.0; SEND
+    SFOR(f, 0, 8) m.tab_hdr[f] = (f == 1) ? 1.0 : 0.0; SEND
+    SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) m.tabY[j][r] = 0.0; SEND } SEND
+    lds_sync();
+}
+
+/* forward: trajectory record of the newest point (see bdf_kernels.hip::store_table) */
+DEV void store_table(double *rec, int lane, int order, double dt, const double (&hT)[QMAX + 1],
+                     const double (&hY)[QMAX + 1][RS])
+{
+    double Y[QMAX + 1][RS];
+    SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) Y[j][r] = hY[j][r]; SEND } SEND
+    SFOR(i, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, 1) {
+            if constexpr (j >= i) {
+                if (j <= order) {
+                    double factor = dt / (hT[j] - hT[j - i]);
+                    SFOR(r, 0, RS) Y[j][r] = factor * (Y[j][r] - Y[j - 1][r]); SEND
+                }
+            }
+        } SEND
+    } SEND
+    if (lane == 0) {
+        rec[0] = (double)order;
+        rec[1] = dt;
+        SFOR(j, 0, (QMAX) + 1) rec[2 + j] = hT[j]; SEND
+    }
+    SFOR(r, 0, RS) {
+        const int i = r * 64 + lane;
+        if (i < NS) { SFOR(j, 0, (QMAX) + 1) rec[8 + j * NS + i] = Y[j][r]; SEND }
+    } SEND
+}
+
+/* ------------------------------------------------------------------------------------ */
+extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
+{
+    const int inst = blockIdx.x;
+    if (inst >= a.B) return;
+    Cw<false> m;
+    setup_common(m, a.ps, a.pr, a.rem_stride, inst, a.ws);
+    m.rtol = a.rtol;
+    SFOR(r, 0, RS) m.atol[r] = (IDX(m, r) < NS) ? a.atol[IDX(m, r) < NS ? IDX(m, r) : 0] : 1.0; SEND
+    m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0;
+    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
+    m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
+    m.traj = nullptr; m.trow = 0;
+
+    double y0[RS], q0[RQ];
+    SFOR(r, 0, RS) y0[r] = (IDX(m, r) < NS) ? a.y0[(int64_t)inst * NS + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND
+    SFOR(r, 0, RQ) q0[r] = 0.0; SEND
+    cv_reinit(m, a.t0, y0, q0);
+
+    const bool store = (a.mode == SA_MODE_ADJ_FWD);
+    double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
+    double *trec = a.traj + (int64_t)inst * TREC;
+    const int64_t trow = a.traj_stride * TREC;
+    double hT[QMAX + 1], hY[QMAX + 1][RS];
+    SFOR(j, 0, (QMAX) + 1) { hT[j] = 0.0; SFOR(r, 0, RS) hY[j][r] = 0.0; SEND } SEND
+
+    int status = CV_SUCCESS, k = 0, np = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
+    while (k < a.n_t && a.tvals[k] == a.t0) {
+        SFOR(r, 0, RS) { if (IDX(m, r) < NS) yo[(int64_t)k * NS + IDX(m, r)] = y0[r]; } SEND
+        k++;
+    }
+    bool done = (k >= a.n_t);
+    StepCtl c;
+    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0; c.saved_t = a.t0;
+    if (!done) {
+        int flag = cv_first_call(m, a.tvals[k]);
+        if (flag != CV_SUCCESS) { status = flag; done = true; }
+        else if (store) {
+            hT[0] = m.tn;
+            SFOR(r, 0, RS) hY[0][r] = m.zn[0][r]; SEND
+            store_table(trec, m.lane, 0, 1.0, hT, hY);
+            np = 1;
+        }
+    }
+    while (!done) {
+        if (!c.in_step) {
+            int ier = cv_pre_step(m);
+            if (ier == CV_ILL_INPUT) { status = ier; done = true; }
+            else if (!store && a.mxstep > 0 && nstloc >= a.mxstep) {
+                retries++; total_retries++;
+                if (retries >= a.max_retries) { status = CV_TOO_MUCH_WORK; done = true; }
+                else nstloc = 0;
+            }
+            if (!done && ier != CV_SUCCESS) { status = ier; done = true; }
+        }
+        if (!done) {
+            attempts++;
+            int r = cv_attempt(m, c);
+            if (r < 0) { status = r; done = true; }
+            else if (r == 1) {
+                nstloc++;
+                if (store) {
+                    if (np >= a.traj_cap) { status = CV_TOO_MUCH_WORK; done = true; }
+                    else {
+                        SFOR_DOWN(j, QMAX, 1) { hT[j] = hT[j - 1]; SFOR(s, 0, RS) hY[j][s] = hY[j - 1][s]; SEND } SEND
+                        hT[0] = m.tn;
+                        SFOR(s, 0, RS) hY[0][s] = m.zn[0][s]; SEND
+                        store_table(trec + (int64_t)np * trow, m.lane, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+                        np++;
+                    }
+                }
+                while (!done && k < a.n_t) {
+                    double tout = a.tvals[k];
+                    if (tout == a.t0) {
+                        SFOR(s, 0, RS) { if (IDX(m, s) < NS) yo[(int64_t)k * NS + IDX(m, s)] = y0[s]; } SEND
+                        k++;
+                    } else if ((m.tn - tout) * m.h >= 0.0) {
+                        double dky[RS], dq[RQ];
+                        cv_get_dky0(m, tout, dky, dq);
+                        SFOR(s, 0, RS) { if (IDX(m, s) < NS) yo[(int64_t)k * NS + IDX(m, s)] = dky[s]; } SEND
+                        k++;
+                        nstloc = 0; retries = 0;
+                    } else break;
+                }
+                if (k >= a.n_t) done = true;
+            }
+        }
+    }
+    if (status != CV_SUCCESS) {
+        for (int j = m.lane; j < a.n_t * NS; j += 64) yo[j] = SA_NAN;
+    }
+    if (m.lane == 0) {
+        a.status[inst] = status;
+        if (store) a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
+        int64_t st[SA_N_STATS];
+        SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
+        accumulate_stats(m, st);
+        st[ST_NPTS] = np; st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+        SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
+{
+    const int inst = blockIdx.x;
+    if (inst >= a.B) return;
+    int64_t st[SA_N_STATS];
+    SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
+    int status = CV_SUCCESS;
+    const int np = a.traj_np[inst];
+    if (a.fwd_status[inst] != CV_SUCCESS || np < 2) status = CV_NO_FWD;
+
+    Cw<true> m;
+    setup_common(m, a.ps, a.pr, a.rem_stride, inst, a.ws);
+    m.rtol = a.rtolB;
+    SFOR(r, 0, RS) m.atol[r] = a.atolB; SEND
+    m.rtolQ = a.rtolQB; m.atolQ = a.atolQB;
+    m.tstop = a.tinitial;
+    m.traj = a.traj + (int64_t)inst * TREC;
+    m.trow = a.traj_stride * TREC;
+    m.np = np;
+    m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + 2] : a.tinitial;
+    m.cur_idx = 0; m.tlo2 = 0.0; m.tlo = m.thi = 0.0;
+    m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
+    m.n_interp = 0; m.n_rebuild = 0;
+
+    double lam[RS], quad[RQ], quad_out[RQ];
+    SFOR(r, 0, RS) lam[r] = 0.0; SEND
+    SFOR(r, 0, RQ) { quad[r] = 0.0; quad_out[r] = 0.0; } SEND
+    const double *g = a.grads + (int64_t)inst * a.grads_stride;
+    bool first_call = true;
+    int total_retries = 0, attempts = 0;
+    cv_reinit(m, a.t0, lam, quad);
+
+    for (int iv = 0; iv <= a.n_t; iv++) {
+        const double t_upper = (iv == 0) ? a.t0 : a.tvals[a.n_t - iv];
+        const double t_lower = (iv == a.n_t) ? a.tend : a.tvals[a.n_t - 1 - iv];
+        if (t_lower < t_upper) {
+            if (status == CV_SUCCESS) {
+                cv_reinit(m, t_upper, lam, quad);
+                if (first_call) {
+                    if ((t_upper - a.tinitial) < 0.0 || (m.tfinal - t_upper) < 0.0) status = CV_BAD_TB0;
+                    first_call = false;
+                }
+                if (status == CV_SUCCESS && ((t_lower - a.tinitial) < 0.0 || (m.tfinal - t_lower) < 0.0)) {
+                    double tfuzz = 100.0 * UROUND * (fabs(a.tinitial) + fabs(m.tfinal));
+                    if ((t_lower - a.tinitial) < -tfuzz || (m.tfinal - t_lower) < -tfuzz) status = CV_ILL_INPUT;
+                }
+                if (status == CV_SUCCESS) {
+                    int flag = cv_first_call(m, t_lower);
+                    if (flag != CV_SUCCESS) status = flag;
+                }
+            }
+            int nstloc = 0, retries = 0;
+            StepCtl c;
+            c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0;
+            c.saved_t = t_upper;
+            bool idone = (status != CV_SUCCESS);
+            while (!idone) {
+                if (!c.in_step) {
+                    int ier = cv_pre_step(m);
+                    if (ier == CV_ILL_INPUT) { status = ier; idone = true; }
+                    else if (a.mxstep > 0 && nstloc >= a.mxstep) {
+                        retries++; total_retries++;
+                        if (retries >= a.max_retries) { status = CV_TOO_MUCH_WORK; idone = true; }
+                        else nstloc = 0;
+                    }
+                    if (!idone && ier != CV_SUCCESS) { status = ier; idone = true; }
+                }
+                if (!idone) {
+                    attempts++;
+                    int r = cv_attempt(m, c);
+                    if (r < 0) { status = r; idone = true; }
+                    else if (r == 1) {
+                        nstloc++;
+                        double troundoff = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.h));
+                        if (fabs(m.tn - m.tstop) <= troundoff) m.tn = m.tstop;
+                        if ((m.tn - t_lower) * m.h >= 0.0) {
+                            cv_get_dky0(m, t_lower, lam, quad_out);
+                            idone = true;
+                        } else {
+                            troundoff = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.h));
+                            if (fabs(m.tn - m.tstop) <= troundoff) { status = CV_TSTOP_RETURN; idone = true; }
+                            else if ((m.tn + m.hprime - m.tstop) * m.h > 0.0) {
+                                m.hprime = (m.tstop - m.tn) * (1.0 - 4.0 * UROUND);
+                                m.eta = m.hprime / m.h;
+                            }
+                        }
+                    }
+                }
+            }
+            if (status == CV_SUCCESS || m.nst > 0) accumulate_stats(m, st);
+            if (status == CV_SUCCESS) { SFOR(r, 0, RQ) quad[r] = quad_out[r]; SEND }
+        }
+        if (iv < a.n_t && status == CV_SUCCESS) {
+            const double *gi = g + (int64_t)(a.n_t - 1 - iv) * NS;
+            SFOR(r, 0, RS) { if (IDX(m, r) < NS) lam[r] -= gi[IDX(m, r)]; } SEND
+        }
+    }
+    SFOR(r, 0, RQ) {
+        if (IDX(m, r) < NQ) a.grad_out[(int64_t)inst * NQ + IDX(m, r)] = (status == CV_SUCCESS) ? quad_out[r] : SA_NAN;
+    } SEND
+    SFOR(r, 0, RS) {
+        if (IDX(m, r) < NS) a.lamda_out[(int64_t)inst * NS + IDX(m, r)] = (status == CV_SUCCESS) ? lam[r] : SA_NAN;
+    } SEND
+    if (m.lane == 0) {
+        a.status[inst] = status;
+        st[ST_NPTS] = np; st[ST_NINTERP] = m.n_interp; st[ST_NREBUILD] = m.n_rebuild;
+        st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+        SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
+    }
+}
+
+/* callback evaluation: the host launches ceil(npts/64) blocks; a block walks its 64 points with
+   the whole wave (inputs staged in LDS exactly as in the integrator) */
+struct ArrayOut {
+    double *p;
+    template <int S> __device__ __forceinline__ void put(double x) const { p[S] = x; }
+};
+
+extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)
+{
+    const int lane = lane_id();
+    for (int q = 0; q < 64; q++) {
+        const int i = blockIdx.x * 64 + q;
+        if (i >= a.npts) break;
+        lds_sync();
+        for (int k = lane; k < NS; k += 64) { s_y[k] = a.y[(int64_t)i * NS + k]; s_lam[k] = a.lam[(int64_t)i * NS + k]; }
+        for (int k = lane; k < NQ; k += 64) s_ps[k] = a.ps[(int64_t)i * NQ + k];
+        lds_sync();
+        const double *prp = a.pr + (int64_t)i * NR;
+        const double t = a.t[i];
+        const int c0 = sa_rhs(t, nullptr, nullptr, prp, ArrayOut{a.rhs + (int64_t)i * NS});
+        const int c1 = sa_jac(t, nullptr, nullptr, prp, ArrayOut{a.jac + (int64_t)i * NS * NS});
+        const int c2 = sa_adj_rhs(t, nullptr, nullptr, nullptr, prp, ArrayOut{a.adj + (int64_t)i * NS});
+        const int c3 = sa_quad_rhs(t, nullptr, nullptr, nullptr, prp, ArrayOut{a.quad + (int64_t)i * NQ});
+        const int c4 = sa_adj_jac(t, nullptr, nullptr, prp, ArrayOut{a.adjjac + (int64_t)i * NS * NS});
+        if (lane == 0) {
+            a.codes[i * 5 + 0] = c0; a.codes[i * 5 + 1] = c1; a.codes[i * 5 + 2] = c2;
+            a.codes[i * 5 + 3] = c3; a.codes[i * 5 + 4] = c4;
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n) return;
+    a.pow_out[i] = rpower_r(a.x[i], a.y[i]);
+    a.sqrt_out[i] = sqrt(a.x[i]);
+    a.div_out[i] = a.x[i] / a.y[i];
+}
+
+/* {n_states, n_sub, n_rem, ABI version, lanes per instance, workspace doubles per instance} */
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, 64, WS_DOUBLES};

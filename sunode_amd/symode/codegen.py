@@ -63,6 +63,16 @@ HELPERS_C = r"""
 #ifndef SA_LAM
 #define SA_LAM(i) lam[i]
 #endif
+#ifndef SA_PS
+#define SA_PS(j) ps[j]
+#endif
+#ifndef SA_PR
+#define SA_PR(j) pr[j]
+#endif
+/* first statement of every callback body (the wave kernel derives a scalar-load view of pr here) */
+#ifndef SA_PROLOGUE
+#define SA_PROLOGUE
+#endif
 #ifndef SA_TEMPLATE
 #define SA_TEMPLATE
 #endif
@@ -147,6 +157,24 @@ class HipExprPrinter(C99CodePrinter):
         return "(((%s) > 0.0) - ((%s) < 0.0))" % (x, x)
 
 
+#: callbacks with more output statements than this are emitted as a chain of chunk functions
+#: (compile time of one huge basic block is superlinear; 10^4 Jacobian entries at n = 100)
+CHUNK_STATEMENTS = 400
+
+
+def _closure(needed, deps, order):
+    """CSE temporaries (in definition order) that the expressions using ``needed`` depend on."""
+    seen = set()
+    stack = list(needed)
+    while stack:
+        name = stack.pop()
+        if name in seen or name not in deps:
+            continue
+        seen.add(name)
+        stack.extend(deps[name])
+    return [name for name in order if name in seen]
+
+
 def emit_function(
     name: str,
     signature: str,
@@ -165,27 +193,55 @@ def emit_function(
     else:
         assigns, reduced = [], []
     printer = HipExprPrinter(symbol_map)
-    lines: List[str] = ["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature)]
-    for var, value in assigns:
-        lines.append("    const double %s = %s;" % (var.name, printer.doprint(value)))
+    temp_text = {var.name: printer.doprint(value) for var, value in assigns}
+    temp_order = [var.name for var, _ in assigns]
+    temp_names = set(temp_order)
+    temp_deps = {var.name: [s.name for s in value.free_symbols if s.name in temp_names] for var, value in assigns}
     written = {}
+    uses = {}
     for k, value in enumerate(reduced):
-        written[int(out_index[k])] = "0.0" if value == 0 else printer.doprint(value)
+        slot = int(out_index[k])
+        written[slot] = "0.0" if value == 0 else printer.doprint(value)
+        uses[slot] = [s.name for s in sym.sympify(value).free_symbols if s.name in temp_names]
+
     # Outputs go through SA_STORE(slot, value): plain kernels / the oracle define it as
     # `out[slot] = value`; the cooperative kernel (one lane per state component) keeps only the
     # slots a lane owns.  x*0.0 is (+-)0 for finite x and NaN for inf/nan: the finiteness check is
     # straight-line on purpose (constant subscripts only, see bdf_kernels.hip on scalar replacement).
-    lines.append("    double chk = 0.0;")
-    for slot in range(n_out):
-        text = written.get(slot, "0.0")
-        if text == "0.0":
-            lines.append("    SA_STORE(%d, 0.0);" % slot)
-        else:
-            lines.append("    { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; }" % (text, slot))
-    lines.append("    (void)t; (void)y; (void)ps; (void)pr; (void)out;")
-    lines.append("    return (chk == 0.0) ? 0 : 1;")
-    lines.append("}")
-    return "\n".join(lines)
+    def body(slots, temps):
+        lines = ["    SA_PROLOGUE"]
+        lines += ["    const double %s = %s;" % (tname, temp_text[tname]) for tname in temps]
+        lines.append("    double chk = 0.0;")
+        for slot in slots:
+            text = written.get(slot, "0.0")
+            if text == "0.0":
+                lines.append("    SA_STORE(%d, 0.0);" % slot)
+            else:
+                lines.append("    { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; }" % (text, slot))
+        lines.append("    (void)t; (void)y; (void)ps; (void)pr; (void)out;")
+        lines.append("    return (chk == 0.0) ? 0 : 1;")
+        return lines
+
+    if n_out <= CHUNK_STATEMENTS:
+        lines = ["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature)]
+        lines += body(range(n_out), temp_order)
+        lines.append("}")
+        return "\n".join(lines)
+
+    # chunked form: same expressions, same evaluation order inside every statement; a temporary
+    # needed by several chunks is recomputed in each (identical value)
+    call_args = ", ".join(part.split()[-1].lstrip("*") for part in signature.split(","))
+    parts, calls = [], []
+    for c, lo in enumerate(range(0, n_out, CHUNK_STATEMENTS)):
+        slots = range(lo, min(lo + CHUNK_STATEMENTS, n_out))
+        needed = [u for slot in slots for u in uses.get(slot, [])]
+        cname = "%s_c%d" % (name, c)
+        parts.append("\n".join(["SA_TEMPLATE SA_FN int %s(%s) {" % (cname, signature)]
+                               + body(slots, _closure(needed, temp_deps, temp_order)) + ["}"]))
+        calls.append("    bad |= %s(%s);" % (cname, call_args))
+    parts.append("\n".join(["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature), "    int bad = 0;"]
+                           + calls + ["    return bad;", "}"]))
+    return "\n".join(parts)
 
 
 def generate_problem_source(
@@ -206,6 +262,8 @@ def generate_problem_source(
     col_major = [j * n + i for i in range(n) for j in range(n)]
     jac = np.asarray(jac, dtype=object).reshape(n, n) if n else np.zeros((0, 0), object)
     adj_jac = np.array([[-jac[j, i] for j in range(n)] for i in range(n)], dtype=object).reshape(n, n)
+    # no __restrict__ on purpose: with it the compiler hoists every load of a 10^4-statement callback
+    # above the stores and spills tens of KB per lane; possible aliasing keeps live ranges per statement
     base = "double t, const double* y, const double* ps, const double* pr, SA_OUT_T out"
     adj = "double t, const double* y, const double* lam, const double* ps, const double* pr, SA_OUT_T out"
     parts = [

@@ -80,9 +80,9 @@ class SympyProblem:
         self._sym_statevec = np.concatenate(svec) if svec else np.zeros((0,), dtype=object)
 
         for j, s in enumerate(self._sym_deriv_paramsvec):
-            self._c_slots[s.name] = "ps[%d]" % j
+            self._c_slots[s.name] = "SA_PS(%d)" % j
         for j, s in enumerate(self._sym_fixed_paramsvec):
-            self._c_slots[s.name] = "pr[%d]" % j
+            self._c_slots[s.name] = "SA_PR(%d)" % j
         for i, s in enumerate(self._sym_statevec):
             self._c_slots[s.name] = "SA_Y(%d)" % i
 

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from tests.helpers import make_oracle, make_problem
-from tools.problems import lv_batch, robertson_batch, seir_batch
+from tools.problems import lv_batch, network_batch, robertson_batch, seir_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -208,12 +208,13 @@ def test_seir_forward_adjoint_vs_oracle_and_truth(golden_dir):
 
 
 @pytest.mark.parametrize("name,group", [("lv", 8), ("notebook", 8), ("robertson", 16),
-                                        ("lv", "mem"), ("notebook", "mem"), ("robertson", "mem")])
+                                        ("lv", "mem"), ("notebook", "mem"), ("robertson", "mem"),
+                                        ("lv", "wave"), ("notebook", "wave"), ("robertson", "wave")])
 def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch):
     """The same problem through the kernel families (SA_FORCE_GROUP): G lanes per instance with
-    butterfly norms and row-distributed LU, or the memory-resident generic kernel ("mem", the
-    mapping of systems with more than 64 states), must reproduce the one-lane-per-instance
-    register kernel bit for bit (and therefore the oracle)."""
+    butterfly norms and row-distributed LU, the wavefront-per-instance kernel with the LDS-resident
+    LU ("wave", 64 < n <= 128) or the memory-resident generic kernel ("mem", n > 128) must
+    reproduce the one-lane-per-instance register kernel bit for bit (and therefore the oracle)."""
     from sunode_amd.solver import AdjointSolver
     prob = make_problem(name)
     rng = np.random.RandomState(3)
@@ -253,11 +254,13 @@ def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch
         np.testing.assert_array_equal(a, b)
 
 
-def test_seir_memory_resident_mapping_vs_oracle(monkeypatch):
-    """SEIR (n = 16, 16 shared fixed parameters read through the global pointer) through the
-    memory-resident kernel: bit-exact against the oracle like the cooperative build."""
+@pytest.mark.parametrize("variant", ["mem", "wave"])
+def test_seir_large_system_mappings_vs_oracle(variant, monkeypatch):
+    """SEIR (n = 16, 16 shared fixed parameters) through the kernels meant for large systems
+    (memory-resident / wavefront-per-instance): bit-exact against the oracle like the
+    cooperative build."""
     from sunode_amd.solver import AdjointSolver
-    monkeypatch.setenv("SA_FORCE_GROUP", "mem")
+    monkeypatch.setenv("SA_FORCE_GROUP", variant)
     prob = make_problem("seir")
     d = seir_batch(70)
     tv = d["tvals"]
@@ -272,6 +275,39 @@ def test_seir_memory_resident_mapping_vs_oracle(monkeypatch):
     yo, so, sto = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, tv, nthreads=8)
     go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
     assert (status == 0).all() and (status_b == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(stats_b[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
+@pytest.mark.parametrize("variant", ["wave", "mem"])
+def test_network100_forward_adjoint_vs_oracle(variant, monkeypatch):
+    """Config 5 (BASELINE.json): 100 states, shared fixed 100x100 rate matrix, 4 differentiated
+    parameters.  Between 65 and 128 states the engine selects the wavefront-per-instance kernel
+    by itself; the memory-resident kernel (the mapping above 128 states) is forced on the same
+    problem over a shorter horizon."""
+    from sunode_amd import _native
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("network100")
+    assert _native.kernel_variant(prob.native_source())[0] == "bdf_wave.hip"
+    if variant == "mem":
+        monkeypatch.setenv("SA_FORCE_GROUP", "mem")
+    B = 6
+    d = network_batch(B)
+    tv = d["tvals"] if variant == "wave" else d["tvals"][:3]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(100)[None, :])
+    tol = 1e-8
+    sol = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol,
+                        quad_abstol=tol, quad_reltol=tol, max_steps=1024)
+    y, status, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], d["pr"])
+    g, lam, status_b, stats_b = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("network100")
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, tv, nthreads=6)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=6)
+    assert (status == 0).all() and (status_b == 0).all() and (so == 0).all() and (sbo == 0).all()
     np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
     np.testing.assert_array_equal(y, yo)
     np.testing.assert_array_equal(stats_b[:, CMP_B], stbo[:, CMP_B])

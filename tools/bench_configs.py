@@ -1,6 +1,6 @@
 """Throughput of the other BASELINE configs (parity-test cases, not the headline bench line).
 
-python tools/bench_configs.py robertson 262144 | seir 16384 | lv 65536
+python tools/bench_configs.py robertson 262144 | seir 16384 | lv 65536 | network100 4096
 Host-memory API (solve_forward_batch / solve_backward_batch); prints kernel times from HIP events.
 """
 import os
@@ -13,13 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sunode_amd import SympyProblem  # noqa: E402
 from sunode_amd.solver import AdjointSolver  # noqa: E402
-from tools.problems import PROBLEMS, lv_batch, robertson_batch, seir_batch  # noqa: E402
+from tools.problems import PROBLEMS, lv_batch, network100, network_batch, robertson_batch, seir_batch  # noqa: E402
 
 
 def main():
     name = sys.argv[1]
     B = int(sys.argv[2])
-    s = PROBLEMS[name]
+    s = network100() if name == "network100" else PROBLEMS[name]
     prob = SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
     if name == "lv":
         d = lv_batch(B)
@@ -29,6 +29,10 @@ def main():
         d = robertson_batch(B)
         ps, pr = d["params"], np.zeros(0)
         rt, at, cap = 1e-8, 1e-10, 2048
+    elif name == "network100":
+        d = network_batch(B)
+        ps, pr = d["ps"], d["pr"]
+        rt, at, cap = 1e-8, 1e-8, 1024
     else:
         d = seir_batch(B)
         ps, pr = d["ps"], d["pr"]
