@@ -123,6 +123,7 @@ class Oracle:
     def eval(self, t, y, lam, ps, pr):
         n, p = self.n, self.p
         y = np.ascontiguousarray(y, float); lam = np.ascontiguousarray(lam, float)
+        pr = self._extend(pr)
         ps = np.ascontiguousarray(np.r_[ps, 0.0], float); pr = np.ascontiguousarray(np.r_[pr, 0.0], float)
         rhs = np.zeros(max(n, 1)); jac = np.zeros(max(n * n, 1)); adj = np.zeros(max(n, 1))
         quad = np.zeros(max(p, 1)); adjjac = np.zeros(max(n * n, 1))
@@ -133,10 +134,18 @@ class Oracle:
                     adjjac=adjjac[:n * n].reshape(n, n).T.copy(), codes=codes)
 
     # -- helpers -----------------------------------------------------------
+    def _extend(self, pr):
+        """user remainder vector -> the one the generated source reads (hoisted fixed-parameter
+        sub-expressions appended; see SympyProblem.extend_remainder)"""
+        pr = np.asarray(pr, float)
+        if pr.size and pr.shape[-1] == self.problem.n_remainder and self.r != self.problem.n_remainder:
+            pr = self.problem.extend_remainder(pr)
+        return pr
+
     def _params(self, B, ps, pr):
         ps = np.ascontiguousarray(np.broadcast_to(np.asarray(ps, float).reshape(-1, self.p) if self.p else
                                                   np.zeros((B, 0)), (B, self.p)))
-        pr = np.asarray(pr, float)
+        pr = self._extend(pr)
         if pr.ndim == 1 or (pr.ndim == 2 and pr.shape[0] == 1 and B != 1):
             pr2 = np.ascontiguousarray(pr.reshape(-1)); stride = 0
         else:

@@ -140,10 +140,12 @@ def kernel_variant(native_source: str):
 
 
 def _size_defines(native_source: str):
+    """-D flags of the device build: problem sizes + SA_KERNEL_DEFINES (tuning / profiling builds,
+    e.g. SA_KERNEL_DEFINES="-DSA_WAVE_PROFILE"; part of the cache key)."""
     import re
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
-    return ["-DSA_BUILD_NS=%d" % n, "-DSA_BUILD_NQ=%d" % p]
+    return ["-DSA_BUILD_NS=%d" % n, "-DSA_BUILD_NQ=%d" % p] + os.environ.get("SA_KERNEL_DEFINES", "").split()
 
 
 def code_object_path(native_source: str) -> str:
@@ -151,7 +153,8 @@ def code_object_path(native_source: str) -> str:
     kern = os.path.join(_CSRC, fname)
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h")]
     deps = [d for d in deps if os.path.exists(d)]
-    extra = native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group + fname.encode()
+    extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group + fname.encode()
+             + os.environ.get("SA_KERNEL_DEFINES", "").encode())
     key = _hash_files(*deps, extra=extra) if os.path.exists(kern) else \
         hashlib.sha256(extra).hexdigest()[:16]
     return os.path.join(_CACHE, "sa_%s.hsaco" % key)

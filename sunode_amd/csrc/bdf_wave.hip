@@ -25,7 +25,7 @@
  * Same algorithm, operation order and rounding as the other builds / the CPU oracle (restated
  * CVODES 5.x; reference call sites /root/reference/sunode/solver.py:467-527, 682-784).
  * Kernel entry points and argument blocks are those of bdf_kernels.hip; sa_meta = {n, p, r, ABI,
- * 64 lanes per instance, workspace doubles per instance}.
+ * 64 * SA_WAVES lanes per instance (= workgroup size), workspace doubles per instance}.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,6 +44,20 @@ __shared__ double s_lam[W_NS > 0 ? W_NS : 1];       /* callback input: adjoint s
 __shared__ double s_ps[W_NQ > 0 ? W_NQ : 1];        /* differentiated parameters of the instance */
 __shared__ uint8_t s_piv[(W_NS + 15) / 16 * 16];    /* pivot rows (n <= 128 fits a byte) */
 
+/* Worker wavefronts: the workgroup of an instance has SA_WAVES wavefronts.  Wavefront 0 runs the
+   integrator; the others sleep on the workgroup barrier and wake up to evaluate their share of the
+   chunks of a generated callback (the callbacks dominate the run time and are embarrassingly
+   parallel over their output statements). */
+#ifndef SA_WAVES
+#define SA_WAVES 4
+#endif
+__shared__ int s_cmd, s_nwaves;
+__shared__ double s_targ;
+__shared__ int s_rc[SA_WAVES];
+enum { CMD_EXIT = 0, CMD_RHS = 1, CMD_QUAD = 2, CMD_JAC = 3 };
+static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#define SA_CHUNK_CALL(c, call) do { if (((c) % s_nwaves) == sa_wave_index()) bad |= call; } while (0)
+
 #define SA_FN static __device__ __attribute__((noinline))
 #define SA_TEMPLATE template <class SinkT>
 #define SA_OUT_T SinkT
@@ -51,12 +65,12 @@ __shared__ uint8_t s_piv[(W_NS + 15) / 16 * 16];    /* pivot rows (n <= 128 fits
 #define SA_Y(i) s_y[i]
 #define SA_LAM(i) s_lam[i]
 #define SA_PS(j) s_ps[j]
-#define SA_PR(j) prc[j]
+typedef __attribute__((address_space(1))) double gdouble;      /* explicit global pointer: cannot alias LDS */
 #define SA_CONST_AS __attribute__((address_space(4)))
-#define SA_PROLOGUE const SA_CONST_AS double *prc = sa_uniform_const(pr);
-
-/* remaining parameters are read-only for the whole launch and identical for all lanes of the
-   wave: a wave-uniform constant-address-space view turns every pr[j] into a scalar load */
+#ifdef SA_WAVE_PR_SCALAR
+/* tuning alternative: remaining parameters through scalar loads of a wave-uniform constant-address-
+   space view.  Measured slower for large shared blocks (100 x 100 rate matrix): scalar loads return
+   out of order, every use waits for lgkmcnt(0), and the 16 KB scalar cache thrashes. */
 static __device__ __forceinline__ const SA_CONST_AS double *sa_uniform_const(const double *p)
 {
     const uint64_t u = (uint64_t)p;
@@ -64,6 +78,19 @@ static __device__ __forceinline__ const SA_CONST_AS double *sa_uniform_const(con
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
     return (const SA_CONST_AS double *)(((uint64_t)hi << 32) | (uint64_t)lo);
 }
+#define SA_PR(j) prc[j]
+#define SA_PROLOGUE const SA_CONST_AS double *prc = sa_uniform_const(pr);
+#else
+/* remaining parameters: broadcast global loads (all lanes read the same address; the vector memory
+   pipe is otherwise idle during a callback and keeps dozens of loads in flight) */
+#define SA_PR(j) prg[j]
+#define SA_PROLOGUE const gdouble *prg = (const gdouble *)pr;
+#endif
+#ifndef SA_WAVE_NO_SCHED_BARRIER
+/* keep the instruction scheduler from hoisting the loads of later statements over earlier ones:
+   with thousands of independent statements that ends in tens of KB of spills */
+#define SA_STMT_END __builtin_amdgcn_sched_barrier(0);
+#endif
 
 #include SA_PROBLEM_HEADER
 #include "sa_device_abi.h"
@@ -112,7 +139,7 @@ DEV void lds_sync()
 
 /* output sinks of the generated callbacks (all lanes hold the same value) */
 struct VecOut {             /* vector-valued callbacks -> workspace vector */
-    double *p;
+    gdouble *p;
     template <int S> __device__ __forceinline__ void put(double x) const { p[S] = x; }
 };
 struct MatOut {             /* n x n callbacks -> the LDS matrix (slot = col * n + row) */
@@ -148,7 +175,18 @@ struct Cw {
     double tab_hdr[8];                /* order, dt, T[6] */
     double tabY[QMAX + 1][RS];
     int n_interp, n_rebuild;
+#ifdef SA_WAVE_PROFILE
+    int64_t prof[8];                  /* 10 ns ticks: rhs, quad, jac, getrf, getrs, matrix copy */
+#endif
 };
+
+#ifdef SA_WAVE_PROFILE                /* tuning builds only: section timers overwrite stats slots 9..15 */
+#define PROF_T0 const int64_t prof_t0 = (int64_t)wall_clock64();
+#define PROF_ADD(m, k) (m).prof[k] += (int64_t)wall_clock64() - prof_t0;
+#else
+#define PROF_T0
+#define PROF_ADD(m, k)
+#endif
 
 #define IDX(m, r) ((r) * 64 + (m).lane)
 
@@ -335,15 +373,69 @@ DEV void fetch_output(const Cw<BWD> &m, double (&out)[NSLOT])
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
+/* every wavefront of the workgroup runs this for the same command; SA_CHUNK_CALL picks its chunks */
+template <bool BWD>
+DEV int run_callback(int cmd, double t, const double *pr, double *obuf)
+{
+    if (cmd == CMD_RHS) {
+        if constexpr (BWD) return sa_adj_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{(gdouble *)obuf});
+        else return sa_rhs(t, nullptr, nullptr, pr, VecOut{(gdouble *)obuf});
+    }
+    if (cmd == CMD_QUAD) return sa_quad_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{(gdouble *)obuf});
+    if constexpr (BWD) return sa_adj_jac(t, nullptr, nullptr, pr, MatOut{});
+    else return sa_jac(t, nullptr, nullptr, pr, MatOut{});
+}
+
+/* wavefront 0: publish the command (the inputs are already staged), evaluate, collect */
+template <bool BWD>
+DEV int dispatch(Cw<BWD> &m, int cmd, double t)
+{
+    if constexpr (SA_WAVES > 1) {
+        if (m.lane == 0) { s_cmd = cmd; s_targ = t; }
+        __syncthreads();
+    }
+    int rc = run_callback<BWD>(cmd, t, m.pr, m.obuf);
+    if constexpr (SA_WAVES > 1) {
+        if (m.lane == 0) s_rc[0] = rc;
+        __syncthreads();
+        SFOR(w, 1, SA_WAVES) rc |= s_rc[w]; SEND
+    }
+    return rc;
+}
+
+template <bool BWD>
+DEV void worker_loop(const double *pr, double *obuf)
+{
+    const int lane = lane_id(), wave = sa_wave_index();
+    for (;;) {
+        __syncthreads();
+        const int cmd = s_cmd;
+        const double t = s_targ;
+        if (cmd == CMD_EXIT) break;
+        const int rc = run_callback<BWD>(cmd, t, pr, obuf);
+        if (lane == 0) s_rc[wave] = rc;
+        __syncthreads();
+    }
+}
+
+template <bool BWD>
+DEV void release_workers(const Cw<BWD> &m)
+{
+    if constexpr (SA_WAVES > 1) {
+        if (m.lane == 0) s_cmd = CMD_EXIT;
+        __syncthreads();
+    }
+}
+
 template <bool BWD>
 DEV int cv_f(Cw<BWD> &m, double t, const double (&ymine)[RS], double (&out)[RS])
 {
     m.nfe++;
+    PROF_T0
     stage_inputs(m, ymine);
-    int rc;
-    if constexpr (BWD) rc = sa_adj_rhs(t, nullptr, nullptr, nullptr, m.pr, VecOut{m.obuf});
-    else rc = sa_rhs(t, nullptr, nullptr, m.pr, VecOut{m.obuf});
+    const int rc = dispatch(m, CMD_RHS, t);
     fetch_output<BWD, RS, NS>(m, out);
+    PROF_ADD(m, 0)
     return rc;
 }
 
@@ -351,49 +443,63 @@ template <bool BWD>
 DEV int cv_fQ(Cw<BWD> &m, double t, const double (&ymine)[RS], double (&out)[RQ])
 {
     m.nfQe++;
+    PROF_T0
     stage_inputs(m, ymine);
-    const int rc = sa_quad_rhs(t, nullptr, nullptr, nullptr, m.pr, VecOut{m.obuf});
+    const int rc = dispatch(m, CMD_QUAD, t);
     fetch_output<BWD, RQ, (NQ > 0 ? NQ : 1)>(m, out);
+    PROF_ADD(m, 1)
     return rc;
 }
 
 template <bool BWD>
 DEV int cv_jac(Cw<BWD> &m, double t, const double (&ymine)[RS])        /* Jacobian -> s_A */
 {
+    PROF_T0
     stage_inputs(m, ymine);
-    int rc;
-    if constexpr (BWD) rc = sa_adj_jac(t, nullptr, nullptr, m.pr, MatOut{});
-    else rc = sa_jac(t, nullptr, nullptr, m.pr, MatOut{});
+    const int rc = dispatch(m, CMD_JAC, t);
     lds_sync();
+    PROF_ADD(m, 2)
     return rc;
 }
 
 /* ---- row-distributed dense LU in LDS (denseGETRF / denseGETRS semantics) ---- */
 #define AL(i, j) s_A[(j) * NS + (i)]
-#define LU_BATCH 4
+#define LU_BATCH 8
 
 template <bool BWD>
 DEV int dense_getrf(Cw<BWD> &m)
 {
+    PROF_T0
     m.nswaps = 0;
     for (int k = 0; k < NS; k++) {
-        /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF) */
-        double best = -1.0;
-        int bi = 1 << 20;
+        /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF).
+           I - gamma*J is close to diagonally dominant, so usually no row beats the diagonal: one
+           ballot settles that case, the arg-max butterfly only runs when some lane disagrees. */
+        double best = fabs(AL(k, k));
+        int bi = k;
+        bool beaten = false;
+        double cand[RS];
         SFOR(r, 0, RS) {
             const int i = IDX(m, r);
-            if (i >= k && i < NS) {
-                const double v = fabs(AL(i, k));
-                if (v > best) { best = v; bi = i; }
-            }
+            cand[r] = (i > k && i < NS) ? fabs(AL(i, k)) : -1.0;
+            beaten = beaten || (cand[r] > best);
         } SEND
-        SFOR(b, 0, 6) {
-            const double ov = shfl_d(best, m.lane ^ (1 << b));
-            const int oi = shfl_i(bi, m.lane ^ (1 << b));
-            const bool take = (ov > best) || (ov == best && oi < bi);
-            best = take ? ov : best;
-            bi = take ? oi : bi;
-        } SEND
+        if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
+            best = -1.0;
+            bi = 1 << 20;
+            SFOR(r, 0, RS) {
+                const int i = IDX(m, r);
+                const double v = (i == k) ? fabs(AL(k, k)) : cand[r];
+                if (i >= k && i < NS && v > best) { best = v; bi = i; }
+            } SEND
+            SFOR(b, 0, 6) {
+                const double ov = shfl_d(best, m.lane ^ (1 << b));
+                const int oi = shfl_i(bi, m.lane ^ (1 << b));
+                const bool take = (ov > best) || (ov == best && oi < bi);
+                best = take ? ov : best;
+                bi = take ? oi : bi;
+            } SEND
+        }
         const int l = __builtin_amdgcn_readfirstlane(bi);
         if (m.lane == 0) s_piv[k] = (uint8_t)l;
         if (best == 0.0) return k + 1;
@@ -443,6 +549,7 @@ DEV int dense_getrf(Cw<BWD> &m)
         }
         lds_sync();
     }
+    PROF_ADD(m, 3)
     return 0;
 }
 
@@ -455,8 +562,9 @@ DEV double bcast_vec(const double (&b)[RS], int k)
 }
 
 template <bool BWD>
-DEV void dense_getrs(const Cw<BWD> &m, double (&b)[RS])
+DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
 {
+    PROF_T0
     if (m.nswaps != 0) {               /* row permutation through the LDS scratch vector */
         lds_sync();
         SFOR(r, 0, RS) { if (IDX(m, r) < NS) s_lam[IDX(m, r)] = b[r]; } SEND
@@ -489,6 +597,7 @@ DEV void dense_getrs(const Cw<BWD> &m, double (&b)[RS])
         } SEND
     }
     if (m.lane == 0) b[0] *= m.inv_piv[0];
+    PROF_ADD(m, 4)
 }
 
 /* ---- CVodeInit / CVodeReInit ---- */
@@ -759,6 +868,7 @@ DEV int cv_lsetup(Cw<BWD> &m, int convfail)
     const double c = -m.gamma;
     lds_sync();
     if (!jbad) {
+        PROF_T0
         m.jcur = 0;
         /* A = I - gamma * savedJ, streamed from the workspace (COPY_BATCH loads in flight per lane) */
         int base = 0;
@@ -774,6 +884,7 @@ DEV int cv_lsetup(Cw<BWD> &m, int convfail)
             const double v = m.sj[idx];
             s_A[idx] = (idx % NS == idx / NS) ? FMA(c, v, 1.0) : v * c;
         }
+        PROF_ADD(m, 5)
     } else {
         m.nje++;
         m.nstlj = m.nst;
@@ -1193,6 +1304,10 @@ DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_st
     SFOR(r, 0, RQ) m.ewtQ[r] = 0.0; SEND
     SFOR(f, 0, 8) m.tab_hdr[f] = (f == 1) ? 1.0 : 0.0; SEND
     SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) m.tabY[j][r] = 0.0; SEND } SEND
+#ifdef SA_WAVE_PROFILE
+    SFOR(i, 0, 8) m.prof[i] = 0; SEND
+    m.prof[7] = -(int64_t)wall_clock64();
+#endif
     lds_sync();
 }
 
@@ -1224,10 +1339,15 @@ DEV void store_table(double *rec, int lane, int order, double dt, const double (
 }
 
 /* ------------------------------------------------------------------------------------ */
-extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
+extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_args a)
 {
     const int inst = blockIdx.x;
     if (inst >= a.B) return;
+    if (threadIdx.x == 0) s_nwaves = SA_WAVES;
+    if (sa_wave_index() != 0) {
+        worker_loop<false>(a.pr + (int64_t)inst * a.rem_stride, a.ws + (int64_t)inst * WS_DOUBLES + WS_OUT);
+        return;
+    }
     Cw<false> m;
     setup_common(m, a.ps, a.pr, a.rem_stride, inst, a.ws);
     m.rtol = a.rtol;
@@ -1311,6 +1431,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             }
         }
     }
+    release_workers(m);
     if (status != CV_SUCCESS) {
         for (int j = m.lane; j < a.n_t * NS; j += 64) yo[j] = SA_NAN;
     }
@@ -1321,14 +1442,23 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
         accumulate_stats(m, st);
         st[ST_NPTS] = np; st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+#ifdef SA_WAVE_PROFILE
+        SFOR(i, 0, 6) st[9 + i] = m.prof[i]; SEND
+        st[15] = m.prof[7] + (int64_t)wall_clock64();
+#endif
         SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
     }
 }
 
-extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
+extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd_args a)
 {
     const int inst = blockIdx.x;
     if (inst >= a.B) return;
+    if (threadIdx.x == 0) s_nwaves = SA_WAVES;
+    if (sa_wave_index() != 0) {
+        worker_loop<true>(a.pr + (int64_t)inst * a.rem_stride, a.ws + (int64_t)inst * WS_DOUBLES + WS_OUT);
+        return;
+    }
     int64_t st[SA_N_STATS];
     SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
     int status = CV_SUCCESS;
@@ -1422,6 +1552,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
             SFOR(r, 0, RS) { if (IDX(m, r) < NS) lam[r] -= gi[IDX(m, r)]; } SEND
         }
     }
+    release_workers(m);
     SFOR(r, 0, RQ) {
         if (IDX(m, r) < NQ) a.grad_out[(int64_t)inst * NQ + IDX(m, r)] = (status == CV_SUCCESS) ? quad_out[r] : SA_NAN;
     } SEND
@@ -1432,6 +1563,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
         a.status[inst] = status;
         st[ST_NPTS] = np; st[ST_NINTERP] = m.n_interp; st[ST_NREBUILD] = m.n_rebuild;
         st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+#ifdef SA_WAVE_PROFILE
+        SFOR(i, 0, 6) st[9 + i] = m.prof[i]; SEND
+        st[15] = m.prof[7] + (int64_t)wall_clock64();
+#endif
         SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
     }
 }
@@ -1439,13 +1574,14 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
 /* callback evaluation: the host launches ceil(npts/64) blocks; a block walks its 64 points with
    the whole wave (inputs staged in LDS exactly as in the integrator) */
 struct ArrayOut {
-    double *p;
+    gdouble *p;
     template <int S> __device__ __forceinline__ void put(double x) const { p[S] = x; }
 };
 
 extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)
 {
     const int lane = lane_id();
+    if (lane == 0) s_nwaves = 1;
     for (int q = 0; q < 64; q++) {
         const int i = blockIdx.x * 64 + q;
         if (i >= a.npts) break;
@@ -1455,11 +1591,11 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)
         lds_sync();
         const double *prp = a.pr + (int64_t)i * NR;
         const double t = a.t[i];
-        const int c0 = sa_rhs(t, nullptr, nullptr, prp, ArrayOut{a.rhs + (int64_t)i * NS});
-        const int c1 = sa_jac(t, nullptr, nullptr, prp, ArrayOut{a.jac + (int64_t)i * NS * NS});
-        const int c2 = sa_adj_rhs(t, nullptr, nullptr, nullptr, prp, ArrayOut{a.adj + (int64_t)i * NS});
-        const int c3 = sa_quad_rhs(t, nullptr, nullptr, nullptr, prp, ArrayOut{a.quad + (int64_t)i * NQ});
-        const int c4 = sa_adj_jac(t, nullptr, nullptr, prp, ArrayOut{a.adjjac + (int64_t)i * NS * NS});
+        const int c0 = sa_rhs(t, nullptr, nullptr, prp, ArrayOut{(gdouble *)(a.rhs + (int64_t)i * NS)});
+        const int c1 = sa_jac(t, nullptr, nullptr, prp, ArrayOut{(gdouble *)(a.jac + (int64_t)i * NS * NS)});
+        const int c2 = sa_adj_rhs(t, nullptr, nullptr, nullptr, prp, ArrayOut{(gdouble *)(a.adj + (int64_t)i * NS)});
+        const int c3 = sa_quad_rhs(t, nullptr, nullptr, nullptr, prp, ArrayOut{(gdouble *)(a.quad + (int64_t)i * NQ)});
+        const int c4 = sa_adj_jac(t, nullptr, nullptr, prp, ArrayOut{(gdouble *)(a.adjjac + (int64_t)i * NS * NS)});
         if (lane == 0) {
             a.codes[i * 5 + 0] = c0; a.codes[i * 5 + 1] = c1; a.codes[i * 5 + 2] = c2;
             a.codes[i * 5 + 3] = c3; a.codes[i * 5 + 4] = c4;
@@ -1477,4 +1613,4 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 }
 
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance, workspace doubles per instance} */
-extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, 64, WS_DOUBLES};
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, 64 * SA_WAVES, WS_DOUBLES};

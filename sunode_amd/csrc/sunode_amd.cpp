@@ -88,12 +88,14 @@ struct sa_solver {
 
 static int launch(sa_solver *s, hipFunction_t f, int32_t n_items, void *args, size_t args_size, int lanes_per_item = 1)
 {
-    const int per_block = 64 / lanes_per_item;
+    /* up to 64 lanes per item: 64-thread blocks carrying 64/lanes items; above: one item per block */
+    const int block = lanes_per_item > 64 ? lanes_per_item : 64;
+    const int per_block = lanes_per_item > 64 ? 1 : 64 / lanes_per_item;
     unsigned grid = (unsigned)((n_items + per_block - 1) / per_block);
     if (grid == 0) return SA_OK;
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_size,
                       HIP_LAUNCH_PARAM_END};
-    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, 64, 1, 1, 0, s->stream, nullptr, config));
+    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, s->stream, nullptr, config));
     return SA_OK;
 }
 
@@ -139,7 +141,7 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
     e = hipModuleGetGlobal(&meta_p, &meta_sz, s->module, "sa_meta");
     if (e != hipSuccess || meta_sz != sizeof(meta) ||
         hipMemcpyDtoH(meta, meta_p, sizeof(meta)) != hipSuccess || meta[3] != SA_ABI_VERSION ||
-        meta[4] < 1 || meta[4] > 64 || (meta[4] & (meta[4] - 1)) != 0 || meta[5] < 0) {
+        meta[4] < 1 || meta[4] > 1024 || (meta[4] & (meta[4] - 1)) != 0 || meta[5] < 0) {
         (void)hipModuleUnload(s->module);
         delete s;
         return fail(SA_ERR_MODULE, "%s: sa_meta missing or ABI mismatch", path);

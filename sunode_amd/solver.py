@@ -119,11 +119,13 @@ class _EngineMixin:
         if r and pr.shape == (r,):
             stride = 0
         elif r and pr.shape == (B, r):
-            stride = r
+            stride = self._problem.n_remainder_native
         elif r:
             raise ValueError(f"params_rem must have shape ({r},) or (B, {r})")
         else:
             stride = 0
+        if r:       # hoisted fixed-parameter sub-expressions ride at the end of the remainder vector
+            pr = np.ascontiguousarray(self._problem.extend_remainder(pr))
         if ps.size == 0:
             ps = np.zeros(1)
         if pr.size == 0:

@@ -43,6 +43,9 @@ import sympy as sym
 from sympy.printing.c import C99CodePrinter
 
 MAX_EXPANDED_POW = 8
+#: sums with at least this many terms are emitted as SUM_WAYS interleaved partial sums
+LONG_SUM_TERMS = 16
+SUM_WAYS = 4
 
 HELPERS_C = r"""
 #ifndef SA_FN
@@ -68,6 +71,15 @@ HELPERS_C = r"""
 #endif
 #ifndef SA_PR
 #define SA_PR(j) pr[j]
+#endif
+/* chunked callbacks: chunk `c` contributes to the return code; a multi-wavefront kernel redefines
+   this to give every wavefront its share of the chunks */
+#ifndef SA_CHUNK_CALL
+#define SA_CHUNK_CALL(c, call) bad |= call
+#endif
+/* after every output statement (kernels with huge callbacks fence the instruction scheduler here) */
+#ifndef SA_STMT_END
+#define SA_STMT_END
 #endif
 /* first statement of every callback body (the wave kernel derives a scalar-load view of pr here) */
 #ifndef SA_PROLOGUE
@@ -108,6 +120,50 @@ class HipExprPrinter(C99CodePrinter):
 
     def _print_Float(self, expr):
         return repr(float(expr))
+
+    def _print_Add(self, expr, order=None):
+        """Long sums are printed as SUM_WAYS interleaved accumulators, each a chain of explicit
+        fused multiply-adds, combined pairwise: a left-to-right sum of 100+ products is one
+        dependent chain of multiplies and adds that a GPU lane (and a CPU core) can only retire at
+        the add latency.  Association and fusing are part of the generated source, so the oracle
+        and every kernel round identically; short sums keep the plain C form."""
+        from sympy.printing.precedence import PRECEDENCE
+        terms = self._as_ordered_terms(expr, order=order)
+        if len(terms) < LONG_SUM_TERMS:
+            return super()._print_Add(expr, order=order)
+
+        def factors(term):
+            """term -> (A, B) printed factors of a product term, or None"""
+            coeff, rest = term.as_coeff_Mul()
+            parts = list(rest.as_ordered_factors()) if rest.is_Mul else [rest]
+            if coeff == 1 or coeff == -1:
+                if len(parts) < 2:
+                    return None
+                a_text = self.parenthesize(parts[0], PRECEDENCE["Mul"])
+                if coeff == -1:
+                    a_text = "-" + a_text
+                b_expr = sym.Mul(*parts[1:])
+            else:
+                a_text = self._print(coeff)
+                b_expr = rest
+            return a_text, self.parenthesize(b_expr, PRECEDENCE["Mul"])
+
+        groups = []
+        for w in range(SUM_WAYS):
+            acc = None
+            for term in terms[w::SUM_WAYS]:
+                if acc is None:
+                    acc = "(%s)" % self._print(term)
+                    continue
+                ab = factors(term)
+                if ab is None:
+                    acc = "(%s + (%s))" % (acc, self._print(term))
+                else:
+                    acc = "fma(%s, %s, %s)" % (ab[0], ab[1], acc)
+            groups.append(acc)
+        while len(groups) > 1:
+            groups = ["(%s + %s)" % (groups[i], groups[i + 1]) for i in range(0, len(groups), 2)]
+        return groups[0]
 
     def _print_Integer(self, expr):
         # keep integers exact but typed double so that 1/2 can never appear
@@ -160,6 +216,9 @@ class HipExprPrinter(C99CodePrinter):
 #: callbacks with more output statements than this are emitted as a chain of chunk functions
 #: (compile time of one huge basic block is superlinear; 10^4 Jacobian entries at n = 100)
 CHUNK_STATEMENTS = 400
+#: ... and callbacks with more generated text than this are split into up to MAX_COST_CHUNKS chunks
+CHUNK_COST = 24000
+MAX_COST_CHUNKS = 16
 
 
 def _closure(needed, deps, order):
@@ -210,19 +269,33 @@ def emit_function(
     # straight-line on purpose (constant subscripts only, see bdf_kernels.hip on scalar replacement).
     def body(slots, temps):
         lines = ["    SA_PROLOGUE"]
-        lines += ["    const double %s = %s;" % (tname, temp_text[tname]) for tname in temps]
+        lines += ["    const double %s = %s; SA_STMT_END" % (tname, temp_text[tname]) for tname in temps]
         lines.append("    double chk = 0.0;")
         for slot in slots:
             text = written.get(slot, "0.0")
             if text == "0.0":
                 lines.append("    SA_STORE(%d, 0.0);" % slot)
             else:
-                lines.append("    { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; }" % (text, slot))
+                lines.append("    { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; } SA_STMT_END"
+                             % (text, slot))
         lines.append("    (void)t; (void)y; (void)ps; (void)pr; (void)out;")
         lines.append("    return (chk == 0.0) ? 0 : 1;")
         return lines
 
-    if n_out <= CHUNK_STATEMENTS:
+    # One function for small callbacks; otherwise a chain of chunk functions balanced by the amount of
+    # generated text (a proxy for the arithmetic): at most CHUNK_STATEMENTS statements per chunk and,
+    # for expensive callbacks, up to MAX_COST_CHUNKS chunks so that a kernel can spread them over
+    # several wavefronts (SA_CHUNK_CALL).
+    def _cost(slot):
+        temps = _closure(uses.get(slot, []), temp_deps, temp_order)
+        return len(written.get(slot, "0.0")) + 16 + sum(len(temp_text[tn]) for tn in temps)
+
+    cost = [_cost(slot) for slot in range(n_out)]
+    total = sum(cost)
+    n_chunks = -(-n_out // CHUNK_STATEMENTS)
+    if total > CHUNK_COST:
+        n_chunks = max(n_chunks, min(MAX_COST_CHUNKS, -(-total // CHUNK_COST), n_out))
+    if n_chunks <= 1:
         lines = ["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature)]
         lines += body(range(n_out), temp_order)
         lines.append("}")
@@ -230,15 +303,22 @@ def emit_function(
 
     # chunked form: same expressions, same evaluation order inside every statement; a temporary
     # needed by several chunks is recomputed in each (identical value)
+    bounds, acc, target = [0], 0, total / n_chunks
+    for slot in range(n_out):
+        acc += cost[slot]
+        full = (slot + 1 - bounds[-1]) >= CHUNK_STATEMENTS
+        if (acc >= target * len(bounds) or full) and slot + 1 < n_out and len(bounds) < n_chunks:
+            bounds.append(slot + 1)
+    bounds.append(n_out)
     call_args = ", ".join(part.split()[-1].lstrip("*") for part in signature.split(","))
     parts, calls = [], []
-    for c, lo in enumerate(range(0, n_out, CHUNK_STATEMENTS)):
-        slots = range(lo, min(lo + CHUNK_STATEMENTS, n_out))
+    for c in range(len(bounds) - 1):
+        slots = range(bounds[c], bounds[c + 1])
         needed = [u for slot in slots for u in uses.get(slot, [])]
         cname = "%s_c%d" % (name, c)
         parts.append("\n".join(["SA_TEMPLATE SA_FN int %s(%s) {" % (cname, signature)]
                                + body(slots, _closure(needed, temp_deps, temp_order)) + ["}"]))
-        calls.append("    bad |= %s(%s);" % (cname, call_args))
+        calls.append("    SA_CHUNK_CALL(%d, %s(%s));" % (c, cname, call_args))
     parts.append("\n".join(["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature), "    int bad = 0;"]
                            + calls + ["    return bad;", "}"]))
     return "\n".join(parts)

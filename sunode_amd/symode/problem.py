@@ -26,6 +26,8 @@ from sunode_amd.symode import codegen
 
 Path = Tuple[str, ...]
 Shape = Tuple[int, ...]
+#: fixed-parameter sub-expressions with at least this many operations are evaluated once on the host
+HOIST_MIN_OPS = 8
 
 data_dtype = np.dtype(np.float64)
 
@@ -124,19 +126,23 @@ class SympyProblem:
             ("error_jac", np.float64, (n, n)),
         ])
         self._native_source: Optional[str] = None
+        self._native_cache = None
+        self._hoisted: List[Any] = []
+        self._hoist_fn = None
         self._host_funcs: Dict[str, Any] = {}
 
     # ------------------------------------------------------------------
     def __getstate__(self):
         # dynamic dataclasses / lambdified host functions are rebuilt on demand, not pickled
         state = dict(self.__dict__)
-        for key in ("_sym_params", "_sym_states", "_host_funcs", "_simplify"):
+        for key in ("_sym_params", "_sym_states", "_host_funcs", "_simplify", "_hoist_fn"):
             state.pop(key, None)
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
         self._host_funcs = {}
+        self._hoist_fn = None
         self._simplify = np.vectorize(self._simplify_func, otypes=[object])
 
     def _declare(self, subset: dtypesubset.DTypeSubset, kind: str, **assumptions) -> Dict[Path, np.ndarray]:
@@ -290,6 +296,74 @@ class SympyProblem:
 
     # ------------------------------------------------------------------
     # device / host native source
+    def _native_exprs(self):
+        """The four expression arrays the native callbacks are generated from, with expensive
+        sub-expressions of the *fixed* (non-differentiated) parameters replaced by extra slots of
+        the remainder vector: such a sub-expression has the same value in every callback
+        evaluation of a solve (a rate-matrix column sum, say), so the host evaluates it once
+        (``extend_remainder``) and the kernels -- and the CPU oracle, which compiles the same
+        source -- just read it.  Problems without such sub-expressions are unaffected."""
+        if self._native_cache is None:
+            arrays = [self._simplify(np.array(a, dtype=object)) for a in
+                      (self._sym_dydt, self._sym_dydt_jac, self._sym_dlamdadt, self._sym_quad_rhs)]
+            fixed = set(self._sym_fixed_paramsvec)
+            table: Dict[Any, sym.Symbol] = {}
+
+            def hoistable(e):
+                fs = e.free_symbols
+                return bool(fs) and fs <= fixed and e.count_ops() >= HOIST_MIN_OPS
+
+            def visit(e):
+                if not isinstance(e, sym.Basic) or e.is_Atom:
+                    return e
+                if hoistable(e):
+                    if e not in table:
+                        table[e] = sym.Symbol("fixedpre_%d" % len(table), real=True)
+                    return table[e]
+                if not (e.free_symbols & fixed):
+                    return e
+                if e.is_Add or e.is_Mul:
+                    # the fixed-parameter-only operands of a sum / product form one candidate
+                    own = [a for a in e.args if a.free_symbols and a.free_symbols <= fixed]
+                    if len(own) >= 2:
+                        group = e.func(*own)
+                        if hoistable(group):
+                            rest = [a for a in e.args if not (a.free_symbols and a.free_symbols <= fixed)]
+                            return e.func(visit(group), *[visit(a) for a in rest])
+                return e.func(*[visit(a) for a in e.args])
+
+            if len(fixed):
+                arrays = [np.array([visit(sym.sympify(x)) for x in a.ravel()], dtype=object).reshape(a.shape)
+                          for a in arrays]
+            self._hoisted = list(table.keys())
+            slots = dict(self._c_slots)
+            for k, symbol in enumerate(table.values()):
+                slots[symbol.name] = "SA_PR(%d)" % (self.n_remainder + k)
+            self._native_cache = (arrays, slots)
+        return self._native_cache
+
+    @property
+    def n_remainder_native(self) -> int:
+        """Length of the remainder vector the native code reads (user part + hoisted values)."""
+        self._native_exprs()
+        return self.n_remainder + len(self._hoisted)
+
+    def extend_remainder(self, pr: np.ndarray) -> np.ndarray:
+        """[..., n_remainder] -> [..., n_remainder_native]: append the hoisted fixed-parameter
+        sub-expressions (evaluated here, once per call, in float64)."""
+        self._native_exprs()
+        pr = np.asarray(pr, dtype=np.float64)
+        if not self._hoisted:
+            return pr
+        if self._hoist_fn is None:
+            self._hoist_fn = sym.lambdify([list(self._sym_fixed_paramsvec)], self._hoisted,
+                                          modules=[_HOST_HELPERS, "numpy"], cse=True)
+        lead = pr.shape[:-1]
+        flat = pr.reshape(-1, self.n_remainder)
+        with np.errstate(all="ignore"):
+            extra = np.array([np.asarray(self._hoist_fn(list(row)), dtype=np.float64) for row in flat])
+        return np.concatenate([flat, extra.reshape(len(flat), -1)], axis=1).reshape(lead + (-1,))
+
     def native_source(self) -> str:
         """Generated header with the five callbacks (HIP ``__device__`` and host C)."""
         if self._native_source is None:
@@ -297,14 +371,12 @@ class SympyProblem:
                 [".".join(p) for p in self.state_subset.paths],
                 [".".join(p) for p in self.params_subset.paths],
                 [".".join(p) for p in self.params_subset.subset_paths])
+            (dydt, jac, dlamdadt, quad), slots = self._native_exprs()
+            if self._hoisted:
+                desc += " hoisted=%d" % len(self._hoisted)
             self._native_source = codegen.generate_problem_source(
-                n_states=self.n_states, n_sub=self.n_params, n_rem=self.n_remainder,
-                symbol_map=self._c_slots,
-                dydt=self._simplify(np.array(self._sym_dydt, dtype=object)),
-                jac=self._simplify(np.array(self._sym_dydt_jac, dtype=object)),
-                dlamdadt=self._simplify(np.array(self._sym_dlamdadt, dtype=object)),
-                quad=self._simplify(np.array(self._sym_quad_rhs, dtype=object)),
-                description=desc,
+                n_states=self.n_states, n_sub=self.n_params, n_rem=self.n_remainder_native,
+                symbol_map=slots, dydt=dydt, jac=jac, dlamdadt=dlamdadt, quad=quad, description=desc,
             )
         return self._native_source
 

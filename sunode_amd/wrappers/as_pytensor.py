@@ -111,8 +111,8 @@ class EvalRhs(Op):
         params, params_fixed, y, tvals = inputs
         eng = self._solver._engine()
         n_t = len(tvals)
-        res = eng.eval_callbacks(tvals, y, np.zeros_like(y), np.tile(params, (n_t, 1)),
-                                 np.tile(params_fixed, (n_t, 1)))
+        fixed = self._solver._problem.extend_remainder(params_fixed) if len(params_fixed) else params_fixed
+        res = eng.eval_callbacks(tvals, y, np.zeros_like(y), np.tile(params, (n_t, 1)), np.tile(fixed, (n_t, 1)))
         if res["codes"][:, 0].any():
             raise ValueError("Bad ode rhs return code: 1")
         outputs[0][0] = res["rhs"]

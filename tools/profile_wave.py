@@ -1,0 +1,43 @@
+"""Section timers of the wavefront-per-instance kernel (SA_KERNEL_DEFINES=-DSA_WAVE_PROFILE builds).
+
+python tools/profile_wave.py <B> [generated-header]     (10 ns ticks from stats slots 9..15)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sunode_amd import SympyProblem  # noqa: E402
+from sunode_amd.solver import AdjointSolver  # noqa: E402
+from tools.problems import network100, network_batch  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1])
+    s = network100()
+    prob = SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
+    if len(sys.argv) > 2:
+        prob._native_source = open(sys.argv[2]).read()
+    d = network_batch(B)
+    tv = d["tvals"]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(100)[None, :])
+    sol = AdjointSolver(prob, abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8,
+                        quad_abstol=1e-8, quad_reltol=1e-8, max_steps=1024)
+    for rep in range(2):
+        y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], d["pr"])
+        g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    f, b = sol._engine().last_kernel_ms()
+    print("B=%d fwd %.1f ms bwd %.1f ms -> %.0f solves/s" % (B, f, b, B / ((f + b) * 1e-3)))
+    names = ["rhs", "quad", "jac", "getrf", "getrs", "copy"]
+    for tag, stt in (("fwd", stats), ("bwd", statsb)):
+        tot = stt[:, 15].mean() * 1e-5
+        parts = ", ".join("%s %.1f" % (n, stt[:, 9 + i].mean() * 1e-5) for i, n in enumerate(names))
+        print("%s per-instance ms: total %.1f | %s | nst %.0f nfe %.0f nsetups %.0f nje %.0f nni %.0f"
+              % (tag, tot, parts, stt[:, 0].mean(), stt[:, 1].mean(), stt[:, 2].mean(), stt[:, 3].mean(),
+                 stt[:, 4].mean()))
+
+
+if __name__ == "__main__":
+    main()
