@@ -154,7 +154,7 @@ def code_object_path(native_source: str) -> str:
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h")]
     deps = [d for d in deps if os.path.exists(d)]
     extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group + fname.encode()
-             + os.environ.get("SA_KERNEL_DEFINES", "").encode())
+             + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode())
     key = _hash_files(*deps, extra=extra) if os.path.exists(kern) else \
         hashlib.sha256(extra).hexdigest()[:16]
     return os.path.join(_CACHE, "sa_%s.hsaco" % key)
@@ -180,6 +180,20 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
               "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-DSA_GROUP=%d" % group] + _size_defines(native_source)
              + ["-I" + _CSRC, kern, "-o", bc0])
         _run([os.path.join(LLVM_BIN, "opt"), "-passes=always-inline,sroa", bc0, "-o", bc1])
+        occupancy = os.environ.get("SA_WAVES_PER_EU")
+        if occupancy:
+            # tuning: cap the register budget of EVERY function (the noinline callbacks included; the
+            # launch-bounds attribute only reaches the kernels) so that `occupancy` waves fit a SIMD
+            ll = os.path.join(tmp, "k1.ll")
+            _run([os.path.join(LLVM_BIN, "llvm-dis"), bc1, "-o", ll])
+            with open(ll) as fh:
+                text = fh.read()
+            import re
+            text = re.sub(r'^(attributes #\d+ = \{.*) \}$',
+                          r'\1 "amdgpu-waves-per-eu"="%s,%s" }' % (occupancy, occupancy), text, flags=re.M)
+            with open(ll, "w") as fh:
+                fh.write(text)
+            bc1 = ll            # clang -x ir reads the textual form as well
         base = [os.path.join(LLVM_BIN, "clang"), "-x", "ir", bc1, "-target", "amdgcn-amd-amdhsa",
                 "-mcpu=" + ARCH, "-O3", "-ffp-contract=off"]
         # the memory-resident build is dominated by the generated callbacks (10^4 statements at

@@ -54,7 +54,7 @@ __shared__ uint8_t s_piv[(W_NS + 15) / 16 * 16];    /* pivot rows (n <= 128 fits
 __shared__ int s_cmd, s_nwaves;
 __shared__ double s_targ;
 __shared__ int s_rc[SA_WAVES];
-enum { CMD_EXIT = 0, CMD_RHS = 1, CMD_QUAD = 2, CMD_JAC = 3 };
+enum { CMD_EXIT = 0, CMD_RHS = 1, CMD_QUAD = 2, CMD_JAC = 3, CMD_GETRF = 4 };
 static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 #define SA_CHUNK_CALL(c, call) do { if (((c) % s_nwaves) == sa_wave_index()) bad |= call; } while (0)
 
@@ -403,6 +403,8 @@ DEV int dispatch(Cw<BWD> &m, int cmd, double t)
     return rc;
 }
 
+DEV int getrf_coop(int lane, int wave, double (&inv_piv)[(W_NS + 63) / 64], int &nswaps);
+
 template <bool BWD>
 DEV void worker_loop(const double *pr, double *obuf)
 {
@@ -412,8 +414,15 @@ DEV void worker_loop(const double *pr, double *obuf)
         const int cmd = s_cmd;
         const double t = s_targ;
         if (cmd == CMD_EXIT) break;
-        const int rc = run_callback<BWD>(cmd, t, pr, obuf);
-        if (lane == 0) s_rc[wave] = rc;
+        if (cmd == CMD_GETRF) {
+            double inv_piv[RS];
+            int nswaps;
+            SFOR(r, 0, RS) inv_piv[r] = 0.0; SEND
+            (void)getrf_coop(lane, wave, inv_piv, nswaps);
+        } else {
+            const int rc = run_callback<BWD>(cmd, t, pr, obuf);
+            if (lane == 0) s_rc[wave] = rc;
+        }
         __syncthreads();
     }
 }
@@ -466,12 +475,20 @@ DEV int cv_jac(Cw<BWD> &m, double t, const double (&ymine)[RS])        /* Jacobi
 #define AL(i, j) s_A[(j) * NS + (i)]
 #define LU_BATCH 8
 
-template <bool BWD>
-DEV int dense_getrf(Cw<BWD> &m)
+/* LU of the LDS matrix by ALL wavefronts of the workgroup (the workers are idle otherwise): every
+   wavefront repeats the pivot search and the scaling of column k on identical data (identical
+   decisions, no communication), the trailing columns are split between the wavefronts, one
+   workgroup barrier per elimination step.  Wavefront 0 writes the scaled column back one step late,
+   when nobody reads the unscaled entries any more. */
+DEV int getrf_coop(int lane, int wave, double (&inv_piv)[RS], int &nswaps)
 {
-    PROF_T0
-    m.nswaps = 0;
+    nswaps = 0;
+    double lcol[RS];
+    SFOR(r, 0, RS) lcol[r] = 0.0; SEND
     for (int k = 0; k < NS; k++) {
+        if (wave == 0 && k > 0) {
+            SFOR(r, 0, RS) { const int i = r * 64 + lane; if (i > k - 1 && i < NS) AL(i, k - 1) = lcol[r]; } SEND
+        }
         /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF).
            I - gamma*J is close to diagonally dominant, so usually no row beats the diagonal: one
            ballot settles that case, the arg-max butterfly only runs when some lane disagrees. */
@@ -480,7 +497,7 @@ DEV int dense_getrf(Cw<BWD> &m)
         bool beaten = false;
         double cand[RS];
         SFOR(r, 0, RS) {
-            const int i = IDX(m, r);
+            const int i = r * 64 + lane;
             cand[r] = (i > k && i < NS) ? fabs(AL(i, k)) : -1.0;
             beaten = beaten || (cand[r] > best);
         } SEND
@@ -488,69 +505,75 @@ DEV int dense_getrf(Cw<BWD> &m)
             best = -1.0;
             bi = 1 << 20;
             SFOR(r, 0, RS) {
-                const int i = IDX(m, r);
+                const int i = r * 64 + lane;
                 const double v = (i == k) ? fabs(AL(k, k)) : cand[r];
                 if (i >= k && i < NS && v > best) { best = v; bi = i; }
             } SEND
             SFOR(b, 0, 6) {
-                const double ov = shfl_d(best, m.lane ^ (1 << b));
-                const int oi = shfl_i(bi, m.lane ^ (1 << b));
+                const double ov = shfl_d(best, lane ^ (1 << b));
+                const int oi = shfl_i(bi, lane ^ (1 << b));
                 const bool take = (ov > best) || (ov == best && oi < bi);
                 best = take ? ov : best;
                 bi = take ? oi : bi;
             } SEND
         }
         const int l = __builtin_amdgcn_readfirstlane(bi);
-        if (m.lane == 0) s_piv[k] = (uint8_t)l;
+        if (wave == 0 && lane == 0) s_piv[k] = (uint8_t)l;
         if (best == 0.0) return k + 1;
-        if (l != k) {                   /* exchange rows k and l, one column per lane */
-            m.nswaps++;
-            lds_sync();
-            for (int c = m.lane; c < NS; c += 64) {
+        if (l != k) {                   /* exchange rows k and l, one column per thread */
+            nswaps++;
+            __syncthreads();
+            for (int c = wave * 64 + lane; c < NS; c += 64 * SA_WAVES) {
                 const double x = AL(k, c), y = AL(l, c);
                 AL(k, c) = y;
                 AL(l, c) = x;
             }
-            lds_sync();
+            __syncthreads();
         }
         const double mult = 1.0 / AL(k, k);
-        double lcol[RS];
         SFOR(r, 0, RS) {
-            const int i = IDX(m, r);
-            m.inv_piv[r] = (i == k) ? mult : m.inv_piv[r];
-            lcol[r] = 0.0;
-            if (i > k && i < NS) { lcol[r] = AL(i, k) * mult; AL(i, k) = lcol[r]; }
+            const int i = r * 64 + lane;
+            inv_piv[r] = (i == k) ? mult : inv_piv[r];
+            lcol[r] = (i > k && i < NS) ? AL(i, k) * mult : 0.0;
         } SEND
-        /* elimination, LU_BATCH columns at a time: all reads of a batch before its writes */
-        int j = k + 1;
-        for (; j + LU_BATCH <= NS; j += LU_BATCH) {
+        /* elimination: this wavefront's batches of LU_BATCH columns, all reads of a batch before its writes */
+        for (int j = k + 1 + wave * LU_BATCH; j < NS; j += LU_BATCH * SA_WAVES) {
             double akj[LU_BATCH], x[LU_BATCH][RS];
             SFOR(u, 0, LU_BATCH) {
-                akj[u] = AL(k, j + u);
-                SFOR(r, 0, RS) { const int i = IDX(m, r); x[u][r] = (i > k && i < NS) ? AL(i, j + u) : 0.0; } SEND
+                const bool on = (j + u) < NS;
+                akj[u] = on ? AL(k, on ? j + u : j) : 0.0;
+                SFOR(r, 0, RS) {
+                    const int i = r * 64 + lane;
+                    x[u][r] = (on && i > k && i < NS) ? AL(i, j + u) : 0.0;
+                } SEND
             } SEND
             SFOR(u, 0, LU_BATCH) {
                 if (akj[u] != 0.0) {
                     SFOR(r, 0, RS) {
-                        const int i = IDX(m, r);
-                        if (i > k && i < NS) AL(i, j + u) = FMA(-akj[u], lcol[r], x[u][r]);
+                        const int i = r * 64 + lane;
+                        if ((j + u) < NS && i > k && i < NS) AL(i, j + u) = FMA(-akj[u], lcol[r], x[u][r]);
                     } SEND
                 }
             } SEND
         }
-        for (; j < NS; j++) {
-            const double a_kj = AL(k, j);
-            if (a_kj != 0.0) {
-                SFOR(r, 0, RS) {
-                    const int i = IDX(m, r);
-                    if (i > k && i < NS) AL(i, j) = FMA(-a_kj, lcol[r], AL(i, j));
-                } SEND
-            }
-        }
-        lds_sync();
+        __syncthreads();
     }
-    PROF_ADD(m, 3)
     return 0;
+}
+
+template <bool BWD>
+DEV int dense_getrf(Cw<BWD> &m)
+{
+    PROF_T0
+    if constexpr (SA_WAVES > 1) {
+        if (m.lane == 0) s_cmd = CMD_GETRF;
+        __syncthreads();
+    }
+    const int ier = getrf_coop(m.lane, 0, m.inv_piv, m.nswaps);
+    if constexpr (SA_WAVES > 1) __syncthreads();
+    lds_sync();
+    PROF_ADD(m, 3)
+    return ier;
 }
 
 /* component k (wave-uniform k) of a lane-distributed vector */

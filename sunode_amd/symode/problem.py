@@ -28,6 +28,8 @@ Path = Tuple[str, ...]
 Shape = Tuple[int, ...]
 #: fixed-parameter sub-expressions with at least this many operations are evaluated once on the host
 HOIST_MIN_OPS = 8
+#: a callback touching at least this many fixed parameters in a scattered order gets an access-order copy
+PACK_MIN_SYMBOLS = 256
 
 data_dtype = np.dtype(np.float64)
 
@@ -128,6 +130,7 @@ class SympyProblem:
         self._native_source: Optional[str] = None
         self._native_cache = None
         self._hoisted: List[Any] = []
+        self._packed: List[int] = []
         self._hoist_fn = None
         self._host_funcs: Dict[str, Any] = {}
 
@@ -339,30 +342,67 @@ class SympyProblem:
             slots = dict(self._c_slots)
             for k, symbol in enumerate(table.values()):
                 slots[symbol.name] = "SA_PR(%d)" % (self.n_remainder + k)
-            self._native_cache = (arrays, slots)
+
+            # Access-order copies: a callback that walks a big block of fixed parameters with a large
+            # stride (the adjoint right-hand side reads the rate matrix by columns) gets its own copy
+            # of those parameters in the order it uses them, appended to the remainder vector by
+            # ``extend_remainder``: sequential, cache-line friendly loads instead of one line per value.
+            base = self.n_remainder + len(self._hoisted)
+            index_of = {sy: k for k, sy in enumerate(self._sym_fixed_paramsvec)}
+            self._packed: List[int] = []
+            packed_arrays = []
+            for tag, a in zip("fjaq", arrays):
+                order: List[Any] = []
+                seen = set()
+                pairs = adjacent = 0
+                for x in a.ravel():
+                    used = sorted((sy for sy in sym.sympify(x).free_symbols if sy in index_of),
+                                  key=lambda sy: sy.name)
+                    for u, v in zip(used, used[1:]):
+                        pairs += 1
+                        adjacent += abs(index_of[u] - index_of[v]) == 1
+                    for sy in used:
+                        if sy not in seen:
+                            seen.add(sy)
+                            order.append(sy)
+                if len(order) >= PACK_MIN_SYMBOLS and pairs and adjacent < 0.5 * pairs:
+                    sub = {}
+                    for sy in order:
+                        new = sym.Symbol("fixedpk%s_%07d" % (tag, len(self._packed)), real=True)
+                        slots[new.name] = "SA_PR(%d)" % (base + len(self._packed))
+                        self._packed.append(index_of[sy])
+                        sub[sy] = new
+                    a = np.array([sym.sympify(x).xreplace(sub) for x in a.ravel()], dtype=object).reshape(a.shape)
+                packed_arrays.append(a)
+            self._native_cache = (packed_arrays, slots)
         return self._native_cache
 
     @property
     def n_remainder_native(self) -> int:
         """Length of the remainder vector the native code reads (user part + hoisted values)."""
         self._native_exprs()
-        return self.n_remainder + len(self._hoisted)
+        return self.n_remainder + len(self._hoisted) + len(self._packed)
 
     def extend_remainder(self, pr: np.ndarray) -> np.ndarray:
         """[..., n_remainder] -> [..., n_remainder_native]: append the hoisted fixed-parameter
         sub-expressions (evaluated here, once per call, in float64)."""
         self._native_exprs()
         pr = np.asarray(pr, dtype=np.float64)
-        if not self._hoisted:
+        if not self._hoisted and not self._packed:
             return pr
-        if self._hoist_fn is None:
-            self._hoist_fn = sym.lambdify([list(self._sym_fixed_paramsvec)], self._hoisted,
-                                          modules=[_HOST_HELPERS, "numpy"], cse=True)
         lead = pr.shape[:-1]
         flat = pr.reshape(-1, self.n_remainder)
-        with np.errstate(all="ignore"):
-            extra = np.array([np.asarray(self._hoist_fn(list(row)), dtype=np.float64) for row in flat])
-        return np.concatenate([flat, extra.reshape(len(flat), -1)], axis=1).reshape(lead + (-1,))
+        pieces = [flat]
+        if self._hoisted:
+            if self._hoist_fn is None:
+                self._hoist_fn = sym.lambdify([list(self._sym_fixed_paramsvec)], self._hoisted,
+                                              modules=[_HOST_HELPERS, "numpy"], cse=True)
+            with np.errstate(all="ignore"):
+                extra = np.array([np.asarray(self._hoist_fn(list(row)), dtype=np.float64) for row in flat])
+            pieces.append(extra.reshape(len(flat), -1))
+        if self._packed:
+            pieces.append(flat[:, np.asarray(self._packed, dtype=np.int64)])
+        return np.concatenate(pieces, axis=1).reshape(lead + (-1,))
 
     def native_source(self) -> str:
         """Generated header with the five callbacks (HIP ``__device__`` and host C)."""
@@ -372,8 +412,8 @@ class SympyProblem:
                 [".".join(p) for p in self.params_subset.paths],
                 [".".join(p) for p in self.params_subset.subset_paths])
             (dydt, jac, dlamdadt, quad), slots = self._native_exprs()
-            if self._hoisted:
-                desc += " hoisted=%d" % len(self._hoisted)
+            if self._hoisted or self._packed:
+                desc += " hoisted=%d packed=%d" % (len(self._hoisted), len(self._packed))
             self._native_source = codegen.generate_problem_source(
                 n_states=self.n_states, n_sub=self.n_params, n_rem=self.n_remainder_native,
                 symbol_map=slots, dydt=dydt, jac=jac, dlamdadt=dlamdadt, quad=quad, description=desc,
