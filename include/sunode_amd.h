@@ -98,6 +98,17 @@ int sa_solve_batch(sa_solver *s, int mem, int32_t B, const double *y0, const dou
                    const double *pr, int32_t rem_stride, double t0, const double *tvals, int32_t n_t,
                    double *y_out, int32_t *status, int64_t *stats);
 
+/* Solver(sens_mode=...).solve, batched (replaces solver.py:360-392 CVodeSensInit /
+   CVodeSensEEtolerances / CVodeSetSensErrCon(1) and :467-527 CVodeSensReInit / CVode / CVodeGetSens).
+   Needs a code object built with forward-sensitivity support (SA_SENS build); otherwise SA_ERR_ARG.
+   ism: 0 = "simultaneous", 1 = "staggered".  scaling [n_sub] = CVodeSetSensParams pbar (NULL: ones).
+   sens0 [B][n_sub][n_states]; sens_out [B][n_t][n_sub][n_states] (the reference's sens_out[i, j, :] per
+   instance).  stats slots SA_ST_NFQE / NETFQ / NINTERP / NREBUILD carry nfSe / netfS / nniS / ncfnS here. */
+int sa_solve_sens_batch(sa_solver *s, int mem, int ism, const double *scaling, int32_t B, const double *y0,
+                        const double *params_sub, const double *params_rem, int32_t rem_stride,
+                        const double *sens0, double t0, const double *tvals, int32_t n_t, double *y_out,
+                        double *sens_out, int32_t *status, int64_t *stats);
+
 /* AdjointSolver.solve_forward (solver.py:682-721): CVodeReInit + CVodeAdjReInit + CVodeF per
    tval; every internal step is stored in the solver's trajectory arena. */
 int sa_solve_forward_batch(sa_solver *s, int mem, int32_t B, const double *y0, const double *ps,

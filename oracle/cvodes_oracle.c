@@ -71,6 +71,10 @@
 #define CV_QRHSFUNC_FAIL (-31)
 #define CV_FIRST_QRHSFUNC_ERR (-32)
 #define CV_REPTD_QRHSFUNC_ERR (-33)
+#define CV_SRHSFUNC_FAIL (-41)
+#define CV_FIRST_SRHSFUNC_ERR (-42)
+#define CV_REPTD_SRHSFUNC_ERR (-43)
+#define CV_UNREC_SRHSFUNC_ERR (-44)
 #define CV_BAD_TB0 (-104)
 #define CV_GETY_BADT (-107)
 
@@ -120,6 +124,7 @@
 #define TRY_AGAIN 5
 #define RHSFUNC_RECVR 9
 #define QRHSFUNC_RECVR 11
+#define SRHSFUNC_RECVR 12
 #define NLS_CONTINUE 901
 #define NLS_CONV_RECVR 902
 #define CV_NO_FAILURES 0
@@ -357,6 +362,14 @@ typedef struct {
     int tstopset;
     double tstop, tretlast;
     long nst, nfe, nje, nsetups, nni, ncfn, netf, nfQe, netfQ, nstlp, nstlj;
+    /* forward sensitivities (CVodeSensInit, EE tolerances, errconS = 1; solver.py:360-392) */
+    int sensi, ism;                          /* ism: 0 = CV_SIMULTANEOUS, 1 = CV_STAGGERED */
+    double pbar[NQD];
+    double znS[QMAX + 1][NQD][NSD];
+    double ewtS[NQD][NSD], acorS[NQD][NSD], tempvS[NQD][NSD], ftempS[NQD][NSD], yS[NQD][NSD];
+    double Jtmp[NSD * NSD];                  /* Jacobian of the sensitivity right-hand side */
+    double crateS, delpS, acnrmS;
+    long nfSe, nniS, ncfnS, netfS, nsetupsS;
     /* linear solver */
     double A[NSD * NSD], savedJ[NSD * NSD];
     int piv[NSD];
@@ -385,6 +398,29 @@ static int cv_jac(cvmem *m, double t, const double *y, double *J)
     if (!m->backward) return sa_jac(t, y, m->ps, m->pr, J);
     if (traj_get_y(m->tr, t, m->ytmp) != CV_SUCCESS) return -1;
     return sa_adj_jac(t, m->ytmp, m->ps, m->pr, J);
+}
+
+/* Sensitivity right-hand side for all parameters at once (symode/problem.py:557-583):
+   out[is] = J(t,y) yS[is] + df/dp_is.  The reference leaves the order of the dot products to BLAS;
+   here: left-to-right FMA chain over j, then the explicit part is added. */
+static int cv_fS(cvmem *m, double t, const double *y, double yS[NQD][NSD], double out[NQD][NSD])
+{
+    m->nfSe++;
+    double dp[NQD * NSD];
+    for (int i = 0; i < NS * NS; i++) m->Jtmp[i] = 0.0;
+    int rc = sa_jac(t, y, m->ps, m->pr, m->Jtmp);
+    if (rc != 0) return rc;
+    rc = sa_dydp(t, y, m->ps, m->pr, dp);
+    int bad = 0;
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) {
+            double acc = m->Jtmp[(size_t)0 * NS + i] * yS[is][0];
+            for (int j = 1; j < NS; j++) acc = FMA(m->Jtmp[(size_t)j * NS + i], yS[is][j], acc);
+            acc = acc + dp[is * NS + i];
+            out[is][i] = acc;
+            bad |= !(acc * 0.0 == 0.0);
+        }
+    return (rc != 0 || bad) ? 1 : 0;
 }
 
 /* ---- vector kernels ---- */
@@ -431,6 +467,31 @@ static int ewtQ_set(cvmem *m, const double *qcur, double *w)
         w[i] = 1.0 / v;
     }
     return 0;
+}
+
+/* cvSensEwtSetEE: weights of pbar*yS with the state tolerances, scaled back by pbar */
+static int sens_ewt_set(cvmem *m, double yScur[NQD][NSD], double w[NQD][NSD])
+{
+    for (int is = 0; is < NQ; is++) {
+        const double pb = m->pbar[is];
+        for (int i = 0; i < NS; i++) {
+            double v = FMA(m->rtol, fabs(pb * yScur[is][i]), m->atol[i]);
+            if (v <= 0.0) return -1;
+            w[is][i] = pb * (1.0 / v);
+        }
+    }
+    return 0;
+}
+
+/* cvSensUpdateNorm / N_VWrmsNorm of a sensitivity wrapper: max over the vectors */
+static double sens_update_norm(double old_nrm, double xS[NQD][NSD], double wS[NQD][NSD])
+{
+    double nrm = old_nrm;
+    for (int is = 0; is < NQ; is++) {
+        double snrm = wrms(xS[is], wS[is], NS);
+        if (snrm > nrm) nrm = snrm;
+    }
+    return nrm;
 }
 
 /* ---- dense LU (SUNDIALS denseGETRF / denseGETRS, column-major) ---- */
@@ -504,6 +565,15 @@ static void cv_reinit(cvmem *m, double t0, const double *y0, const double *q0)
     m->tretlast = t0;
 }
 
+/* CVodeSensReInit: znS[0] = yS0, counters */
+static void cv_sens_reinit(cvmem *m, const double *yS0 /* [NQ][NS] */)
+{
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) m->znS[0][is][i] = yS0[is * NS + i];
+    m->nfSe = m->nniS = m->ncfnS = m->netfS = m->nsetupsS = 0;
+    m->crateS = 1.0; m->delpS = 0.0; m->acnrmS = 0.0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* cvHin and helpers                                                           */
 /* ------------------------------------------------------------------------- */
@@ -534,6 +604,18 @@ static double cv_upper_bound_h0(cvmem *m, double tdist)
         }
         if (hubQ_inv > hub_inv) hub_inv = hubQ_inv;
     }
+    if (m->sensi) {          /* errconS */
+        double wS[NQD][NSD];
+        sens_ewt_set(m, m->znS[0], wS);
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) {
+                double t2 = fabs(m->znS[0][is][i]);
+                double t1 = 1.0 / wS[is][i];
+                t1 = FMA(HUB_FACTOR, t2, t1);
+                double v = fabs(m->znS[1][is][i]) / t1;
+                if (v > hub_inv) hub_inv = v;
+            }
+    }
     double hub = HUB_FACTOR * tdist;
     if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
     return hub;
@@ -542,9 +624,17 @@ static double cv_upper_bound_h0(cvmem *m, double tdist)
 static int cv_ydd_norm(cvmem *m, double hg, double *yddnrm)
 {
     for (int i = 0; i < NS; i++) m->y[i] = FMA(hg, m->zn[1][i], m->zn[0][i]);
+    if (m->sensi)
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) m->yS[is][i] = FMA(hg, m->znS[1][is][i], m->znS[0][is][i]);
     int retval = cv_f(m, m->tn + hg, m->y, m->tempv);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return RHSFUNC_RECVR;
+    if (m->sensi) {
+        retval = cv_fS(m, m->tn + hg, m->y, m->yS, m->tempvS);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return SRHSFUNC_RECVR;
+    }
     if (m->quadr && m->errconQ) {
         retval = cv_fQ(m, m->tn + hg, m->y, m->tempvQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -561,6 +651,14 @@ static int cv_ydd_norm(cvmem *m, double hg, double *yddnrm)
             m->tempvQ[i] = (1.0 / hg) * m->tempvQ[i];
         }
         *yddnrm = quad_update_norm(m, *yddnrm, m->tempvQ, m->ewtQ);
+    }
+    if (m->sensi) {
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) {
+                m->tempvS[is][i] = m->tempvS[is][i] - m->znS[1][is][i];
+                m->tempvS[is][i] = (1.0 / hg) * m->tempvS[is][i];
+            }
+        *yddnrm = sens_update_norm(*yddnrm, m->tempvS, m->ewtS);
     }
     return CV_SUCCESS;
 }
@@ -623,6 +721,8 @@ static void cv_rescale(cvmem *m)
     for (int j = 1; j <= m->q; j++) {
         for (int i = 0; i < NS; i++) m->zn[j][i] *= factor;
         if (m->quadr) for (int i = 0; i < NQ; i++) m->znQ[j][i] *= factor;
+        if (m->sensi)
+            for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->znS[j][is][i] *= factor;
         factor *= m->eta;
     }
     m->h = m->hscale * m->eta;
@@ -656,6 +756,13 @@ static void cv_increase_bdf(cvmem *m)
         for (int j = 2; j <= m->q; j++)
             for (int i = 0; i < NQ; i++) m->znQ[j][i] = FMA(m->l[j], m->znQ[L][i], m->znQ[j][i]);
     }
+    if (m->sensi)
+        for (int is = 0; is < NQ; is++) {
+            for (int i = 0; i < NS; i++) m->znS[L][is][i] = A1 * m->znS[QMAX][is][i];
+            for (int j = 2; j <= m->q; j++)
+                for (int i = 0; i < NS; i++)
+                    m->znS[j][is][i] = FMA(m->l[j], m->znS[L][is][i], m->znS[j][is][i]);
+        }
 }
 
 static void cv_decrease_bdf(cvmem *m)
@@ -673,6 +780,11 @@ static void cv_decrease_bdf(cvmem *m)
     if (m->quadr)
         for (int j = 2; j < m->q; j++)
             for (int i = 0; i < NQ; i++) m->znQ[j][i] = FMA(-m->l[j], m->znQ[m->q][i], m->znQ[j][i]);
+    if (m->sensi)
+        for (int is = 0; is < NQ; is++)
+            for (int j = 2; j < m->q; j++)
+                for (int i = 0; i < NS; i++)
+                    m->znS[j][is][i] = FMA(-m->l[j], m->znS[m->q][is][i], m->znS[j][is][i]);
 }
 
 static void cv_adjust_order(cvmem *m, int deltaq)
@@ -703,6 +815,9 @@ static void cv_predict(cvmem *m)
         for (int j = m->q; j >= k; j--) {
             for (int i = 0; i < NS; i++) m->zn[j - 1][i] = m->zn[j - 1][i] + m->zn[j][i];
             if (m->quadr) for (int i = 0; i < NQ; i++) m->znQ[j - 1][i] = m->znQ[j - 1][i] + m->znQ[j][i];
+            if (m->sensi)
+                for (int is = 0; is < NQ; is++)
+                    for (int i = 0; i < NS; i++) m->znS[j - 1][is][i] = m->znS[j - 1][is][i] + m->znS[j][is][i];
         }
 }
 
@@ -713,6 +828,9 @@ static void cv_restore(cvmem *m, double saved_t)
         for (int j = m->q; j >= k; j--) {
             for (int i = 0; i < NS; i++) m->zn[j - 1][i] = m->zn[j - 1][i] - m->zn[j][i];
             if (m->quadr) for (int i = 0; i < NQ; i++) m->znQ[j - 1][i] = m->znQ[j - 1][i] - m->znQ[j][i];
+            if (m->sensi)
+                for (int is = 0; is < NQ; is++)
+                    for (int i = 0; i < NS; i++) m->znS[j - 1][is][i] = m->znS[j - 1][is][i] - m->znS[j][is][i];
         }
 }
 
@@ -817,6 +935,7 @@ static int cv_nls_lsetup(cvmem *m, int jbad, int *convfail)
     m->gamrat = 1.0;
     m->gammap = m->gamma;
     m->crate = 1.0;
+    m->crateS = 1.0;
     m->nstlp = m->nst;
     if (retval < 0) return CV_LSETUP_FAIL;
     if (retval > 0) return NLS_CONV_RECVR;
@@ -859,18 +978,43 @@ static int cv_nls_conv_test(cvmem *m, int curiter, const double *delta, const do
     return NLS_CONTINUE;
 }
 
-/* cvNls + SUNNonlinSolSolve_Newton */
+/* residual of the combined (state + sensitivities) system: cvNlsResidualSensSim */
+static int cv_nls_residual_sens(cvmem *m, double resS[NQD][NSD])
+{
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) m->yS[is][i] = m->znS[0][is][i] + m->acorS[is][i];
+    int retval = cv_fS(m, m->tn, m->y, m->yS, m->ftempS);
+    if (retval < 0) return CV_SRHSFUNC_FAIL;
+    if (retval > 0) return SRHSFUNC_RECVR;
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) {
+            resS[is][i] = FMA(m->rl1, m->znS[1][is][i], m->acorS[is][i]);
+            resS[is][i] = FMA(-m->gamma, m->ftempS[is][i], resS[is][i]);
+        }
+    return CV_SUCCESS;
+}
+
+/* cvNls + SUNNonlinSolSolve_Newton; with ism = CV_SIMULTANEOUS the iteration runs on the wrapper
+   vector (y, yS_1..yS_Ns): one linear solve per member with the same factorisation, norms = max over
+   the members (N_VWrmsNorm_SensWrapper) */
 static int cv_nls(cvmem *m, int nflag)
 {
+    const int sim = m->sensi && m->ism == 0;
     int convfail = ((nflag == FIRST_CALL) || (nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
     int callSetup = (nflag == PREV_CONV_FAIL) || (nflag == PREV_ERR_FAIL) || (m->nst == 0) ||
                     (m->nst >= m->nstlp + MSBP) || (fabs(m->gamrat - 1.0) > DGMAX);
     for (int i = 0; i < NS; i++) m->acor[i] = 0.0;
+    if (sim) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->acorS[is][i] = 0.0;
     double delta[NSD];
+    double deltaS[NQD][NSD];
     int jbad = 0, retval;
     for (;;) {
         retval = cv_nls_residual(m, m->acor, delta);
         if (retval != CV_SUCCESS) break;
+        if (sim) {
+            retval = cv_nls_residual_sens(m, deltaS);
+            if (retval != CV_SUCCESS) break;
+        }
         if (callSetup) {
             retval = cv_nls_lsetup(m, jbad, &convfail);
             if (retval != CV_SUCCESS) break;
@@ -881,33 +1025,114 @@ static int cv_nls(cvmem *m, int nflag)
             for (int i = 0; i < NS; i++) delta[i] = -1.0 * delta[i];
             cv_lsolve(m, delta);
             for (int i = 0; i < NS; i++) m->acor[i] = m->acor[i] + delta[i];
-            retval = cv_nls_conv_test(m, curiter, delta, m->acor);
+            if (sim) {
+                for (int is = 0; is < NQ; is++) {
+                    for (int i = 0; i < NS; i++) deltaS[is][i] = -1.0 * deltaS[is][i];
+                    cv_lsolve(m, deltaS[is]);
+                    for (int i = 0; i < NS; i++) m->acorS[is][i] = m->acorS[is][i] + deltaS[is][i];
+                }
+                /* cvNlsConvTestSensSim */
+                double del = sens_update_norm(wrms(delta, m->ewt, NS), deltaS, m->ewtS);
+                if (curiter > 0) m->crate = fmax(CRDOWN * m->crate, del / m->delp);
+                double dcon = del * fmin(1.0, m->crate) * m->tq[4];
+                if (dcon <= 1.0) {
+                    m->acnrm = (curiter == 0) ? del
+                                              : sens_update_norm(wrms(m->acor, m->ewt, NS), m->acorS, m->ewtS);
+                    retval = CV_SUCCESS;
+                } else if ((curiter >= 1) && (del > RDIV * m->delp)) retval = NLS_CONV_RECVR;
+                else { m->delp = del; retval = NLS_CONTINUE; }
+            } else {
+                retval = cv_nls_conv_test(m, curiter, delta, m->acor);
+            }
             if (retval == CV_SUCCESS) { m->nls_jcur = 0; break; }
             if (retval != NLS_CONTINUE) break;
             curiter++;
             if (curiter >= NLS_MAXCOR) { retval = NLS_CONV_RECVR; break; }
             retval = cv_nls_residual(m, m->acor, delta);
             if (retval != CV_SUCCESS) break;
+            if (sim) {
+                retval = cv_nls_residual_sens(m, deltaS);
+                if (retval != CV_SUCCESS) break;
+            }
         }
         if (retval == CV_SUCCESS) break;
         if ((retval > 0) && !m->nls_jcur) {
             callSetup = 1;
             jbad = 1;
             for (int i = 0; i < NS; i++) m->acor[i] = 0.0;
+            if (sim) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->acorS[is][i] = 0.0;
             continue;
         }
         break;
     }
     if (retval != CV_SUCCESS) return retval;
     for (int i = 0; i < NS; i++) m->y[i] = m->zn[0][i] + m->acor[i];
+    if (sim)
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) m->yS[is][i] = m->znS[0][is][i] + m->acorS[is][i];
     return CV_SUCCESS;
 }
 
-static int cv_handle_nflag(cvmem *m, int *nflagPtr, double saved_t, int *ncfPtr)
+/* cvStgrNls: Newton iteration on the sensitivity systems alone (ism = CV_STAGGERED), state fixed at
+   the converged y; own convergence-rate estimate; one retry with a fresh Jacobian */
+static int cv_stgr_nls(cvmem *m)
+{
+    int callSetup = 0, jbad = 0, convfail = CV_FAIL_OTHER, retval;
+    double deltaS[NQD][NSD];
+    for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->acorS[is][i] = 0.0;
+    for (;;) {
+        retval = cv_nls_residual_sens(m, deltaS);
+        if (retval != CV_SUCCESS) break;
+        if (callSetup) {
+            retval = cv_nls_lsetup(m, jbad, &convfail);
+            m->nsetupsS++;
+            if (retval != CV_SUCCESS) break;
+        }
+        int curiter = 0;
+        for (;;) {
+            m->nniS++;
+            for (int is = 0; is < NQ; is++) {
+                for (int i = 0; i < NS; i++) deltaS[is][i] = -1.0 * deltaS[is][i];
+                cv_lsolve(m, deltaS[is]);
+                for (int i = 0; i < NS; i++) m->acorS[is][i] = m->acorS[is][i] + deltaS[is][i];
+            }
+            /* cvNlsConvTestSensStg */
+            double del = sens_update_norm(0.0, deltaS, m->ewtS);
+            if (curiter > 0) m->crateS = fmax(CRDOWN * m->crateS, del / m->delpS);
+            double dcon = del * fmin(1.0, m->crateS) * m->tq[4];
+            if (dcon <= 1.0) {
+                if (m->sensi) m->acnrmS = (curiter == 0) ? del : sens_update_norm(0.0, m->acorS, m->ewtS);
+                retval = CV_SUCCESS;
+                m->nls_jcur = 0;
+                break;
+            }
+            if ((curiter >= 1) && (del > RDIV * m->delpS)) { retval = NLS_CONV_RECVR; break; }
+            m->delpS = del;
+            curiter++;
+            if (curiter >= NLS_MAXCOR) { retval = NLS_CONV_RECVR; break; }
+            retval = cv_nls_residual_sens(m, deltaS);
+            if (retval != CV_SUCCESS) break;
+        }
+        if (retval == CV_SUCCESS) break;
+        if ((retval > 0) && !m->nls_jcur) {
+            callSetup = 1;
+            jbad = 1;
+            for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->acorS[is][i] = 0.0;
+            continue;
+        }
+        break;
+    }
+    if (retval != CV_SUCCESS) return retval;
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) m->yS[is][i] = m->znS[0][is][i] + m->acorS[is][i];
+    return CV_SUCCESS;
+}
+
+static int cv_handle_nflag(cvmem *m, int *nflagPtr, double saved_t, int *ncfPtr, long *ncfnPtr)
 {
     int nflag = *nflagPtr;
     if (nflag == CV_SUCCESS) return DO_ERROR_TEST;
-    m->ncfn++;
+    (*ncfnPtr)++;
     cv_restore(m, saved_t);
     if (nflag < 0) return nflag;
     (*ncfPtr)++;
@@ -916,6 +1141,7 @@ static int cv_handle_nflag(cvmem *m, int *nflagPtr, double saved_t, int *ncfPtr)
         if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
         if (nflag == QRHSFUNC_RECVR) return CV_REPTD_QRHSFUNC_ERR;
+        if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
     }
     m->eta = ETACF;              /* max(ETACF, hmin/|h|) with hmin = 0 */
     *nflagPtr = PREV_CONV_FAIL;
@@ -960,6 +1186,13 @@ static int cv_do_error_test(cvmem *m, int *nflagPtr, double saved_t, double acor
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
     for (int i = 0; i < NS; i++) m->zn[1][i] = m->h * m->tempv[i];
+    if (m->sensi) {
+        retval = cv_fS(m, m->tn, m->zn[0], m->znS[0], m->tempvS);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return CV_UNREC_SRHSFUNC_ERR;
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) m->znS[1][is][i] = m->h * m->tempvS[is][i];
+    }
     if (m->quadr) {
         retval = cv_fQ(m, m->tn, m->zn[0], m->tempvQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -995,8 +1228,15 @@ static void cv_complete_step(cvmem *m)
     if (m->quadr)
         for (int j = 0; j <= m->q; j++)
             for (int i = 0; i < NQ; i++) m->znQ[j][i] = FMA(m->l[j], m->acorQ[i], m->znQ[j][i]);
+    if (m->sensi)
+        for (int is = 0; is < NQ; is++)
+            for (int j = 0; j <= m->q; j++)
+                for (int i = 0; i < NS; i++)
+                    m->znS[j][is][i] = FMA(m->l[j], m->acorS[is][i], m->znS[j][is][i]);
     m->qwait--;
     if ((m->qwait == 1) && (m->q != QMAX)) {
+        if (m->sensi)
+            for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->znS[QMAX][is][i] = m->acorS[is][i];
         for (int i = 0; i < NS; i++) m->zn[QMAX][i] = m->acor[i];
         if (m->quadr && m->errconQ) for (int i = 0; i < NQ; i++) m->znQ[QMAX][i] = m->acorQ[i];
         m->saved_tq5 = m->tq[5];
@@ -1022,6 +1262,7 @@ static double cv_compute_etaqm1(cvmem *m)
     if (m->q > 1) {
         double ddn = wrms(m->zn[m->q], m->ewt, NS);
         if (m->quadr && m->errconQ) ddn = quad_update_norm(m, ddn, m->znQ[m->q], m->ewtQ);
+        if (m->sensi) ddn = sens_update_norm(ddn, m->znS[m->q], m->ewtS);
         ddn = ddn * m->tq[1];
         m->etaqm1 = 1.0 / (rpower_r(BIAS1 * ddn, 1.0 / m->q) + ADDON);
     }
@@ -1039,6 +1280,12 @@ static double cv_compute_etaqp1(cvmem *m)
         if (m->quadr && m->errconQ) {
             for (int i = 0; i < NQ; i++) m->tempvQ[i] = FMA(-cquot, m->znQ[QMAX][i], m->acorQ[i]);
             dup = quad_update_norm(m, dup, m->tempvQ, m->ewtQ);
+        }
+        if (m->sensi) {
+            for (int is = 0; is < NQ; is++)
+                for (int i = 0; i < NS; i++)
+                    m->tempvS[is][i] = FMA(-cquot, m->znS[QMAX][is][i], m->acorS[is][i]);
+            dup = sens_update_norm(dup, m->tempvS, m->ewtS);
         }
         dup = dup * m->tq[3];
         m->etaqp1 = 1.0 / (rpower_r(BIAS3 * dup, 1.0 / (m->L + 1)) + ADDON);
@@ -1065,6 +1312,8 @@ static void cv_choose_eta(cvmem *m)
         m->qprime = m->q + 1;
         for (int i = 0; i < NS; i++) m->zn[QMAX][i] = m->acor[i];
         if (m->quadr && m->errconQ) for (int i = 0; i < NQ; i++) m->znQ[QMAX][i] = m->acorQ[i];
+        if (m->sensi)
+            for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->znS[QMAX][is][i] = m->acorS[is][i];
     }
 }
 
@@ -1094,23 +1343,41 @@ static void cv_prepare_next_step(cvmem *m, double dsm)
 static int cv_step(cvmem *m)
 {
     double saved_t = m->tn, dsm = 0.0, dsmQ = 0.0;
-    int ncf = 0, nef = 0, nefQ = 0;
+    int ncf = 0, nef = 0, nefQ = 0, ncfS = 0, nefS = 0;
     int nflag = FIRST_CALL, kflag, eflag;
     if ((m->nst > 0) && (m->hprime != m->h)) cv_adjust_params(m);
     for (;;) {
         cv_predict(m);
         cv_set(m);
         nflag = cv_nls(m, nflag);
-        kflag = cv_handle_nflag(m, &nflag, saved_t, &ncf);
+        kflag = cv_handle_nflag(m, &nflag, saved_t, &ncf, &m->ncfn);
         if (kflag == PREDICT_AGAIN) continue;
         if (kflag != DO_ERROR_TEST) return kflag;
         eflag = cv_do_error_test(m, &nflag, saved_t, m->acnrm, &nef, &m->netf, &dsm);
         if (eflag == TRY_AGAIN) continue;
         if (eflag != CV_SUCCESS) return eflag;
+        if (m->sensi && m->ism == 1) {      /* CV_STAGGERED: sensitivities after the state passed */
+            ncf = nef = 0;
+            /* f at the converged y (cvStep: needed by the sensitivity right-hand side); a recoverable
+               failure is treated as a convergence failure: predict again, exactly as CVODES does */
+            int retval = cv_f(m, m->tn, m->y, m->ftemp);
+            if (retval < 0) return CV_RHSFUNC_FAIL;
+            if (retval > 0) { nflag = PREV_CONV_FAIL; continue; }
+            nflag = cv_stgr_nls(m);
+            kflag = cv_handle_nflag(m, &nflag, saved_t, &ncfS, &m->ncfnS);
+            if (kflag == PREDICT_AGAIN) continue;
+            if (kflag != DO_ERROR_TEST) return kflag;
+            double dsmS = 0.0;
+            m->acnrmS = sens_update_norm(0.0, m->acorS, m->ewtS);
+            eflag = cv_do_error_test(m, &nflag, saved_t, m->acnrmS, &nefS, &m->netfS, &dsmS);
+            if (eflag == TRY_AGAIN) continue;
+            if (eflag != CV_SUCCESS) return eflag;
+            if (dsmS > dsm) dsm = dsmS;
+        }
         if (m->quadr) {
             ncf = nef = 0;
             nflag = cv_quad_nls(m);
-            kflag = cv_handle_nflag(m, &nflag, saved_t, &ncf);
+            kflag = cv_handle_nflag(m, &nflag, saved_t, &ncf, &m->ncfn);
             if (kflag == PREDICT_AGAIN) continue;
             if (kflag != DO_ERROR_TEST) return kflag;
             if (m->errconQ) {
@@ -1128,6 +1395,8 @@ static int cv_step(cvmem *m)
     m->etamax = (m->nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
     for (int i = 0; i < NS; i++) m->acor[i] = m->tq[2] * m->acor[i];
     if (m->quadr) for (int i = 0; i < NQ; i++) m->acorQ[i] = m->tq[2] * m->acorQ[i];
+    if (m->sensi)
+        for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->acorS[is][i] = m->tq[2] * m->acorS[is][i];
     return CV_SUCCESS;
 }
 
@@ -1162,14 +1431,45 @@ static int cv_get_dky0(cvmem *m, double t, double *dky, double *dkyQ)
     return CV_SUCCESS;
 }
 
+/* CVodeGetSensDky with k = 0, all parameters */
+static int cv_get_sens_dky0(cvmem *m, double t, double *dkyS /* [NQ][NS] */)
+{
+    double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m->tn) + fabs(m->hu));
+    if (m->hu < 0.0) tfuzz = -tfuzz;
+    double tp = m->tn - m->hu - tfuzz;
+    double tn1 = m->tn + tfuzz;
+    if ((t - tp) * (t - tn1) > 0.0) return CV_BAD_T;
+    double s = (t - m->tn) / m->h;
+    double cvals[QMAX + 1];
+    int nvec = 0;
+    for (int j = m->q; j >= 0; j--) {
+        double c = 1.0;
+        for (int i = 0; i < j; i++) c *= s;
+        cvals[nvec++] = c;
+    }
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) {
+            double acc = cvals[0] * m->znS[m->q][is][i];
+            for (int v = 1; v < nvec; v++) acc = FMA(cvals[v], m->znS[m->q - v][is][i], acc);
+            dkyS[is * NS + i] = acc;
+        }
+    return CV_SUCCESS;
+}
+
 /* First-call block of CVode(): f(t0,y0), h0, scale zn[1]. */
 static int cv_first_call(cvmem *m, double tout)
 {
     if (ewt_set(m, m->zn[0], m->ewt) != 0) return CV_ILL_INPUT;
     if (m->quadr && m->errconQ) if (ewtQ_set(m, m->znQ[0], m->ewtQ) != 0) return CV_ILL_INPUT;
+    if (m->sensi) if (sens_ewt_set(m, m->znS[0], m->ewtS) != 0) return CV_ILL_INPUT;
     int retval = cv_f(m, m->tn, m->zn[0], m->zn[1]);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+    if (m->sensi) {
+        retval = cv_fS(m, m->tn, m->zn[0], m->znS[0], m->znS[1]);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return CV_FIRST_SRHSFUNC_ERR;
+    }
     if (m->quadr) {
         retval = cv_fQ(m, m->tn, m->zn[0], m->znQ[1]);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -1190,6 +1490,8 @@ static int cv_first_call(cvmem *m, double tout)
     m->hprime = m->h;
     for (int i = 0; i < NS; i++) m->zn[1][i] = m->h * m->zn[1][i];
     if (m->quadr) for (int i = 0; i < NQ; i++) m->znQ[1][i] = m->h * m->znQ[1][i];
+    if (m->sensi)
+        for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) m->znS[1][is][i] = m->h * m->znS[1][is][i];
     return CV_SUCCESS;
 }
 
@@ -1199,9 +1501,11 @@ static int cv_pre_step(cvmem *m)
     if (m->nst > 0) {
         if (ewt_set(m, m->zn[0], m->ewt) != 0) return CV_ILL_INPUT;
         if (m->quadr && m->errconQ) if (ewtQ_set(m, m->znQ[0], m->ewtQ) != 0) return CV_ILL_INPUT;
+        if (m->sensi) if (sens_ewt_set(m, m->znS[0], m->ewtS) != 0) return CV_ILL_INPUT;
     }
     double nrm = wrms(m->zn[0], m->ewt, NS);
     if (m->quadr && m->errconQ) nrm = quad_update_norm(m, nrm, m->znQ[0], m->ewtQ);
+    if (m->sensi) nrm = sens_update_norm(nrm, m->znS[0], m->ewtS);
     m->tolsf = UROUND * nrm;
     if (m->tolsf > 1.0) { m->tolsf *= 2.0; return CV_TOO_MUCH_ACC; }
     m->tolsf = 1.0;
@@ -1356,6 +1660,47 @@ static int solve_plain_one(const orc_config *cfg, const double *y0, const double
         for (int i = 0; i < NS; i++) y_out[(size_t)k * NS + i] = ybuf[i];
     }
     export_stats(m, NULL, st);
+    free(m);
+    return status;
+}
+
+/* sunode Solver.solve with sens_mode (solver.py:467-527, 360-392): CVodeReInit + CVodeSensReInit, then
+   CVode(NORMAL) + CVodeGetSens per tval */
+static int solve_sens_one(const orc_config *cfg, int ism, const double *pbar, const double *y0, const double *ps,
+                          const double *pr, const double *sens0, double t0, const double *tvals, int n_t,
+                          double *y_out, double *sens_out, int64_t *st)
+{
+    cvmem *m = (cvmem *)calloc(1, sizeof(cvmem));
+    m->ps = ps; m->pr = pr; m->backward = 0; m->tr = NULL;
+    m->rtol = cfg->rtol; for (int i = 0; i < NS; i++) m->atol[i] = cfg->atol[i];
+    m->quadr = 0; m->errconQ = 0; m->mxstep = cfg->mxstep; m->tstopset = 0;
+    m->sensi = 1; m->ism = ism;
+    for (int is = 0; is < NQ; is++) m->pbar[is] = pbar ? fabs(pbar[is]) : 1.0;
+    cv_reinit(m, t0, y0, NULL);
+    cv_sens_reinit(m, sens0);
+    int status = CV_SUCCESS;
+    double ybuf[NSD], tret;
+    for (int k = 0; k < n_t && status == CV_SUCCESS; k++) {
+        double t = tvals[k];
+        if (t == t0) {
+            for (int i = 0; i < NS; i++) y_out[(size_t)k * NS + i] = y0[i];
+            for (int j = 0; j < NQ * NS; j++) sens_out[(size_t)k * NQ * NS + j] = sens0[j];
+            continue;
+        }
+        int retval = CV_TOO_MUCH_WORK, retry;
+        for (retry = 0; retry < cfg->max_retries_fwd; retry++) {
+            retval = cv_cvode_normal(m, t, ybuf, NULL, &tret);
+            if (retval == CV_SUCCESS) break;
+            if (retval != CV_TOO_MUCH_WORK) break;
+            st[ST_RETRIES]++;
+        }
+        if (retval != CV_SUCCESS) { status = retval; break; }
+        for (int i = 0; i < NS; i++) y_out[(size_t)k * NS + i] = ybuf[i];
+        if (cv_get_sens_dky0(m, t, sens_out + (size_t)k * NQ * NS) != CV_SUCCESS) { status = CV_BAD_T; break; }
+    }
+    export_stats(m, NULL, st);
+    /* sensitivity counters ride in the quadrature / interpolation slots of the adjoint path */
+    st[ST_NFQE] = m->nfSe; st[ST_NETFQ] = m->netfS; st[ST_NINTERP] = m->nniS; st[ST_NREBUILD] = m->ncfnS;
     free(m);
     return status;
 }
@@ -1520,6 +1865,25 @@ int orc_solve_batch(const orc_config *cfg, int B, const double *y0, const double
         status[b] = solve_plain_one(cfg, y0 + (size_t)b * NS, ps + (size_t)b * NQ,
                                     pr + (size_t)b * rem_stride, t0, tvals, n_t, yo, st);
         if (status[b] != CV_SUCCESS) fill_nan(yo, (size_t)n_t * NS);
+    }
+    return 0;
+}
+
+int orc_solve_sens_batch(const orc_config *cfg, int ism, const double *pbar, int B, const double *y0,
+                         const double *ps, const double *pr, int rem_stride, const double *sens0, double t0,
+                         const double *tvals, int n_t, double *y_out, double *sens_out, int32_t *status,
+                         int64_t *stats, int nthreads)
+{
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int b = 0; b < B; b++) {
+        int64_t *st = stats + (size_t)b * ST_COUNT;
+        memset(st, 0, sizeof(int64_t) * ST_COUNT);
+        double *yo = y_out + (size_t)b * n_t * NS;
+        double *so = sens_out + (size_t)b * n_t * NQ * NS;
+        status[b] = solve_sens_one(cfg, ism, pbar, y0 + (size_t)b * NS, ps + (size_t)b * NQ,
+                                   pr + (size_t)b * rem_stride, sens0 + (size_t)b * NQ * NS, t0, tvals, n_t,
+                                   yo, so, st);
+        if (status[b] != CV_SUCCESS) { fill_nan(yo, (size_t)n_t * NS); fill_nan(so, (size_t)n_t * NQ * NS); }
     }
     return 0;
 }

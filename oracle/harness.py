@@ -175,6 +175,22 @@ class Oracle:
                                _ptr(status, ctypes.c_int32), _ptr(stats, ctypes.c_int64), nthreads)
         return y_out, status, stats
 
+    def solve_sens(self, cfg, y0, ps, pr, sens0, t0, tvals, mode="simultaneous", scaling_factors=None, nthreads=1):
+        """Solver(sens_mode=...).solve: returns (y_out [B,n_t,n], sens_out [B,n_t,p,n], status, stats)."""
+        y0 = np.ascontiguousarray(np.asarray(y0, float).reshape(-1, self.n)); B = y0.shape[0]
+        ps, pr, stride = self._params(B, ps, pr)
+        sens0 = np.ascontiguousarray(np.broadcast_to(np.asarray(sens0, float), (B, self.p, self.n)))
+        tvals = np.ascontiguousarray(tvals, float); n_t = len(tvals)
+        y_out = np.zeros((B, n_t, self.n)); sens_out = np.zeros((B, n_t, self.p, self.n))
+        status = np.zeros(B, np.int32); stats = np.zeros((B, N_STATS), np.int64)
+        pbar = None if scaling_factors is None else np.ascontiguousarray(scaling_factors, float)
+        self.L.orc_solve_sens_batch(ctypes.byref(cfg.c), {"simultaneous": 0, "staggered": 1}[mode],
+                                    _ptr(pbar) if pbar is not None else None, B, _ptr(y0), _ptr(ps), _ptr(pr),
+                                    stride, _ptr(sens0), ctypes.c_double(t0), _ptr(tvals), n_t, _ptr(y_out),
+                                    _ptr(sens_out), _ptr(status, ctypes.c_int32), _ptr(stats, ctypes.c_int64),
+                                    nthreads)
+        return y_out, sens_out, status, stats
+
     def solve_forward(self, cfg, y0, ps, pr, t0, tvals, nthreads=1):
         y0 = np.ascontiguousarray(np.asarray(y0, float).reshape(-1, self.n)); B = y0.shape[0]
         ps, pr, stride = self._params(B, ps, pr)

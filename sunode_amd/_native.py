@@ -103,8 +103,12 @@ def _extra_codegen_flags():
 REGISTER_KERNEL_MAX_STATES = 5
 
 
-def kernel_variant(native_source: str):
+def kernel_variant(native_source: str, sens: bool = False):
     """(source file, lanes per instance) for a generated problem header.
+
+    ``sens=True`` (forward sensitivities, ``Solver(sens_mode=...)``): the memory-resident kernel
+    built with ``-DSA_SENS`` for every system size -- the only family carrying the sensitivity
+    corrector so far.
 
     n <= 5 states: thread-per-instance, the whole integrator in one lane's registers.
     up to 64: cooperative, G = next power of two >= max(n_states, n_sub, 8) lanes per instance.
@@ -117,7 +121,7 @@ def kernel_variant(native_source: str):
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
     forced = os.environ.get("SA_FORCE_GROUP")
-    if forced == "mem" or (not forced and max(n, p) > 128):
+    if sens or forced == "mem" or (not forced and max(n, p) > 128):
         return "bdf_mem.hip", 1
     if forced == "wave" or (not forced and max(n, p) > 64):
         if max(n, p) > 128 or n < 1:
@@ -148,25 +152,27 @@ def _size_defines(native_source: str):
     return ["-DSA_BUILD_NS=%d" % n, "-DSA_BUILD_NQ=%d" % p] + os.environ.get("SA_KERNEL_DEFINES", "").split()
 
 
-def code_object_path(native_source: str) -> str:
-    fname, group = kernel_variant(native_source)
+def code_object_path(native_source: str, sens: bool = False) -> str:
+    fname, group = kernel_variant(native_source, sens)
     kern = os.path.join(_CSRC, fname)
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h")]
     deps = [d for d in deps if os.path.exists(d)]
     extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group + fname.encode()
-             + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode())
+             + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode()
+             + (b"SENS" if sens else b""))
     key = _hash_files(*deps, extra=extra) if os.path.exists(kern) else \
         hashlib.sha256(extra).hexdigest()[:16]
     return os.path.join(_CACHE, "sa_%s.hsaco" % key)
 
 
-def build_code_object(native_source: str, force: bool = False, keep_temps: bool = False) -> str:
+def build_code_object(native_source: str, force: bool = False, keep_temps: bool = False,
+                      sens: bool = False) -> str:
     """Compile the integrator kernels for one problem to a gfx950 code object (cached)."""
     os.makedirs(_CACHE, exist_ok=True)
-    out = code_object_path(native_source)
+    out = code_object_path(native_source, sens)
     if os.path.exists(out) and not force:
         return out
-    fname, group = kernel_variant(native_source)
+    fname, group = kernel_variant(native_source, sens)
     kern = os.path.join(_CSRC, fname)
     hdr = out[:-6] + ".h"
     with open(hdr, "w") as fh:
@@ -178,6 +184,7 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
         _run([hipcc, "--offload-arch=" + ARCH, "--cuda-device-only", "-emit-llvm", "-c", "-O0",
               "-Xclang", "-disable-O0-optnone", "-ffp-contract=off", "-std=c++17",
               "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-DSA_GROUP=%d" % group] + _size_defines(native_source)
+             + (["-DSA_SENS=1"] if sens else [])
              + ["-I" + _CSRC, kern, "-o", bc0])
         _run([os.path.join(LLVM_BIN, "opt"), "-passes=always-inline,sroa", bc0, "-o", bc1])
         occupancy = os.environ.get("SA_WAVES_PER_EU")
@@ -246,12 +253,14 @@ def load_library() -> ctypes.CDLL:
     L.sa_solve_forward_batch.argtypes = fwd
     L.sa_solve_backward_batch.argtypes = [vp, ctypes.c_int, i32, _dp, _dp, i32, dbl, dbl, _dp, i32, _dp, i64,
                                           _dp, _dp, _dp, _dp]
+    L.sa_solve_sens_batch.argtypes = [vp, ctypes.c_int, ctypes.c_int, _dp, i32, _dp, _dp, _dp, i32, _dp, dbl, _dp,
+                                      i32, _dp, _dp, _dp, _dp]
     L.sa_eval_callbacks.argtypes = [vp, ctypes.c_int, i32] + [_dp] * 11
     L.sa_math_probe.argtypes = [vp, i32] + [_dp] * 5
     L.sa_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.sa_set_stream.argtypes = [vp, vp]
     L.sa_synchronize.argtypes = [vp]
-    for name in ("sa_solver_create", "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch",
+    for name in ("sa_solver_create", "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
                  "sa_solve_forward_batch", "sa_solve_backward_batch", "sa_eval_callbacks", "sa_math_probe",
                  "sa_last_kernel_ms", "sa_set_stream", "sa_synchronize"):
         getattr(L, name).restype = ctypes.c_int
@@ -260,7 +269,8 @@ def load_library() -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = ["sa_abi_version", "sa_last_error", "sa_solver_create", "sa_solver_destroy",
-                    "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_forward_batch",
+                    "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
+                    "sa_solve_forward_batch",
                     "sa_solve_backward_batch", "sa_eval_callbacks", "sa_math_probe", "sa_last_kernel_ms",
                     "sa_set_stream", "sa_synchronize"]
 
@@ -287,9 +297,9 @@ class NativeSolver:
 
     def __init__(self, native_source: str, *, device: int = 0, rtol=1e-10, atol=1e-10, rtolB=1e-10,
                  atolB=1e-10, rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
-                 max_retries_bwd=50, traj_capacity=2048, n_states: Optional[int] = None):
+                 max_retries_bwd=50, traj_capacity=2048, n_states: Optional[int] = None, sens: bool = False):
         self.L = load_library()
-        self.code_object = build_code_object(native_source)
+        self.code_object = build_code_object(native_source, sens=sens)
         self._h = ctypes.c_void_p()
         self._n_hint = n_states
         self._opt_kw = dict(device=device, rtol=rtol, atol=atol, rtolB=rtolB, atolB=atolB, rtolQB=rtolQB,
@@ -348,6 +358,12 @@ class NativeSolver:
         self._check(self.L.sa_solve_backward_batch(self._h, mem, B, _addr(ps), _addr(pr), rem_stride, float(t0),
                                                    float(tend), _addr(tvals), n_t, _addr(grads), int(grads_stride),
                                                    _addr(grad_out), _addr(lamda_out), _addr(status), _addr(stats)))
+
+    def solve_sens(self, mem, ism, scaling, B, y0, ps, pr, rem_stride, sens0, t0, tvals, n_t, y_out, sens_out,
+                   status, stats):
+        self._check(self.L.sa_solve_sens_batch(self._h, mem, int(ism), _addr(scaling), B, _addr(y0), _addr(ps),
+                                               _addr(pr), rem_stride, _addr(sens0), float(t0), _addr(tvals), n_t,
+                                               _addr(y_out), _addr(sens_out), _addr(status), _addr(stats)))
 
     def eval_callbacks(self, t, y, lam, ps, pr):
         npts = len(t)

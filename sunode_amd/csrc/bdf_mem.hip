@@ -63,7 +63,22 @@ constexpr int next_pow2_c(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 #define O_INVP (O_PIV + NS)
 #define O_HY (O_INVP + NS)
 #define O_TREE (O_HY + 6 * NS)
+#ifdef SA_SENS      /* forward sensitivities: Nordsieck arrays and work vectors of the NQ sensitivity systems */
+#define O_ZNS (O_TREE + PS_TREE)
+#define O_EWTS (O_ZNS + 6 * NQ * NS)
+#define O_ACORS (O_EWTS + NQ * NS)
+#define O_TEMPVS (O_ACORS + NQ * NS)
+#define O_FTEMPS (O_TEMPVS + NQ * NS)
+#define O_YS (O_FTEMPS + NQ * NS)
+#define O_DELTAS (O_YS + NQ * NS)
+#define O_DP (O_DELTAS + NQ * NS)
+#define O_JT (O_DP + NQ * NS)
+#define WS_DOUBLES (O_JT + NS * NS)
+#define ZNS(m, j, is, i) W(m, O_ZNS, ((j) * NQ + (is)) * NS + (i))
+#define VS(m, off, is, i) W(m, off, (is) * NS + (i))
+#else
 #define WS_DOUBLES (O_TREE + PS_TREE)
+#endif
 
 /* strided sink for the generated callbacks: slot k of the output lives at p[k * stride] */
 struct StrideSink {
@@ -95,6 +110,10 @@ struct Cm {
     int ilast, newdata, have_last, cur_idx;
     double last_t, tlo, thi, tlo2;
     int n_interp, n_rebuild;
+    /* forward sensitivities (only the SA_SENS build sets sensi) */
+    int sensi, ism;
+    double pbar[NQD], crateS, delpS, acnrmS;
+    int nfSe, nniS, ncfnS, netfS, nsetupsS;
 };
 
 #define W(m, off, i) (m).w[(int64_t)((off) + (i)) * (m).S]
@@ -152,6 +171,35 @@ DEV int ewtQ_set(Cm<BWD> &m, int qoff, int woff)
     }
     return bad ? -1 : 0;
 }
+
+#ifdef SA_SENS
+/* cvSensEwtSetEE / cvSensUpdateNorm (see the oracle) */
+template <bool BWD>
+DEV int sens_ewt_set(Cm<BWD> &m, int ysoff, int woff)
+{
+    int bad = 0;
+    for (int is = 0; is < NQ; is++) {
+        const double pb = pick(m.pbar, is);
+        for (int i = 0; i < NS; i++) {
+            double v = FMA(m.rtol, fabs(pb * VS(m, ysoff, is, i)), atol_of(m, i));
+            bad |= (v <= 0.0);
+            VS(m, woff, is, i) = pb * (1.0 / v);
+        }
+    }
+    return bad ? -1 : 0;
+}
+
+template <bool BWD>
+DEV double sens_update_norm(Cm<BWD> &m, double old_nrm, int xoff, int woff)
+{
+    double nrm = old_nrm;
+    for (int is = 0; is < NQ; is++) {
+        double snrm = wrms_off(m, xoff + is * NS, woff + is * NS, NS);
+        if (snrm > nrm) nrm = snrm;
+    }
+    return nrm;
+}
+#endif
 
 /* ---- stored trajectory (records as in bdf_kernels.hip, read straight from global memory) ---- */
 template <bool BWD>
@@ -261,6 +309,29 @@ DEV int cv_jac(Cm<BWD> &m, double t, int yoff)
     return sa_jac(t, &W(m, yoff, 0), m.ps, m.pr, sink);
 }
 
+#ifdef SA_SENS
+/* sensitivity right-hand side for all parameters: out[is] = J(t,y) yS[is] + df/dp_is (oracle cv_fS) */
+template <bool BWD>
+DEV int cv_fS(Cm<BWD> &m, double t, int yoff, int ysoff, int outoff)
+{
+    m.nfSe++;
+    StrideSink sj{&W(m, O_JT, 0), m.S}, sp{&W(m, O_DP, 0), m.S};
+    int rc = sa_jac(t, &W(m, yoff, 0), m.ps, m.pr, sj);
+    if (rc != 0) return rc;
+    rc = sa_dydp(t, &W(m, yoff, 0), m.ps, m.pr, sp);
+    int bad = 0;
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) {
+            double acc = W(m, O_JT, 0 * NS + i) * VS(m, ysoff, is, 0);
+            for (int j = 1; j < NS; j++) acc = FMA(W(m, O_JT, j * NS + i), VS(m, ysoff, is, j), acc);
+            acc = acc + VS(m, O_DP, is, i);
+            VS(m, outoff, is, i) = acc;
+            bad |= !(acc * 0.0 == 0.0);
+        }
+    return (rc != 0 || bad) ? 1 : 0;
+}
+#endif
+
 /* ---- dense LU (denseGETRF / denseGETRS, column-major) on the workspace matrix ---- */
 #define AE(m, i, j) W(m, O_A, (j) * NS + (i))
 
@@ -329,6 +400,8 @@ DEV void cv_reinit(Cm<BWD> &m, double t0)
     m.gamma = m.gammap = 0.0; m.gamrat = 1.0; m.crate = 1.0; m.delp = 0.0;
     m.acnrm = 0.0; m.saved_tq5 = 0.0;
     m.jcur = 0; m.nls_jcur = 0;
+    m.crateS = 1.0; m.delpS = 0.0; m.acnrmS = 0.0;
+    m.nfSe = m.nniS = m.ncfnS = m.netfS = m.nsetupsS = 0;
     SFOR(i, 0, 7) { m.tau[i] = 0.0; m.l[i] = 0.0; } SEND
     SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
 }
@@ -358,6 +431,19 @@ DEV double cv_upper_bound_h0(Cm<BWD> &m, double tdist)
         }
         if (hubQ_inv > hub_inv) hub_inv = hubQ_inv;
     }
+#ifdef SA_SENS
+    if (m.sensi) {
+        sens_ewt_set(m, O_ZNS, O_TEMPVS);
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) {
+                double t2 = fabs(ZNS(m, 0, is, i));
+                double t1 = 1.0 / VS(m, O_TEMPVS, is, i);
+                t1 = FMA(HUB_FACTOR, t2, t1);
+                double v = fabs(ZNS(m, 1, is, i)) / t1;
+                if (v > hub_inv) hub_inv = v;
+            }
+    }
+#endif
     double hub = HUB_FACTOR * tdist;
     if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
     return hub;
@@ -368,9 +454,21 @@ DEV int cv_ydd_norm(Cm<BWD> &m, double hg, double *yddnrm)
 {
     for (int i = 0; i < NS; i++) W(m, O_Y, i) = FMA(hg, ZN(m, 1, i), ZN(m, 0, i));
     if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+#ifdef SA_SENS
+    if (m.sensi)
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) VS(m, O_YS, is, i) = FMA(hg, ZNS(m, 1, is, i), ZNS(m, 0, is, i));
+#endif
     int retval = cv_f(m, m.tn + hg, O_Y, O_TEMPV);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return RHSFUNC_RECVR;
+#ifdef SA_SENS
+    if (m.sensi) {
+        retval = cv_fS(m, m.tn + hg, O_Y, O_YS, O_TEMPVS);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return SRHSFUNC_RECVR;
+    }
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn + hg, O_Y, O_TEMPVQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -388,6 +486,16 @@ DEV int cv_ydd_norm(Cm<BWD> &m, double hg, double *yddnrm)
         }
         *yddnrm = quad_update_norm(m, *yddnrm, O_TEMPVQ);
     }
+#ifdef SA_SENS
+    if (m.sensi) {
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) {
+                double v = VS(m, O_TEMPVS, is, i) - ZNS(m, 1, is, i);
+                VS(m, O_TEMPVS, is, i) = (1.0 / hg) * v;
+            }
+        *yddnrm = sens_update_norm(m, *yddnrm, O_TEMPVS, O_EWTS);
+    }
+#endif
     return CV_SUCCESS;
 }
 
@@ -450,6 +558,9 @@ DEV void cv_rescale(Cm<BWD> &m)
     for (int j = 1; j <= m.q; j++) {
         for (int i = 0; i < NS; i++) ZN(m, j, i) *= factor;
         if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j, i) *= factor;
+#ifdef SA_SENS
+        if (m.sensi) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) ZNS(m, j, is, i) *= factor;
+#endif
         factor *= m.eta;
     }
     m.h = m.hscale * m.eta;
@@ -487,6 +598,16 @@ DEV void cv_increase_bdf(Cm<BWD> &m)
             for (int i = 0; i < NQ; i++) ZNQ(m, j, i) = FMA(lj, ZNQ(m, L, i), ZNQ(m, j, i));
         }
     }
+#ifdef SA_SENS
+    if (m.sensi)
+        for (int is = 0; is < NQ; is++) {
+            for (int i = 0; i < NS; i++) ZNS(m, L, is, i) = A1 * ZNS(m, QMAX, is, i);
+            for (int j = 2; j <= m.q; j++) {
+                const double lj = pick(m.l, j);
+                for (int i = 0; i < NS; i++) ZNS(m, j, is, i) = FMA(lj, ZNS(m, L, is, i), ZNS(m, j, is, i));
+            }
+        }
+#endif
 }
 
 template <bool BWD>
@@ -506,6 +627,11 @@ DEV void cv_decrease_bdf(Cm<BWD> &m)
         const double lj = pick(m.l, j);
         for (int i = 0; i < NS; i++) ZN(m, j, i) = FMA(-lj, ZN(m, m.q, i), ZN(m, j, i));
         if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j, i) = FMA(-lj, ZNQ(m, m.q, i), ZNQ(m, j, i));
+#ifdef SA_SENS
+        if (m.sensi)
+            for (int is = 0; is < NQ; is++)
+                for (int i = 0; i < NS; i++) ZNS(m, j, is, i) = FMA(-lj, ZNS(m, m.q, is, i), ZNS(m, j, is, i));
+#endif
     }
 }
 
@@ -528,6 +654,11 @@ DEV void cv_predict(Cm<BWD> &m)
         for (int j = m.q; j >= k; j--) {
             for (int i = 0; i < NS; i++) ZN(m, j - 1, i) = ZN(m, j - 1, i) + ZN(m, j, i);
             if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j - 1, i) = ZNQ(m, j - 1, i) + ZNQ(m, j, i);
+#ifdef SA_SENS
+            if (m.sensi)
+                for (int is = 0; is < NQ; is++)
+                    for (int i = 0; i < NS; i++) ZNS(m, j - 1, is, i) = ZNS(m, j - 1, is, i) + ZNS(m, j, is, i);
+#endif
         }
 }
 
@@ -539,6 +670,11 @@ DEV void cv_restore(Cm<BWD> &m, double saved_t)
         for (int j = m.q; j >= k; j--) {
             for (int i = 0; i < NS; i++) ZN(m, j - 1, i) = ZN(m, j - 1, i) - ZN(m, j, i);
             if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j - 1, i) = ZNQ(m, j - 1, i) - ZNQ(m, j, i);
+#ifdef SA_SENS
+            if (m.sensi)
+                for (int is = 0; is < NQ; is++)
+                    for (int i = 0; i < NS; i++) ZNS(m, j - 1, is, i) = ZNS(m, j - 1, is, i) - ZNS(m, j, is, i);
+#endif
         }
 }
 
@@ -583,6 +719,7 @@ DEV int cv_nls_lsetup(Cm<BWD> &m, int jbad, int &convfail)
     m.gamrat = 1.0;
     m.gammap = m.gamma;
     m.crate = 1.0;
+    m.crateS = 1.0;
     m.nstlp = m.nst;
     if (retval < 0) return CV_LSETUP_FAIL;
     if (retval > 0) return NLS_CONV_RECVR;
@@ -603,13 +740,61 @@ DEV int cv_nls_residual(Cm<BWD> &m)          /* res -> O_DELTA */
     return CV_SUCCESS;
 }
 
+#ifdef SA_SENS
+/* cvNlsResidualSensSim: residuals of the sensitivity systems -> O_DELTAS */
+template <bool BWD>
+DEV int cv_nls_residual_sens(Cm<BWD> &m)
+{
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) VS(m, O_YS, is, i) = ZNS(m, 0, is, i) + VS(m, O_ACORS, is, i);
+    int retval = cv_fS(m, m.tn, O_Y, O_YS, O_FTEMPS);
+    if (retval < 0) return CV_SRHSFUNC_FAIL;
+    if (retval > 0) return SRHSFUNC_RECVR;
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) {
+            double r = FMA(m.rl1, ZNS(m, 1, is, i), VS(m, O_ACORS, is, i));
+            VS(m, O_DELTAS, is, i) = FMA(-m.gamma, VS(m, O_FTEMPS, is, i), r);
+        }
+    return CV_SUCCESS;
+}
+
+/* one Newton update of every sensitivity system with the current factorisation */
+template <bool BWD>
+DEV void cv_sens_newton_update(Cm<BWD> &m)
+{
+    for (int is = 0; is < NQ; is++) {
+        for (int i = 0; i < NS; i++) VS(m, O_DELTAS, is, i) = -1.0 * VS(m, O_DELTAS, is, i);
+        dense_getrs(m, O_DELTAS + is * NS);
+        if (m.gamrat != 1.0) {
+            double s = 2.0 / (1.0 + m.gamrat);
+            for (int i = 0; i < NS; i++) VS(m, O_DELTAS, is, i) *= s;
+        }
+        for (int i = 0; i < NS; i++) VS(m, O_ACORS, is, i) = VS(m, O_ACORS, is, i) + VS(m, O_DELTAS, is, i);
+    }
+}
+#endif
+
 template <bool BWD>
 DEV int cv_newton_pass(Cm<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
 {
+#ifdef SA_SENS
+    const bool sim = m.sensi && m.ism == 0;
+#else
+    const bool sim = false;
+#endif
     in_loop = 0;
     for (int i = 0; i < NS; i++) W(m, O_ACOR, i) = 0.0;
+#ifdef SA_SENS
+    if (sim) for (int j = 0; j < NQ * NS; j++) W(m, O_ACORS, j) = 0.0;
+#endif
     int retval = cv_nls_residual(m);
     if (retval != CV_SUCCESS) return retval;
+#ifdef SA_SENS
+    if (sim) {
+        retval = cv_nls_residual_sens(m);
+        if (retval != CV_SUCCESS) return retval;
+    }
+#endif
     if (callSetup) {
         retval = cv_nls_lsetup(m, jbad, convfail);
         if (retval != CV_SUCCESS) return retval;
@@ -626,10 +811,22 @@ DEV int cv_newton_pass(Cm<BWD> &m, int callSetup, int jbad, int &convfail, int &
         }
         for (int i = 0; i < NS; i++) W(m, O_ACOR, i) = W(m, O_ACOR, i) + W(m, O_DELTA, i);
         double del = wrms_n(m, O_DELTA);
+#ifdef SA_SENS
+        if (sim) {
+            cv_sens_newton_update(m);
+            del = sens_update_norm(m, del, O_DELTAS, O_EWTS);
+        }
+#endif
         if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
         double dcon = del * fmin(1.0, m.crate) * m.tq[4];
         if (dcon <= 1.0) {
-            m.acnrm = (curiter == 0) ? del : wrms_n(m, O_ACOR);
+            if (curiter == 0) m.acnrm = del;
+            else {
+                m.acnrm = wrms_n(m, O_ACOR);
+#ifdef SA_SENS
+                if (sim) m.acnrm = sens_update_norm(m, m.acnrm, O_ACORS, O_EWTS);
+#endif
+            }
             m.nls_jcur = 0;
             return CV_SUCCESS;
         }
@@ -639,8 +836,65 @@ DEV int cv_newton_pass(Cm<BWD> &m, int callSetup, int jbad, int &convfail, int &
         if (curiter >= NLS_MAXCOR) return NLS_CONV_RECVR;
         retval = cv_nls_residual(m);
         if (retval != CV_SUCCESS) return retval;
+#ifdef SA_SENS
+        if (sim) {
+            retval = cv_nls_residual_sens(m);
+            if (retval != CV_SUCCESS) return retval;
+        }
+#endif
     }
 }
+
+#ifdef SA_SENS
+/* cvStgrNls (ism = CV_STAGGERED): Newton on the sensitivity systems with the state fixed */
+template <bool BWD>
+DEV int cv_stgr_nls(Cm<BWD> &m)
+{
+    int callSetup = 0, jbad = 0, convfail = CV_FAIL_OTHER, retval;
+    for (int j = 0; j < NQ * NS; j++) W(m, O_ACORS, j) = 0.0;
+    for (;;) {
+        retval = cv_nls_residual_sens(m);
+        if (retval != CV_SUCCESS) break;
+        if (callSetup) {
+            retval = cv_nls_lsetup(m, jbad, convfail);
+            m.nsetupsS++;
+            if (retval != CV_SUCCESS) break;
+        }
+        int curiter = 0;
+        for (;;) {
+            m.nniS++;
+            cv_sens_newton_update(m);
+            double del = sens_update_norm(m, 0.0, O_DELTAS, O_EWTS);
+            if (curiter > 0) m.crateS = fmax(CRDOWN * m.crateS, del / m.delpS);
+            double dcon = del * fmin(1.0, m.crateS) * m.tq[4];
+            if (dcon <= 1.0) {
+                m.acnrmS = (curiter == 0) ? del : sens_update_norm(m, 0.0, O_ACORS, O_EWTS);
+                retval = CV_SUCCESS;
+                m.nls_jcur = 0;
+                break;
+            }
+            if ((curiter >= 1) && (del > RDIV * m.delpS)) { retval = NLS_CONV_RECVR; break; }
+            m.delpS = del;
+            curiter++;
+            if (curiter >= NLS_MAXCOR) { retval = NLS_CONV_RECVR; break; }
+            retval = cv_nls_residual_sens(m);
+            if (retval != CV_SUCCESS) break;
+        }
+        if (retval == CV_SUCCESS) break;
+        if ((retval > 0) && !m.nls_jcur) {
+            callSetup = 1;
+            jbad = 1;
+            for (int j = 0; j < NQ * NS; j++) W(m, O_ACORS, j) = 0.0;
+            continue;
+        }
+        break;
+    }
+    if (retval != CV_SUCCESS) return retval;
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) VS(m, O_YS, is, i) = ZNS(m, 0, is, i) + VS(m, O_ACORS, is, i);
+    return CV_SUCCESS;
+}
+#endif
 
 template <bool BWD>
 DEV int cv_error_test_failed(Cm<BWD> &m, double saved_t, double dsm, int &nef, int &netf_counter)
@@ -675,6 +929,15 @@ DEV int cv_error_test_failed(Cm<BWD> &m, double saved_t, double dsm, int &nef, i
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
     for (int i = 0; i < NS; i++) ZN(m, 1, i) = m.h * W(m, O_TEMPV, i);
+#ifdef SA_SENS
+    if (m.sensi) {
+        retval = cv_fS(m, m.tn, O_ZN, O_ZNS, O_TEMPVS);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return CV_UNREC_SRHSFUNC_ERR;
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) ZNS(m, 1, is, i) = m.h * VS(m, O_TEMPVS, is, i);
+    }
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, O_ZN, O_TEMPVQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -698,8 +961,19 @@ DEV void cv_complete_step(Cm<BWD> &m)
         for (int i = 0; i < NS; i++) ZN(m, j, i) = FMA(lj, W(m, O_ACOR, i), ZN(m, j, i));
         if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j, i) = FMA(lj, W(m, O_ACORQ, i), ZNQ(m, j, i));
     }
+#ifdef SA_SENS
+    if (m.sensi)
+        for (int is = 0; is < NQ; is++)
+            for (int j = 0; j <= m.q; j++) {
+                const double lj = pick(m.l, j);
+                for (int i = 0; i < NS; i++) ZNS(m, j, is, i) = FMA(lj, VS(m, O_ACORS, is, i), ZNS(m, j, is, i));
+            }
+#endif
     m.qwait--;
     if ((m.qwait == 1) && (m.q != QMAX)) {
+#ifdef SA_SENS
+        if (m.sensi) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) ZNS(m, QMAX, is, i) = VS(m, O_ACORS, is, i);
+#endif
         for (int i = 0; i < NS; i++) ZN(m, QMAX, i) = W(m, O_ACOR, i);
         if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, QMAX, i) = W(m, O_ACORQ, i);
         m.saved_tq5 = m.tq[5];
@@ -740,6 +1014,9 @@ DEV void cv_prepare_next_step(Cm<BWD> &m, double dsm)
     if (m.q > 1) {
         double ddn = wrms_off(m, O_ZN + m.q * NS, O_EWT, NS);
         if (BWD) { double dq = wrms_off(m, O_ZNQ + m.q * NQ, O_EWTQ, NQ); ddn = ddn > dq ? ddn : dq; }
+#ifdef SA_SENS
+        if (m.sensi) ddn = sens_update_norm(m, ddn, O_ZNS + m.q * NQ * NS, O_EWTS);
+#endif
         ddn = ddn * m.tq[1];
         m.etaqm1 = 1.0 / (rpower_r(BIAS1 * ddn, inv_int(m.q)) + ADDON);
     }
@@ -756,6 +1033,14 @@ DEV void cv_prepare_next_step(Cm<BWD> &m, double dsm)
                 for (int i = 0; i < NQ; i++) W(m, O_TEMPVQ, i) = FMA(-cquot, ZNQ(m, QMAX, i), W(m, O_ACORQ, i));
                 dup = quad_update_norm(m, dup, O_TEMPVQ);
             }
+#ifdef SA_SENS
+            if (m.sensi) {
+                for (int is = 0; is < NQ; is++)
+                    for (int i = 0; i < NS; i++)
+                        VS(m, O_TEMPVS, is, i) = FMA(-cquot, ZNS(m, QMAX, is, i), VS(m, O_ACORS, is, i));
+                dup = sens_update_norm(m, dup, O_TEMPVS, O_EWTS);
+            }
+#endif
             dup = dup * m.tq[3];
             m.etaqp1 = 1.0 / (rpower_r(BIAS3 * dup, inv_int(m.L + 1)) + ADDON);
         }
@@ -775,6 +1060,9 @@ DEV void cv_prepare_next_step(Cm<BWD> &m, double dsm)
         m.qprime = m.q + 1;
         for (int i = 0; i < NS; i++) ZN(m, QMAX, i) = W(m, O_ACOR, i);
         if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, QMAX, i) = W(m, O_ACORQ, i);
+#ifdef SA_SENS
+        if (m.sensi) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) ZNS(m, QMAX, is, i) = VS(m, O_ACORS, is, i);
+#endif
     }
     cv_set_eta(m);
 }
@@ -813,10 +1101,20 @@ DEV int cv_first_call(Cm<BWD> &m, double tout)
 {
     if (ewt_set(m, O_ZN, O_EWT) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, O_ZNQ, O_EWTQ) != 0) return CV_ILL_INPUT; }
+#ifdef SA_SENS
+    if (m.sensi) { if (sens_ewt_set(m, O_ZNS, O_EWTS) != 0) return CV_ILL_INPUT; }
+#endif
     if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
     int retval = cv_f(m, m.tn, O_ZN, O_ZN + NS);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+#ifdef SA_SENS
+    if (m.sensi) {
+        retval = cv_fS(m, m.tn, O_ZN, O_ZNS, O_ZNS + NQ * NS);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return CV_FIRST_SRHSFUNC_ERR;
+    }
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, O_ZN, O_ZNQ + NQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -836,6 +1134,9 @@ DEV int cv_first_call(Cm<BWD> &m, double tout)
     m.hprime = m.h;
     for (int i = 0; i < NS; i++) ZN(m, 1, i) = m.h * ZN(m, 1, i);
     if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, 1, i) = m.h * ZNQ(m, 1, i);
+#ifdef SA_SENS
+    if (m.sensi) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) ZNS(m, 1, is, i) = m.h * ZNS(m, 1, is, i);
+#endif
     return CV_SUCCESS;
 }
 
@@ -844,28 +1145,35 @@ DEV int cv_pre_step(Cm<BWD> &m)
 {
     if (ewt_set(m, O_ZN, O_EWT) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, O_ZNQ, O_EWTQ) != 0) return CV_ILL_INPUT; }
+#ifdef SA_SENS
+    if (m.sensi) { if (sens_ewt_set(m, O_ZNS, O_EWTS) != 0) return CV_ILL_INPUT; }
+#endif
     double nrm = wrms_n(m, O_ZN);
     if (BWD) nrm = quad_update_norm(m, nrm, O_ZNQ);
+#ifdef SA_SENS
+    if (m.sensi) nrm = sens_update_norm(m, nrm, O_ZNS, O_EWTS);
+#endif
     if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
     return CV_SUCCESS;
 }
 
 struct StepCtl {
-    int in_step, redo, nflag, ncf, nef, nefQ, convfail;
+    int in_step, redo, nflag, ncf, nef, nefQ, convfail, ncfS, nefS;
     double saved_t;
 };
 
 template <bool BWD>
-DEV int cv_handle_nflag_failed(Cm<BWD> &m, StepCtl &c, int nflag)
+DEV int cv_handle_nflag_failed(Cm<BWD> &m, StepCtl &c, int nflag, int &ncf, int &ncfn)
 {
-    m.ncfn++;
+    ncfn++;
     cv_restore(m, c.saved_t);
     if (nflag < 0) return nflag;
-    c.ncf++;
+    ncf++;
     m.etamax = 1.0;
-    if (c.ncf == MXNCF) {
+    if (ncf == MXNCF) {
         if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
+        if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
         return CV_REPTD_QRHSFUNC_ERR;
     }
     m.eta = ETACF;
@@ -880,6 +1188,7 @@ DEV int cv_attempt(Cm<BWD> &m, StepCtl &c)
     if (!c.in_step) {
         c.saved_t = m.tn;
         c.ncf = c.nef = c.nefQ = 0;
+        c.ncfS = c.nefS = 0;
         c.nflag = FIRST_CALL;
         c.redo = 0;
         if ((m.nst > 0) && (m.hprime != m.h)) {
@@ -913,7 +1222,7 @@ DEV int cv_attempt(Cm<BWD> &m, StepCtl &c)
         return 0;
     }
     c.redo = 0;
-    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls);
+    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls, c.ncf, m.ncfn);
 
     for (int i = 0; i < NS; i++) W(m, O_Y, i) = ZN(m, 0, i) + W(m, O_ACOR, i);
     double dsm = m.acnrm * m.tq[2];
@@ -921,10 +1230,32 @@ DEV int cv_attempt(Cm<BWD> &m, StepCtl &c)
         c.nflag = PREV_ERR_FAIL;
         return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
     }
+#ifdef SA_SENS
+    if (m.sensi && m.ism == 0) {
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) VS(m, O_YS, is, i) = ZNS(m, 0, is, i) + VS(m, O_ACORS, is, i);
+    }
+    if (m.sensi && m.ism == 1) {         /* CV_STAGGERED: sensitivities after the state passed (oracle cv_step) */
+        c.ncf = c.nef = 0;
+        int retval = cv_f(m, m.tn, O_Y, O_FTEMP);
+        if (retval < 0) return CV_RHSFUNC_FAIL;
+        if (retval > 0) { c.nflag = PREV_CONV_FAIL; return 0; }
+        const int nflagS = cv_stgr_nls(m);
+        if (nflagS != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nflagS, c.ncfS, m.ncfnS);
+        m.acnrmS = sens_update_norm(m, 0.0, O_ACORS, O_EWTS);
+        const double dsmS = m.acnrmS * m.tq[2];
+        if (dsmS > 1.0) {
+            c.nflag = PREV_ERR_FAIL;
+            return cv_error_test_failed(m, c.saved_t, dsmS, c.nefS, m.netfS);
+        }
+        if (dsmS > dsm) dsm = dsmS;
+    }
+#endif
     if (BWD) {
         c.ncf = c.nef = 0;
         int retval = cv_fQ(m, m.tn, O_Y, O_ACORQ);
-        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR);
+        if (retval != 0)
+            return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR, c.ncf, m.ncfn);
         for (int i = 0; i < NQ; i++) {
             double v = FMA(m.h, W(m, O_ACORQ, i), -ZNQ(m, 1, i));
             W(m, O_ACORQ, i) = m.rl1 * v;
@@ -942,6 +1273,9 @@ DEV int cv_attempt(Cm<BWD> &m, StepCtl &c)
     m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
     for (int i = 0; i < NS; i++) W(m, O_ACOR, i) = m.tq[2] * W(m, O_ACOR, i);
     if (BWD) for (int i = 0; i < NQ; i++) W(m, O_ACORQ, i) = m.tq[2] * W(m, O_ACORQ, i);
+#ifdef SA_SENS
+    if (m.sensi) for (int j = 0; j < NQ * NS; j++) W(m, O_ACORS, j) = m.tq[2] * W(m, O_ACORS, j);
+#endif
     c.in_step = 0;
     return 1;
 }
@@ -979,6 +1313,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
     Cm<false> m;
+    m.sensi = 0; m.ism = 0;
     m.S = a.ws_stride;
     m.w = a.ws + inst;
     SFOR(i, 0, NQ) m.ps[i] = a.ps[(int64_t)inst * NQ + i]; SEND
@@ -1012,7 +1347,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     }
     bool done = (k >= a.n_t);
     StepCtl c;
-    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0; c.saved_t = a.t0;
+    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.ncfS = c.nefS = 0; c.convfail = 0; c.saved_t = a.t0;
     if (!done) {
         int flag = cv_first_call(m, a.tvals[k]);
         if (flag != CV_SUCCESS) { status = flag; done = true; }
@@ -1090,6 +1425,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     if (a.fwd_status[inst] != CV_SUCCESS || np < 2) status = CV_NO_FWD;
 
     Cm<true> m;
+    m.sensi = 0; m.ism = 0;
     m.S = a.ws_stride;
     m.w = a.ws + inst;
     SFOR(i, 0, NQ) m.ps[i] = a.ps[(int64_t)inst * NQ + i]; SEND
@@ -1141,7 +1477,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
             }
             int nstloc = 0, retries = 0;
             StepCtl c;
-            c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0;
+            c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.ncfS = c.nefS = 0; c.convfail = 0;
             c.saved_t = t_upper;
             bool idone = (status != CV_SUCCESS);
             while (!idone) {
@@ -1192,6 +1528,130 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
     SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
 }
+
+#ifdef SA_SENS
+/* CVodeGetSensDky(k = 0) for all parameters -> dst[is * NS + i] */
+template <bool BWD>
+DEV int cv_get_sens_dky0(Cm<BWD> &m, double t, double *dst)
+{
+    double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.hu));
+    if (m.hu < 0.0) tfuzz = -tfuzz;
+    double tp = m.tn - m.hu - tfuzz;
+    double tn1 = m.tn + tfuzz;
+    if ((t - tp) * (t - tn1) > 0.0) return CV_BAD_T;
+    double s = (t - m.tn) / m.h;
+    double pw[QMAX + 1];
+    pw[0] = 1.0;
+    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
+    const double pq = pick(pw, m.q);
+    for (int is = 0; is < NQ; is++)
+        for (int i = 0; i < NS; i++) {
+            double acc = pq * ZNS(m, m.q, is, i);
+            for (int j = m.q - 1; j >= 0; j--) acc = FMA(pick(pw, j), ZNS(m, j, is, i), acc);
+            dst[is * NS + i] = acc;
+        }
+    return CV_SUCCESS;
+}
+
+/* Solver(sens_mode).solve (reference solver.py:467-527): CVodeReInit + CVodeSensReInit, then per output
+   time CVode(NORMAL) with the mxstep x max_retries budget, CVodeGetSens */
+extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
+{
+    const int inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= a.B) return;
+    Cm<false> m;
+    m.S = a.ws_stride;
+    m.w = a.ws + inst;
+    SFOR(i, 0, NQ) { m.ps[i] = a.ps[(int64_t)inst * NQ + i]; m.pbar[i] = a.pbar[i]; } SEND
+    m.pr = a.pr + (int64_t)inst * a.rem_stride;
+    m.rtol = a.rtol; m.atol_p = a.atol; m.atol_s = 0.0;
+    m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
+    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
+    m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
+    m.traj = nullptr; m.tS = 0;
+    m.sensi = 1; m.ism = a.ism;
+
+    const double *y0 = a.y0 + (int64_t)inst * NS;
+    const double *s0 = a.sens0 + (int64_t)inst * NQ * NS;
+    for (int j = 0; j <= QMAX; j++) {
+        for (int i = 0; i < NS; i++) ZN(m, j, i) = 0.0;
+        for (int k = 0; k < NQ * NS; k++) W(m, O_ZNS, j * NQ * NS + k) = 0.0;
+    }
+    for (int i = 0; i < NS; i++) {
+        ZN(m, 0, i) = y0[i];
+        W(m, O_ACOR, i) = 0.0; W(m, O_TEMPV, i) = 0.0; W(m, O_FTEMP, i) = 0.0; W(m, O_Y, i) = 0.0;
+    }
+    for (int k = 0; k < NQ * NS; k++) {
+        W(m, O_ZNS, k) = s0[k];
+        W(m, O_ACORS, k) = 0.0; W(m, O_TEMPVS, k) = 0.0; W(m, O_FTEMPS, k) = 0.0; W(m, O_YS, k) = 0.0;
+        W(m, O_EWTS, k) = 0.0;
+    }
+    cv_reinit(m, a.t0);
+
+    double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
+    double *so = a.sens_out + (int64_t)inst * a.n_t * NQ * NS;
+    int status = CV_SUCCESS, k = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
+    while (k < a.n_t && a.tvals[k] == a.t0) {
+        for (int i = 0; i < NS; i++) yo[(int64_t)k * NS + i] = y0[i];
+        for (int j = 0; j < NQ * NS; j++) so[(int64_t)k * NQ * NS + j] = s0[j];
+        k++;
+    }
+    bool done = (k >= a.n_t);
+    StepCtl c;
+    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.ncfS = c.nefS = 0; c.convfail = 0;
+    c.saved_t = a.t0;
+    if (!done) {
+        int flag = cv_first_call(m, a.tvals[k]);
+        if (flag != CV_SUCCESS) { status = flag; done = true; }
+    }
+    while (!done) {
+        if (!c.in_step) {
+            int ier = cv_pre_step(m);
+            if (ier == CV_ILL_INPUT) { status = ier; done = true; }
+            else if (a.mxstep > 0 && nstloc >= a.mxstep) {
+                retries++; total_retries++;
+                if (retries >= a.max_retries) { status = CV_TOO_MUCH_WORK; done = true; }
+                else nstloc = 0;
+            }
+            if (!done && ier != CV_SUCCESS) { status = ier; done = true; }
+        }
+        if (!done) {
+            attempts++;
+            int r = cv_attempt(m, c);
+            if (r < 0) { status = r; done = true; }
+            else if (r == 1) {
+                nstloc++;
+                while (!done && k < a.n_t) {
+                    double tout = a.tvals[k];
+                    if (tout == a.t0) {
+                        for (int i = 0; i < NS; i++) yo[(int64_t)k * NS + i] = y0[i];
+                        for (int j = 0; j < NQ * NS; j++) so[(int64_t)k * NQ * NS + j] = s0[j];
+                        k++;
+                    } else if ((m.tn - tout) * m.h >= 0.0) {
+                        cv_get_dky0(m, tout, yo + (int64_t)k * NS, 1, O_QOUT);
+                        cv_get_sens_dky0(m, tout, so + (int64_t)k * NQ * NS);
+                        k++;
+                        nstloc = 0; retries = 0;
+                    } else break;
+                }
+                if (k >= a.n_t) done = true;
+            }
+        }
+    }
+    if (status != CV_SUCCESS) {
+        for (int j = 0; j < a.n_t * NS; j++) yo[j] = SA_NAN;
+        for (int j = 0; j < a.n_t * NQ * NS; j++) so[j] = SA_NAN;
+    }
+    a.status[inst] = status;
+    int64_t st[SA_N_STATS];
+    SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
+    accumulate_stats(m, st);
+    /* sensitivity counters ride in the quadrature / interpolation slots of the adjoint path */
+    st[ST_NFQE] = m.nfSe; st[ST_NETFQ] = m.netfS; st[ST_NINTERP] = m.nniS; st[ST_NREBUILD] = m.ncfnS;
+    st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+    SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
+}
+#endif
 
 /* callback evaluation + arithmetic probe (plain arrays, unit stride) */
 extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)

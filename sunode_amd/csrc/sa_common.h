@@ -58,6 +58,10 @@ DEV void sfor_down(F &&f)          /* B, B-1, ..., E (inclusive) */
 #define CV_FIRST_QRHSFUNC_ERR (-32)
 #define CV_REPTD_QRHSFUNC_ERR (-33)
 #define CV_UNREC_QRHSFUNC_ERR (-34)
+#define CV_SRHSFUNC_FAIL (-41)
+#define CV_FIRST_SRHSFUNC_ERR (-42)
+#define CV_REPTD_SRHSFUNC_ERR (-43)
+#define CV_UNREC_SRHSFUNC_ERR (-44)
 #define CV_NO_FWD (-102)
 #define CV_BAD_TB0 (-104)
 #define CV_GETY_BADT (-107)
@@ -102,6 +106,7 @@ DEV void sfor_down(F &&f)          /* B, B-1, ..., E (inclusive) */
 #define PREV_ERR_FAIL 103
 #define RHSFUNC_RECVR 9
 #define QRHSFUNC_RECVR 11
+#define SRHSFUNC_RECVR 12
 #define NLS_CONV_RECVR 902
 #define CV_NO_FAILURES 0
 #define CV_FAIL_BAD_J 1

@@ -59,6 +59,22 @@ typedef struct {
     int64_t ws_stride;
 } sa_bwd_args;
 
+/* Solver(sens_mode=...).solve: forward solve + forward sensitivities (SA_SENS build of bdf_mem.hip).
+   sens0 [B][p][n], sens_out [B][n_t][p][n] (row `is` = derivative w.r.t. differentiated parameter `is`,
+   as the reference's sens_out[i, j, :], solver.py:527); ism 0 = simultaneous, 1 = staggered corrector;
+   pbar [p] = |scaling_factors| (ones by default). */
+typedef struct {
+    int32_t B, n_t, ism, mxstep, max_retries, rem_stride, reserved0, reserved1;
+    double t0, rtol;
+    const double *atol, *pbar;
+    const double *y0, *ps, *pr, *sens0, *tvals;
+    double *y_out, *sens_out;
+    int32_t *status;
+    int64_t *stats;
+    double *ws;
+    int64_t ws_stride;
+} sa_sens_args;
+
 typedef struct {
     int32_t npts, reserved;
     const double *t, *y, *lam, *ps, *pr;      /* [npts], [npts][n], [npts][n], [npts][p], [npts][r] */

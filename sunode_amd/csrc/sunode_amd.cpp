@@ -69,6 +69,7 @@ struct sa_solver {
     DevBuf ws;
     hipModule_t module = nullptr;
     hipFunction_t k_forward = nullptr, k_backward = nullptr, k_eval = nullptr, k_math = nullptr;
+    hipFunction_t k_sens = nullptr;            /* only in forward-sensitivity builds */
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   /* fwd start/stop, bwd start/stop */
@@ -157,6 +158,7 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
             return fail(SA_ERR_MODULE, "%s: kernel %s not found", path, names[i]);
         }
     }
+    if (hipModuleGetFunction(&s->k_sens, s->module, "sa_k_sens") != hipSuccess) s->k_sens = nullptr;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipModuleUnload(s->module);
         delete s;
@@ -336,6 +338,65 @@ extern "C" int sa_solve_batch(sa_solver *s, int mem, int32_t B, const double *y0
                               double *y_out, int32_t *status, int64_t *stats)
 {
     return forward_common(s, SA_MODE_PLAIN, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats);
+}
+
+extern "C" int sa_solve_sens_batch(sa_solver *s, int mem, int ism, const double *scaling, int32_t B,
+                                   const double *y0, const double *ps, const double *pr, int32_t rem_stride,
+                                   const double *sens0, double t0, const double *tvals, int32_t n_t,
+                                   double *y_out, double *sens_out, int32_t *status, int64_t *stats)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    if (!s->k_sens) return fail(SA_ERR_ARG, "this code object was built without forward-sensitivity support");
+    if (B < 0 || n_t < 0) return fail(SA_ERR_ARG, "negative size");
+    if (ism != 0 && ism != 1) return fail(SA_ERR_ARG, "ism must be 0 (simultaneous) or 1 (staggered)");
+    if (rem_stride != 0 && rem_stride != s->r) return fail(SA_ERR_ARG, "rem_stride must be 0 or n_rem=%d", s->r);
+    HIP_TRY(hipSetDevice(s->device));
+    if (B == 0 || n_t == 0) return SA_OK;
+    const size_t nB = (size_t)B, np_n = (size_t)s->p * s->n;
+    std::vector<double> pbar((size_t)(s->p > 0 ? s->p : 1), 1.0);
+    if (scaling) for (int i = 0; i < s->p; i++) pbar[i] = scaling[i] < 0 ? -scaling[i] : scaling[i];
+    const double *d_y0 = y0, *d_ps = ps, *d_pr = pr, *d_tv = tvals, *d_s0 = sens0;
+    double *d_yout = y_out, *d_sout = sens_out;
+    int32_t *d_status = status;
+    int64_t *d_stats = stats;
+    int rc;
+    const void *q;
+    if ((rc = stage_in(s, s->s_misc[0], pbar.data(), sizeof(double) * pbar.size(), &q))) return rc;
+    const double *d_pbar = (const double *)q;
+    if (mem == SA_MEM_HOST) {
+        if ((rc = stage_in(s, s->s_y0, y0, sizeof(double) * nB * s->n, &q))) return rc; d_y0 = (const double *)q;
+        if ((rc = stage_in(s, s->s_ps, ps, sizeof(double) * nB * s->p, &q))) return rc; d_ps = (const double *)q;
+        if ((rc = stage_in(s, s->s_pr, pr, sizeof(double) * (rem_stride ? nB : 1) * s->r, &q))) return rc; d_pr = (const double *)q;
+        if ((rc = stage_in(s, s->s_tvals, tvals, sizeof(double) * n_t, &q))) return rc; d_tv = (const double *)q;
+        if ((rc = stage_in(s, s->s_grads, sens0, sizeof(double) * nB * np_n, &q))) return rc; d_s0 = (const double *)q;
+        if ((rc = s->s_yout.ensure(sizeof(double) * nB * n_t * s->n))) return rc; d_yout = (double *)s->s_yout.p;
+        if ((rc = s->s_gout.ensure(sizeof(double) * nB * n_t * (np_n ? np_n : 1)))) return rc; d_sout = (double *)s->s_gout.p;
+        if ((rc = s->s_status.ensure(sizeof(int32_t) * nB))) return rc; d_status = (int32_t *)s->s_status.p;
+        if ((rc = s->s_stats.ensure(sizeof(int64_t) * nB * SA_N_STATS))) return rc; d_stats = (int64_t *)s->s_stats.p;
+    } else if (mem != SA_MEM_DEVICE) {
+        return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
+    }
+    sa_sens_args a;
+    memset(&a, 0, sizeof a);
+    a.B = B; a.n_t = n_t; a.ism = ism; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_fwd;
+    a.rem_stride = rem_stride; a.t0 = t0; a.rtol = s->opt.rtol;
+    a.atol = (const double *)s->d_atol.p; a.pbar = d_pbar;
+    a.y0 = d_y0; a.ps = d_ps; a.pr = d_pr; a.sens0 = d_s0; a.tvals = d_tv;
+    a.y_out = d_yout; a.sens_out = d_sout; a.status = d_status; a.stats = d_stats;
+    if ((rc = bind_workspace(s, B, &a.ws, &a.ws_stride))) return rc;
+    HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+    if ((rc = launch(s, s->k_sens, B, &a, sizeof a, s->group))) return rc;
+    HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+    s->have_fwd_time = true;
+    if (mem == SA_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(y_out, d_yout, sizeof(double) * nB * n_t * s->n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(sens_out, d_sout, sizeof(double) * nB * n_t * np_n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
+        if (stats)
+            HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(int64_t) * nB * SA_N_STATS, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));      /* pbar staging buffer is host-owned */
+    return SA_OK;
 }
 
 extern "C" int sa_solve_forward_batch(sa_solver *s, int mem, int32_t B, const double *y0, const double *ps,

@@ -31,6 +31,8 @@ ERRORS: Dict[int, str] = {
     -25: "CV_BAD_T", -26: "CV_BAD_DKY", -27: "CV_TOO_CLOSE", -28: "CV_VECTOROP_ERR",
     -30: "CV_NO_QUAD", -31: "CV_QRHSFUNC_FAIL", -32: "CV_FIRST_QRHSFUNC_ERR",
     -33: "CV_REPTD_QRHSFUNC_ERR", -34: "CV_UNREC_QRHSFUNC_ERR",
+    -40: "CV_NO_SENS", -41: "CV_SRHSFUNC_FAIL", -42: "CV_FIRST_SRHSFUNC_ERR", -43: "CV_REPTD_SRHSFUNC_ERR",
+    -44: "CV_UNREC_SRHSFUNC_ERR", -45: "CV_BAD_IS",
     -101: "CV_NO_ADJ", -102: "CV_NO_FWD", -103: "CV_NO_BCK", -104: "CV_BAD_TB0",
     -105: "CV_REIFWD_FAIL", -106: "CV_FWD_FAIL", -107: "CV_GETY_BADT",
 }
@@ -38,6 +40,28 @@ ERRORS: Dict[int, str] = {
 
 class SolverError(RuntimeError):
     pass
+
+
+def initial_sensitivities(problem) -> np.ndarray:
+    """sens0 [n_params, n_states] of the forward-sensitivity Op (reference wrappers/as_pytensor.py:201-230): zero, except that a
+    differentiated parameter living under the top-level key ``__initial_values`` IS an initial value --
+    its sensitivity starts as the unit vector of the state entry with the same path."""
+    offsets, pos = {}, 0
+    for path in problem.state_subset.paths:
+        offsets[path] = pos
+        pos += int(np.prod(problem.state_subset.flat_shapes[path], dtype=int))
+    sens0 = np.zeros((problem.n_params, problem.n_states))
+    row = 0
+    for path in problem.params_subset.subset_paths:
+        n_items = int(np.prod(problem.params_subset.flat_shapes[path], dtype=int))
+        if path and path[0] == "__initial_values":
+            state_path = tuple(path[1:])
+            if state_path not in offsets:
+                raise ValueError("no state with path %s for initial-value parameter" % (state_path,))
+            for k in range(n_items):
+                sens0[row + k, offsets[state_path] + k] = 1.0
+        row += n_items
+    return sens0
 
 
 def _flat_state(problem, y0) -> np.ndarray:
@@ -144,11 +168,16 @@ class Solver(_EngineMixin):
                  scaling_factors: Optional[np.ndarray] = None, constraints: Optional[np.ndarray] = None,
                  solver="BDF", linear_solver="dense", linear_solver_kwargs=None, mxsteps: int = 500,
                  device: int = 0):
-        if sens_mode not in (None, False):
-            if sens_mode not in ("simultaneous", "staggered"):
-                raise ValueError('sens_mode must be one of "simultaneous" and "staggered".')
-            raise NotImplementedError("forward sensitivities are not part of the MI355X hot path yet; "
-                                      "use AdjointSolver for gradients")
+        if sens_mode in (None, False):
+            sens_mode = None
+        elif sens_mode == "staggered1":
+            raise ValueError("staggered1 not implemented.")            # as the reference, solver.py:365-366
+        elif sens_mode not in ("simultaneous", "staggered"):
+            raise ValueError('sens_mode must be one of "simultaneous" and "staggered".')
+        if scaling_factors is not None:
+            scaling_factors = np.ascontiguousarray(scaling_factors, dtype=np.float64)
+            if scaling_factors.shape != (problem.n_params,):
+                raise ValueError("Invalid shape of scaling_factors.")
         if solver != "BDF":
             if solver == "ADAMS":
                 raise NotImplementedError("only the BDF method is implemented on the device")
@@ -165,27 +194,35 @@ class Solver(_EngineMixin):
         self._abstol, self._reltol = abstol, reltol
         self._linear_solver_kind = linear_solver
         self._linear_solver_kwargs = linear_solver_kwargs or {}
-        self._sens_mode = None
-        self._compute_sens = False
+        self._sens_mode = sens_mode
+        self._compute_sens = sens_mode is not None
+        self._scaling_factors = scaling_factors
         self._mxsteps = mxsteps
         self._device = device
         self._set_tolerances(abstol, reltol)
         self._state_names = ["_problem", "_user_data", "_constraints", "_abstol", "_reltol",
-                             "_linear_solver_kind", "_linear_solver_kwargs", "_sens_mode", "_mxsteps",
-                             "_device", "_state_names"]
+                             "_linear_solver_kind", "_linear_solver_kwargs", "_sens_mode", "_scaling_factors",
+                             "_mxsteps", "_device", "_state_names"]
         self._init_native()
 
     def _init_native(self):
         self._source = self._problem.native_source()
-        _native.build_code_object(self._source)      # compile at construction like the reference JITs
+        # compile at construction like the reference JITs; sensitivity solves use their own build
+        _native.build_code_object(self._source, sens=self._compute_sens)
         self._native = None
+
+    def _engine(self) -> _native.NativeSolver:
+        if self._native is None:
+            self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
+                                                sens=self._compute_sens, **self._native_kwargs())
+        return self._native
 
     def __getstate__(self):
         return {name: self.__dict__[name] for name in self._state_names}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        self._compute_sens = False
+        self._compute_sens = self._sens_mode is not None
         self._set_tolerances(self._abstol, self._reltol)
         self._init_native()
 
@@ -205,19 +242,55 @@ class Solver(_EngineMixin):
                     traj_capacity=2)
 
     def make_output_buffers(self, tvals):
-        return np.zeros((len(tvals), self._problem.n_states))
+        """y_out, or (y_out, sens_out) when sensitivities are computed (reference solver.py:419-426)."""
+        n, p = self._problem.n_states, self._problem.n_params
+        y_out = np.zeros((len(tvals), n))
+        if self._compute_sens:
+            return y_out, np.zeros((len(tvals), p, n))
+        return y_out
 
     def solve(self, t0, tvals, y0, y_out, *, sens0=None, sens_out=None, max_retries=5):
+        if self._compute_sens and (sens0 is None or sens_out is None):
+            raise ValueError('"sens_out" and "sens0" are required when computin sensitivities.')
         y0 = _flat_state(self._problem, y0)
         ps, pr = self._problem.flat_params(self._user_data)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
-        yo, status, _ = self.solve_batch(t0, tvals, y0[None], ps[None], pr, max_retries=max_retries)
+        if self._compute_sens:
+            yo, so, status, _ = self.solve_sens_batch(t0, tvals, y0[None], ps[None], pr,
+                                                      np.asarray(sens0, dtype=np.float64)[None],
+                                                      max_retries=max_retries)
+        else:
+            yo, status, _ = self.solve_batch(t0, tvals, y0[None], ps[None], pr, max_retries=max_retries)
         if status[0] != 0:
             code = int(status[0])
             if code == -1:
                 raise SolverError("Too many solver retries.")
             raise SolverError(f"Solving ode failed: {ERRORS.get(code, 'unknown')} ({code})")
         y_out[...] = yo[0]
+        if self._compute_sens:
+            sens_out[...] = so[0]
+
+    def solve_sens_batch(self, t0, tvals, y0, params_sub, params_rem, sens0, *, max_retries=5
+                         ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        """Forward solve + forward sensitivities for B draws (``sens_mode`` must be set): returns
+        (y_out [B,n_t,n], sens_out [B,n_t,p,n], status [B], stats [B,16]); ``sens0`` is [B,p,n] or [p,n]."""
+        if not self._compute_sens:
+            raise ValueError("construct the Solver with sens_mode='simultaneous' or 'staggered'")
+        eng = self._engine()
+        if max_retries != eng._opt_kw["max_retries_fwd"]:
+            eng.set_options(max_retries_fwd=max_retries)
+        B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
+        n, p = self._problem.n_states, self._problem.n_params
+        sens0 = np.ascontiguousarray(np.broadcast_to(np.asarray(sens0, dtype=np.float64), (B, p, n)))
+        tvals = np.ascontiguousarray(tvals, dtype=np.float64)
+        y_out = np.zeros((B, len(tvals), n))
+        sens_out = np.zeros((B, len(tvals), p, n))
+        status = np.zeros(B, np.int32)
+        stats = np.zeros((B, _native.N_STATS), np.int64)
+        eng.solve_sens(_native.SA_MEM_HOST, 0 if self._sens_mode == "simultaneous" else 1, self._scaling_factors,
+                       B, y0, ps, pr, stride, sens0 if sens0.size else np.zeros(1), t0, tvals, len(tvals), y_out,
+                       sens_out if sens_out.size else np.zeros(1), status, stats)
+        return y_out, sens_out, status, stats
 
     def solve_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5
                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

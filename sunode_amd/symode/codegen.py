@@ -36,7 +36,7 @@ from __future__ import annotations
 
 import hashlib
 from itertools import count
-from typing import Dict, Iterable, List, Sequence, Tuple
+from typing import Optional,  Dict, Iterable, List, Sequence, Tuple
 
 import numpy as np
 import sympy as sym
@@ -334,9 +334,11 @@ def generate_problem_source(
     jac: np.ndarray,
     dlamdadt: np.ndarray,
     quad: np.ndarray,
+    dydp_t: Optional[np.ndarray] = None,
     description: str = "",
 ) -> str:
-    """Full generated header: sizes + helpers + the five callbacks."""
+    """Full generated header: sizes + helpers + the five callbacks of the adjoint path and the
+    parameter derivative of the right-hand side (forward sensitivities)."""
     n = n_states
     # column-major slot of J[i, j] is j*n + i (reference problem.py:345,377 numba.farray)
     col_major = [j * n + i for i in range(n) for j in range(n)]
@@ -363,6 +365,13 @@ def generate_problem_source(
                       list(range(n_sub)), n_sub, symbol_map, "q_").replace(
                           "(void)pr;", "(void)pr; (void)lam;"),
         emit_function("sa_adj_jac", base, adj_jac, col_major, n * n, symbol_map, "b_"),
+        # d f / d p, stored [n_sub][n_states] (row `is` = derivative w.r.t. differentiated parameter `is`):
+        # the explicit part of the sensitivity right-hand side yS' = J yS + df/dp (reference
+        # symode/problem.py:557-583)
+        emit_function("sa_dydp", base,
+                      np.asarray(dydp_t if dydp_t is not None else np.zeros((n_sub, n), dtype=object),
+                                 dtype=object).ravel(),
+                      list(range(n_sub * n)), n_sub * n, symbol_map, "s_"),
         "",
     ]
     return "\n".join(parts)

@@ -308,7 +308,8 @@ class SympyProblem:
         source -- just read it.  Problems without such sub-expressions are unaffected."""
         if self._native_cache is None:
             arrays = [self._simplify(np.array(a, dtype=object)) for a in
-                      (self._sym_dydt, self._sym_dydt_jac, self._sym_dlamdadt, self._sym_quad_rhs)]
+                      (self._sym_dydt, self._sym_dydt_jac, self._sym_dlamdadt, self._sym_quad_rhs,
+                       np.array(self._sym_dydp, dtype=object).T)]
             fixed = set(self._sym_fixed_paramsvec)
             table: Dict[Any, sym.Symbol] = {}
 
@@ -351,7 +352,7 @@ class SympyProblem:
             index_of = {sy: k for k, sy in enumerate(self._sym_fixed_paramsvec)}
             self._packed: List[int] = []
             packed_arrays = []
-            for tag, a in zip("fjaq", arrays):
+            for tag, a in zip("fjaqs", arrays):
                 order: List[Any] = []
                 seen = set()
                 pairs = adjacent = 0
@@ -411,12 +412,13 @@ class SympyProblem:
                 [".".join(p) for p in self.state_subset.paths],
                 [".".join(p) for p in self.params_subset.paths],
                 [".".join(p) for p in self.params_subset.subset_paths])
-            (dydt, jac, dlamdadt, quad), slots = self._native_exprs()
+            (dydt, jac, dlamdadt, quad, dydp_t), slots = self._native_exprs()
             if self._hoisted or self._packed:
                 desc += " hoisted=%d packed=%d" % (len(self._hoisted), len(self._packed))
             self._native_source = codegen.generate_problem_source(
                 n_states=self.n_states, n_sub=self.n_params, n_rem=self.n_remainder_native,
-                symbol_map=slots, dydt=dydt, jac=jac, dlamdadt=dlamdadt, quad=quad, description=desc,
+                symbol_map=slots, dydt=dydt, jac=jac, dlamdadt=dlamdadt, quad=quad, dydp_t=dydp_t,
+                description=desc,
             )
         return self._native_source
 

@@ -2,9 +2,9 @@
 
 Counterpart of /root/reference/sunode/wrappers/as_pytensor.py (``solve_ivp`` ``:20-137``,
 ``EvalRhs`` ``:140-183``, ``SolveODEAdjoint`` ``:266-308``, ``SolveODEAdjointBackward``
-``:311-344``) on top of the HIP engine.  Only the adjoint path (the hot path of this build) is
-provided; ``derivatives='forward'`` raises ``NotImplementedError``.  On top of the reference's
-per-draw Ops there is a batched pair (``SolveODEAdjointBatch`` / ``...BatchBackward``) whose
+``:311-344``) on top of the HIP engine.  Both gradient paths are wired: ``derivatives='adjoint'``
+(``SolveODEAdjoint``) and ``derivatives='forward'`` (``SolveODE``, forward sensitivities, ``:186-264``).
+On top of the reference's per-draw Ops there is a batched pair (``SolveODEAdjointBatch`` / ``...BatchBackward``) whose
 leading axis is the parameter draw, which is what actually feeds a GPU.
 
 pytensor is an optional dependency: importing this module without it raises ``ImportError``.
@@ -26,7 +26,7 @@ except ImportError as exc:  # pragma: no cover - depends on the environment
     raise ImportError("sunode_amd.wrappers.as_pytensor needs pytensor, which is not installed") from exc
 
 from sunode_amd.dtypesubset import as_flattened
-from sunode_amd.solver import AdjointSolver, SolverError
+from sunode_amd.solver import AdjointSolver, Solver, SolverError, initial_sensitivities
 from sunode_amd.symode.problem import SympyProblem
 
 
@@ -67,11 +67,11 @@ def solve_ivp(t0, y0, params, tvals, rhs: Callable, derivatives: str = "adjoint"
 
     Returns ``(solution_dict, flat_solution, problem, solver, y0_flat, params_subs_flat)``."""
     solver_kwargs = dict(solver_kwargs or {})
-    if derivatives == "forward":
-        raise NotImplementedError("forward sensitivities are not implemented by the HIP engine; "
-                                  "use derivatives='adjoint'")
-    if derivatives != "adjoint":
-        raise ValueError("derivatives must be 'adjoint'")
+    if derivatives not in ("adjoint", "forward"):
+        raise ValueError("derivatives must be 'adjoint' or 'forward'")
+    if derivatives == "forward" and "sens_mode" not in solver_kwargs:
+        raise ValueError("When `derivatives='forward'`, the `solver_kwargs` must contain one of "
+                         "`sens_mode={\"simultaneous\" | \"staggered\"}`.")
 
     y0_dims = _static_dims(y0)
     params_dims = _static_dims(params)
@@ -91,6 +91,12 @@ def solve_ivp(t0, y0, params, tvals, rhs: Callable, derivatives: str = "adjoint"
     t0 = pt.as_tensor_variable(t0, dtype="float64")
     tvals = pt.as_tensor_variable(tvals, dtype="float64")
 
+    if derivatives == "forward":       # reference :127-134: one more pair of return values
+        solver = make_solver(problem, **solver_kwargs) if make_solver else Solver(problem, **solver_kwargs)
+        wrapper = SolveODE(solver)
+        flat_solution, flat_sens = wrapper(y0_flat, params_subs_flat, params_rem_flat, t0, tvals)
+        solution = problem.flat_solution_as_dict(flat_solution)
+        return solution, flat_solution, problem, solver, y0_flat, params_subs_flat, flat_sens, wrapper
     solver = make_solver(problem, **solver_kwargs) if make_solver else AdjointSolver(problem, **solver_kwargs)
     flat_solution = SolveODEAdjoint(solver)(y0_flat, params_subs_flat, params_rem_flat, t0, tvals)
     solution = problem.flat_solution_as_dict(flat_solution)
@@ -116,6 +122,37 @@ class EvalRhs(Op):
         if res["codes"][:, 0].any():
             raise ValueError("Bad ode rhs return code: 1")
         outputs[0][0] = res["rhs"]
+
+
+class SolveODE(Op):
+    """Forward solve + forward sensitivities of one draw (reference ``SolveODE``, :186-264)."""
+    itypes = [pt.dvector, pt.dvector, pt.dvector, pt.dscalar, pt.dvector]   # y0, params, fixed, t0, tvals
+    otypes = [pt.dmatrix, pt.dtensor3]                                       # y_out, sens_out [n_t, p, n]
+    __props__ = ("_solver_id",)
+
+    def __init__(self, solver):
+        self._solver = solver
+        self._solver_id = id(solver)
+        self._sens0 = initial_sensitivities(solver._problem)
+
+    def perform(self, node, inputs, outputs):
+        y0, params, params_fixed, t0, tvals = inputs
+        y, sens, status, _ = self._solver.solve_sens_batch(float(t0), tvals, y0[None], params[None], params_fixed,
+                                                           self._sens0)
+        outputs[0][0] = y[0]            # failed solves are NaN-filled by the engine (reference :245-247)
+        outputs[1][0] = sens[0]
+
+    def grad(self, inputs, g):
+        g, g_sens = g
+        _, params, params_fixed, t0, tvals = inputs
+        solution, sens = self(*inputs)
+        return [
+            pt.zeros_like(inputs[0]),
+            pt.sum(g[:, None, :] * sens, (0, -1)),
+            grad_not_implemented(self, 2, params_fixed),
+            grad_not_implemented(self, 3, t0),
+            (EvalRhs(self._solver)(params, params_fixed, solution, tvals) * g).sum(-1),
+        ]
 
 
 class SolveODEAdjoint(Op):

@@ -1,0 +1,161 @@
+"""Forward sensitivities (``Solver(sens_mode=...)``, reference solver.py:360-392, 467-527).
+
+CPU: the oracle's sensitivity corrector (simultaneous and staggered) against truth fixtures
+(sensitivity equations integrated by scipy at 1e-13, tools/make_golden_sens.py) and the host-side
+argument checks.  GPU (-m gpu): the device path through the C ABI, bit-for-bit against the oracle.
+Tolerance vs truth: 2e-5 of the largest |dy/dp| of the instance at rtol = atol = 1e-8 (the BDF global
+error at this tolerance, as for the states), 1e-6 at 1e-10.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_oracle, make_problem
+
+
+def _load(golden_dir, name):
+    t = np.load(os.path.join(golden_dir, "truth_sens_%s.npz" % name))
+    return {k: t[k] for k in t.files}
+
+
+def _rel_err(S, truth):
+    scale = np.abs(truth).max(axis=(1, 3), keepdims=True)          # per instance and parameter
+    return float(np.max(np.abs(S - truth) / scale))
+
+
+@pytest.mark.parametrize("name,tol,bar", [("lv", 1e-8, 2e-5), ("lv", 1e-10, 1e-6), ("robertson", 1e-8, 2e-4)])
+@pytest.mark.parametrize("mode", ["simultaneous", "staggered"])
+def test_oracle_sensitivities_match_truth(name, tol, bar, mode, golden_dir):
+    t = _load(golden_dir, name)
+    prob = make_problem(name)
+    orc = make_oracle(name)
+    atol = 1e-10 if name == "robertson" else tol
+    cfg = orc.config(rtol=tol, atol=atol)
+    sens0 = np.zeros((prob.n_params, prob.n_states))
+    y, S, status, stats = orc.solve_sens(cfg, t["y0"], t["ps"], t["pr"], sens0, float(t["t0"]), t["tvals"], mode=mode)
+    assert (status == 0).all()
+    assert _rel_err(S, t["sens"]) < bar
+    ys = np.abs(t["y_out"]).max(axis=(0, 1))
+    assert np.max(np.abs(y - t["y_out"]) / ys) < 1e-5
+    # the sensitivity systems take part in the error test: more steps than the plain solve, and
+    # the staggered corrector evaluates f once more per step
+    y_plain, _, stats_plain = orc.solve(cfg, t["y0"], t["ps"], t["pr"], float(t["t0"]), t["tvals"])
+    assert (stats[:, 0] >= stats_plain[:, 0]).all()
+    assert (stats[:, 9] > 0).all()                                  # sensitivity rhs evaluations
+
+
+def test_oracle_sens_initial_condition_and_scaling(golden_dir):
+    """sens0 != 0 propagates linearly; scaling_factors (CVodeSetSensParams pbar) only reweights
+    the error test: same sensitivities within tolerance."""
+    t = _load(golden_dir, "lv")
+    prob = make_problem("lv")
+    orc = make_oracle("lv")
+    cfg = orc.config(rtol=1e-10, atol=1e-10)
+    tv = t["tvals"]
+    z = np.zeros((2, 2))
+    _, S0, st, _ = orc.solve_sens(cfg, t["y0"][:1], t["ps"][:1], t["pr"][:1], z, 0.0, tv)
+    e = np.array([[1.0, 0.0], [0.0, 0.0]])                          # d y0[0] / d p0 = 1
+    _, S1, st1, _ = orc.solve_sens(cfg, t["y0"][:1], t["ps"][:1], t["pr"][:1], e, 0.0, tv)
+    assert (st == 0).all() and (st1 == 0).all()
+    assert np.array_equal(S1[0, 0], e)                              # row of tvals[0] == t0 is sens0
+    d = S1 - S0                                                     # = dy/dy0[0] for parameter 0, zero for parameter 1
+    assert np.max(np.abs(d[0, :, 1])) < 1e-6
+    assert np.max(np.abs(d[0, -1, 0])) > 1e-3
+    _, S2, st2, _ = orc.solve_sens(cfg, t["y0"][:1], t["ps"][:1], t["pr"][:1], z, 0.0, tv,
+                                   scaling_factors=np.array([10.0, 0.1]))
+    assert (st2 == 0).all()
+    assert _rel_err(S2, t["sens"][:1]) < 1e-5
+
+
+def test_solver_sens_argument_checks():
+    from sunode_amd import _native
+    from sunode_amd.solver import Solver
+    prob = make_problem("lv")
+    with pytest.raises(ValueError):
+        Solver(prob, sens_mode="staggered1")
+    with pytest.raises(ValueError):
+        Solver(prob, sens_mode="both")
+    with pytest.raises(ValueError):
+        Solver(prob, sens_mode="simultaneous", scaling_factors=np.ones(3))
+    sol = Solver(prob, sens_mode="staggered")                        # compiles the sensitivity build
+    assert _native.kernel_variant(prob.native_source(), sens=True)[0] == "bdf_mem.hip"
+    assert os.path.exists(_native.code_object_path(prob.native_source(), sens=True))
+    with pytest.raises(ValueError):
+        sol.solve(0.0, np.linspace(0, 1, 3), np.ones(2), np.zeros((3, 2)))      # sens0 / sens_out missing
+
+
+def test_initial_value_parameters_seed_the_sensitivities():
+    """`__initial_values` parameters (reference wrappers/as_pytensor.py:37-39, 211-230): their
+    sensitivity starts as the unit vector of the matching state entry."""
+    from sunode_amd import SympyProblem
+    from sunode_amd.solver import initial_sensitivities
+
+    def rhs(t, y, p):
+        return {"x": [-p.k * y.x[0], p.k * y.x[0] - y.x[1]], "z": -y.z}
+
+    prob = SympyProblem({"k": (), "__initial_values": {"x": (2,), "z": ()}}, {"x": (2,), "z": ()}, rhs,
+                        [("k",), ("__initial_values", "x"), ("__initial_values", "z")])
+    s0 = initial_sensitivities(prob)
+    assert s0.shape == (4, 3)
+    np.testing.assert_array_equal(s0, [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    from oracle.harness import Oracle
+    orc = Oracle(prob, tag="ivp")
+    cfg = orc.config(rtol=1e-10, atol=1e-12)
+    tv = np.linspace(0, 1, 5)
+    y, S, st, _ = orc.solve_sens(cfg, [[1.0, 0.5, 2.0]], [[0.7, 1.0, 0.5, 2.0]], np.zeros(0), s0, 0.0, tv)
+    assert (st == 0).all()
+    # analytic: x0 = a exp(-k t); z = c exp(-t)
+    np.testing.assert_allclose(S[0, :, 1, 0], np.exp(-0.7 * tv), rtol=1e-7)           # d x0 / d x0(0)
+    np.testing.assert_allclose(S[0, :, 3, 2], np.exp(-tv), rtol=1e-7)                 # d z / d z(0)
+    np.testing.assert_allclose(S[0, :, 0, 0], -tv * np.exp(-0.7 * tv), rtol=1e-6, atol=1e-9)   # d x0 / d k
+    np.testing.assert_allclose(S[0, :, 2, 1], np.exp(-tv), rtol=1e-7)                 # d x1 / d x1(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lv", "robertson"])
+@pytest.mark.parametrize("mode", ["simultaneous", "staggered"])
+def test_device_sensitivities_bitexact_vs_oracle(name, mode, golden_dir):
+    from sunode_amd.solver import Solver
+    from tools.problems import lv_batch, robertson_batch
+    prob = make_problem(name)
+    B = 70                                                           # ragged vs the 64-lane wavefront
+    if name == "lv":
+        d = lv_batch(B)
+        ps, pr = d["params"][:, :2], d["params"][:, 2:]
+        rtol, atol = 1e-8, 1e-8
+    else:
+        d = robertson_batch(B)
+        ps, pr = d["params"], np.zeros(0)
+        rtol, atol = 1e-8, 1e-10
+    tv = d["tvals"]
+    sens0 = np.zeros((prob.n_params, prob.n_states))
+    sol = Solver(prob, abstol=atol, reltol=rtol, sens_mode=mode)
+    y, S, status, stats = sol.solve_sens_batch(0.0, tv, d["y0"], ps, pr, sens0)
+    orc = make_oracle(name)
+    cfg = orc.config(rtol=rtol, atol=atol)
+    yo, So, so, sto = orc.solve_sens(cfg, d["y0"], ps, pr, sens0, 0.0, tv, mode=mode, nthreads=8)
+    assert (status == 0).all() and (so == 0).all()
+    cmp = [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13]                # + nfSe, netfS, nniS, ncfnS, retries
+    np.testing.assert_array_equal(stats[:, cmp], sto[:, cmp])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(S, So)
+    t = _load(golden_dir, name)
+    k = len(t["y0"])
+    assert _rel_err(S[:k], t["sens"]) < (2e-5 if name == "lv" else 2e-4)
+
+
+@pytest.mark.gpu
+def test_device_sens_scalar_api_and_failures():
+    """Reference-shaped call (solver.py:467): caller-allocated y_out / sens_out, SolverError on failure."""
+    from sunode_amd.solver import Solver, SolverError
+    prob = make_problem("lv")
+    sol = Solver(prob, abstol=1e-8, reltol=1e-8, sens_mode="simultaneous")
+    sol.set_params_dict({"alpha": 0.1, "beta": 0.2, "gamma": 0.3, "delta": 0.4})
+    tv = np.linspace(0, 10)
+    y_out = np.zeros((50, 2)); sens_out = np.zeros((50, 2, 2))
+    sol.solve(0.0, tv, np.array([1.0, 0.1]), y_out, sens0=np.zeros((2, 2)), sens_out=sens_out)
+    assert abs(y_out[-1, 0] - 1.32497001) < 1e-5 and abs(y_out[-1, 1] - 1.04585428) < 1e-5
+    assert np.isfinite(sens_out).all() and np.abs(sens_out[-1]).max() > 0.1
+    with pytest.raises(SolverError):                                  # non-finite rhs from the start
+        sol.solve(0.0, tv, np.array([np.inf, 0.1]), y_out, sens0=np.zeros((2, 2)), sens_out=sens_out)

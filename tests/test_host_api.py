@@ -75,8 +75,8 @@ def test_solver_construction_like_reference_tests():
 def test_unsupported_reference_options_raise():
     from sunode_amd.solver import AdjointSolver, Solver
     prob = make_problem("lv")
-    with pytest.raises(NotImplementedError):
-        Solver(prob, sens_mode="simultaneous")
+    with pytest.raises(ValueError):
+        Solver(prob, sens_mode="staggered1")      # as the reference (solver.py:365-366)
     with pytest.raises(ValueError):
         Solver(prob, sens_mode="bogus")
     with pytest.raises(NotImplementedError):
