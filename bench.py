@@ -35,6 +35,20 @@ def make_problem():
     return SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this same command (profiles/pmc_traffic.json, collected as MI355X_MICROARCH.md prescribes: separate
+    passes, KiB units, calibrated on the known arena size); None when no such profile is in the tree.
+    Counters cannot be collected from inside the timed run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)[kernel]
+        return float(rec["fetch"] + rec["write"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def usable_cores() -> int:
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -180,7 +194,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": "instance-sharded x%d" % world,
                        "failed_instances": failed},
             "roofline": {"bound": "hbm", "kernel": "sa_k_backward", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("sa_k_backward"),
                          "algorithmic_bytes_per_launch": bwd_bytes, "kernel_ms": 1e3 * bwd_s,
                          "forward_kernel_ms": 1e3 * fwd_s, "forward_bytes_per_launch": fwd_bytes,
                          "note": "path is latency/fp64-VALU bound, not HBM bound (SURVEY 8d)"},
