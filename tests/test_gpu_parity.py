@@ -164,9 +164,13 @@ def test_scalar_api_readme_example():
     assert out.view(prob.state_dtype)["hares"].shape == (50, 1)
 
 
-def test_failures_are_per_instance():
-    """A draw that exhausts the step budget gets CV_TOO_MUCH_WORK + NaN rows; its neighbours finish."""
+@pytest.mark.parametrize("variant", [None, "16", "wave", "mem"])
+def test_failures_are_per_instance(variant, monkeypatch):
+    """A draw that exhausts the step budget gets CV_TOO_MUCH_WORK + NaN rows; its neighbours finish
+    (every kernel family)."""
     from sunode_amd.solver import Solver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
     prob = make_problem("robertson")
     sol = Solver(prob, abstol=1e-10, reltol=1e-8, mxsteps=100)
     params = np.tile([0.04, 1e4, 3e7], (4, 1))
@@ -176,6 +180,41 @@ def test_failures_are_per_instance():
     assert status.tolist() == [-1, -1, 0, -1]
     assert np.isnan(y[[0, 1, 3]]).all() and np.isfinite(y[2]).all()
     assert (stats[[0, 1, 3], 13] == 2).all()
+
+
+@pytest.mark.parametrize("variant", ["16", "wave", "mem"])
+def test_per_instance_fixed_parameters_and_bad_draws(variant, monkeypatch):
+    """SEIR with a different contact matrix per draw (remainder parameters [B][r], rem_stride = r) and
+    one draw with a non-finite parameter: the bad draw reports a right-hand-side failure, the others
+    match the oracle bit for bit."""
+    from sunode_amd.solver import AdjointSolver
+    monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem("seir")
+    B = 9
+    d = seir_batch(B)
+    rng = np.random.RandomState(5)
+    pr = d["pr"][None, :] * np.exp(0.1 * rng.randn(B, 16))
+    ps = d["ps"].copy()
+    ps[4, 0] = np.nan
+    tv = d["tvals"][:11]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(16)[None, :])
+    tol = 1e-8
+    sol = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol,
+                        quad_abstol=tol, quad_reltol=tol, max_steps=1024)
+    y, status, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+    g, lam, status_b, stats_b = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("seir")
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], ps, pr, 0.0, tv, nthreads=4)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=4)
+    assert status.tolist() == so.tolist() and status_b.tolist() == sbo.tolist()
+    assert status[4] != 0 and status_b[4] != 0 and (np.delete(status, 4) == 0).all()
+    assert np.isnan(y[4]).all() and np.isnan(g[4]).all()
+    ok = np.arange(B) != 4
+    np.testing.assert_array_equal(y[ok], yo[ok])
+    np.testing.assert_array_equal(g[ok], go[ok])
+    np.testing.assert_array_equal(lam[ok], lo[ok])
+    np.testing.assert_array_equal(stats[ok][:, CMP], sto[ok][:, CMP])
 
 
 def test_seir_forward_adjoint_vs_oracle_and_truth(golden_dir):
