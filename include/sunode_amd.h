@@ -125,6 +125,16 @@ int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const double *ps, 
                             int32_t n_t, const double *grads, int64_t grads_stride,
                             double *grad_out, double *lamda_out, int32_t *status, int64_t *stats);
 
+/* Same, with the optional per-output-time results of solve_backward (solver.py:778-781): the adjoint state and
+   the accumulated quadrature right after every jump.  lamda_all_out [B][n_t][n], quad_all_out [B][n_t][p],
+   either may be NULL; rows follow the reference's indexing lamda_all_out[-i] (i-th jump counted from the last
+   output time: rows 0, n_t-1, n_t-2, ..., 1). */
+int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, const double *params_sub,
+                                const double *params_rem, int32_t rem_stride, double t0, double tend,
+                                const double *tvals, int32_t n_t, const double *grads, int64_t grads_stride,
+                                double *grad_out, double *lamda_out, double *lamda_all_out,
+                                double *quad_all_out, int32_t *status, int64_t *stats);
+
 /* Evaluate the generated callbacks on the device (what make_sundials_rhs / _jac_dense /
    _adjoint_rhs / _adjoint_quad_rhs / _adjoint_jac_dense compute, problem.py:156-383).
    t [npts], y/lam [npts][n], ps [npts][p], pr [npts][r]; jac/adjjac column-major n*n;

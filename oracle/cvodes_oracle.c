@@ -1750,7 +1750,7 @@ static int solve_forward_one(const orc_config *cfg, const double *y0, const doub
 static int solve_backward_one(const orc_config *cfg, const double *ps, const double *pr,
                               double t0, double tend, const double *tvals, int n_t,
                               const double *grads, double *grad_out, double *lamda_out,
-                              traj_t *tr, int64_t *st)
+                              traj_t *tr, int64_t *st, double *lamda_all, double *quad_all)
 {
     cvmem *m = (cvmem *)calloc(1, sizeof(cvmem));
     m->ps = ps; m->pr = pr; m->backward = 1; m->tr = tr;
@@ -1795,6 +1795,10 @@ static int solve_backward_one(const orc_config *cfg, const double *ps, const dou
         if (iv < n_t) {
             const double *g = grads + (size_t)(n_t - 1 - iv) * NS;
             for (int i = 0; i < NS; i++) lam[i] -= g[i];
+            /* solver.py:778-781: lamda_all_out[-i] / quad_all_out[-i] (row 0 for the first jump) */
+            const size_t row = (iv == 0) ? 0 : (size_t)(n_t - iv);
+            if (lamda_all) for (int i = 0; i < NS; i++) lamda_all[row * NS + i] = lam[i];
+            if (quad_all) for (int i = 0; i < NQ; i++) quad_all[row * NQ + i] = quad[i];
         }
     }
     for (int i = 0; i < NQ; i++) grad_out[i] = quad_out[i];
@@ -1909,7 +1913,7 @@ int orc_solve_forward_batch(orc_batch *bt, const orc_config *cfg, int B, const d
 int orc_solve_backward_batch(orc_batch *bt, const orc_config *cfg, int B, const double *ps, const double *pr,
                              int rem_stride, double t0, double tend, const double *tvals, int n_t,
                              const double *grads, long grads_stride, double *grad_out, double *lamda_out,
-                             int32_t *status, int64_t *stats, int nthreads)
+                             int32_t *status, int64_t *stats, int nthreads, double *lamda_all, double *quad_all)
 {
     if (B > bt->B) return -1;
 #pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
@@ -1921,6 +1925,8 @@ int orc_solve_backward_batch(orc_batch *bt, const orc_config *cfg, int B, const 
             status[b] = -102;
             fill_nan(grad_out + (size_t)b * NQ, NQ);
             fill_nan(lamda_out + (size_t)b * NS, NS);
+            if (lamda_all) fill_nan(lamda_all + (size_t)b * n_t * NS, (size_t)n_t * NS);
+            if (quad_all) fill_nan(quad_all + (size_t)b * n_t * NQ, (size_t)n_t * NQ);
             continue;
         }
         tr->newdata = 1;
@@ -1928,7 +1934,13 @@ int orc_solve_backward_batch(orc_batch *bt, const orc_config *cfg, int B, const 
         tr->n_interp = tr->n_rebuild = 0;
         status[b] = solve_backward_one(cfg, ps + (size_t)b * NQ, pr + (size_t)b * rem_stride, t0, tend,
                                        tvals, n_t, grads + (size_t)b * grads_stride,
-                                       grad_out + (size_t)b * NQ, lamda_out + (size_t)b * NS, tr, st);
+                                       grad_out + (size_t)b * NQ, lamda_out + (size_t)b * NS, tr, st,
+                                       lamda_all ? lamda_all + (size_t)b * n_t * NS : NULL,
+                                       quad_all ? quad_all + (size_t)b * n_t * NQ : NULL);
+        if (status[b] != CV_SUCCESS) {
+            if (lamda_all) fill_nan(lamda_all + (size_t)b * n_t * NS, (size_t)n_t * NS);
+            if (quad_all) fill_nan(quad_all + (size_t)b * n_t * NQ, (size_t)n_t * NQ);
+        }
         if (status[b] != CV_SUCCESS) {
             fill_nan(grad_out + (size_t)b * NQ, NQ);
             fill_nan(lamda_out + (size_t)b * NS, NS);

@@ -203,17 +203,21 @@ class Oracle:
                                        _ptr(status, ctypes.c_int32), _ptr(stats, ctypes.c_int64), nthreads)
         return y_out, status, stats
 
-    def solve_backward(self, cfg, t0, tend, tvals, grads, nthreads=1):
+    def solve_backward(self, cfg, t0, tend, tvals, grads, nthreads=1, return_all=False):
         B, ps, pr, stride = self._fwd
         tvals = np.ascontiguousarray(tvals, float); n_t = len(tvals)
         grads = np.ascontiguousarray(grads, float)
         gstride = 0 if grads.ndim == 2 else n_t * self.n
         grad_out = np.zeros((B, max(self.p, 1))); lamda_out = np.zeros((B, max(self.n, 1)))
         status = np.zeros(B, np.int32); stats = np.zeros((B, N_STATS), np.int64)
+        lam_all = np.zeros((B, n_t, max(self.n, 1))); quad_all = np.zeros((B, n_t, max(self.p, 1)))
         self.L.orc_solve_backward_batch(ctypes.c_void_p(self._batch), ctypes.byref(cfg.c), B, _ptr(ps), _ptr(pr),
                                         stride, ctypes.c_double(t0), ctypes.c_double(tend), _ptr(tvals), n_t,
                                         _ptr(grads), ctypes.c_long(gstride), _ptr(grad_out), _ptr(lamda_out),
-                                        _ptr(status, ctypes.c_int32), _ptr(stats, ctypes.c_int64), nthreads)
+                                        _ptr(status, ctypes.c_int32), _ptr(stats, ctypes.c_int64), nthreads,
+                                        _ptr(lam_all) if return_all else None, _ptr(quad_all) if return_all else None)
+        if return_all:
+            return grad_out[:, :self.p], lamda_out[:, :self.n], status, stats, lam_all, quad_all[:, :, :self.p]
         return grad_out[:, :self.p], lamda_out[:, :self.n], status, stats
 
     def trajectory(self, i):

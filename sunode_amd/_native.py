@@ -127,6 +127,12 @@ def kernel_variant(native_source: str, sens: bool = False):
         if max(n, p) > 128 or n < 1:
             raise NativeBuildError("the wavefront-per-instance kernel covers 1 <= n_states <= 128, n_sub <= 128")
         return "bdf_wave.hip", 64
+    if forced and forced.startswith("wave"):        # "wave16": bdf_wave.hip with 16 lanes per instance
+        g = int(forced[4:])
+        if g < max(n, p) or g > 64 or g & (g - 1) or g < 8:
+            raise NativeBuildError("bdf_wave.hip group size %d must be a power of two in [max(n, p)=%d, 64]"
+                                   % (g, max(n, p)))
+        return "bdf_wave.hip", g
     if forced:
         g = int(forced)
     elif n <= REGISTER_KERNEL_MAX_STATES:
@@ -205,7 +211,9 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
                 "-mcpu=" + ARCH, "-O3", "-ffp-contract=off"]
         # the memory-resident build is dominated by the generated callbacks (10^4 statements at
         # n = 100): default scheduler there, the ILP strategies take several times longer
-        extra = [] if fname in ("bdf_mem.hip", "bdf_wave.hip") else _extra_codegen_flags()
+        extra = _extra_codegen_flags()
+        if fname in ("bdf_mem.hip", "bdf_wave.hip") and "SA_CLANG_FLAGS" not in os.environ:
+            extra = []
         try:
             _run(base + extra + ["-c", "-o", obj])
         except NativeBuildError:
@@ -255,14 +263,16 @@ def load_library() -> ctypes.CDLL:
                                           _dp, _dp, _dp, _dp]
     L.sa_solve_sens_batch.argtypes = [vp, ctypes.c_int, ctypes.c_int, _dp, i32, _dp, _dp, _dp, i32, _dp, dbl, _dp,
                                       i32, _dp, _dp, _dp, _dp]
+    L.sa_solve_backward_batch_all.argtypes = [vp, ctypes.c_int, i32, _dp, _dp, i32, dbl, dbl, _dp, i32, _dp, i64,
+                                              _dp, _dp, _dp, _dp, _dp, _dp]
     L.sa_eval_callbacks.argtypes = [vp, ctypes.c_int, i32] + [_dp] * 11
     L.sa_math_probe.argtypes = [vp, i32] + [_dp] * 5
     L.sa_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.sa_set_stream.argtypes = [vp, vp]
     L.sa_synchronize.argtypes = [vp]
     for name in ("sa_solver_create", "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
-                 "sa_solve_forward_batch", "sa_solve_backward_batch", "sa_eval_callbacks", "sa_math_probe",
-                 "sa_last_kernel_ms", "sa_set_stream", "sa_synchronize"):
+                 "sa_solve_forward_batch", "sa_solve_backward_batch", "sa_solve_backward_batch_all",
+                 "sa_eval_callbacks", "sa_math_probe", "sa_last_kernel_ms", "sa_set_stream", "sa_synchronize"):
         getattr(L, name).restype = ctypes.c_int
     _LIB = L
     return L
@@ -271,7 +281,8 @@ def load_library() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = ["sa_abi_version", "sa_last_error", "sa_solver_create", "sa_solver_destroy",
                     "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
                     "sa_solve_forward_batch",
-                    "sa_solve_backward_batch", "sa_eval_callbacks", "sa_math_probe", "sa_last_kernel_ms",
+                    "sa_solve_backward_batch", "sa_solve_backward_batch_all", "sa_eval_callbacks", "sa_math_probe",
+                    "sa_last_kernel_ms",
                     "sa_set_stream", "sa_synchronize"]
 
 
@@ -354,10 +365,11 @@ class NativeSolver:
                        n_t, _addr(y_out), _addr(status), _addr(stats)))
 
     def solve_backward(self, mem, B, ps, pr, rem_stride, t0, tend, tvals, n_t, grads, grads_stride, grad_out,
-                       lamda_out, status, stats):
-        self._check(self.L.sa_solve_backward_batch(self._h, mem, B, _addr(ps), _addr(pr), rem_stride, float(t0),
-                                                   float(tend), _addr(tvals), n_t, _addr(grads), int(grads_stride),
-                                                   _addr(grad_out), _addr(lamda_out), _addr(status), _addr(stats)))
+                       lamda_out, status, stats, lamda_all=None, quad_all=None):
+        self._check(self.L.sa_solve_backward_batch_all(
+            self._h, mem, B, _addr(ps), _addr(pr), rem_stride, float(t0), float(tend), _addr(tvals), n_t,
+            _addr(grads), int(grads_stride), _addr(grad_out), _addr(lamda_out), _addr(lamda_all), _addr(quad_all),
+            _addr(status), _addr(stats)))
 
     def solve_sens(self, mem, ism, scaling, B, y0, ps, pr, rem_stride, sens0, t0, tvals, n_t, y_out, sens_out,
                    status, stats):

@@ -1265,9 +1265,16 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
         if (iv < a.n_t && status == CV_SUCCESS) {
             const double *gi = g + (int64_t)(a.n_t - 1 - iv) * NS;
             if (m.li < NS) lam -= gi[m.li < NS ? m.li : 0];
+            const int64_t row = (int64_t)inst * a.n_t + (iv == 0 ? 0 : a.n_t - iv);
+            if (a.lamda_all && m.li < NS) a.lamda_all[row * NS + m.li] = lam;
+            if (a.quad_all && m.li < NQ) a.quad_all[row * NQ + m.li] = quad;
         }
     }
-    if (status != CV_SUCCESS) { quad_out = SA_NAN; lam = SA_NAN; }
+    if (status != CV_SUCCESS) {
+        quad_out = SA_NAN; lam = SA_NAN;
+        if (a.lamda_all) for (int j = m.li; j < a.n_t * NS; j += G) a.lamda_all[(int64_t)inst * a.n_t * NS + j] = SA_NAN;
+        if (a.quad_all) for (int j = m.li; j < a.n_t * NQ; j += G) a.quad_all[(int64_t)inst * a.n_t * NQ + j] = SA_NAN;
+    }
     if (m.li < NQ) a.grad_out[(int64_t)inst * NQ + m.li] = quad_out;
     if (m.li < NS) a.lamda_out[(int64_t)inst * NS + m.li] = lam;
     if (m.li == 0) {

@@ -1381,9 +1381,14 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
         if (iv < a.n_t && status == CV_SUCCESS) {
             const double *gi = g + (int64_t)(a.n_t - 1 - iv) * NS;
             SFOR(i, 0, NS) lam[i] -= gi[i]; SEND
+            const int64_t row = (int64_t)inst * a.n_t + (iv == 0 ? 0 : a.n_t - iv);
+            if (a.lamda_all) { SFOR(i, 0, NS) a.lamda_all[row * NS + i] = lam[i]; SEND }
+            if (a.quad_all) { SFOR(i, 0, NQ) a.quad_all[row * NQ + i] = quad[i]; SEND }
         }
     }
     if (status != CV_SUCCESS) {
+        if (a.lamda_all) for (int j = 0; j < a.n_t * NS; j++) a.lamda_all[(int64_t)inst * a.n_t * NS + j] = SA_NAN;
+        if (a.quad_all) for (int j = 0; j < a.n_t * NQ; j++) a.quad_all[(int64_t)inst * a.n_t * NQ + j] = SA_NAN;
         SFOR(i, 0, NQ) quad_out[i] = SA_NAN; SEND
         SFOR(i, 0, NS) lam[i] = SA_NAN; SEND
     }

@@ -1519,7 +1519,14 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
         if (iv < a.n_t && status == CV_SUCCESS) {
             const double *gi = g + (int64_t)(a.n_t - 1 - iv) * NS;
             for (int i = 0; i < NS; i++) W(m, O_LAM, i) -= gi[i];
+            const int64_t row = (int64_t)inst * a.n_t + (iv == 0 ? 0 : a.n_t - iv);
+            if (a.lamda_all) for (int i = 0; i < NS; i++) a.lamda_all[row * NS + i] = W(m, O_LAM, i);
+            if (a.quad_all) for (int i = 0; i < NQ; i++) a.quad_all[row * NQ + i] = W(m, O_QUAD, i);
         }
+    }
+    if (status != CV_SUCCESS) {
+        if (a.lamda_all) for (int j = 0; j < a.n_t * NS; j++) a.lamda_all[(int64_t)inst * a.n_t * NS + j] = SA_NAN;
+        if (a.quad_all) for (int j = 0; j < a.n_t * NQ; j++) a.quad_all[(int64_t)inst * a.n_t * NQ + j] = SA_NAN;
     }
     for (int i = 0; i < NQ; i++) a.grad_out[(int64_t)inst * NQ + i] = (status == CV_SUCCESS) ? W(m, O_QOUT, i) : SA_NAN;
     for (int i = 0; i < NS; i++) a.lamda_out[(int64_t)inst * NS + i] = (status == CV_SUCCESS) ? W(m, O_LAM, i) : SA_NAN;

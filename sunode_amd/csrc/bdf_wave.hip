@@ -38,11 +38,33 @@
 #define W_NS SA_BUILD_NS
 #define W_NQ SA_BUILD_NQ
 
-__shared__ double s_A[W_NS * W_NS];                 /* Newton matrix / its LU, column-major */
-__shared__ double s_y[W_NS > 0 ? W_NS : 1];         /* callback input: state (backward: interpolated forward state) */
-__shared__ double s_lam[W_NS > 0 ? W_NS : 1];       /* callback input: adjoint state; scratch for the LU solves */
-__shared__ double s_ps[W_NQ > 0 ? W_NQ : 1];        /* differentiated parameters of the instance */
-__shared__ uint8_t s_piv[(W_NS + 15) / 16 * 16];    /* pivot rows (n <= 128 fits a byte) */
+/* Lanes per instance: 64 (a whole wavefront, the default) or a smaller power of two >= max(n, p)
+   (SA_GROUP = 8..32: 64/G instances share a wavefront, every instance has its own slice of the LDS
+   arrays; the mapping for systems of 6..64 states). */
+#ifndef SA_GROUP
+#define SA_GROUP 64
+#endif
+#if SA_GROUP < 64
+#undef SA_WAVES
+#define SA_WAVES 1                   /* worker wavefronts need the whole-wavefront mapping */
+#define G SA_GROUP
+#else
+#define G 64
+#endif
+#define KPW (64 / G)
+#define W_NQD (W_NQ > 0 ? W_NQ : 1)
+#define W_PIV ((W_NS + 15) / 16 * 16)
+__shared__ double s_A[KPW * W_NS * W_NS];           /* Newton matrix / its LU, column-major, per instance */
+__shared__ double s_y[KPW * W_NS];                  /* callback input: state (backward: interpolated forward state) */
+__shared__ double s_lam[KPW * W_NS];                /* callback input: adjoint state; scratch for the LU solves */
+__shared__ double s_ps[KPW * W_NQD];                /* differentiated parameters of the instance */
+__shared__ uint8_t s_piv[KPW * W_PIV];              /* pivot rows (n <= 128 fits a byte) */
+/* index of the calling lane's instance within its wavefront */
+static __device__ __forceinline__ int sa_grp()
+{
+    if (KPW == 1) return 0;
+    return (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) / G;
+}
 
 /* Worker wavefronts: the workgroup of an instance has SA_WAVES wavefronts.  Wavefront 0 runs the
    integrator; the others sleep on the workgroup barrier and wake up to evaluate their share of the
@@ -51,6 +73,7 @@ __shared__ uint8_t s_piv[(W_NS + 15) / 16 * 16];    /* pivot rows (n <= 128 fits
 #ifndef SA_WAVES
 #define SA_WAVES 4
 #endif
+static_assert(G == 64 || SA_WAVES == 1, "worker wavefronts need 64 lanes per instance");
 __shared__ int s_cmd, s_nwaves;
 __shared__ double s_targ;
 __shared__ int s_rc[SA_WAVES];
@@ -62,9 +85,11 @@ static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_
 #define SA_TEMPLATE template <class SinkT>
 #define SA_OUT_T SinkT
 #define SA_STORE(slot, value) out.template put<(slot)>(value)
-#define SA_Y(i) s_y[i]
-#define SA_LAM(i) s_lam[i]
-#define SA_PS(j) s_ps[j]
+#define SA_Y(i) sa_yv[i]
+#define SA_LAM(i) sa_lv[i]
+#define SA_PS(j) sa_pv[j]
+#define SA_LDS_VIEWS const double *sa_yv = s_y + sa_grp() * W_NS; const double *sa_lv = s_lam + sa_grp() * W_NS; \
+    const double *sa_pv = s_ps + sa_grp() * W_NQD; (void)sa_yv; (void)sa_lv; (void)sa_pv;
 typedef __attribute__((address_space(1))) double gdouble;      /* explicit global pointer: cannot alias LDS */
 #define SA_CONST_AS __attribute__((address_space(4)))
 #ifdef SA_WAVE_PR_SCALAR
@@ -79,12 +104,12 @@ static __device__ __forceinline__ const SA_CONST_AS double *sa_uniform_const(con
     return (const SA_CONST_AS double *)(((uint64_t)hi << 32) | (uint64_t)lo);
 }
 #define SA_PR(j) prc[j]
-#define SA_PROLOGUE const SA_CONST_AS double *prc = sa_uniform_const(pr);
+#define SA_PROLOGUE SA_LDS_VIEWS const SA_CONST_AS double *prc = sa_uniform_const(pr);
 #else
 /* remaining parameters: broadcast global loads (all lanes read the same address; the vector memory
    pipe is otherwise idle during a callback and keeps dozens of loads in flight) */
 #define SA_PR(j) prg[j]
-#define SA_PROLOGUE const gdouble *prg = (const gdouble *)pr;
+#define SA_PROLOGUE SA_LDS_VIEWS const gdouble *prg = (const gdouble *)pr;
 #endif
 #ifndef SA_WAVE_NO_SCHED_BARRIER
 /* keep the instruction scheduler from hoisting the loads of later statements over earlier ones:
@@ -97,10 +122,13 @@ static __device__ __forceinline__ const SA_CONST_AS double *sa_uniform_const(con
 #include "sa_common.h"
 
 static_assert(NS == W_NS && NQ == W_NQ, "SA_BUILD_NS / SA_BUILD_NQ do not match the generated header");
-static_assert(NS <= 128 && NQ <= 128 && NS >= 1, "the wave kernel covers 1 <= n <= 128, p <= 128");
+static_assert(NS <= 2 * G && NQ <= 2 * G && NS >= 1 && NS <= 128, "at most two register slots per vector");
 
-#define RS ((NS + 63) / 64)                    /* register slots of a state vector */
-#define RQ (NQ > 0 ? (NQ + 63) / 64 : 1)       /* register slots of a quadrature vector */
+#define RS ((NS + G - 1) / G)                  /* register slots of a state vector */
+#define RQ (NQ > 0 ? (NQ + G - 1) / G : 1)     /* register slots of a quadrature vector */
+constexpr int ilog2_c(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
+#define LOG2G ilog2_c(G)
+#define GMASK (G == 64 ? ~0ull : ((1ull << G) - 1ull))
 #define TREC (8 + 6 * NS)
 #define SA_NAN __builtin_bit_cast(double, (uint64_t)0x7ff8000000000000ULL)
 constexpr int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -142,14 +170,17 @@ struct VecOut {             /* vector-valued callbacks -> workspace vector */
     gdouble *p;
     template <int S> __device__ __forceinline__ void put(double x) const { p[S] = x; }
 };
-struct MatOut {             /* n x n callbacks -> the LDS matrix (slot = col * n + row) */
-    template <int S> __device__ __forceinline__ void put(double x) const { s_A[S] = x; }
+struct MatOut {             /* n x n callbacks -> the instance's LDS matrix (slot = col * n + row) */
+    int base;
+    template <int S> __device__ __forceinline__ void put(double x) const { s_A[base + S] = x; }
 };
 
 /* ------------------------------------------------------------------------------------ */
 template <bool BWD>
 struct Cw {
-    int lane;
+    int lane;                         /* lane in the wavefront */
+    int li, gbase;                    /* lane within its instance's group, first lane of the group */
+    int abase, vbase, pbase, kbase;   /* the group's slices of s_A / s_y,s_lam / s_ps / s_piv */
     double zn[QMAX + 1][RS], znQ[QMAX + 1][RQ], zsave[RS], zsaveQ[RQ];
     double ewt[RS], acor[RS], tempv[RS], ftemp[RS], y[RS], ytmp[RS], atol[RS];
     double ewtQ[RQ], acorQ[RQ], tempvQ[RQ];
@@ -188,7 +219,7 @@ struct Cw {
 #define PROF_ADD(m, k)
 #endif
 
-#define IDX(m, r) ((r) * 64 + (m).lane)
+#define IDX(m, r) ((r) * G + (m).li)
 
 /* sum over all lanes and slots: xor-butterfly per slot, then the slot totals pairwise */
 template <int NSLOT>
@@ -199,7 +230,7 @@ DEV double wave_sum(int lane, const double (&v)[NSLOT])
     SFOR(r, 0, P) {
         if constexpr (r < NSLOT) {
             double x = v[r];
-            SFOR(b, 0, 6) x = x + shfl_d(x, lane ^ (1 << b)); SEND
+            SFOR(b, 0, LOG2G) x = x + shfl_d(x, lane ^ (1 << b)); SEND
             s[r] = x;
         } else {
             s[r] = 0.0;
@@ -212,7 +243,7 @@ DEV double wave_sum(int lane, const double (&v)[NSLOT])
 
 DEV double wave_max(int lane, double x)
 {
-    SFOR(b, 0, 6) { const double o = shfl_d(x, lane ^ (1 << b)); x = x > o ? x : o; } SEND
+    SFOR(b, 0, LOG2G) { const double o = shfl_d(x, lane ^ (1 << b)); x = x > o ? x : o; } SEND
     return x;
 }
 
@@ -358,8 +389,8 @@ DEV void stage_inputs(const Cw<BWD> &m, const double (&ymine)[RS])
     lds_sync();
     SFOR(r, 0, RS) {
         if (IDX(m, r) < NS) {
-            if constexpr (BWD) { s_y[IDX(m, r)] = m.ytmp[r]; s_lam[IDX(m, r)] = ymine[r]; }
-            else s_y[IDX(m, r)] = ymine[r];
+            if constexpr (BWD) { s_y[m.vbase + IDX(m, r)] = m.ytmp[r]; s_lam[m.vbase + IDX(m, r)] = ymine[r]; }
+            else s_y[m.vbase + IDX(m, r)] = ymine[r];
         }
     } SEND
     lds_sync();
@@ -382,8 +413,8 @@ DEV int run_callback(int cmd, double t, const double *pr, double *obuf)
         else return sa_rhs(t, nullptr, nullptr, pr, VecOut{(gdouble *)obuf});
     }
     if (cmd == CMD_QUAD) return sa_quad_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{(gdouble *)obuf});
-    if constexpr (BWD) return sa_adj_jac(t, nullptr, nullptr, pr, MatOut{});
-    else return sa_jac(t, nullptr, nullptr, pr, MatOut{});
+    if constexpr (BWD) return sa_adj_jac(t, nullptr, nullptr, pr, MatOut{sa_grp() * NS * NS});
+    else return sa_jac(t, nullptr, nullptr, pr, MatOut{sa_grp() * NS * NS});
 }
 
 /* wavefront 0: publish the command (the inputs are already staged), evaluate, collect */
@@ -391,19 +422,23 @@ template <bool BWD>
 DEV int dispatch(Cw<BWD> &m, int cmd, double t)
 {
     if constexpr (SA_WAVES > 1) {
-        if (m.lane == 0) { s_cmd = cmd; s_targ = t; }
+        if (m.li == 0) { s_cmd = cmd; s_targ = t; }
         __syncthreads();
     }
     int rc = run_callback<BWD>(cmd, t, m.pr, m.obuf);
     if constexpr (SA_WAVES > 1) {
-        if (m.lane == 0) s_rc[0] = rc;
+        if (m.li == 0) s_rc[0] = rc;
         __syncthreads();
         SFOR(w, 1, SA_WAVES) rc |= s_rc[w]; SEND
     }
     return rc;
 }
 
-DEV int getrf_coop(int lane, int wave, double (&inv_piv)[(W_NS + 63) / 64], int &nswaps);
+/* coordinates of a lane for the LU routines (workers build one without an integrator state) */
+struct Grp {
+    int lane, li, gbase, abase, kbase, wave;
+};
+DEV int getrf_coop(const Grp &g, double (&inv_piv)[(W_NS + G - 1) / G], int &nswaps);
 
 template <bool BWD>
 DEV void worker_loop(const double *pr, double *obuf)
@@ -418,7 +453,8 @@ DEV void worker_loop(const double *pr, double *obuf)
             double inv_piv[RS];
             int nswaps;
             SFOR(r, 0, RS) inv_piv[r] = 0.0; SEND
-            (void)getrf_coop(lane, wave, inv_piv, nswaps);
+            const Grp g{lane, lane, 0, 0, 0, wave};
+            (void)getrf_coop(g, inv_piv, nswaps);
         } else {
             const int rc = run_callback<BWD>(cmd, t, pr, obuf);
             if (lane == 0) s_rc[wave] = rc;
@@ -431,7 +467,7 @@ template <bool BWD>
 DEV void release_workers(const Cw<BWD> &m)
 {
     if constexpr (SA_WAVES > 1) {
-        if (m.lane == 0) s_cmd = CMD_EXIT;
+        if (m.li == 0) s_cmd = CMD_EXIT;
         __syncthreads();
     }
 }
@@ -472,22 +508,31 @@ DEV int cv_jac(Cw<BWD> &m, double t, const double (&ymine)[RS])        /* Jacobi
 }
 
 /* ---- row-distributed dense LU in LDS (denseGETRF / denseGETRS semantics) ---- */
-#define AL(i, j) s_A[(j) * NS + (i)]
+#define AL(i, j) s_A[g.abase + (j) * NS + (i)]
 #define LU_BATCH 8
 
-/* LU of the LDS matrix by ALL wavefronts of the workgroup (the workers are idle otherwise): every
-   wavefront repeats the pivot search and the scaling of column k on identical data (identical
-   decisions, no communication), the trailing columns are split between the wavefronts, one
-   workgroup barrier per elimination step.  Wavefront 0 writes the scaled column back one step late,
-   when nobody reads the unscaled entries any more. */
-DEV int getrf_coop(int lane, int wave, double (&inv_piv)[RS], int &nswaps)
+/* barrier between the phases of an elimination step: the workgroup when worker wavefronts take part,
+   otherwise the LDS ordering of the (possibly diverged) wavefront */
+DEV void lu_sync()
+{
+    if constexpr (SA_WAVES > 1) __syncthreads();
+    else lds_sync();
+}
+
+/* LU of the instance's LDS matrix.  With worker wavefronts (G = 64) ALL wavefronts of the workgroup take
+   part: every wavefront repeats the pivot search and the scaling of column k on identical data (identical
+   decisions, no communication), the trailing columns are split between the wavefronts, one workgroup
+   barrier per elimination step; wavefront 0 writes the scaled column back one step late, when nobody
+   reads the unscaled entries any more.  With G < 64 lanes per instance the group works alone. */
+DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
 {
     nswaps = 0;
     double lcol[RS];
     SFOR(r, 0, RS) lcol[r] = 0.0; SEND
     for (int k = 0; k < NS; k++) {
-        if (wave == 0 && k > 0) {
-            SFOR(r, 0, RS) { const int i = r * 64 + lane; if (i > k - 1 && i < NS) AL(i, k - 1) = lcol[r]; } SEND
+        if (g.wave == 0 && k > 0) {
+            SFOR(r, 0, RS) { const int i = r * G + g.li; if (i > k - 1 && i < NS) AL(i, k - 1) = lcol[r]; } SEND
+            if constexpr (SA_WAVES == 1) lds_sync();
         }
         /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF).
            I - gamma*J is close to diagonally dominant, so usually no row beats the diagonal: one
@@ -497,66 +542,66 @@ DEV int getrf_coop(int lane, int wave, double (&inv_piv)[RS], int &nswaps)
         bool beaten = false;
         double cand[RS];
         SFOR(r, 0, RS) {
-            const int i = r * 64 + lane;
+            const int i = r * G + g.li;
             cand[r] = (i > k && i < NS) ? fabs(AL(i, k)) : -1.0;
             beaten = beaten || (cand[r] > best);
         } SEND
-        if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
+        if (((__builtin_amdgcn_ballot_w64(beaten) >> g.gbase) & GMASK) != 0) {
             best = -1.0;
             bi = 1 << 20;
             SFOR(r, 0, RS) {
-                const int i = r * 64 + lane;
+                const int i = r * G + g.li;
                 const double v = (i == k) ? fabs(AL(k, k)) : cand[r];
                 if (i >= k && i < NS && v > best) { best = v; bi = i; }
             } SEND
-            SFOR(b, 0, 6) {
-                const double ov = shfl_d(best, lane ^ (1 << b));
-                const int oi = shfl_i(bi, lane ^ (1 << b));
+            SFOR(b, 0, LOG2G) {
+                const double ov = shfl_d(best, g.lane ^ (1 << b));
+                const int oi = shfl_i(bi, g.lane ^ (1 << b));
                 const bool take = (ov > best) || (ov == best && oi < bi);
                 best = take ? ov : best;
                 bi = take ? oi : bi;
             } SEND
         }
-        const int l = __builtin_amdgcn_readfirstlane(bi);
-        if (wave == 0 && lane == 0) s_piv[k] = (uint8_t)l;
+        const int l = bi;               /* identical in every lane of the group */
+        if (g.wave == 0 && g.li == 0) s_piv[g.kbase + k] = (uint8_t)l;
         if (best == 0.0) return k + 1;
-        if (l != k) {                   /* exchange rows k and l, one column per thread */
+        if (l != k) {                   /* exchange rows k and l, one column per lane */
             nswaps++;
-            __syncthreads();
-            for (int c = wave * 64 + lane; c < NS; c += 64 * SA_WAVES) {
+            lu_sync();
+            for (int c = g.wave * G + g.li; c < NS; c += G * SA_WAVES) {
                 const double x = AL(k, c), y = AL(l, c);
                 AL(k, c) = y;
                 AL(l, c) = x;
             }
-            __syncthreads();
+            lu_sync();
         }
         const double mult = 1.0 / AL(k, k);
         SFOR(r, 0, RS) {
-            const int i = r * 64 + lane;
+            const int i = r * G + g.li;
             inv_piv[r] = (i == k) ? mult : inv_piv[r];
             lcol[r] = (i > k && i < NS) ? AL(i, k) * mult : 0.0;
         } SEND
         /* elimination: this wavefront's batches of LU_BATCH columns, all reads of a batch before its writes */
-        for (int j = k + 1 + wave * LU_BATCH; j < NS; j += LU_BATCH * SA_WAVES) {
+        for (int j = k + 1 + g.wave * LU_BATCH; j < NS; j += LU_BATCH * SA_WAVES) {
             double akj[LU_BATCH], x[LU_BATCH][RS];
             SFOR(u, 0, LU_BATCH) {
                 const bool on = (j + u) < NS;
                 akj[u] = on ? AL(k, on ? j + u : j) : 0.0;
                 SFOR(r, 0, RS) {
-                    const int i = r * 64 + lane;
+                    const int i = r * G + g.li;
                     x[u][r] = (on && i > k && i < NS) ? AL(i, j + u) : 0.0;
                 } SEND
             } SEND
             SFOR(u, 0, LU_BATCH) {
                 if (akj[u] != 0.0) {
                     SFOR(r, 0, RS) {
-                        const int i = r * 64 + lane;
+                        const int i = r * G + g.li;
                         if ((j + u) < NS && i > k && i < NS) AL(i, j + u) = FMA(-akj[u], lcol[r], x[u][r]);
                     } SEND
                 }
             } SEND
         }
-        __syncthreads();
+        lu_sync();
     }
     return 0;
 }
@@ -566,10 +611,11 @@ DEV int dense_getrf(Cw<BWD> &m)
 {
     PROF_T0
     if constexpr (SA_WAVES > 1) {
-        if (m.lane == 0) s_cmd = CMD_GETRF;
+        if (m.li == 0) s_cmd = CMD_GETRF;
         __syncthreads();
     }
-    const int ier = getrf_coop(m.lane, 0, m.inv_piv, m.nswaps);
+    const Grp g{m.lane, m.li, m.gbase, m.abase, m.kbase, 0};
+    const int ier = getrf_coop(g, m.inv_piv, m.nswaps);
     if constexpr (SA_WAVES > 1) __syncthreads();
     lds_sync();
     PROF_ADD(m, 3)
@@ -577,35 +623,37 @@ DEV int dense_getrf(Cw<BWD> &m)
 }
 
 /* component k (wave-uniform k) of a lane-distributed vector */
-DEV double bcast_vec(const double (&b)[RS], int k)
+DEV double bcast_vec(const double (&b)[RS], int k, int gbase)
 {
     double v = b[0];
-    SFOR(r, 1, RS) v = ((k >> 6) == r) ? b[r] : v; SEND
-    return readlane_d(v, k & 63);
+    SFOR(r, 1, RS) v = ((k / G) == r) ? b[r] : v; SEND
+    if constexpr (G == 64) return readlane_d(v, k & 63);        /* k is wave-uniform */
+    else return shfl_d(v, gbase + (k & (G - 1)));               /* k is uniform within the group only */
 }
 
 template <bool BWD>
 DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
 {
     PROF_T0
+    const Grp g{m.lane, m.li, m.gbase, m.abase, m.kbase, 0};
     if (m.nswaps != 0) {               /* row permutation through the LDS scratch vector */
         lds_sync();
-        SFOR(r, 0, RS) { if (IDX(m, r) < NS) s_lam[IDX(m, r)] = b[r]; } SEND
+        SFOR(r, 0, RS) { if (IDX(m, r) < NS) s_lam[m.vbase + IDX(m, r)] = b[r]; } SEND
         lds_sync();
         for (int k = 0; k < NS; k++) {
-            const int pk = s_piv[k];
+            const int pk = s_piv[m.kbase + k];
             if (pk != k) {
-                const double bk = s_lam[k], bp = s_lam[pk];
+                const double bk = s_lam[m.vbase + k], bp = s_lam[m.vbase + pk];
                 lds_sync();
-                if (m.lane == 0) { s_lam[k] = bp; s_lam[pk] = bk; }
+                if (m.li == 0) { s_lam[m.vbase + k] = bp; s_lam[m.vbase + pk] = bk; }
                 lds_sync();
             }
         }
-        SFOR(r, 0, RS) { if (IDX(m, r) < NS) b[r] = s_lam[IDX(m, r)]; } SEND
+        SFOR(r, 0, RS) { if (IDX(m, r) < NS) b[r] = s_lam[m.vbase + IDX(m, r)]; } SEND
         lds_sync();
     }
     for (int k = 0; k < NS - 1; k++) {
-        const double bk = bcast_vec(b, k);
+        const double bk = bcast_vec(b, k, m.gbase);
         SFOR(r, 0, RS) {
             const int i = IDX(m, r);
             if (i > k && i < NS) b[r] = FMA(-AL(i, k), bk, b[r]);
@@ -613,13 +661,13 @@ DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
     }
     for (int k = NS - 1; k > 0; k--) {
         SFOR(r, 0, RS) { if (IDX(m, r) == k) b[r] *= m.inv_piv[r]; } SEND
-        const double bk = bcast_vec(b, k);
+        const double bk = bcast_vec(b, k, m.gbase);
         SFOR(r, 0, RS) {
             const int i = IDX(m, r);
             if (i < k) b[r] = FMA(-AL(i, k), bk, b[r]);
         } SEND
     }
-    if (m.lane == 0) b[0] *= m.inv_piv[0];
+    if (m.li == 0) b[0] *= m.inv_piv[0];
     PROF_ADD(m, 4)
 }
 
@@ -895,17 +943,17 @@ DEV int cv_lsetup(Cw<BWD> &m, int convfail)
         m.jcur = 0;
         /* A = I - gamma * savedJ, streamed from the workspace (COPY_BATCH loads in flight per lane) */
         int base = 0;
-        for (; base + COPY_BATCH * 64 <= NS * NS; base += COPY_BATCH * 64) {
+        for (; base + COPY_BATCH * G <= NS * NS; base += COPY_BATCH * G) {
             double v[COPY_BATCH];
-            SFOR(u, 0, COPY_BATCH) v[u] = m.sj[base + u * 64 + m.lane]; SEND
+            SFOR(u, 0, COPY_BATCH) v[u] = m.sj[base + u * G + m.li]; SEND
             SFOR(u, 0, COPY_BATCH) {
-                const int idx = base + u * 64 + m.lane;
-                s_A[idx] = (idx % NS == idx / NS) ? FMA(c, v[u], 1.0) : v[u] * c;
+                const int idx = base + u * G + m.li;
+                s_A[m.abase + idx] = (idx % NS == idx / NS) ? FMA(c, v[u], 1.0) : v[u] * c;
             } SEND
         }
-        for (int idx = base + m.lane; idx < NS * NS; idx += 64) {
+        for (int idx = base + m.li; idx < NS * NS; idx += G) {
             const double v = m.sj[idx];
-            s_A[idx] = (idx % NS == idx / NS) ? FMA(c, v, 1.0) : v * c;
+            s_A[m.abase + idx] = (idx % NS == idx / NS) ? FMA(c, v, 1.0) : v * c;
         }
         PROF_ADD(m, 5)
     } else {
@@ -914,10 +962,10 @@ DEV int cv_lsetup(Cw<BWD> &m, int convfail)
         m.jcur = 1;
         jret = cv_jac(m, m.tn, m.y);
         if (jret == 0) {
-            for (int idx = m.lane; idx < NS * NS; idx += 64) {
-                const double v = s_A[idx];
+            for (int idx = m.li; idx < NS * NS; idx += G) {
+                const double v = s_A[m.abase + idx];
                 m.sj[idx] = v;
-                s_A[idx] = (idx % NS == idx / NS) ? FMA(c, v, 1.0) : v * c;
+                s_A[m.abase + idx] = (idx % NS == idx / NS) ? FMA(c, v, 1.0) : v * c;
             }
         }
     }
@@ -1318,10 +1366,16 @@ template <bool BWD>
 DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_stride, int inst, double *ws)
 {
     m.lane = lane_id();
+    m.li = m.lane & (G - 1);
+    m.gbase = m.lane & ~(G - 1);
+    {
+        const int grp = m.lane / G;
+        m.abase = grp * NS * NS; m.vbase = grp * NS; m.pbase = grp * W_NQD; m.kbase = grp * W_PIV;
+    }
     m.pr = pr + (int64_t)inst * rem_stride;
     m.sj = ws + (int64_t)inst * WS_DOUBLES + WS_SJ;
     m.obuf = ws + (int64_t)inst * WS_DOUBLES + WS_OUT;
-    for (int j = m.lane; j < NQ; j += 64) s_ps[j] = ps[(int64_t)inst * NQ + j];
+    for (int j = m.li; j < NQ; j += G) s_ps[m.pbase + j] = ps[(int64_t)inst * NQ + j];
     m.nswaps = 0;
     SFOR(r, 0, RS) { m.inv_piv[r] = 0.0; m.ytmp[r] = 0.0; m.ewt[r] = 0.0; } SEND
     SFOR(r, 0, RQ) m.ewtQ[r] = 0.0; SEND
@@ -1356,7 +1410,7 @@ DEV void store_table(double *rec, int lane, int order, double dt, const double (
         SFOR(j, 0, (QMAX) + 1) rec[2 + j] = hT[j]; SEND
     }
     SFOR(r, 0, RS) {
-        const int i = r * 64 + lane;
+        const int i = r * G + lane;
         if (i < NS) { SFOR(j, 0, (QMAX) + 1) rec[8 + j * NS + i] = Y[j][r]; SEND }
     } SEND
 }
@@ -1364,7 +1418,7 @@ DEV void store_table(double *rec, int lane, int order, double dt, const double (
 /* ------------------------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_args a)
 {
-    const int inst = blockIdx.x;
+    const int inst = blockIdx.x * KPW + sa_grp();
     if (inst >= a.B) return;
     if (threadIdx.x == 0) s_nwaves = SA_WAVES;
     if (sa_wave_index() != 0) {
@@ -1406,7 +1460,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
         else if (store) {
             hT[0] = m.tn;
             SFOR(r, 0, RS) hY[0][r] = m.zn[0][r]; SEND
-            store_table(trec, m.lane, 0, 1.0, hT, hY);
+            store_table(trec, m.li, 0, 1.0, hT, hY);
             np = 1;
         }
     }
@@ -1433,7 +1487,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
                         SFOR_DOWN(j, QMAX, 1) { hT[j] = hT[j - 1]; SFOR(s, 0, RS) hY[j][s] = hY[j - 1][s]; SEND } SEND
                         hT[0] = m.tn;
                         SFOR(s, 0, RS) hY[0][s] = m.zn[0][s]; SEND
-                        store_table(trec + (int64_t)np * trow, m.lane, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+                        store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
                         np++;
                     }
                 }
@@ -1456,9 +1510,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     }
     release_workers(m);
     if (status != CV_SUCCESS) {
-        for (int j = m.lane; j < a.n_t * NS; j += 64) yo[j] = SA_NAN;
+        for (int j = m.li; j < a.n_t * NS; j += G) yo[j] = SA_NAN;
     }
-    if (m.lane == 0) {
+    if (m.li == 0) {
         a.status[inst] = status;
         if (store) a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
         int64_t st[SA_N_STATS];
@@ -1475,7 +1529,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
 
 extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd_args a)
 {
-    const int inst = blockIdx.x;
+    const int inst = blockIdx.x * KPW + sa_grp();
     if (inst >= a.B) return;
     if (threadIdx.x == 0) s_nwaves = SA_WAVES;
     if (sa_wave_index() != 0) {
@@ -1573,16 +1627,23 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
         if (iv < a.n_t && status == CV_SUCCESS) {
             const double *gi = g + (int64_t)(a.n_t - 1 - iv) * NS;
             SFOR(r, 0, RS) { if (IDX(m, r) < NS) lam[r] -= gi[IDX(m, r)]; } SEND
+            const int64_t row = (int64_t)inst * a.n_t + (iv == 0 ? 0 : a.n_t - iv);
+            if (a.lamda_all) { SFOR(r, 0, RS) { if (IDX(m, r) < NS) a.lamda_all[row * NS + IDX(m, r)] = lam[r]; } SEND }
+            if (a.quad_all) { SFOR(r, 0, RQ) { if (IDX(m, r) < NQ) a.quad_all[row * NQ + IDX(m, r)] = quad[r]; } SEND }
         }
     }
     release_workers(m);
+    if (status != CV_SUCCESS) {
+        if (a.lamda_all) for (int j = m.li; j < a.n_t * NS; j += G) a.lamda_all[(int64_t)inst * a.n_t * NS + j] = SA_NAN;
+        if (a.quad_all) for (int j = m.li; j < a.n_t * NQ; j += G) a.quad_all[(int64_t)inst * a.n_t * NQ + j] = SA_NAN;
+    }
     SFOR(r, 0, RQ) {
         if (IDX(m, r) < NQ) a.grad_out[(int64_t)inst * NQ + IDX(m, r)] = (status == CV_SUCCESS) ? quad_out[r] : SA_NAN;
     } SEND
     SFOR(r, 0, RS) {
         if (IDX(m, r) < NS) a.lamda_out[(int64_t)inst * NS + IDX(m, r)] = (status == CV_SUCCESS) ? lam[r] : SA_NAN;
     } SEND
-    if (m.lane == 0) {
+    if (m.li == 0) {
         a.status[inst] = status;
         st[ST_NPTS] = np; st[ST_NINTERP] = m.n_interp; st[ST_NREBUILD] = m.n_rebuild;
         st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
@@ -1603,14 +1664,17 @@ struct ArrayOut {
 
 extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)
 {
-    const int lane = lane_id();
+    const int lane = lane_id(), li = lane & (G - 1), grp = lane / G;
     if (lane == 0) s_nwaves = 1;
-    for (int q = 0; q < 64; q++) {
-        const int i = blockIdx.x * 64 + q;
+    for (int q = 0; q < G; q++) {                 /* every group of the wavefront walks its own points */
+        const int i = blockIdx.x * 64 + q * KPW + grp;
         if (i >= a.npts) break;
         lds_sync();
-        for (int k = lane; k < NS; k += 64) { s_y[k] = a.y[(int64_t)i * NS + k]; s_lam[k] = a.lam[(int64_t)i * NS + k]; }
-        for (int k = lane; k < NQ; k += 64) s_ps[k] = a.ps[(int64_t)i * NQ + k];
+        for (int k = li; k < NS; k += G) {
+            s_y[grp * NS + k] = a.y[(int64_t)i * NS + k];
+            s_lam[grp * NS + k] = a.lam[(int64_t)i * NS + k];
+        }
+        for (int k = li; k < NQ; k += G) s_ps[grp * W_NQD + k] = a.ps[(int64_t)i * NQ + k];
         lds_sync();
         const double *prp = a.pr + (int64_t)i * NR;
         const double t = a.t[i];
@@ -1619,7 +1683,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)
         const int c2 = sa_adj_rhs(t, nullptr, nullptr, nullptr, prp, ArrayOut{(gdouble *)(a.adj + (int64_t)i * NS)});
         const int c3 = sa_quad_rhs(t, nullptr, nullptr, nullptr, prp, ArrayOut{(gdouble *)(a.quad + (int64_t)i * NQ)});
         const int c4 = sa_adj_jac(t, nullptr, nullptr, prp, ArrayOut{(gdouble *)(a.adjjac + (int64_t)i * NS * NS)});
-        if (lane == 0) {
+        if (li == 0) {
             a.codes[i * 5 + 0] = c0; a.codes[i * 5 + 1] = c1; a.codes[i * 5 + 2] = c2;
             a.codes[i * 5 + 3] = c3; a.codes[i * 5 + 4] = c4;
         }
@@ -1636,4 +1700,4 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 }
 
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance, workspace doubles per instance} */
-extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, 64 * SA_WAVES, WS_DOUBLES};
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, G * SA_WAVES, WS_DOUBLES};

@@ -57,6 +57,10 @@ typedef struct {
     const int32_t *traj_np;
     double *ws;
     int64_t ws_stride;
+    /* optional (NULL: not wanted): adjoint state / accumulated quadrature right after every jump, laid out
+       [B][n_t][n] / [B][n_t][p] with the reference's row order (solver.py:778-781 writes row -i for the
+       i-th jump counted from the last output time, i.e. row 0, n_t-1, n_t-2, ..., 1) */
+    double *lamda_all, *quad_all;
 } sa_bwd_args;
 
 /* Solver(sens_mode=...).solve: forward solve + forward sensitivities (SA_SENS build of bdf_mem.hip).

@@ -411,6 +411,16 @@ extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const d
                                        int32_t n_t, const double *grads, int64_t grads_stride, double *grad_out,
                                        double *lamda_out, int32_t *status, int64_t *stats)
 {
+    return sa_solve_backward_batch_all(s, mem, B, ps, pr, rem_stride, t0, tend, tvals, n_t, grads, grads_stride,
+                                       grad_out, lamda_out, nullptr, nullptr, status, stats);
+}
+
+extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, const double *ps, const double *pr,
+                                           int32_t rem_stride, double t0, double tend, const double *tvals,
+                                           int32_t n_t, const double *grads, int64_t grads_stride,
+                                           double *grad_out, double *lamda_out, double *lamda_all_out,
+                                           double *quad_all_out, int32_t *status, int64_t *stats)
+{
     if (!s) return fail(SA_ERR_ARG, "null solver");
     if (B != s->fwd_B) return fail(SA_ERR_ARG, "backward batch %d does not match the last forward batch %d", B, s->fwd_B);
     if (rem_stride != 0 && rem_stride != s->r) return fail(SA_ERR_ARG, "rem_stride must be 0 or n_rem=%d", s->r);
@@ -419,7 +429,7 @@ extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const d
     if (B == 0) return SA_OK;
     const size_t nB = (size_t)B;
     const double *d_ps = ps, *d_pr = pr, *d_tv = tvals, *d_g = grads;
-    double *d_gout = grad_out, *d_lout = lamda_out;
+    double *d_gout = grad_out, *d_lout = lamda_out, *d_lall = lamda_all_out, *d_qall = quad_all_out;
     int32_t *d_status = status;
     int64_t *d_stats = stats;
     int rc;
@@ -431,6 +441,8 @@ extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const d
         if ((rc = stage_in(s, s->s_grads, grads, sizeof(double) * (grads_stride ? nB : 1) * n_t * s->n, &q))) return rc; d_g = (const double *)q;
         if ((rc = s->s_gout.ensure(sizeof(double) * nB * (s->p > 0 ? s->p : 1)))) return rc; d_gout = (double *)s->s_gout.p;
         if ((rc = s->s_lout.ensure(sizeof(double) * nB * (s->n > 0 ? s->n : 1)))) return rc; d_lout = (double *)s->s_lout.p;
+        if (lamda_all_out) { if ((rc = s->s_misc[1].ensure(sizeof(double) * nB * n_t * (s->n > 0 ? s->n : 1)))) return rc; d_lall = (double *)s->s_misc[1].p; }
+        if (quad_all_out) { if ((rc = s->s_misc[2].ensure(sizeof(double) * nB * n_t * (s->p > 0 ? s->p : 1)))) return rc; d_qall = (double *)s->s_misc[2].p; }
         if ((rc = s->s_status.ensure(sizeof(int32_t) * nB))) return rc; d_status = (int32_t *)s->s_status.p;
         if ((rc = s->s_stats.ensure(sizeof(int64_t) * nB * SA_N_STATS))) return rc; d_stats = (int64_t *)s->s_stats.p;
     } else if (mem != SA_MEM_DEVICE) {
@@ -446,6 +458,7 @@ extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const d
     a.ps = d_ps; a.pr = d_pr; a.tvals = d_tv; a.grads = d_g; a.grad_out = d_gout; a.lamda_out = d_lout;
     a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
     a.traj = (const double *)s->traj.p; a.traj_np = (const int32_t *)s->traj_np.p;
+    a.lamda_all = d_lall; a.quad_all = d_qall;
     if ((rc = bind_workspace(s, B, &a.ws, &a.ws_stride))) return rc;
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     if ((rc = launch(s, s->k_backward, B, &a, sizeof a, s->group))) return rc;
@@ -454,6 +467,10 @@ extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const d
     if (mem == SA_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(grad_out, d_gout, sizeof(double) * nB * s->p, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipMemcpyAsync(lamda_out, d_lout, sizeof(double) * nB * s->n, hipMemcpyDeviceToHost, s->stream));
+        if (lamda_all_out)
+            HIP_TRY(hipMemcpyAsync(lamda_all_out, d_lall, sizeof(double) * nB * n_t * s->n, hipMemcpyDeviceToHost, s->stream));
+        if (quad_all_out)
+            HIP_TRY(hipMemcpyAsync(quad_all_out, d_qall, sizeof(double) * nB * n_t * s->p, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipMemcpyAsync(status, d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
         if (stats)
             HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(int64_t) * nB * SA_N_STATS, hipMemcpyDeviceToHost, s->stream));

@@ -377,10 +377,10 @@ class AdjointSolver(_EngineMixin):
 
     def solve_backward(self, t0, tend, tvals, grads, grad_out, lamda_out, lamda_all_out=None,
                        quad_all_out=None, max_retries=50):
-        if lamda_all_out is not None or quad_all_out is not None:
-            raise NotImplementedError("lamda_all_out / quad_all_out are not produced by the device kernel")
         grads = np.ascontiguousarray(grads, dtype=np.float64)
-        g, lam, status, _ = self.solve_backward_batch(t0, tend, tvals, grads[None], max_retries=max_retries)
+        want_all = lamda_all_out is not None or quad_all_out is not None
+        res = self.solve_backward_batch(t0, tend, tvals, grads[None], max_retries=max_retries, return_all=want_all)
+        g, lam, status = res[0], res[1], res[2]
         if status[0] != 0:
             code = int(status[0])
             if code == -1:
@@ -388,6 +388,10 @@ class AdjointSolver(_EngineMixin):
             raise SolverError(f"Solving ode failed: {ERRORS.get(code, 'unknown')} ({code})")
         grad_out[...] = g[0]
         lamda_out[...] = lam[0]
+        if lamda_all_out is not None:
+            lamda_all_out[...] = res[4][0]
+        if quad_all_out is not None:
+            quad_all_out[...] = res[5][0]
 
     # -- batch API -------------------------------------------------------------------------
     def solve_forward_batch(self, t0, tvals, y0, params_sub, params_rem):
@@ -403,11 +407,13 @@ class AdjointSolver(_EngineMixin):
         self._last_forward = (B, ps, pr, stride)
         return y_out, status, stats
 
-    def solve_backward_batch(self, t0, tend, tvals, grads, *, max_retries=50):
+    def solve_backward_batch(self, t0, tend, tvals, grads, *, max_retries=50, return_all=False):
         """Adjoint pass for the batch of the last ``solve_forward_batch``.
 
         ``grads``: [B, n_t, n] or [n_t, n] (shared).  Returns (grad_out [B,p] = dL/dp,
-        lamda_out [B,n] = -dL/dy0, status [B], stats [B,16])."""
+        lamda_out [B,n] = -dL/dy0, status [B], stats [B,16]); with ``return_all`` also
+        (lamda_all [B,n_t,n], quad_all [B,n_t,p]): adjoint state and accumulated quadrature right
+        after every jump, rows ordered as the reference's ``lamda_all_out[-i]`` (solver.py:778-781)."""
         if self._last_forward is None:
             raise SolverError("solve_backward called before solve_forward")
         eng = self._engine()
@@ -428,6 +434,10 @@ class AdjointSolver(_EngineMixin):
         lamda_out = np.zeros((B, max(n, 1)))
         status = np.zeros(B, np.int32)
         stats = np.zeros((B, _native.N_STATS), np.int64)
+        lam_all = np.zeros((B, n_t, max(n, 1))) if return_all else None
+        quad_all = np.zeros((B, n_t, max(p, 1))) if return_all else None
         eng.solve_backward(_native.SA_MEM_HOST, B, ps, pr, stride, t0, tend, tvals, n_t, grads, gstride,
-                           grad_out, lamda_out, status, stats)
+                           grad_out, lamda_out, status, stats, lam_all, quad_all)
+        if return_all:
+            return grad_out[:, :p], lamda_out[:, :n], status, stats, lam_all[:, :, :n], quad_all[:, :, :p]
         return grad_out[:, :p], lamda_out[:, :n], status, stats

@@ -248,7 +248,8 @@ def test_seir_forward_adjoint_vs_oracle_and_truth(golden_dir):
 
 @pytest.mark.parametrize("name,group", [("lv", 8), ("notebook", 8), ("robertson", 16),
                                         ("lv", "mem"), ("notebook", "mem"), ("robertson", "mem"),
-                                        ("lv", "wave"), ("notebook", "wave"), ("robertson", "wave")])
+                                        ("lv", "wave"), ("notebook", "wave"), ("robertson", "wave"),
+                                        ("lv", "wave8"), ("robertson", "wave16")])
 def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch):
     """The same problem through the kernel families (SA_FORCE_GROUP): G lanes per instance with
     butterfly norms and row-distributed LU, the wavefront-per-instance kernel with the LDS-resident
@@ -293,7 +294,7 @@ def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("variant", ["mem", "wave"])
+@pytest.mark.parametrize("variant", ["mem", "wave", "wave16", "wave32"])
 def test_seir_large_system_mappings_vs_oracle(variant, monkeypatch):
     """SEIR (n = 16, 16 shared fixed parameters) through the kernels meant for large systems
     (memory-resident / wavefront-per-instance): bit-exact against the oracle like the
@@ -352,6 +353,41 @@ def test_network100_forward_adjoint_vs_oracle(variant, monkeypatch):
     np.testing.assert_array_equal(stats_b[:, CMP_B], stbo[:, CMP_B])
     np.testing.assert_array_equal(g, go)
     np.testing.assert_array_equal(lam, lo)
+
+
+@pytest.mark.parametrize("variant", [None, "16", "wave", "mem"])
+def test_lamda_all_out_and_quad_all_out(variant, monkeypatch):
+    """Optional per-output-time results of solve_backward (reference solver.py:778-781) from every
+    kernel family, bit-for-bit against the oracle; scalar API fills caller-allocated arrays."""
+    from sunode_amd.solver import AdjointSolver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem("robertson")
+    d = robertson_batch(5)
+    tv = d["tvals"]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(3)[None, :])
+    kw = dict(abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8, quad_abstol=1e-10,
+              quad_reltol=1e-8)
+    sol = AdjointSolver(prob, **kw)
+    sol.solve_forward_batch(0.0, tv, d["y0"], d["params"], np.zeros(0))
+    g, lam, st, _, lam_all, quad_all = sol.solve_backward_batch(tv[-1], 0.0, tv, grads, return_all=True)
+    orc = make_oracle("robertson")
+    cfg = orc.config(rtol=1e-8, atol=1e-10, rtolB=1e-8, atolB=1e-10, rtolQB=1e-8, atolQB=1e-10)
+    orc.solve_forward(cfg, d["y0"], d["params"], np.zeros(0), 0.0, tv)
+    go, lo, so, _, lao, qao = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, return_all=True)
+    assert (st == 0).all() and (so == 0).all()
+    np.testing.assert_array_equal(lam_all, lao)
+    np.testing.assert_array_equal(quad_all, qao)
+    np.testing.assert_array_equal(g, go)
+    if variant is None:
+        sol.set_params_dict({"k1": float(d["params"][0, 0]), "k2": float(d["params"][0, 1]),
+                             "k3": float(d["params"][0, 2])})
+        y_out, grad_out, lamda_out = sol.make_output_buffers(tv)
+        la = np.zeros((len(tv), 3)); qa = np.zeros((len(tv), 3))
+        sol.solve_forward(0.0, tv, d["y0"][0], y_out)
+        sol.solve_backward(tv[-1], 0.0, tv, grads, grad_out, lamda_out, lamda_all_out=la, quad_all_out=qa)
+        np.testing.assert_array_equal(la, lao[0])
+        np.testing.assert_array_equal(qa, qao[0])
 
 
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):

@@ -174,3 +174,31 @@ def test_failure_reporting():
     y, st, stats = orc.solve(cfg, [[1.0, 0, 0]], [[0.04, 1e4, 3e7]], np.zeros(0), 0.0, np.array([0.0, 4e4]))
     assert st[0] == -1 and np.isnan(y[0]).all()        # CV_TOO_MUCH_WORK after the retries
     assert stats[0][13] == 2
+
+
+def test_lamda_all_and_quad_all_follow_the_reference_indexing():
+    """solver.py:778-781: after the i-th jump (counted from the last output time) the reference stores
+    the adjoint state / accumulated quadrature in row -i: row 0 first, then n_t-1, n_t-2, ..., 1.
+    Cross-check with separate backward solves over shortened horizons."""
+    prob = make_problem("lv")
+    orc = make_oracle("lv")
+    tol = 1e-9
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    tv = np.linspace(0.0, 4.0, 5)
+    y0 = np.array([[1.0, 0.1]]); ps = np.array([[0.1, 0.2]]); pr = np.array([[0.3, 0.4]])
+    grads = np.cos(np.arange(10.0)).reshape(5, 2)
+    orc.solve_forward(cfg, y0, ps, pr, 0.0, tv)
+    g, lam, st, _, lam_all, quad_all = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, return_all=True)
+    assert (st == 0).all()
+    n_t = len(tv)
+    # the state right after the jump at tvals[k] is what a backward solve over the later output times
+    # only (tvals[k:], grads[k:], tend = tvals[k]) returns as lamda_out / grad_out
+    for k in range(n_t):
+        i = n_t - 1 - k                       # jump index counted from the last output time
+        row = 0 if i == 0 else n_t - i        # lamda_all_out[-i]
+        orc.solve_forward(cfg, y0, ps, pr, 0.0, tv)
+        gk, lamk, stk, _ = orc.solve_backward(cfg, tv[-1], tv[k], tv[k:], grads[k:])
+        assert (stk == 0).all()
+        np.testing.assert_allclose(lam_all[0, row], lamk[0], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(quad_all[0, row], gk[0], rtol=1e-8, atol=1e-11)
+    np.testing.assert_array_equal(lam_all[0, 1], lam[0])      # last jump (at tvals[0] = t0): row -(n_t-1) = 1
