@@ -76,6 +76,9 @@ typedef struct sa_options {
     int32_t max_retries_fwd;   /* sunode: 5  (solver.py:467) */
     int32_t max_retries_bwd;   /* sunode: 50 (solver.py:724) */
     int32_t traj_capacity;     /* stored points per instance (CVodeAdjInit steps; arena rows) */
+    const double *constraints; /* CVodeSetConstraints (solver.py:230-233, 569-572): host pointer to n_states values
+                                  in {0, +-1, +-2} or NULL; forward problem only; needs a code object built with
+                                  constraint support (SA_CONSTRAINTS), otherwise the vector is ignored */
 } sa_options;
 
 int sa_abi_version(void);

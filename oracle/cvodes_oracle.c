@@ -125,6 +125,8 @@
 #define RHSFUNC_RECVR 9
 #define QRHSFUNC_RECVR 11
 #define SRHSFUNC_RECVR 12
+#define CONSTR_RECVR 10
+#define CV_CONSTR_FAIL (-15)
 #define NLS_CONTINUE 901
 #define NLS_CONV_RECVR 902
 #define CV_NO_FAILURES 0
@@ -362,6 +364,9 @@ typedef struct {
     int tstopset;
     double tstop, tretlast;
     long nst, nfe, nje, nsetups, nni, ncfn, netf, nfQe, netfQ, nstlp, nstlj;
+    /* inequality constraints (CVodeSetConstraints, solver.py:230-233, 569-572) */
+    int constraints_set;
+    double constraints[NSD];
     /* forward sensitivities (CVodeSensInit, EE tolerances, errconS = 1; solver.py:360-392) */
     int sensi, ism;                          /* ism: 0 = CV_SIMULTANEOUS, 1 = CV_STAGGERED */
     double pbar[NQD];
@@ -1128,6 +1133,44 @@ static int cv_stgr_nls(cvmem *m)
     return CV_SUCCESS;
 }
 
+/* N_VConstrMask entry: 1 where the constraint c on x is violated */
+static int constr_violated(double c, double x)
+{
+    if (c == 2.0) return !(x > 0.0);
+    if (c == 1.0) return !(x >= 0.0);
+    if (c == -1.0) return !(x <= 0.0);
+    if (c == -2.0) return !(x < 0.0);
+    return 0;
+}
+
+/* cvCheckConstraints: small violations are absorbed into the correction, large ones shrink the step */
+static int cv_check_constraints(cvmem *m)
+{
+    double mm[NSD], v[NSD];
+    int any = 0;
+    for (int i = 0; i < NS; i++) { mm[i] = constr_violated(m->constraints[i], m->y[i]) ? 1.0 : 0.0; any |= (mm[i] != 0.0); }
+    if (!any) return CV_SUCCESS;
+    for (int i = 0; i < NS; i++) {
+        double a = (fabs(m->constraints[i]) >= 1.5) ? 1.0 : 0.0;     /* strict constraints aim 0.1 tolerances inside */
+        double tmp = (a * m->constraints[i]) / m->ewt[i];
+        tmp = FMA(-0.1, tmp, m->y[i]);
+        v[i] = tmp * mm[i];
+    }
+    double vnorm = wrms(v, m->ewt, NS);
+    if (vnorm * m->tq[4] <= 1.0) {       /* CVODES: vnorm <= tq[4]; tq[4] is stored inverted here */
+        for (int i = 0; i < NS; i++) m->acor[i] = m->acor[i] - v[i];
+        return CV_SUCCESS;
+    }
+    double minq = 1e308;                  /* N_VMinQuotient(zn[0], mm * (zn[0] - y)) */
+    for (int i = 0; i < NS; i++) {
+        double d = mm[i] * (m->zn[0][i] - m->y[i]);
+        if (d != 0.0) { double qv = m->zn[0][i] / d; if (qv < minq) minq = qv; }
+    }
+    m->eta = 0.9 * minq;
+    m->eta = fmax(m->eta, 0.1);
+    return CONSTR_RECVR;
+}
+
 static int cv_handle_nflag(cvmem *m, int *nflagPtr, double saved_t, int *ncfPtr, long *ncfnPtr)
 {
     int nflag = *nflagPtr;
@@ -1142,8 +1185,9 @@ static int cv_handle_nflag(cvmem *m, int *nflagPtr, double saved_t, int *ncfPtr,
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
         if (nflag == QRHSFUNC_RECVR) return CV_REPTD_QRHSFUNC_ERR;
         if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
+        if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
     }
-    m->eta = ETACF;              /* max(ETACF, hmin/|h|) with hmin = 0 */
+    if (nflag != CONSTR_RECVR) m->eta = ETACF;   /* max(ETACF, hmin/|h|), hmin = 0; CONSTR_RECVR: eta set by the check */
     *nflagPtr = PREV_CONV_FAIL;
     cv_rescale(m);
     return PREDICT_AGAIN;
@@ -1350,6 +1394,7 @@ static int cv_step(cvmem *m)
         cv_predict(m);
         cv_set(m);
         nflag = cv_nls(m, nflag);
+        if (nflag == CV_SUCCESS && m->constraints_set) nflag = cv_check_constraints(m);
         kflag = cv_handle_nflag(m, &nflag, saved_t, &ncf, &m->ncfn);
         if (kflag == PREDICT_AGAIN) continue;
         if (kflag != DO_ERROR_TEST) return kflag;
@@ -1459,6 +1504,10 @@ static int cv_get_sens_dky0(cvmem *m, double t, double *dkyS /* [NQ][NS] */)
 /* First-call block of CVode(): f(t0,y0), h0, scale zn[1]. */
 static int cv_first_call(cvmem *m, double tout)
 {
+    if (m->constraints_set) {           /* cvInitialSetup: y0 must satisfy the constraints */
+        if (m->sensi && m->ism == 0) return CV_ILL_INPUT;
+        for (int i = 0; i < NS; i++) if (constr_violated(m->constraints[i], m->zn[0][i])) return CV_ILL_INPUT;
+    }
     if (ewt_set(m, m->zn[0], m->ewt) != 0) return CV_ILL_INPUT;
     if (m->quadr && m->errconQ) if (ewtQ_set(m, m->znQ[0], m->ewtQ) != 0) return CV_ILL_INPUT;
     if (m->sensi) if (sens_ewt_set(m, m->znS[0], m->ewtS) != 0) return CV_ILL_INPUT;
@@ -1613,6 +1662,8 @@ typedef struct {
     int max_retries_fwd;    /* sunode: 5 */
     int max_retries_bwd;    /* sunode: 50 */
     int max_traj_points;    /* 0 = unbounded; mirrors the device arena capacity */
+    int constraints_set, pad;
+    double constraints[NSD];    /* CVodeSetConstraints: 0 none, +-1 (>= / <= 0), +-2 (> / < 0); forward problem only */
 } orc_config;
 
 typedef struct {
@@ -1641,6 +1692,7 @@ static int solve_plain_one(const orc_config *cfg, const double *y0, const double
     m->ps = ps; m->pr = pr; m->backward = 0; m->tr = NULL;
     m->rtol = cfg->rtol; for (int i = 0; i < NS; i++) m->atol[i] = cfg->atol[i];
     m->quadr = 0; m->errconQ = 0; m->mxstep = cfg->mxstep; m->tstopset = 0;
+    m->constraints_set = cfg->constraints_set; for (int i = 0; i < NS; i++) m->constraints[i] = cfg->constraints[i];
     cv_reinit(m, t0, y0, NULL);
     int status = CV_SUCCESS;
     double ybuf[NSD], tret;
@@ -1675,6 +1727,7 @@ static int solve_sens_one(const orc_config *cfg, int ism, const double *pbar, co
     m->rtol = cfg->rtol; for (int i = 0; i < NS; i++) m->atol[i] = cfg->atol[i];
     m->quadr = 0; m->errconQ = 0; m->mxstep = cfg->mxstep; m->tstopset = 0;
     m->sensi = 1; m->ism = ism;
+    m->constraints_set = cfg->constraints_set; for (int i = 0; i < NS; i++) m->constraints[i] = cfg->constraints[i];
     for (int is = 0; is < NQ; is++) m->pbar[is] = pbar ? fabs(pbar[is]) : 1.0;
     cv_reinit(m, t0, y0, NULL);
     cv_sens_reinit(m, sens0);
@@ -1713,6 +1766,7 @@ static int solve_forward_one(const orc_config *cfg, const double *y0, const doub
     m->ps = ps; m->pr = pr; m->backward = 0; m->tr = tr;
     m->rtol = cfg->rtol; for (int i = 0; i < NS; i++) m->atol[i] = cfg->atol[i];
     m->quadr = 0; m->errconQ = 0; m->mxstep = cfg->mxstep; m->tstopset = 0;
+    m->constraints_set = cfg->constraints_set; for (int i = 0; i < NS; i++) m->constraints[i] = cfg->constraints[i];
     cv_reinit(m, t0, y0, NULL);
     tr->np = 0; tr->n_interp = tr->n_rebuild = 0;
     int status = CV_SUCCESS, first = 1;

@@ -103,7 +103,7 @@ def _extra_codegen_flags():
 REGISTER_KERNEL_MAX_STATES = 5
 
 
-def kernel_variant(native_source: str, sens: bool = False):
+def kernel_variant(native_source: str, sens: bool = False, constraints: bool = False):
     """(source file, lanes per instance) for a generated problem header.
 
     ``sens=True`` (forward sensitivities, ``Solver(sens_mode=...)``): the memory-resident kernel
@@ -158,24 +158,26 @@ def _size_defines(native_source: str):
     return ["-DSA_BUILD_NS=%d" % n, "-DSA_BUILD_NQ=%d" % p] + os.environ.get("SA_KERNEL_DEFINES", "").split()
 
 
-def code_object_path(native_source: str, sens: bool = False) -> str:
+def code_object_path(native_source: str, sens: bool = False, constraints: bool = False) -> str:
     fname, group = kernel_variant(native_source, sens)
     kern = os.path.join(_CSRC, fname)
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h")]
     deps = [d for d in deps if os.path.exists(d)]
     extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group + fname.encode()
              + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode()
-             + (b"SENS" if sens else b""))
+             + (b"SENS" if sens else b"") + (b"CONSTR" if constraints else b""))
     key = _hash_files(*deps, extra=extra) if os.path.exists(kern) else \
         hashlib.sha256(extra).hexdigest()[:16]
     return os.path.join(_CACHE, "sa_%s.hsaco" % key)
 
 
 def build_code_object(native_source: str, force: bool = False, keep_temps: bool = False,
-                      sens: bool = False) -> str:
-    """Compile the integrator kernels for one problem to a gfx950 code object (cached)."""
+                      sens: bool = False, constraints: bool = False) -> str:
+    """Compile the integrator kernels for one problem to a gfx950 code object (cached).
+    ``constraints=True`` builds the variant that enforces CVodeSetConstraints-style inequality
+    constraints (a separate code object: the default build carries no trace of them)."""
     os.makedirs(_CACHE, exist_ok=True)
-    out = code_object_path(native_source, sens)
+    out = code_object_path(native_source, sens, constraints)
     if os.path.exists(out) and not force:
         return out
     fname, group = kernel_variant(native_source, sens)
@@ -190,7 +192,7 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
         _run([hipcc, "--offload-arch=" + ARCH, "--cuda-device-only", "-emit-llvm", "-c", "-O0",
               "-Xclang", "-disable-O0-optnone", "-ffp-contract=off", "-std=c++17",
               "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-DSA_GROUP=%d" % group] + _size_defines(native_source)
-             + (["-DSA_SENS=1"] if sens else [])
+             + (["-DSA_SENS=1"] if sens else []) + (["-DSA_CONSTRAINTS=1"] if constraints else [])
              + ["-I" + _CSRC, kern, "-o", bc0])
         _run([os.path.join(LLVM_BIN, "opt"), "-passes=always-inline,sroa", bc0, "-o", bc1])
         occupancy = os.environ.get("SA_WAVES_PER_EU")
@@ -234,7 +236,7 @@ class _Options(ctypes.Structure):
                 ("atol", ctypes.POINTER(ctypes.c_double)), ("rtolB", ctypes.c_double), ("atolB", ctypes.c_double),
                 ("rtolQB", ctypes.c_double), ("atolQB", ctypes.c_double), ("mxstep", ctypes.c_int32),
                 ("max_retries_fwd", ctypes.c_int32), ("max_retries_bwd", ctypes.c_int32),
-                ("traj_capacity", ctypes.c_int32)]
+                ("traj_capacity", ctypes.c_int32), ("constraints", ctypes.POINTER(ctypes.c_double))]
 
 
 _LIB: Optional[ctypes.CDLL] = None
@@ -308,14 +310,15 @@ class NativeSolver:
 
     def __init__(self, native_source: str, *, device: int = 0, rtol=1e-10, atol=1e-10, rtolB=1e-10,
                  atolB=1e-10, rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
-                 max_retries_bwd=50, traj_capacity=2048, n_states: Optional[int] = None, sens: bool = False):
+                 max_retries_bwd=50, traj_capacity=2048, n_states: Optional[int] = None, sens: bool = False,
+                 constraints=None):
         self.L = load_library()
-        self.code_object = build_code_object(native_source, sens=sens)
+        self.code_object = build_code_object(native_source, sens=sens, constraints=constraints is not None)
         self._h = ctypes.c_void_p()
         self._n_hint = n_states
         self._opt_kw = dict(device=device, rtol=rtol, atol=atol, rtolB=rtolB, atolB=atolB, rtolQB=rtolQB,
                             atolQB=atolQB, mxstep=mxstep, max_retries_fwd=max_retries_fwd,
-                            max_retries_bwd=max_retries_bwd, traj_capacity=traj_capacity)
+                            max_retries_bwd=max_retries_bwd, traj_capacity=traj_capacity, constraints=constraints)
         opt, keep = self._make_options(n_states if n_states is not None else 64)
         rc = self.L.sa_solver_create(self.code_object.encode(), ctypes.byref(opt), ctypes.byref(self._h))
         self._check(rc)
@@ -336,7 +339,11 @@ class NativeSolver:
         opt.rtolQB, opt.atolQB = float(kw["rtolQB"]), float(kw["atolQB"])
         opt.mxstep, opt.max_retries_fwd = int(kw["mxstep"]), int(kw["max_retries_fwd"])
         opt.max_retries_bwd, opt.traj_capacity = int(kw["max_retries_bwd"]), int(kw["traj_capacity"])
-        return opt, atol
+        cons = None
+        if kw.get("constraints") is not None:
+            cons = np.ascontiguousarray(np.broadcast_to(np.asarray(kw["constraints"], dtype=np.float64), (max(n, 1),)))
+            opt.constraints = cons.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        return opt, (atol, cons)
 
     def set_options(self, **kw):
         self._opt_kw.update(kw)

@@ -87,6 +87,10 @@ struct Cc {
     /* component li of the vectors (zero for padding lanes li >= n / li >= p) */
     double zn[QMAX + 1], znQ[QMAX + 1], zsave, zsaveQ;
     double ewt, acor, tempv, ftemp, y, ewtQ, acorQ, tempvQ, ytmp, atol;
+#ifdef SA_CONSTRAINTS
+    double cons;                      /* CVodeSetConstraints entry of the lane's component */
+    int constr;
+#endif
     double Arow[NSD], Srow[NSD];      /* row li of I - gamma*J (LU in place) and of the saved Jacobian */
     double inv_piv;                   /* 1/pivot of row li */
     int piv[NSD];                     /* pivot rows (replicated) */
@@ -876,6 +880,11 @@ DEV int cv_get_dky0(const Cc<BWD> &m, double t, double &dky, double &dkyQ)
 template <bool BWD>
 DEV int cv_first_call(Cc<BWD> &m, double tout)
 {
+#ifdef SA_CONSTRAINTS
+    if (!BWD && m.constr) {
+        if (gmax(m, ((m.li < NS) && constr_violated(m.cons, m.zn[0])) ? 1.0 : 0.0) > 0.0) return CV_ILL_INPUT;
+    }
+#endif
     if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
     if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
@@ -931,9 +940,10 @@ DEV int cv_handle_nflag_failed(Cc<BWD> &m, StepCtl &c, int nflag)
     if (c.ncf == MXNCF) {
         if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
+        if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
         return CV_REPTD_QRHSFUNC_ERR;
     }
-    m.eta = ETACF;
+    if (nflag != CONSTR_RECVR) m.eta = ETACF;         /* CONSTR_RECVR: eta was set by the constraint check */
     c.nflag = PREV_CONV_FAIL;
     cv_rescale(m);
     return 0;
@@ -983,6 +993,28 @@ DEV int cv_attempt(Cc<BWD> &m, StepCtl &c)
     if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls);
 
     m.y = m.zn[0] + m.acor;
+#ifdef SA_CONSTRAINTS
+    if (!BWD && m.constr) {             /* cvCheckConstraints (see the oracle) */
+        const bool bad = (m.li < NS) && constr_violated(m.cons, m.y);
+        const double mm = bad ? 1.0 : 0.0;
+        if (gmax(m, mm) > 0.0) {
+            const double aa = (fabs(m.cons) >= 1.5) ? 1.0 : 0.0;
+            double tmp = (aa * m.cons) / m.ewt;
+            tmp = FMA(-0.1, tmp, m.y);
+            const double v = (m.li < NS) ? tmp * mm : 0.0;
+            const double vnorm = wrms_n(m, v, m.ewt);
+            if (vnorm * m.tq[4] <= 1.0) {
+                m.acor = m.acor - v;
+            } else {
+                const double d = mm * (m.zn[0] - m.y);
+                const double qv = (m.li < NS && d != 0.0) ? m.zn[0] / d : 1e308;
+                const double minq = -gmax(m, -qv);
+                m.eta = fmax(0.9 * minq, 0.1);
+                return cv_handle_nflag_failed(m, c, CONSTR_RECVR);
+            }
+        }
+    }
+#endif
     double dsm = m.acnrm * m.tq[2];
     if (dsm > 1.0) {
         c.nflag = PREV_ERR_FAIL;
@@ -1072,6 +1104,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     if (inst >= a.B) return;
     load_params(m, a.ps, a.pr, a.rem_stride, inst);
     m.rtol = a.rtol;
+#ifdef SA_CONSTRAINTS
+    m.constr = (a.constraints != nullptr);
+    m.cons = (m.constr && m.li < NS) ? a.constraints[m.li < NS ? m.li : 0] : 0.0;
+#endif
     m.atol = (m.li < NS) ? a.atol[m.li < NS ? m.li : 0] : 1.0;
     m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0; m.ewtQ = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;

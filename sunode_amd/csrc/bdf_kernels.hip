@@ -59,6 +59,10 @@ struct Cv {
     double znQ[QMAX + 1][NQD];
     double zsave[NSD], zsaveQ[NQD];
     double ewt[NSD], acor[NSD], tempv[NSD], ftemp[NSD], y[NSD];
+#ifdef SA_CONSTRAINTS
+    double cons[NSD];                 /* CVodeSetConstraints vector (all zero: none) */
+    int constr;
+#endif
     double ewtQ[NQD], acorQ[NQD], tempvQ[NQD];
     double ytmp[NSD];                 /* interpolated forward state (backward only) */
     double atol[NSD];
@@ -943,6 +947,13 @@ DEV int cv_get_dky0(const Cv<BWD> &m, double t, double *dky, double *dkyQ)
 template <bool BWD>
 DEV int cv_first_call(Cv<BWD> &m, double tout)
 {
+#ifdef SA_CONSTRAINTS
+    if (!BWD && m.constr) {             /* cvInitialSetup: y0 must satisfy the constraints */
+        bool bad = false;
+        SFOR(i, 0, NS) bad = bad || constr_violated(m.cons[i], m.zn[0][i]); SEND
+        if (bad) return CV_ILL_INPUT;
+    }
+#endif
     if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
     if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
@@ -1003,9 +1014,10 @@ DEV int cv_handle_nflag_failed(Cv<BWD> &m, StepCtl &c, int nflag)
     if (c.ncf == MXNCF) {
         if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
+        if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
         return CV_REPTD_QRHSFUNC_ERR;
     }
-    m.eta = ETACF;
+    if (nflag != CONSTR_RECVR) m.eta = ETACF;         /* CONSTR_RECVR: eta was set by the constraint check */
     c.nflag = PREV_CONV_FAIL;
     cv_rescale(m);
     return 0;
@@ -1077,6 +1089,34 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
     if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls);
 
     SFOR(i, 0, NS) m.y[i] = m.zn[0][i] + m.acor[i]; SEND
+#ifdef SA_CONSTRAINTS
+    if (!BWD && m.constr) {             /* cvCheckConstraints (see the oracle) */
+        double mm[NSD], v[NSD];
+        bool any = false;
+        SFOR(i, 0, NS) { const bool bad = constr_violated(m.cons[i], m.y[i]); mm[i] = bad ? 1.0 : 0.0; any = any || bad; } SEND
+        if (any) {
+            SFOR(i, 0, NS) {
+                const double aa = (fabs(m.cons[i]) >= 1.5) ? 1.0 : 0.0;
+                double tmp = (aa * m.cons[i]) / m.ewt[i];
+                tmp = FMA(-0.1, tmp, m.y[i]);
+                v[i] = tmp * mm[i];
+            } SEND
+            const double vnorm = wrms<NS>(v, m.ewt);
+            if (vnorm * m.tq[4] <= 1.0) {
+                SFOR(i, 0, NS) m.acor[i] = m.acor[i] - v[i]; SEND
+            } else {
+                double minq = 1e308;
+                SFOR(i, 0, NS) {
+                    const double d = mm[i] * (m.zn[0][i] - m.y[i]);
+                    const double qv = m.zn[0][i] / d;
+                    minq = (d != 0.0 && qv < minq) ? qv : minq;
+                } SEND
+                m.eta = fmax(0.9 * minq, 0.1);
+                return cv_handle_nflag_failed(m, c, CONSTR_RECVR);
+            }
+        }
+    }
+#endif
     double dsm = m.acnrm * m.tq[2];
     if (dsm > 1.0) {
         c.nflag = PREV_ERR_FAIL;
@@ -1165,6 +1205,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     Cv<false> m;
     load_params(m, a.ps, a.pr, a.rem_stride, inst);
     m.rtol = a.rtol;
+#ifdef SA_CONSTRAINTS
+    m.constr = (a.constraints != nullptr);
+    SFOR(i, 0, NS) m.cons[i] = m.constr ? a.constraints[i] : 0.0; SEND
+#endif
     SFOR(i, 0, NS) m.atol[i] = a.atol[i]; SEND
     m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0;

@@ -111,6 +111,7 @@ struct Cm {
     double last_t, tlo, thi, tlo2;
     int n_interp, n_rebuild;
     /* forward sensitivities (only the SA_SENS build sets sensi) */
+    const double *cons;        /* CVodeSetConstraints vector (global) or nullptr */
     int sensi, ism;
     double pbar[NQD], crateS, delpS, acnrmS;
     int nfSe, nniS, ncfnS, netfS, nsetupsS;
@@ -1099,6 +1100,12 @@ DEV int cv_get_dky0(Cm<BWD> &m, double t, double *dky, int64_t dstride, int qoff
 template <bool BWD>
 DEV int cv_first_call(Cm<BWD> &m, double tout)
 {
+#ifdef SA_CONSTRAINTS
+    if (!BWD && m.cons) {
+        if (m.sensi && m.ism == 0) return CV_ILL_INPUT;       /* CVODES: no constraints with the simultaneous corrector */
+        for (int i = 0; i < NS; i++) if (constr_violated(m.cons[i], ZN(m, 0, i))) return CV_ILL_INPUT;
+    }
+#endif
     if (ewt_set(m, O_ZN, O_EWT) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, O_ZNQ, O_EWTQ) != 0) return CV_ILL_INPUT; }
 #ifdef SA_SENS
@@ -1174,9 +1181,10 @@ DEV int cv_handle_nflag_failed(Cm<BWD> &m, StepCtl &c, int nflag, int &ncf, int 
         if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
         if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
+        if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
         return CV_REPTD_QRHSFUNC_ERR;
     }
-    m.eta = ETACF;
+    if (nflag != CONSTR_RECVR) m.eta = ETACF;         /* CONSTR_RECVR: eta was set by the constraint check */
     c.nflag = PREV_CONV_FAIL;
     cv_rescale(m);
     return 0;
@@ -1225,6 +1233,36 @@ DEV int cv_attempt(Cm<BWD> &m, StepCtl &c)
     if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls, c.ncf, m.ncfn);
 
     for (int i = 0; i < NS; i++) W(m, O_Y, i) = ZN(m, 0, i) + W(m, O_ACOR, i);
+#ifdef SA_CONSTRAINTS
+    if (!BWD && m.cons) {               /* cvCheckConstraints (see the oracle); mask in O_FTEMP, v in O_TEMPV */
+        bool any = false;
+        for (int i = 0; i < NS; i++) {
+            const bool bad = constr_violated(m.cons[i], W(m, O_Y, i));
+            W(m, O_FTEMP, i) = bad ? 1.0 : 0.0;
+            any = any || bad;
+        }
+        if (any) {
+            for (int i = 0; i < NS; i++) {
+                const double aa = (fabs(m.cons[i]) >= 1.5) ? 1.0 : 0.0;
+                double tmp = (aa * m.cons[i]) / W(m, O_EWT, i);
+                tmp = FMA(-0.1, tmp, W(m, O_Y, i));
+                W(m, O_TEMPV, i) = tmp * W(m, O_FTEMP, i);
+            }
+            const double vnorm = wrms_n(m, O_TEMPV);
+            if (vnorm * m.tq[4] <= 1.0) {
+                for (int i = 0; i < NS; i++) W(m, O_ACOR, i) = W(m, O_ACOR, i) - W(m, O_TEMPV, i);
+            } else {
+                double minq = 1e308;
+                for (int i = 0; i < NS; i++) {
+                    const double d = W(m, O_FTEMP, i) * (ZN(m, 0, i) - W(m, O_Y, i));
+                    if (d != 0.0) { const double qv = ZN(m, 0, i) / d; if (qv < minq) minq = qv; }
+                }
+                m.eta = fmax(0.9 * minq, 0.1);
+                return cv_handle_nflag_failed(m, c, CONSTR_RECVR, c.ncf, m.ncfn);
+            }
+        }
+    }
+#endif
     double dsm = m.acnrm * m.tq[2];
     if (dsm > 1.0) {
         c.nflag = PREV_ERR_FAIL;
@@ -1313,7 +1351,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
     Cm<false> m;
-    m.sensi = 0; m.ism = 0;
+    m.sensi = 0; m.ism = 0; m.cons = a.constraints;
     m.S = a.ws_stride;
     m.w = a.ws + inst;
     SFOR(i, 0, NQ) m.ps[i] = a.ps[(int64_t)inst * NQ + i]; SEND
@@ -1425,7 +1463,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     if (a.fwd_status[inst] != CV_SUCCESS || np < 2) status = CV_NO_FWD;
 
     Cm<true> m;
-    m.sensi = 0; m.ism = 0;
+    m.sensi = 0; m.ism = 0; m.cons = nullptr;
     m.S = a.ws_stride;
     m.w = a.ws + inst;
     SFOR(i, 0, NQ) m.ps[i] = a.ps[(int64_t)inst * NQ + i]; SEND
@@ -1576,7 +1614,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
     m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
     m.traj = nullptr; m.tS = 0;
-    m.sensi = 1; m.ism = a.ism;
+    m.sensi = 1; m.ism = a.ism; m.cons = nullptr;
 
     const double *y0 = a.y0 + (int64_t)inst * NS;
     const double *s0 = a.sens0 + (int64_t)inst * NQ * NS;

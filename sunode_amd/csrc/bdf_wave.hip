@@ -183,6 +183,10 @@ struct Cw {
     int abase, vbase, pbase, kbase;   /* the group's slices of s_A / s_y,s_lam / s_ps / s_piv */
     double zn[QMAX + 1][RS], znQ[QMAX + 1][RQ], zsave[RS], zsaveQ[RQ];
     double ewt[RS], acor[RS], tempv[RS], ftemp[RS], y[RS], ytmp[RS], atol[RS];
+#ifdef SA_CONSTRAINTS
+    double cons[RS];                  /* CVodeSetConstraints entries of the lane's components */
+    int constr;
+#endif
     double ewtQ[RQ], acorQ[RQ], tempvQ[RQ];
     double inv_piv[RS];               /* 1/pivot of the rows the lane owns */
     int nswaps;                       /* row exchanges of the current factorisation */
@@ -1217,6 +1221,13 @@ DEV int cv_get_dky0(const Cw<BWD> &m, double t, double (&dky)[RS], double (&dkyQ
 template <bool BWD>
 DEV int cv_first_call(Cw<BWD> &m, double tout)
 {
+#ifdef SA_CONSTRAINTS
+    if (!BWD && m.constr) {
+        double bad = 0.0;
+        SFOR(r, 0, RS) bad = ((IDX(m, r) < NS) && constr_violated(m.cons[r], m.zn[0][r])) ? 1.0 : bad; SEND
+        if (wave_max(m.lane, bad) > 0.0) return CV_ILL_INPUT;
+    }
+#endif
     if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
     if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
@@ -1272,9 +1283,10 @@ DEV int cv_handle_nflag_failed(Cw<BWD> &m, StepCtl &c, int nflag)
     if (c.ncf == MXNCF) {
         if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
+        if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
         return CV_REPTD_QRHSFUNC_ERR;
     }
-    m.eta = ETACF;
+    if (nflag != CONSTR_RECVR) m.eta = ETACF;         /* CONSTR_RECVR: eta was set by the constraint check */
     c.nflag = PREV_CONV_FAIL;
     cv_rescale(m);
     return 0;
@@ -1324,6 +1336,39 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
     if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls);
 
     SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
+#ifdef SA_CONSTRAINTS
+    if (!BWD && m.constr) {             /* cvCheckConstraints (see the oracle) */
+        double mm[RS], v[RS];
+        double anyv = 0.0;
+        SFOR(r, 0, RS) {
+            const bool bad = (IDX(m, r) < NS) && constr_violated(m.cons[r], m.y[r]);
+            mm[r] = bad ? 1.0 : 0.0;
+            anyv = bad ? 1.0 : anyv;
+        } SEND
+        if (wave_max(m.lane, anyv) > 0.0) {
+            SFOR(r, 0, RS) {
+                const double aa = (fabs(m.cons[r]) >= 1.5) ? 1.0 : 0.0;
+                double tmp = (aa * m.cons[r]) / m.ewt[r];
+                tmp = FMA(-0.1, tmp, m.y[r]);
+                v[r] = (IDX(m, r) < NS) ? tmp * mm[r] : 0.0;
+            } SEND
+            const double vnorm = wrms_n(m, v, m.ewt);
+            if (vnorm * m.tq[4] <= 1.0) {
+                SFOR(r, 0, RS) m.acor[r] = m.acor[r] - v[r]; SEND
+            } else {
+                double q = 1e308;
+                SFOR(r, 0, RS) {
+                    const double d = mm[r] * (m.zn[0][r] - m.y[r]);
+                    const double qv = (IDX(m, r) < NS && d != 0.0) ? m.zn[0][r] / d : 1e308;
+                    q = qv < q ? qv : q;
+                } SEND
+                const double minq = -wave_max(m.lane, -q);
+                m.eta = fmax(0.9 * minq, 0.1);
+                return cv_handle_nflag_failed(m, c, CONSTR_RECVR);
+            }
+        }
+    }
+#endif
     double dsm = m.acnrm * m.tq[2];
     if (dsm > 1.0) {
         c.nflag = PREV_ERR_FAIL;
@@ -1428,6 +1473,10 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     Cw<false> m;
     setup_common(m, a.ps, a.pr, a.rem_stride, inst, a.ws);
     m.rtol = a.rtol;
+#ifdef SA_CONSTRAINTS
+    m.constr = (a.constraints != nullptr);
+    SFOR(r, 0, RS) m.cons[r] = (m.constr && IDX(m, r) < NS) ? a.constraints[IDX(m, r) < NS ? IDX(m, r) : 0] : 0.0; SEND
+#endif
     SFOR(r, 0, RS) m.atol[r] = (IDX(m, r) < NS) ? a.atol[IDX(m, r) < NS ? IDX(m, r) : 0] : 1.0; SEND
     m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;

@@ -107,6 +107,8 @@ DEV void sfor_down(F &&f)          /* B, B-1, ..., E (inclusive) */
 #define RHSFUNC_RECVR 9
 #define QRHSFUNC_RECVR 11
 #define SRHSFUNC_RECVR 12
+#define CONSTR_RECVR 10
+#define CV_CONSTR_FAIL (-15)
 #define NLS_CONV_RECVR 902
 #define CV_NO_FAILURES 0
 #define CV_FAIL_BAD_J 1
@@ -176,6 +178,17 @@ DEV double rpower_r(double base, double expo)
 {
     if (base <= 0.0) return 0.0;
     return det_exp(expo * det_log(base));
+}
+
+/* N_VConstrMask entry: true where the inequality constraint c (0, +-1: >= / <= 0, +-2: > / < 0) on x fails */
+DEV bool constr_violated(double c, double x)
+{
+    bool v = false;
+    v = (c == 2.0) ? !(x > 0.0) : v;
+    v = (c == 1.0) ? !(x >= 0.0) : v;
+    v = (c == -1.0) ? !(x <= 0.0) : v;
+    v = (c == -2.0) ? !(x < 0.0) : v;
+    return v;
 }
 
 /* 1/k for k = 1..7, identical to the correctly rounded quotient 1.0/k */

@@ -41,6 +41,7 @@ typedef struct {
     int32_t *traj_np;
     double *ws;               /* memory-resident kernels only: [sa_meta[5]][ws_stride] doubles */
     int64_t ws_stride;
+    const double *constraints; /* [n] CVodeSetConstraints vector or NULL (read by SA_CONSTRAINTS builds only) */
 } sa_fwd_args;
 
 typedef struct {

@@ -77,6 +77,9 @@ struct sa_solver {
     sa_options opt{};
     std::vector<double> atol;
     DevBuf d_atol;
+    std::vector<double> constraints;
+    DevBuf d_constraints;
+    bool have_constraints = false;
     /* trajectory arena + forward bookkeeping of the last forward batch */
     DevBuf traj, traj_np, fwd_status;
     int64_t traj_stride = 0;
@@ -110,6 +113,17 @@ static int apply_options(sa_solver *s, const sa_options *opt)
     s->opt = *opt;
     s->atol.assign(opt->atol, opt->atol + s->n);
     s->opt.atol = nullptr;
+    s->have_constraints = (opt->constraints != nullptr && s->n > 0);
+    s->opt.constraints = nullptr;
+    if (s->have_constraints) {
+        s->constraints.assign(opt->constraints, opt->constraints + s->n);
+        for (double c : s->constraints)
+            if (!(c == 0.0 || c == 1.0 || c == -1.0 || c == 2.0 || c == -2.0))
+                return fail(SA_ERR_ARG, "constraints entries must be 0, +-1 or +-2");
+        int rc2 = s->d_constraints.ensure(sizeof(double) * s->n);
+        if (rc2) return rc2;
+        HIP_TRY(hipMemcpy(s->d_constraints.p, s->constraints.data(), sizeof(double) * s->n, hipMemcpyHostToDevice));
+    }
     int rc = s->d_atol.ensure(sizeof(double) * (s->n > 0 ? s->n : 1));
     if (rc) return rc;
     if (s->n > 0)
@@ -303,6 +317,7 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
     a.traj_cap = s->opt.traj_capacity; a.rem_stride = rem_stride;
     a.t0 = t0; a.rtol = s->opt.rtol; a.atol = (const double *)s->d_atol.p;
     a.y0 = d_y0; a.ps = d_ps; a.pr = d_pr; a.tvals = d_tv; a.y_out = d_yout; a.status = d_status; a.stats = d_stats;
+    a.constraints = s->have_constraints ? (const double *)s->d_constraints.p : nullptr;
     if (mode == SA_MODE_ADJ_FWD) {
         int64_t stride = ((int64_t)B + 63) / 64 * 64;
         size_t rows = (size_t)s->opt.traj_capacity;

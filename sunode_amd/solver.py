@@ -187,7 +187,13 @@ class Solver(_EngineMixin):
                 raise NotImplementedError("the device integrator always uses dense LU with the analytic Jacobian")
             raise ValueError(f"Unknown linear solver: {linear_solver}")
         if constraints is not None:
-            raise NotImplementedError("constraints are not implemented on the device")
+            constraints = np.broadcast_to(np.asarray(constraints, dtype=np.float64), (problem.n_states,)).copy()
+            if not np.isin(constraints, (0.0, 1.0, -1.0, 2.0, -2.0)).all():
+                raise ValueError("constraints entries must be 0, +-1 or +-2 (CVodeSetConstraints)")
+            if sens_mode == "simultaneous":
+                raise ValueError("constraints can not be enforced with the simultaneous sensitivity corrector")
+            if sens_mode is not None:
+                raise NotImplementedError("constraints together with forward sensitivities")
         self._problem = problem
         self._user_data = problem.make_user_data()
         self._constraints = constraints
@@ -208,13 +214,14 @@ class Solver(_EngineMixin):
     def _init_native(self):
         self._source = self._problem.native_source()
         # compile at construction like the reference JITs; sensitivity solves use their own build
-        _native.build_code_object(self._source, sens=self._compute_sens)
+        _native.build_code_object(self._source, sens=self._compute_sens, constraints=self._constraints is not None)
         self._native = None
 
     def _engine(self) -> _native.NativeSolver:
         if self._native is None:
             self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
-                                                sens=self._compute_sens, **self._native_kwargs())
+                                                sens=self._compute_sens, constraints=self._constraints,
+                                                **self._native_kwargs())
         return self._native
 
     def __getstate__(self):
@@ -331,20 +338,28 @@ class AdjointSolver(_EngineMixin):
             raise NotImplementedError("only polynomial interpolation of the forward trajectory is implemented")
         if interpolation != "polynomial":
             raise ValueError(f"Unknown interpolation {interpolation}.")
-        if constraints is not None:
-            raise NotImplementedError("constraints are not implemented on the device")
+        if constraints is not None:           # forward problem only, as in the reference (solver.py:569-572)
+            constraints = np.broadcast_to(np.asarray(constraints, dtype=np.float64), (problem.n_states,)).copy()
+            if not np.isin(constraints, (0.0, 1.0, -1.0, 2.0, -2.0)).all():
+                raise ValueError("constraints entries must be 0, +-1 or +-2 (CVodeSetConstraints)")
         self._problem = problem
         self._user_data = problem.make_user_data()
-        self._constraints = None
+        self._constraints = constraints
         self._set_tolerances(abstol, reltol)
         self._tolB = (float(backward_reltol), float(backward_abstol), float(quad_reltol), float(quad_abstol))
         self._mxsteps = mxsteps
         self._max_steps = int(min(max_steps, checkpoint_n + 1))
         self._device = device
         self._source = problem.native_source()
-        _native.build_code_object(self._source)
+        _native.build_code_object(self._source, constraints=self._constraints is not None)
         self._native = None
         self._last_forward = None
+
+    def _engine(self) -> _native.NativeSolver:
+        if self._native is None:
+            self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
+                                                constraints=self._constraints, **self._native_kwargs())
+        return self._native
 
     def _set_tolerances(self, atol=None, rtol=None):
         atol, rtol = np.array(atol, dtype=float), np.array(rtol, dtype=float)

@@ -390,6 +390,43 @@ def test_lamda_all_out_and_quad_all_out(variant, monkeypatch):
         np.testing.assert_array_equal(qa, qao[0])
 
 
+@pytest.mark.parametrize("variant", [None, "16", "wave", "mem"])
+def test_inequality_constraints_match_oracle(variant, monkeypatch):
+    """Solver / AdjointSolver(constraints=...) (reference solver.py:230-233, 569-572): the constraint build of
+    every kernel family follows the oracle bit for bit, including draws that end in CV_CONSTR_FAIL / CV_ILL_INPUT."""
+    from sunode_amd.solver import AdjointSolver, Solver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem("robertson")
+    B = 6
+    d = robertson_batch(B)
+    tv = np.array([0.0] + [4.0 * 10.0 ** k for k in range(11)])
+    y0 = d["y0"].copy()
+    y0[3] = [0.0, 0.5, 0.5]                                   # violates y1 > 0 at t0
+    cons = np.array([2.0, 1.0, 1.0])
+    sol = Solver(prob, abstol=1e-7, reltol=1e-4, constraints=cons, mxsteps=5000)
+    y, st, stats = sol.solve_batch(0.0, tv, y0, d["params"], np.zeros(0))
+    orc = make_oracle("robertson")
+    cfg = orc.config(rtol=1e-4, atol=1e-7, mxstep=5000, constraints=cons)
+    yo, so, sto = orc.solve(cfg, y0, d["params"], np.zeros(0), 0.0, tv)
+    assert st.tolist() == so.tolist() and st[3] == -22 and (np.delete(st, 3) == 0).any()
+    ok = st == 0
+    np.testing.assert_array_equal(y[ok], yo[ok])
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    assert np.nanmin(y[ok]) >= 0.0
+    # unconstrained, the same draws leave the physical region
+    free = Solver(prob, abstol=1e-7, reltol=1e-4, mxsteps=5000)
+    yf, stf, _ = free.solve_batch(0.0, tv, d["y0"], d["params"], np.zeros(0))
+    assert np.nanmin(yf) < -1.0
+    # the adjoint solver applies the constraints to its forward pass
+    adj = AdjointSolver(prob, abstol=1e-7, reltol=1e-4, constraints=cons, mxsteps=5000, max_steps=4096)
+    ya, sta, statsa = adj.solve_forward_batch(0.0, tv[:8], y0, d["params"], np.zeros(0))
+    yao, sao, statsao = orc.solve_forward(orc.config(rtol=1e-4, atol=1e-7, mxstep=5000, constraints=cons),
+                                          y0, d["params"], np.zeros(0), 0.0, tv[:8])
+    assert sta.tolist() == sao.tolist()
+    np.testing.assert_array_equal(ya[sta == 0], yao[sao == 0])
+
+
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
     orc = make_oracle(name)
     cfg = orc.config(**cfg_kw)

@@ -91,6 +91,10 @@ def test_unsupported_reference_options_raise():
         AdjointSolver(prob, adjoint_solver="RK4")
     with pytest.raises(ValueError):
         Solver(prob, abstol=np.ones(3))          # wrong length for a 2-state problem
+    with pytest.raises(ValueError):
+        Solver(prob, constraints=[3.0, 0.0])     # CVodeSetConstraints accepts 0, +-1, +-2
+    with pytest.raises(ValueError):
+        Solver(prob, constraints=[1.0, 1.0], sens_mode="simultaneous")
 
 
 def test_parameter_plumbing_matches_reference_semantics():

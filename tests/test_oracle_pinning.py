@@ -202,3 +202,24 @@ def test_lamda_all_and_quad_all_follow_the_reference_indexing():
         np.testing.assert_allclose(lam_all[0, row], lamk[0], rtol=1e-8, atol=1e-11)
         np.testing.assert_allclose(quad_all[0, row], gk[0], rtol=1e-8, atol=1e-11)
     np.testing.assert_array_equal(lam_all[0, 1], lam[0])      # last jump (at tvals[0] = t0): row -(n_t-1) = 1
+
+
+def test_oracle_inequality_constraints_keep_robertson_physical():
+    """CVodeSetConstraints semantics (solver.py:230-233): at rtol 1e-4 the unconstrained Robertson solve
+    leaves the physical region and blows up by t = 4e10 (the textbook failure); with y >= 0 enforced the
+    solve stays non-negative and reaches the right asymptote (y1 ~ 1/(2 k2/k1 ... ) -> ~5e-8 at t = 4e10)."""
+    prob = make_problem("robertson")
+    orc = make_oracle("robertson")
+    tv = np.array([0.0] + [4.0 * 10.0 ** k for k in range(11)])
+    y0 = np.array([[1.0, 0.0, 0.0]]); ps = np.array([[0.04, 1e4, 3e7]])
+    free = orc.config(rtol=1e-4, atol=1e-7, mxstep=5000)
+    y, st, stats = orc.solve(free, y0, ps, np.zeros(0), 0.0, tv)
+    assert st[0] == 0 and y.min() < -1.0
+    con = orc.config(rtol=1e-4, atol=1e-7, mxstep=5000, constraints=[1.0, 1.0, 1.0])
+    yc, stc, statsc = orc.solve(con, y0, ps, np.zeros(0), 0.0, tv)
+    assert stc[0] == 0 and yc.min() >= 0.0
+    assert abs(yc[0, -1].sum() - 1.0) < 1e-3 and 1e-8 < yc[0, -1, 0] < 2e-7
+    # an initial state outside the feasible region is an input error (cvInitialSetup)
+    bad = orc.config(rtol=1e-4, atol=1e-7, constraints=[2.0, 0.0, 0.0])
+    _, stb, _ = orc.solve(bad, np.array([[0.0, 0.5, 0.5]]), ps, np.zeros(0), 0.0, tv[:3])
+    assert stb[0] == -22
