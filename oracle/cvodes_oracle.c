@@ -222,7 +222,9 @@ typedef struct {
     int np, cap;
     double *t;
     double *y;          /* [np][NS] */
+    double *yd;         /* [np][NS] y'(t) at the point (CV_HERMITE only) */
     int *order;
+    int hermite;        /* interpolation type: 0 = CV_POLYNOMIAL, 1 = CV_HERMITE */
     double tinitial, tfinal;
     /* interpolation cache (ca_mem->ca_ilast, ca_IMnewData, ca_T, ca_Y) */
     int ilast, newdata;
@@ -235,18 +237,20 @@ typedef struct {
     long n_interp, n_rebuild;
 } traj_t;
 
-static int traj_push(traj_t *tr, double t, const double *y, int order, int max_pts)
+static int traj_push(traj_t *tr, double t, const double *y, const double *yd, int order, int max_pts)
 {
     if (max_pts > 0 && tr->np >= max_pts) return -1;
     if (tr->np == tr->cap) {
         int ncap = tr->cap ? 2 * tr->cap : 128;
         tr->t = (double *)realloc(tr->t, sizeof(double) * ncap);
         tr->y = (double *)realloc(tr->y, sizeof(double) * ncap * NSD);
+        tr->yd = (double *)realloc(tr->yd, sizeof(double) * ncap * NSD);
         tr->order = (int *)realloc(tr->order, sizeof(int) * ncap);
         tr->cap = ncap;
     }
     tr->t[tr->np] = t;
     for (int i = 0; i < NS; i++) tr->y[(size_t)tr->np * NSD + i] = y[i];
+    for (int i = 0; i < NS; i++) tr->yd[(size_t)tr->np * NSD + i] = yd ? yd[i] : 0.0;
     tr->order[tr->np] = order;
     tr->np++;
     return 0;
@@ -303,6 +307,33 @@ static int traj_get_y(traj_t *tr, double t, double *y)
     tr->last_t = t;
     if (indx == 0) {
         for (int i = 0; i < NS; i++) y[i] = tr->last_y[i] = tr->y[i];
+        return CV_SUCCESS;
+    }
+    if (tr->hermite) {
+        /* CVAhermiteGetY: cubic Hermite on [t0, t1] = [t[indx-1], t[indx]] from y, y' at both ends;
+           Y[0] = y1 - y0 - delta y0',  Y[1] = delta (y1' + y0') - 2 (y1 - y0), rebuilt when the index moves */
+        const double t0 = tr->t[indx - 1], t1 = tr->t[indx];
+        const double delta = t1 - t0;
+        const double *y0 = tr->y + (size_t)(indx - 1) * NSD, *yd0 = tr->yd + (size_t)(indx - 1) * NSD;
+        if (newpoint) {
+            tr->n_rebuild++;
+            const double *y1 = tr->y + (size_t)indx * NSD, *yd1 = tr->yd + (size_t)indx * NSD;
+            for (int i = 0; i < NS; i++) {
+                const double dy = y1[i] - y0[i];
+                tr->Y[0][i] = FMA(-delta, yd0[i], dy);
+                tr->Y[1][i] = FMA(delta, yd1[i] + yd0[i], -2.0 * dy);
+            }
+        }
+        const double factor1 = t - t0;
+        double factor2 = factor1 / delta;
+        factor2 = factor2 * factor2;
+        const double factor3 = factor2 * (t - t1) / delta;
+        for (int i = 0; i < NS; i++) {
+            double acc = FMA(factor1, yd0[i], y0[i]);
+            acc = FMA(factor2, tr->Y[0][i], acc);
+            acc = FMA(factor3, tr->Y[1][i], acc);
+            y[i] = tr->last_y[i] = acc;
+        }
         return CV_SUCCESS;
     }
     double dt = fabs(tr->t[indx] - tr->t[indx - 1]);
@@ -1662,7 +1693,7 @@ typedef struct {
     int max_retries_fwd;    /* sunode: 5 */
     int max_retries_bwd;    /* sunode: 50 */
     int max_traj_points;    /* 0 = unbounded; mirrors the device arena capacity */
-    int constraints_set, pad;
+    int constraints_set, hermite;   /* hermite: CVodeAdjInit(..., CV_HERMITE) instead of CV_POLYNOMIAL */
     double constraints[NSD];    /* CVodeSetConstraints: 0 none, +-1 (>= / <= 0), +-2 (> / < 0); forward problem only */
 } orc_config;
 
@@ -1768,14 +1799,22 @@ static int solve_forward_one(const orc_config *cfg, const double *y0, const doub
     m->quadr = 0; m->errconQ = 0; m->mxstep = cfg->mxstep; m->tstopset = 0;
     m->constraints_set = cfg->constraints_set; for (int i = 0; i < NS; i++) m->constraints[i] = cfg->constraints[i];
     cv_reinit(m, t0, y0, NULL);
-    tr->np = 0; tr->n_interp = tr->n_rebuild = 0;
+    tr->np = 0; tr->n_interp = tr->n_rebuild = 0; tr->hermite = cfg->hermite;
     int status = CV_SUCCESS, first = 1;
     for (int k = 0; k < n_t && status == CV_SUCCESS; k++) {
         double tout = tvals[k];
         if (tout == t0) { for (int i = 0; i < NS; i++) y_out[(size_t)k * NS + i] = y0[i]; continue; }   /* solver.py:707, row k */
         if (first) {
             tr->tinitial = m->tn;
-            traj_push(tr, m->tn, m->zn[0], 0, 0);
+            tr->hermite = cfg->hermite;
+            if (cfg->hermite) {          /* CVAhermiteStorePnt at nst == 0: y' = f(t0, y0), evaluated outside the counters */
+                double yd0[NSD];
+                long keep = m->nfe;
+                if (cv_f(m, m->tn, m->zn[0], yd0) != 0) { status = CV_RHSFUNC_FAIL; m->nfe = keep; break; }
+                m->nfe = keep;
+                traj_push(tr, m->tn, m->zn[0], yd0, 0, 0);
+            } else
+            traj_push(tr, m->tn, m->zn[0], NULL, 0, 0);
             tr->tfinal = m->tn;
             first = 0;
         } else if ((m->tn - tout) * m->h >= 0.0) {
@@ -1785,7 +1824,9 @@ static int solve_forward_one(const orc_config *cfg, const double *y0, const doub
         for (;;) {
             int flag = cv_cvode_one_step(m, tout);
             if (flag < 0) { status = flag; break; }
-            if (traj_push(tr, m->tn, m->zn[0], m->qu, cfg->max_traj_points) != 0) { status = CV_TOO_MUCH_WORK; break; }
+            double ydp[NSD];            /* CVAhermiteStorePnt: y' = zn[1] / h */
+            for (int i = 0; i < NS; i++) ydp[i] = (1.0 / m->h) * m->zn[1][i];
+            if (traj_push(tr, m->tn, m->zn[0], cfg->hermite ? ydp : NULL, m->qu, cfg->max_traj_points) != 0) { status = CV_TOO_MUCH_WORK; break; }
             tr->tfinal = m->tn;
             if ((m->tn - tout) * m->h >= 0.0) {
                 cv_get_dky0(m, tout, y_out + (size_t)k * NS, NULL);
@@ -1893,7 +1934,7 @@ orc_batch *orc_batch_new(int B)
 void orc_batch_free(orc_batch *b)
 {
     if (!b) return;
-    for (int i = 0; i < b->B; i++) { free(b->traj[i].t); free(b->traj[i].y); free(b->traj[i].order); }
+    for (int i = 0; i < b->B; i++) { free(b->traj[i].t); free(b->traj[i].y); free(b->traj[i].yd); free(b->traj[i].order); }
     free(b->traj);
     free(b);
 }

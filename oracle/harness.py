@@ -64,7 +64,7 @@ def build_oracle_library(native_source: str, tag: Optional[str] = None, opt: str
 class OracleConfig:
     def __init__(self, n_states, rtol=1e-10, atol=1e-10, rtolB=1e-10, atolB=1e-10,
                  rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
-                 max_retries_bwd=50, max_traj_points=0, constraints=None):
+                 max_retries_bwd=50, max_traj_points=0, constraints=None, hermite=False):
         nsd = max(n_states, 1)
 
         class _Cfg(ctypes.Structure):
@@ -73,7 +73,7 @@ class OracleConfig:
                         ("rtolQB", ctypes.c_double), ("atolQB", ctypes.c_double),
                         ("mxstep", ctypes.c_int), ("max_retries_fwd", ctypes.c_int),
                         ("max_retries_bwd", ctypes.c_int), ("max_traj_points", ctypes.c_int),
-                        ("constraints_set", ctypes.c_int), ("pad", ctypes.c_int),
+                        ("constraints_set", ctypes.c_int), ("hermite", ctypes.c_int),
                         ("constraints", ctypes.c_double * nsd)]
         c = _Cfg()
         c.rtol = rtol
@@ -84,6 +84,7 @@ class OracleConfig:
         c.mxstep, c.max_retries_fwd, c.max_retries_bwd = mxstep, max_retries_fwd, max_retries_bwd
         c.max_traj_points = max_traj_points
         c.constraints_set = 0 if constraints is None else 1
+        c.hermite = 1 if hermite else 0
         if constraints is not None:
             for i, v in enumerate(np.broadcast_to(np.asarray(constraints, dtype=float), (n_states,))):
                 c.constraints[i] = float(v)

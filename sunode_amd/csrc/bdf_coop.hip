@@ -114,6 +114,10 @@ struct Cc {
     int ilast, newdata, have_last, cur_idx;
     double last_t, tlo, thi, tlo2;
     double *ltab;                     /* LDS copy of the current divided-difference table (per instance) */
+#ifdef SA_HERMITE                     /* CV_HERMITE: cubic on [t0,t1] from y, y' at both ends (own component) */
+    double h_t0, h_t1, h_y0, h_yd0, h_Y0, h_Y1;
+    double f0;                        /* f(t0, y0) of the first stored point */
+#endif
     int n_interp, n_rebuild;
 };
 
@@ -246,6 +250,34 @@ DEV int interp_y(Cc<BWD> &m, double t)
         m.ytmp = (m.li < NS) ? m.traj[8 + (m.li < NS ? m.li : 0)] : 0.0;      /* record 0: Y[0] = y(t0) */
         return CV_SUCCESS;
     }
+#ifdef SA_HERMITE
+    {
+        const int c = (m.li < NS) ? m.li : 0;
+        if (newpoint) {             /* CVAhermiteGetY: rebuild Y[0], Y[1] when the index moves (see the oracle) */
+            m.n_rebuild++;
+            m.cur_idx = indx;
+            const double *r0 = m.traj + (int64_t)(indx - 1) * m.trow, *r1 = m.traj + (int64_t)indx * m.trow;
+            m.h_t0 = r0[2]; m.h_t1 = r1[2];
+            const double delta = m.h_t1 - m.h_t0;
+            m.h_y0 = r0[8 + c]; m.h_yd0 = r0[8 + NS + c];
+            const double y1 = r1[8 + c], yd1 = r1[8 + NS + c];
+            const double dy = y1 - m.h_y0;
+            m.h_Y0 = FMA(-delta, m.h_yd0, dy);
+            m.h_Y1 = FMA(delta, yd1 + m.h_yd0, -2.0 * dy);
+            if (indx == m.ilast) m.tlo2 = (indx >= 2) ? point_time(m, indx - 2) : m.tlo;
+        }
+        const double delta = m.h_t1 - m.h_t0;
+        const double factor1 = t - m.h_t0;
+        double factor2 = factor1 / delta;
+        factor2 = factor2 * factor2;
+        const double factor3 = factor2 * (t - m.h_t1) / delta;
+        double acc = FMA(factor1, m.h_yd0, m.h_y0);
+        acc = FMA(factor2, m.h_Y0, acc);
+        acc = FMA(factor3, m.h_Y1, acc);
+        m.ytmp = (m.li < NS) ? acc : 0.0;
+        return CV_SUCCESS;
+    }
+#endif
     if (newpoint) {
         m.n_rebuild++;
         m.cur_idx = indx;
@@ -891,6 +923,9 @@ DEV int cv_first_call(Cc<BWD> &m, double tout)
     int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+#ifdef SA_HERMITE
+    m.f0 = m.zn[1];
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, m.zn[0], m.znQ[1]);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -1072,6 +1107,15 @@ DEV void accumulate_stats(const Cc<BWD> &m, int64_t *acc)
     acc[ST_NFQE] += m.nfQe; acc[ST_NETFQ] += m.netfQ;
 }
 
+#ifdef SA_HERMITE
+/* CV_HERMITE data point: {t, y, y'} in the slots r[2], r[8 + i], r[8 + n + i] of a record */
+DEV void store_hermite(double *r, int li, double t, double y, double yd)
+{
+    if (li == 0) { r[0] = 0.0; r[1] = 1.0; r[2] = t; }
+    if (li < NS) { r[8 + li] = y; r[8 + NS + li] = yd; }
+}
+#endif
+
 /* forward: trajectory record of the newest point (see bdf_kernels.hip::store_table) */
 DEV void store_table(double *r, int li, int order, double dt, const double (&hT)[QMAX + 1], const double (&hY)[QMAX + 1])
 {
@@ -1139,7 +1183,11 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         else if (store) {
             hT[0] = m.tn;
             hY[0] = m.zn[0];
+#ifdef SA_HERMITE
+            store_hermite(trec, m.li, m.tn, m.zn[0], m.f0);
+#else
             store_table(trec, m.li, 0, 1.0, hT, hY);
+#endif
             np = 1;
         }
     }
@@ -1166,7 +1214,11 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                         SFOR_DOWN(j, QMAX, 1) { hT[j] = hT[j - 1]; hY[j] = hY[j - 1]; } SEND
                         hT[0] = m.tn;
                         hY[0] = m.zn[0];
+#ifdef SA_HERMITE
+                        store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], (1.0 / m.h) * m.zn[1]);
+#else
                         store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+#endif
                         np++;
                     }
                 }

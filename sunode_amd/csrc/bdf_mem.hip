@@ -262,6 +262,35 @@ DEV int interp_y(Cm<BWD> &m, double t)
         for (int i = 0; i < NS; i++) W(m, O_YTMP, i) = rec(m, 0, 8 + i);
         return CV_SUCCESS;
     }
+#ifdef SA_HERMITE
+    {   /* CVAhermiteGetY (see the oracle); Y0 / Y1 of the interval live in O_HY[0..n) / O_HY[n..2n) */
+        const double t0 = rec(m, indx - 1, 2), t1 = rec(m, indx, 2);
+        const double delta = t1 - t0;
+        if (newpoint) {
+            m.n_rebuild++;
+            m.cur_idx = indx;
+            for (int i = 0; i < NS; i++) {
+                const double y0 = rec(m, indx - 1, 8 + i), yd0 = rec(m, indx - 1, 8 + NS + i);
+                const double y1 = rec(m, indx, 8 + i), yd1 = rec(m, indx, 8 + NS + i);
+                const double dy = y1 - y0;
+                W(m, O_HY, i) = FMA(-delta, yd0, dy);
+                W(m, O_HY, NS + i) = FMA(delta, yd1 + yd0, -2.0 * dy);
+            }
+            if (indx == m.ilast) m.tlo2 = (indx >= 2) ? point_time(m, indx - 2) : m.tlo;
+        }
+        const double factor1 = t - t0;
+        double factor2 = factor1 / delta;
+        factor2 = factor2 * factor2;
+        const double factor3 = factor2 * (t - t1) / delta;
+        for (int i = 0; i < NS; i++) {
+            double acc = FMA(factor1, rec(m, indx - 1, 8 + NS + i), rec(m, indx - 1, 8 + i));
+            acc = FMA(factor2, W(m, O_HY, i), acc);
+            acc = FMA(factor3, W(m, O_HY, NS + i), acc);
+            W(m, O_YTMP, i) = acc;
+        }
+        return CV_SUCCESS;
+    }
+#endif
     if (newpoint) {
         m.n_rebuild++;
         m.cur_idx = indx;
@@ -1115,6 +1144,9 @@ DEV int cv_first_call(Cm<BWD> &m, double tout)
     int retval = cv_f(m, m.tn, O_ZN, O_ZN + NS);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+#ifdef SA_HERMITE
+    if (!BWD) for (int i = 0; i < NS; i++) W(m, O_HY, 5 * NS + i) = ZN(m, 1, i);
+#endif
 #ifdef SA_SENS
     if (m.sensi) {
         retval = cv_fS(m, m.tn, O_ZN, O_ZNS, O_ZNS + NQ * NS);
@@ -1345,6 +1377,22 @@ DEV void store_table(Cm<BWD> &m, double *r, int64_t tS, int order, double dt, co
 #undef RF
 }
 
+#ifdef SA_HERMITE
+/* CV_HERMITE data point {t, y, y'}; y' = f(t0, y0) (kept in O_HY[5n..6n) by cv_first_call) for the first
+   point, zn[1] / h afterwards */
+template <bool BWD>
+DEV void store_hermite(Cm<BWD> &m, double *r, int64_t tS, double t, bool first)
+{
+    r[0] = 0.0;
+    r[(int64_t)1 * tS] = 1.0;
+    r[(int64_t)2 * tS] = t;
+    for (int i = 0; i < NS; i++) {
+        r[(int64_t)(8 + i) * tS] = ZN(m, 0, i);
+        r[(int64_t)(8 + NS + i) * tS] = first ? W(m, O_HY, 5 * NS + i) : (1.0 / m.h) * ZN(m, 1, i);
+    }
+}
+#endif
+
 /* ------------------------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
 {
@@ -1390,9 +1438,13 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         int flag = cv_first_call(m, a.tvals[k]);
         if (flag != CV_SUCCESS) { status = flag; done = true; }
         else if (store) {
+#ifdef SA_HERMITE
+            store_hermite(m, trec, tS, m.tn, true);
+#else
             hT[0] = m.tn;
             for (int i = 0; i < NS; i++) W(m, O_HY, i) = ZN(m, 0, i);
             store_table(m, trec, tS, 0, 1.0, hT);
+#endif
             np = 1;
         }
     }
@@ -1416,12 +1468,16 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                 if (store) {
                     if (np >= a.traj_cap) { status = CV_TOO_MUCH_WORK; done = true; }
                     else {
+#ifdef SA_HERMITE
+                        store_hermite(m, trec + (int64_t)np * TREC * tS, tS, m.tn, false);
+#else
                         SFOR_DOWN(j, QMAX, 1) hT[j] = hT[j - 1]; SEND
                         hT[0] = m.tn;
                         for (int j = QMAX; j >= 1; j--)
                             for (int i = 0; i < NS; i++) W(m, O_HY, j * NS + i) = W(m, O_HY, (j - 1) * NS + i);
                         for (int i = 0; i < NS; i++) W(m, O_HY, i) = ZN(m, 0, i);
                         store_table(m, trec + (int64_t)np * TREC * tS, tS, m.qu, fabs(hT[0] - hT[1]), hT);
+#endif
                         np++;
                     }
                 }

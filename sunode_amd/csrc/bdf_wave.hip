@@ -209,6 +209,9 @@ struct Cw {
     double last_t, tlo, thi, tlo2;
     double tab_hdr[8];                /* order, dt, T[6] */
     double tabY[QMAX + 1][RS];
+#ifdef SA_HERMITE
+    double f0[RS];                    /* f(t0, y0) of the first stored point */
+#endif
     int n_interp, n_rebuild;
 #ifdef SA_WAVE_PROFILE
     int64_t prof[8];                  /* 10 ns ticks: rhs, quad, jac, getrf, getrs, matrix copy */
@@ -357,6 +360,38 @@ DEV int interp_y(Cw<BWD> &m, double t)
         SFOR(r, 0, RS) m.ytmp[r] = (IDX(m, r) < NS) ? m.traj[8 + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND
         return CV_SUCCESS;
     }
+#ifdef SA_HERMITE
+    {   /* CVAhermiteGetY (see the oracle): tab_hdr[2..3] = t0, t1; tabY[0..3] = y0, y0', Y0, Y1 of the interval */
+        if (newpoint) {
+            m.n_rebuild++;
+            m.cur_idx = indx;
+            const double *r0 = m.traj + (int64_t)(indx - 1) * m.trow, *r1 = m.traj + (int64_t)indx * m.trow;
+            m.tab_hdr[2] = r0[2]; m.tab_hdr[3] = r1[2];
+            const double delta = m.tab_hdr[3] - m.tab_hdr[2];
+            SFOR(s, 0, RS) {
+                const int c = IDX(m, s) < NS ? IDX(m, s) : 0;
+                const double y0 = r0[8 + c], yd0 = r0[8 + NS + c], y1 = r1[8 + c], yd1 = r1[8 + NS + c];
+                const double dy = y1 - y0;
+                m.tabY[0][s] = y0; m.tabY[1][s] = yd0;
+                m.tabY[2][s] = FMA(-delta, yd0, dy);
+                m.tabY[3][s] = FMA(delta, yd1 + yd0, -2.0 * dy);
+            } SEND
+            if (indx == m.ilast) m.tlo2 = (indx >= 2) ? point_time(m, indx - 2) : m.tlo;
+        }
+        const double delta = m.tab_hdr[3] - m.tab_hdr[2];
+        const double factor1 = t - m.tab_hdr[2];
+        double factor2 = factor1 / delta;
+        factor2 = factor2 * factor2;
+        const double factor3 = factor2 * (t - m.tab_hdr[3]) / delta;
+        SFOR(s, 0, RS) {
+            double acc = FMA(factor1, m.tabY[1][s], m.tabY[0][s]);
+            acc = FMA(factor2, m.tabY[2][s], acc);
+            acc = FMA(factor3, m.tabY[3][s], acc);
+            m.ytmp[s] = (IDX(m, s) < NS) ? acc : 0.0;
+        } SEND
+        return CV_SUCCESS;
+    }
+#endif
     if (newpoint) {
         m.n_rebuild++;
         m.cur_idx = indx;
@@ -1234,6 +1269,9 @@ DEV int cv_first_call(Cw<BWD> &m, double tout)
     int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+#ifdef SA_HERMITE
+    SFOR(r, 0, RS) m.f0[r] = m.zn[1][r]; SEND
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, m.zn[0], m.znQ[1]);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -1433,6 +1471,18 @@ DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_st
     lds_sync();
 }
 
+#ifdef SA_HERMITE
+/* CV_HERMITE data point: {t, y, y'} in the slots rec[2], rec[8 + i], rec[8 + n + i] of a record */
+DEV void store_hermite(double *rec, int li, double t, const double (&y)[RS], const double (&yd)[RS])
+{
+    if (li == 0) { rec[0] = 0.0; rec[1] = 1.0; rec[2] = t; }
+    SFOR(r, 0, RS) {
+        const int i = r * G + li;
+        if (i < NS) { rec[8 + i] = y[r]; rec[8 + NS + i] = yd[r]; }
+    } SEND
+}
+#endif
+
 /* forward: trajectory record of the newest point (see bdf_kernels.hip::store_table) */
 DEV void store_table(double *rec, int lane, int order, double dt, const double (&hT)[QMAX + 1],
                      const double (&hY)[QMAX + 1][RS])
@@ -1509,7 +1559,11 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
         else if (store) {
             hT[0] = m.tn;
             SFOR(r, 0, RS) hY[0][r] = m.zn[0][r]; SEND
+#ifdef SA_HERMITE
+            store_hermite(trec, m.li, m.tn, m.zn[0], m.f0);
+#else
             store_table(trec, m.li, 0, 1.0, hT, hY);
+#endif
             np = 1;
         }
     }
@@ -1536,7 +1590,15 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
                         SFOR_DOWN(j, QMAX, 1) { hT[j] = hT[j - 1]; SFOR(s, 0, RS) hY[j][s] = hY[j - 1][s]; SEND } SEND
                         hT[0] = m.tn;
                         SFOR(s, 0, RS) hY[0][s] = m.zn[0][s]; SEND
+#ifdef SA_HERMITE
+                        {
+                            double ydp[RS];
+                            SFOR(s, 0, RS) ydp[s] = (1.0 / m.h) * m.zn[1][s]; SEND
+                            store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], ydp);
+                        }
+#else
                         store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+#endif
                         np++;
                     }
                 }

@@ -334,10 +334,9 @@ class AdjointSolver(_EngineMixin):
             raise ValueError(f"Unknown solver {adjoint_solver}.")
         if solver != "BDF" or adjoint_solver != "BDF":
             raise NotImplementedError("only the BDF method is implemented on the device")
-        if interpolation == "hermite":
-            raise NotImplementedError("only polynomial interpolation of the forward trajectory is implemented")
-        if interpolation != "polynomial":
+        if interpolation not in ("polynomial", "hermite"):
             raise ValueError(f"Unknown interpolation {interpolation}.")
+        self._hermite = interpolation == "hermite"
         if constraints is not None:           # forward problem only, as in the reference (solver.py:569-572)
             constraints = np.broadcast_to(np.asarray(constraints, dtype=np.float64), (problem.n_states,)).copy()
             if not np.isin(constraints, (0.0, 1.0, -1.0, 2.0, -2.0)).all():
@@ -351,14 +350,15 @@ class AdjointSolver(_EngineMixin):
         self._max_steps = int(min(max_steps, checkpoint_n + 1))
         self._device = device
         self._source = problem.native_source()
-        _native.build_code_object(self._source, constraints=self._constraints is not None)
+        _native.build_code_object(self._source, constraints=self._constraints is not None, hermite=self._hermite)
         self._native = None
         self._last_forward = None
 
     def _engine(self) -> _native.NativeSolver:
         if self._native is None:
             self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
-                                                constraints=self._constraints, **self._native_kwargs())
+                                                constraints=self._constraints, hermite=self._hermite,
+                                                **self._native_kwargs())
         return self._native
 
     def _set_tolerances(self, atol=None, rtol=None):

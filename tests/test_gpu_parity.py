@@ -427,6 +427,47 @@ def test_inequality_constraints_match_oracle(variant, monkeypatch):
     np.testing.assert_array_equal(ya[sta == 0], yao[sao == 0])
 
 
+@pytest.mark.parametrize("name,variant", [("lv", None), ("robertson", "16"), ("seir", None), ("seir", "wave"),
+                                          ("seir", "wave16"), ("seir", "mem")])
+def test_hermite_interpolation_matches_oracle(name, variant, monkeypatch):
+    """AdjointSolver(interpolation='hermite') (reference solver.py:581-582): Hermite builds of the
+    cooperative / wave / memory kernels (small systems use the cooperative one) against the oracle."""
+    from sunode_amd import _native
+    from sunode_amd.solver import AdjointSolver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem(name)
+    B = 37
+    if name == "lv":
+        d = lv_batch(B); ps, pr = d["params"][:, :2], d["params"][:, 2:]; rt, at = 1e-8, 1e-8
+        assert _native.kernel_variant(prob.native_source(), hermite=True) == ("bdf_coop.hip", 8)
+    elif name == "robertson":
+        d = robertson_batch(B); ps, pr = d["params"], np.zeros(0); rt, at = 1e-8, 1e-10
+    else:
+        B = 20
+        d = seir_batch(B); ps, pr = d["ps"], d["pr"]; rt, at = 1e-8, 1e-8
+    tv = d["tvals"]
+    n = prob.n_states
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(n)[None, :])
+    sol = AdjointSolver(prob, abstol=at, reltol=rt, backward_abstol=at, backward_reltol=rt, quad_abstol=at,
+                        quad_reltol=rt, interpolation="hermite", max_steps=2048)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle(name)
+    cfg = orc.config(rtol=rt, atol=at, rtolB=rt, atolB=at, rtolQB=rt, atolQB=at, hermite=True)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], ps, pr, 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (st == 0).all() and (stb == 0).all() and (so == 0).all() and (sbo == 0).all()
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(stats_b_cols(statsb), stats_b_cols(stbo))
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
+def stats_b_cols(stats):
+    return stats[:, CMP_B]
+
+
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
     orc = make_oracle(name)
     cfg = orc.config(**cfg_kw)

@@ -85,8 +85,8 @@ def test_unsupported_reference_options_raise():
         Solver(prob, linear_solver="spgmr")
     with pytest.raises(ValueError):
         Solver(prob, linear_solver="nope")
-    with pytest.raises(NotImplementedError):
-        AdjointSolver(prob, interpolation="hermite")
+    with pytest.raises(ValueError):
+        AdjointSolver(prob, interpolation="spline")
     with pytest.raises(ValueError):
         AdjointSolver(prob, adjoint_solver="RK4")
     with pytest.raises(ValueError):

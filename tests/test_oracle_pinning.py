@@ -223,3 +223,25 @@ def test_oracle_inequality_constraints_keep_robertson_physical():
     bad = orc.config(rtol=1e-4, atol=1e-7, constraints=[2.0, 0.0, 0.0])
     _, stb, _ = orc.solve(bad, np.array([[0.0, 0.5, 0.5]]), ps, np.zeros(0), 0.0, tv[:3])
     assert stb[0] == -22
+
+
+@pytest.mark.parametrize("tol,bar", [(1e-8, 4e-6), (1e-10, 1e-7)])
+def test_oracle_hermite_interpolation_gradients_match_truth(tol, bar, golden_dir):
+    """AdjointSolver(interpolation='hermite') (reference solver.py:581-582, CVodeAdjInit(CV_HERMITE)): cubic
+    Hermite interpolation of the stored forward trajectory; gradients within the same bars as the polynomial
+    variant, forward pass untouched."""
+    t = np.load(os.path.join(golden_dir, "truth_lv.npz"))
+    orc = make_oracle("lv")
+    res = {}
+    for hermite in (False, True):
+        cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol, hermite=hermite)
+        y, st, stats = orc.solve_forward(cfg, t["y0"], t["ps"], t["pr"], float(t["t0"]), t["tvals"])
+        g, lam, stb, statsb = orc.solve_backward(cfg, t["tvals"][-1], float(t["t0"]), t["tvals"], t["grads"])
+        assert (st == 0).all() and (stb == 0).all()
+        res[hermite] = (y, stats, g, lam)
+        scale = np.abs(t["grad_params"]).max(axis=1, keepdims=True)
+        assert np.max(np.abs(g - t["grad_params"]) / scale) < bar
+        assert np.max(np.abs(-lam - t["grad_y0"]) / np.abs(t["grad_y0"]).max(axis=1, keepdims=True)) < bar
+    np.testing.assert_array_equal(res[False][0], res[True][0])               # same forward solution
+    np.testing.assert_array_equal(res[False][1][:, :9], res[True][1][:, :9])
+    assert not np.array_equal(res[False][2], res[True][2])                   # different interpolants
