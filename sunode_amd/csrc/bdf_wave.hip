@@ -109,7 +109,24 @@ static __device__ __forceinline__ const SA_CONST_AS double *sa_uniform_const(con
 /* remaining parameters: broadcast global loads (all lanes read the same address; the vector memory
    pipe is otherwise idle during a callback and keeps dozens of loads in flight) */
 #define SA_PR(j) prg[j]
+#ifndef SA_WAVE_NO_PREFETCH
+/* A chunk function touches the parameter ranges it is about to read with ONE load per 8 KB (every lane a
+   different 128-byte line); the values are parked in sa_pf[] and only consumed by the epilogue, so nothing
+   waits for them -- but the statements' own broadcast loads then hit the L1 instead of paying the L2 latency
+   at the head of every statement. */
+static __device__ __forceinline__ double sa_touch(const gdouble *p, int n)
+{
+    const int k = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16;
+    return p[k < n ? k : 0];
+}
+#define SA_PROLOGUE SA_LDS_VIEWS const gdouble *prg = (const gdouble *)pr; \
+    double sa_pf[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; (void)sa_pf;
+#define SA_PREFETCH_PR(k, lo, hi) sa_pf[k] = sa_touch(prg + (lo), (hi) - (lo) + 1)
+#define SA_EPILOGUE asm volatile("" :: "v"(sa_pf[0]), "v"(sa_pf[1]), "v"(sa_pf[2]), "v"(sa_pf[3]), \
+                                 "v"(sa_pf[4]), "v"(sa_pf[5]), "v"(sa_pf[6]), "v"(sa_pf[7]));
+#else
 #define SA_PROLOGUE SA_LDS_VIEWS const gdouble *prg = (const gdouble *)pr;
+#endif
 #endif
 #ifndef SA_WAVE_NO_SCHED_BARRIER
 /* keep the instruction scheduler from hoisting the loads of later statements over earlier ones:

@@ -35,6 +35,7 @@ pytensor Ops pass around, ``wrappers/as_pytensor.py:86-106``).
 from __future__ import annotations
 
 import hashlib
+import re
 from itertools import count
 from typing import Optional,  Dict, Iterable, List, Sequence, Tuple
 
@@ -80,6 +81,14 @@ HELPERS_C = r"""
 /* after every output statement (kernels with huge callbacks fence the instruction scheduler here) */
 #ifndef SA_STMT_END
 #define SA_STMT_END
+#endif
+/* chunk functions name the slots lo..hi of the remaining-parameter vector they are about to read */
+#ifndef SA_PREFETCH_PR
+#define SA_PREFETCH_PR(k, lo, hi)     /* k = 0..7: ordinal of the range within the function */
+#endif
+/* last statement of every callback body before the return */
+#ifndef SA_EPILOGUE
+#define SA_EPILOGUE
 #endif
 /* first statement of every callback body (the wave kernel derives a scalar-load view of pr here) */
 #ifndef SA_PROLOGUE
@@ -219,6 +228,12 @@ CHUNK_STATEMENTS = 400
 #: ... and callbacks with more generated text than this are split into up to MAX_COST_CHUNKS chunks
 CHUNK_COST = 24000
 MAX_COST_CHUNKS = 16
+#: chunk functions announce the remaining-parameter ranges they read (SA_PREFETCH_PR): indices closer than
+#: PREFETCH_GAP are one range, ranges shorter than PREFETCH_MIN are not worth a touch
+PREFETCH_GAP = 16
+PREFETCH_MIN = 32
+PREFETCH_MAX_RANGES = 8
+PREFETCH_PIECE = 1024          # doubles covered by one touch (64 lanes x one 128-byte line)
 
 
 def _closure(needed, deps, order):
@@ -267,9 +282,29 @@ def emit_function(
     # `out[slot] = value`; the cooperative kernel (one lane per state component) keeps only the
     # slots a lane owns.  x*0.0 is (+-)0 for finite x and NaN for inf/nan: the finiteness check is
     # straight-line on purpose (constant subscripts only, see bdf_kernels.hip on scalar replacement).
-    def body(slots, temps):
+    def body(slots, temps, prefetch=False):
         lines = ["    SA_PROLOGUE"]
-        lines += ["    const double %s = %s; SA_STMT_END" % (tname, temp_text[tname]) for tname in temps]
+        stmts = ["    const double %s = %s; SA_STMT_END" % (tname, temp_text[tname]) for tname in temps]
+        if prefetch:
+            # remaining-parameter slots this chunk reads, as a few contiguous ranges: a kernel may touch them
+            # up front so that the statements' own loads hit the cache (SA_PREFETCH_PR)
+            text = "".join(stmts) + "".join(written.get(slot, "") for slot in slots)
+            idx = sorted({int(k) for k in re.findall(r"SA_PR\((\d+)\)", text)})
+            ranges = []
+            for k in idx:
+                if ranges and k - ranges[-1][1] <= PREFETCH_GAP:
+                    ranges[-1][1] = k
+                else:
+                    ranges.append([k, k])
+            pieces = []
+            for lo, hi in ranges:
+                if hi - lo < PREFETCH_MIN:
+                    continue
+                for start in range(lo, hi + 1, PREFETCH_PIECE):
+                    pieces.append((start, min(start + PREFETCH_PIECE - 1, hi)))
+            if len(pieces) <= PREFETCH_MAX_RANGES:
+                lines += ["    SA_PREFETCH_PR(%d, %d, %d);" % (k, lo, hi) for k, (lo, hi) in enumerate(pieces)]
+        lines += stmts
         lines.append("    double chk = 0.0;")
         for slot in slots:
             text = written.get(slot, "0.0")
@@ -279,6 +314,7 @@ def emit_function(
                 lines.append("    { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; } SA_STMT_END"
                              % (text, slot))
         lines.append("    (void)t; (void)y; (void)ps; (void)pr; (void)out;")
+        lines.append("    SA_EPILOGUE")
         lines.append("    return (chk == 0.0) ? 0 : 1;")
         return lines
 
@@ -317,7 +353,7 @@ def emit_function(
         needed = [u for slot in slots for u in uses.get(slot, [])]
         cname = "%s_c%d" % (name, c)
         parts.append("\n".join(["SA_TEMPLATE SA_FN int %s(%s) {" % (cname, signature)]
-                               + body(slots, _closure(needed, temp_deps, temp_order)) + ["}"]))
+                               + body(slots, _closure(needed, temp_deps, temp_order), prefetch=True) + ["}"]))
         calls.append("    SA_CHUNK_CALL(%d, %s(%s));" % (c, cname, call_args))
     parts.append("\n".join(["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature), "    int bad = 0;"]
                            + calls + ["    return bad;", "}"]))
