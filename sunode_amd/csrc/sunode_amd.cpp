@@ -172,7 +172,11 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
             return fail(SA_ERR_MODULE, "%s: kernel %s not found", path, names[i]);
         }
     }
-    if (hipModuleGetFunction(&s->k_sens, s->module, "sa_k_sens") != hipSuccess) s->k_sens = nullptr;
+    if (hipModuleGetFunction(&s->k_sens, s->module, "sa_k_sens") != hipSuccess) {
+        s->k_sens = nullptr;
+        (void)hipGetLastError();     /* the optional kernel is absent: do not leave hipErrorNotFound behind for
+                                        other users of the runtime in this process (PyTorch checks it) */
+    }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipModuleUnload(s->module);
         delete s;
