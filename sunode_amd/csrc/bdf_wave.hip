@@ -81,7 +81,11 @@ enum { CMD_EXIT = 0, CMD_RHS = 1, CMD_QUAD = 2, CMD_JAC = 3, CMD_GETRF = 4 };
 static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 #define SA_CHUNK_CALL(c, call) do { if (((c) % s_nwaves) == sa_wave_index()) bad |= call; } while (0)
 
+#ifdef SA_WAVE_INLINE_CALLBACKS      /* small callbacks: no call ABI between the integrator state and the callback */
+#define SA_FN static __device__ __forceinline__
+#else
 #define SA_FN static __device__ __attribute__((noinline))
+#endif
 #define SA_TEMPLATE template <class SinkT>
 #define SA_OUT_T SinkT
 #define SA_STORE(slot, value) out.template put<(slot)>(value)
