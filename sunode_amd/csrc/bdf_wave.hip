@@ -135,7 +135,14 @@ static __device__ __forceinline__ double sa_touch(const gdouble *p, int n)
 #ifndef SA_WAVE_NO_SCHED_BARRIER
 /* keep the instruction scheduler from hoisting the loads of later statements over earlier ones:
    with thousands of independent statements that ends in tens of KB of spills */
+#ifdef SA_WAVE_NO_MEM_CLOBBER
 #define SA_STMT_END __builtin_amdgcn_sched_barrier(0);
+#else
+/* ... and a compiler-level memory barrier: without it the LDS reads of the state (and of the adjoint state)
+   are kept in registers across ALL statements of a chunk -- 2 x 100 doubles at n = 100 -- and the allocator
+   spills them to scratch; re-reading LDS per statement is far cheaper */
+#define SA_STMT_END asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
 
 #include SA_PROBLEM_HEADER
@@ -569,7 +576,10 @@ DEV int cv_jac(Cw<BWD> &m, double t, const double (&ymine)[RS])        /* Jacobi
 
 /* ---- row-distributed dense LU in LDS (denseGETRF / denseGETRS semantics) ---- */
 #define AL(i, j) s_A[g.abase + (j) * NS + (i)]
+#ifndef LU_BATCH
 #define LU_BATCH 8
+#endif
+#define GETRS_DEPTH 4
 
 /* barrier between the phases of an elimination step: the workgroup when worker wavefronts take part,
    otherwise the LDS ordering of the (possibly diverged) wavefront */
@@ -712,20 +722,45 @@ DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
         SFOR(r, 0, RS) { if (IDX(m, r) < NS) b[r] = s_lam[m.vbase + IDX(m, r)]; } SEND
         lds_sync();
     }
-    for (int k = 0; k < NS - 1; k++) {
-        const double bk = bcast_vec(b, k, m.gbase);
-        SFOR(r, 0, RS) {
-            const int i = IDX(m, r);
-            if (i > k && i < NS) b[r] = FMA(-AL(i, k), bk, b[r]);
+    /* The chain through b is inherently serial (one broadcast + one FMA per step); the matrix column of the
+       NEXT step does not depend on it, so it is fetched from LDS one step ahead (GETRS_DEPTH columns in
+       flight) instead of inside the dependent chain. */
+    {
+        double col[GETRS_DEPTH][RS];
+        SFOR(d, 0, GETRS_DEPTH) {
+            SFOR(r, 0, RS) { const int i = IDX(m, r); col[d][r] = (d < NS - 1 && i > d && i < NS) ? AL(i, d) : 0.0; } SEND
         } SEND
-    }
-    for (int k = NS - 1; k > 0; k--) {
-        SFOR(r, 0, RS) { if (IDX(m, r) == k) b[r] *= m.inv_piv[r]; } SEND
-        const double bk = bcast_vec(b, k, m.gbase);
-        SFOR(r, 0, RS) {
-            const int i = IDX(m, r);
-            if (i < k) b[r] = FMA(-AL(i, k), bk, b[r]);
+        for (int k0 = 0; k0 < NS - 1; k0 += GETRS_DEPTH) {
+            SFOR(d, 0, GETRS_DEPTH) {
+                const int k = k0 + d;
+                if (k < NS - 1) {
+                    double cur[RS];
+                    SFOR(r, 0, RS) cur[r] = col[d][r]; SEND
+                    const int kn = k + GETRS_DEPTH;          /* refill this slot with the column GETRS_DEPTH ahead */
+                    SFOR(r, 0, RS) { const int i = IDX(m, r); col[d][r] = (kn < NS - 1 && i > kn && i < NS) ? AL(i, kn) : 0.0; } SEND
+                    const double bk = bcast_vec(b, k, m.gbase);
+                    SFOR(r, 0, RS) { const int i = IDX(m, r); if (i > k && i < NS) b[r] = FMA(-cur[r], bk, b[r]); } SEND
+                }
+            } SEND
+        }
+        SFOR(d, 0, GETRS_DEPTH) {
+            const int k = NS - 1 - d;
+            SFOR(r, 0, RS) { const int i = IDX(m, r); col[d][r] = (k > 0 && i < k) ? AL(i, k) : 0.0; } SEND
         } SEND
+        for (int k0 = NS - 1; k0 > 0; k0 -= GETRS_DEPTH) {
+            SFOR(d, 0, GETRS_DEPTH) {
+                const int k = k0 - d;
+                if (k > 0) {
+                    double cur[RS];
+                    SFOR(r, 0, RS) cur[r] = col[d][r]; SEND
+                    const int kn = k - GETRS_DEPTH;
+                    SFOR(r, 0, RS) { const int i = IDX(m, r); col[d][r] = (kn > 0 && i < kn) ? AL(i, kn) : 0.0; } SEND
+                    SFOR(r, 0, RS) { if (IDX(m, r) == k) b[r] *= m.inv_piv[r]; } SEND
+                    const double bk = bcast_vec(b, k, m.gbase);
+                    SFOR(r, 0, RS) { const int i = IDX(m, r); if (i < k) b[r] = FMA(-cur[r], bk, b[r]); } SEND
+                }
+            } SEND
+        }
     }
     if (m.li == 0) b[0] *= m.inv_piv[0];
     PROF_ADD(m, 4)

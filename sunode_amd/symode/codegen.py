@@ -227,7 +227,7 @@ class HipExprPrinter(C99CodePrinter):
 CHUNK_STATEMENTS = 400
 #: ... and callbacks with more generated text than this are split into up to MAX_COST_CHUNKS chunks
 CHUNK_COST = 24000
-MAX_COST_CHUNKS = 16
+MAX_COST_CHUNKS = 4
 #: chunk functions announce the remaining-parameter ranges they read (SA_PREFETCH_PR): indices closer than
 #: PREFETCH_GAP are one range, ranges shorter than PREFETCH_MIN are not worth a touch
 PREFETCH_GAP = 16
