@@ -468,45 +468,60 @@ def stats_b_cols(stats):
     return stats[:, CMP_B]
 
 
+_TORCH_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+from sunode_amd import _native
+from sunode_amd.solver import AdjointSolver
+from tests.helpers import make_problem
+from tools.problems import lv_batch
+
+prob = make_problem("lv")
+d = lv_batch(300)
+ps = d["params"][:, prob.params_subset.subset_index]
+pr = d["params"][:, prob.params_subset.remainder_index]
+dev = torch.device("cuda", 0)
+tol = 1e-8
+tv = d["tvals"]
+n_t = len(tv)
+t = {k: torch.tensor(np.ascontiguousarray(v), device=dev) for k, v in dict(ps=ps, pr=pr, y0=d["y0"], tvals=tv).items()}
+grads = torch.ones((n_t, 2), dtype=torch.float64, device=dev)
+y_out = torch.empty((300, n_t, 2), dtype=torch.float64, device=dev)
+g_out = torch.empty((300, 2), dtype=torch.float64, device=dev)
+l_out = torch.empty((300, 2), dtype=torch.float64, device=dev)
+st_f = torch.empty(300, dtype=torch.int32, device=dev); st_b = torch.empty(300, dtype=torch.int32, device=dev)
+sf = torch.empty((300, 16), dtype=torch.int64, device=dev); sb = torch.empty((300, 16), dtype=torch.int64, device=dev)
+eng = _native.NativeSolver(prob.native_source(), device=0, rtol=tol, atol=tol, rtolB=tol, atolB=tol,
+                           rtolQB=tol, atolQB=tol, traj_capacity=512, n_states=2)
+torch.cuda.synchronize()                          # raises if solver creation left an error behind
+eng.solve(_native.SA_MEM_DEVICE, 300, t["y0"], t["ps"], t["pr"], 2, 0.0, t["tvals"], n_t, y_out, st_f, sf, adjoint=True)
+eng.solve_backward(_native.SA_MEM_DEVICE, 300, t["ps"], t["pr"], 2, float(tv[-1]), 0.0, t["tvals"], n_t, grads, 0,
+                   g_out, l_out, st_b, sb)
+eng.synchronize()
+assert int((st_f != 0).sum().item()) == 0 and int((st_b != 0).sum().item()) == 0
+assert np.isfinite(float((y_out.sum() + g_out.sum()).item()))
+torch.cuda.synchronize()
+host = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol, quad_abstol=tol,
+                     quad_reltol=tol, max_steps=512)
+y, _, _ = host.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+g, lam, _, _ = host.solve_backward_batch(tv[-1], 0.0, tv, np.ones((n_t, 2)))
+assert np.array_equal(y_out.cpu().numpy(), y)
+assert np.array_equal(g_out.cpu().numpy(), g) and np.array_equal(l_out.cpu().numpy(), lam)
+print("TORCH_PATH_OK")
+"""
+
+
 def test_device_resident_buffers_with_torch():
     """The path bench.py times: torch-ROCm tensors in, tensors out (SA_MEM_DEVICE), PyTorch kernels on the
-    same device before and after.  The library must not leave a HIP error behind for PyTorch to trip over,
-    and the results must equal the host-buffer path."""
-    import torch
-    from sunode_amd import _native
-    from sunode_amd.solver import AdjointSolver
-    prob, d, ps, pr = _lv_inputs(300)
-    dev = torch.device("cuda", 0)
-    tol = 1e-8
-    tv = d["tvals"]
-    n_t = len(tv)
-    t = {k: torch.tensor(np.ascontiguousarray(v), device=dev) for k, v in
-         dict(ps=ps, pr=pr, y0=d["y0"], tvals=tv).items()}
-    grads = torch.ones((n_t, 2), dtype=torch.float64, device=dev)
-    y_out = torch.empty((300, n_t, 2), dtype=torch.float64, device=dev)
-    g_out = torch.empty((300, 2), dtype=torch.float64, device=dev)
-    l_out = torch.empty((300, 2), dtype=torch.float64, device=dev)
-    st_f = torch.empty(300, dtype=torch.int32, device=dev); st_b = torch.empty(300, dtype=torch.int32, device=dev)
-    sf = torch.empty((300, 16), dtype=torch.int64, device=dev); sb = torch.empty((300, 16), dtype=torch.int64, device=dev)
-    eng = _native.NativeSolver(prob.native_source(), device=0, rtol=tol, atol=tol, rtolB=tol, atolB=tol,
-                               rtolQB=tol, atolQB=tol, traj_capacity=512, n_states=2)
-    torch.cuda.synchronize()                          # raises if solver creation left an error behind
-    eng.solve(_native.SA_MEM_DEVICE, 300, t["y0"], t["ps"], t["pr"], 2, 0.0, t["tvals"], n_t, y_out, st_f, sf,
-              adjoint=True)
-    eng.solve_backward(_native.SA_MEM_DEVICE, 300, t["ps"], t["pr"], 2, float(tv[-1]), 0.0, t["tvals"], n_t, grads,
-                       0, g_out, l_out, st_b, sb)
-    eng.synchronize()
-    assert int((st_f != 0).sum().item()) == 0 and int((st_b != 0).sum().item()) == 0
-    total = float((y_out.sum() + g_out.sum()).item())
-    assert np.isfinite(total)
-    torch.cuda.synchronize()
-    host = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol, quad_abstol=tol,
-                         quad_reltol=tol, max_steps=512)
-    y, _, _ = host.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
-    g, lam, _, _ = host.solve_backward_batch(tv[-1], 0.0, tv, np.ones((n_t, 2)))
-    np.testing.assert_array_equal(y_out.cpu().numpy(), y)
-    np.testing.assert_array_equal(g_out.cpu().numpy(), g)
-    np.testing.assert_array_equal(l_out.cpu().numpy(), lam)
+    same device before and after -- in a fresh process, like bench.py.  The library must not leave a HIP error
+    behind for PyTorch to trip over, and the results must equal the host-buffer path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _TORCH_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "TORCH_PATH_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
 
 
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
