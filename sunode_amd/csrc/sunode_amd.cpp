@@ -197,7 +197,7 @@ extern "C" void sa_solver_destroy(sa_solver *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     DevBuf *bufs[] = {&s->d_atol, &s->traj, &s->traj_np, &s->fwd_status, &s->s_y0,
                       &s->s_ps, &s->s_pr, &s->s_tvals, &s->s_yout, &s->s_status, &s->s_stats, &s->s_grads,
-                      &s->s_gout, &s->s_lout};
+                      &s->s_gout, &s->s_lout, &s->ws, &s->d_constraints};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : s->s_misc) b.release();
     for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
