@@ -182,10 +182,15 @@ class Solver(_EngineMixin):
             if solver == "ADAMS":
                 raise NotImplementedError("only the BDF method is implemented on the device")
             raise ValueError(f"Unknown solver {solver}.")
-        if linear_solver != "dense":
-            if linear_solver in ("dense_finitediff", "spgmr", "spgmr_finitediff", "band"):
-                raise NotImplementedError("the device integrator always uses dense LU with the analytic Jacobian")
+        if linear_solver not in ("dense", "dense_finitediff", "spgmr", "spgmr_finitediff", "band"):
             raise ValueError(f"Unknown linear solver: {linear_solver}")
+        if linear_solver != "dense":
+            # The reference offers these as alternative ways to solve the same Newton systems (solver.py:326-358).
+            # The device integrator has one: dense LU of I - gamma*J with the analytic Jacobian.  The option is
+            # accepted so that reference code runs unchanged; results agree to the integration tolerance.
+            import warnings
+            warnings.warn(f"linear_solver={linear_solver!r}: the MI355X integrator always uses dense LU with the "
+                          "analytic Jacobian", RuntimeWarning, stacklevel=2)
         if constraints is not None:
             constraints = np.broadcast_to(np.asarray(constraints, dtype=np.float64), (problem.n_states,)).copy()
             if not np.isin(constraints, (0.0, 1.0, -1.0, 2.0, -2.0)).all():

@@ -524,6 +524,58 @@ def test_device_resident_buffers_with_torch():
     assert res.returncode == 0 and "TORCH_PATH_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
 
 
+def _check_call_solve(solver, params, deriv):
+    """The reference's own helper (sunode/test_solve.py:81-117), reference call shapes."""
+    solver.set_params_dict(params)
+    time = np.linspace(0, 1)
+    if deriv == "forward":
+        y_buffer, sense_buffer = solver.make_output_buffers(time)
+        solver.solve(0, time, np.ones_like(y_buffer[0]), y_buffer, sens0=np.zeros_like(sense_buffer[0]),
+                     sens_out=sense_buffer)
+        return time, y_buffer, sense_buffer
+    if deriv == "backward":
+        y_buffer, grads_buffer, lamda_buffer = solver.make_output_buffers(time)
+        solver.solve_forward(0, time, np.ones_like(y_buffer[0]), y_buffer)
+        grads = np.ones((len(time), y_buffer.shape[-1]))
+        solver.solve_backward(time[-1], time[0], time, grads, grads_buffer, lamda_buffer)
+        return time, y_buffer, grads_buffer, lamda_buffer
+    y_buffer = solver.make_output_buffers(time)
+    solver.solve(0, time, np.ones_like(y_buffer[0]), y_buffer)
+    return time, y_buffer
+
+
+def test_reference_test_declare_sens_and_linear_solver_kwarg():
+    """sunode/test_solve.py:120-181 run against the device engine, plus the analytic answers the reference
+    does not check: x' = x + b, x(0) = 1  ->  x = (1 + b) e^t - b, dx/db = e^t - 1, dL/db = sum_k (e^{t_k} - 1)."""
+    import warnings
+    from sunode_amd import SympyProblem
+    from sunode_amd.solver import AdjointSolver, Solver
+
+    def rhs(t, y, p):
+        return {"x": y.x + p.a.b}
+
+    problem = SympyProblem({"a": {"b": ()}}, {"x": ()}, rhs, derivative_params=[("a", "b")])
+    vals = {"a": {"b": 0.2}}
+    for mode in ("simultaneous", "staggered"):
+        t, y, sens = _check_call_solve(Solver(problem, sens_mode=mode), vals, "forward")
+        np.testing.assert_allclose(y[:, 0], 1.2 * np.exp(t) - 0.2, rtol=1e-8)
+        np.testing.assert_allclose(sens[:, 0, 0], np.exp(t) - 1.0, rtol=1e-7, atol=1e-9)
+    t, y = _check_call_solve(Solver(problem), vals, None)
+    np.testing.assert_allclose(y[:, 0], 1.2 * np.exp(t) - 0.2, rtol=1e-8)
+    t, y, g, lam = _check_call_solve(AdjointSolver(problem), vals, "backward")
+    np.testing.assert_allclose(g[0], np.sum(np.exp(t) - 1.0), rtol=1e-7)
+    np.testing.assert_allclose(-lam[0], np.sum(np.exp(t)), rtol=1e-7)         # dL/dx(0)
+
+    problem2 = SympyProblem({"b": ()}, {"x": ()}, lambda t, y, p: {"x": y.x}, derivative_params=[])
+    for linear_solver in ["dense", "dense_finitediff", "spgmr_finitediff", "spgmr", "band"]:
+        kw = {"upper_bandwidth": 1, "lower_bandwidth": 1} if linear_solver == "band" else {}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            solver = Solver(problem2, linear_solver=linear_solver, linear_solver_kwargs=kw)
+        t, y = _check_call_solve(solver, {"b": 0.2}, None)
+        np.testing.assert_allclose(y[:, 0], np.exp(t), rtol=1e-8)
+
+
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
     orc = make_oracle(name)
     cfg = orc.config(**cfg_kw)

@@ -81,8 +81,8 @@ def test_unsupported_reference_options_raise():
         Solver(prob, sens_mode="bogus")
     with pytest.raises(NotImplementedError):
         Solver(prob, solver="ADAMS")
-    with pytest.raises(NotImplementedError):
-        Solver(prob, linear_solver="spgmr")
+    with pytest.warns(RuntimeWarning):
+        Solver(prob, linear_solver="spgmr")      # accepted like the reference, served by the dense analytic path
     with pytest.raises(ValueError):
         Solver(prob, linear_solver="nope")
     with pytest.raises(ValueError):
