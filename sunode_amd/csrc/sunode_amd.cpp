@@ -294,7 +294,6 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
     if (!s) return fail(SA_ERR_ARG, "null solver");
     if (B < 0 || n_t < 0) return fail(SA_ERR_ARG, "negative size");
     if (rem_stride != 0 && rem_stride != s->r) return fail(SA_ERR_ARG, "rem_stride must be 0 or n_rem=%d", s->r);
-    if (s->r > 32 && rem_stride != 0 && mem == SA_MEM_HOST && false) return fail(SA_ERR_ARG, "unreachable");
     HIP_TRY(hipSetDevice(s->device));
     if (B == 0 || n_t == 0) return SA_OK;
     const size_t nB = (size_t)B;
