@@ -150,7 +150,7 @@ static __device__ __forceinline__ double sa_touch(const gdouble *p, int n)
 #include "sa_common.h"
 
 static_assert(NS == W_NS && NQ == W_NQ, "SA_BUILD_NS / SA_BUILD_NQ do not match the generated header");
-static_assert(NS <= 2 * G && NQ <= 2 * G && NS >= 1 && NS <= 128, "at most two register slots per vector");
+static_assert(NS <= 8 * G && NQ <= 8 * G && NS >= 1 && NS <= 128, "at most eight register slots per vector");
 
 #define RS ((NS + G - 1) / G)                  /* register slots of a state vector */
 #define RQ (NQ > 0 ? (NQ + G - 1) / G : 1)     /* register slots of a quadrature vector */
@@ -256,6 +256,18 @@ struct Cw {
 
 #define IDX(m, r) ((r) * G + (m).li)
 
+/* pairwise (balanced-tree) sum of P = 2^k slot totals */
+template <int P>
+DEV double slot_tree(const double (&s)[P])
+{
+    if constexpr (P == 1) return s[0];
+    else {
+        double half[P / 2];
+        SFOR(i, 0, P / 2) half[i] = s[2 * i] + s[2 * i + 1]; SEND
+        return slot_tree<P / 2>(half);
+    }
+}
+
 /* sum over all lanes and slots: xor-butterfly per slot, then the slot totals pairwise */
 template <int NSLOT>
 DEV double wave_sum(int lane, const double (&v)[NSLOT])
@@ -271,9 +283,7 @@ DEV double wave_sum(int lane, const double (&v)[NSLOT])
             s[r] = 0.0;
         }
     } SEND
-    if constexpr (P == 1) return s[0];
-    else if constexpr (P == 2) return s[0] + s[1];
-    else { static_assert(P <= 2, "more than two slots: extend the slot tree"); return 0.0; }
+    return slot_tree<P>(s);
 }
 
 DEV double wave_max(int lane, double x)

@@ -294,11 +294,11 @@ def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("variant", ["mem", "wave", "wave16", "wave32"])
+@pytest.mark.parametrize("variant", ["16", "mem", "wave", "wave4", "wave16", "wave32"])
 def test_seir_large_system_mappings_vs_oracle(variant, monkeypatch):
-    """SEIR (n = 16, 16 shared fixed parameters) through the kernels meant for large systems
-    (memory-resident / wavefront-per-instance): bit-exact against the oracle like the
-    cooperative build."""
+    """SEIR (n = 16, 16 shared fixed parameters; the engine's own choice is bdf_wave.hip with 8 lanes per
+    instance) through the other mappings: cooperative with 16 lanes, memory-resident, wavefront-per-instance,
+    4 / 16 / 32 lanes per instance: all bit-exact against the oracle."""
     from sunode_amd.solver import AdjointSolver
     monkeypatch.setenv("SA_FORCE_GROUP", variant)
     prob = make_problem("seir")

@@ -49,6 +49,22 @@ def main():
         g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
         wall = time.perf_counter() - t0
         f, b = sol._engine().last_kernel_ms()
+    if "--cpu" in sys.argv:
+        # the CPU oracle on the box's host cores, same workload, bounded sample (the checker timed as a baseline)
+        from oracle.harness import Oracle
+        from bench import usable_cores
+        nc = usable_cores()
+        ns = {"lv": 65536, "robertson": 16384, "seir": 2048, "network100": 64}[name]
+        ds = {"lv": lv_batch, "robertson": robertson_batch, "seir": seir_batch, "network100": network_batch}[name](ns)
+        ps_s, pr_s = (ds["params"][:, :2], ds["params"][:, 2:]) if name == "lv" else \
+            ((ds["params"], np.zeros(0)) if name == "robertson" else (ds["ps"], ds["pr"]))
+        orc = Oracle(prob, tag=name, opt="-O1" if name == "network100" else "-O2")
+        cfg = orc.config(rtol=rt, atol=at, rtolB=rt, atolB=at, rtolQB=rt, atolQB=at)
+        t1 = time.perf_counter()
+        orc.solve_forward(cfg, ds["y0"], ps_s, pr_s, 0.0, tv, nthreads=nc)
+        orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=nc)
+        cpu = time.perf_counter() - t1
+        print("%s CPU oracle: %d instances in %.2f s on %d cores -> %.3g solves/s" % (name, ns, cpu, nc, ns / cpu))
     print("%s B=%d: fwd kernel %.2f ms, bwd kernel %.2f ms, wall (host arrays) %.1f ms -> %.3g solves/s (kernels), "
           "failed %d/%d, fwd steps %.0f, bwd steps %.0f, bwd wave-iters %.0f"
           % (name, B, f, b, 1e3 * wall, B / ((f + b) * 1e-3), int((st != 0).sum()), int((stb != 0).sum()),

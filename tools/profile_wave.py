@@ -1,6 +1,6 @@
 """Section timers of the wavefront-per-instance kernel (SA_KERNEL_DEFINES=-DSA_WAVE_PROFILE builds).
 
-python tools/profile_wave.py <B> [generated-header]     (10 ns ticks from stats slots 9..15)
+python tools/profile_wave.py <B> [generated-header | seir]     (10 ns ticks from stats slots 9..15)
 """
 import os
 import sys
@@ -16,13 +16,19 @@ from tools.problems import network100, network_batch  # noqa: E402
 
 def main():
     B = int(sys.argv[1])
-    s = network100()
-    prob = SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
-    if len(sys.argv) > 2:
-        prob._native_source = open(sys.argv[2]).read()
-    d = network_batch(B)
+    if len(sys.argv) > 2 and sys.argv[2] == "seir":
+        from tools.problems import PROBLEMS, seir_batch
+        s = PROBLEMS["seir"]
+        prob = SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
+        d = seir_batch(B)
+    else:
+        s = network100()
+        prob = SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
+        if len(sys.argv) > 2:
+            prob._native_source = open(sys.argv[2]).read()
+        d = network_batch(B)
     tv = d["tvals"]
-    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(100)[None, :])
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(prob.n_states)[None, :])
     sol = AdjointSolver(prob, abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8,
                         quad_abstol=1e-8, quad_reltol=1e-8, max_steps=1024)
     for rep in range(2):
