@@ -617,13 +617,15 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
         /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF).
            I - gamma*J is close to diagonally dominant, so usually no row beats the diagonal: one
            ballot settles that case, the arg-max butterfly only runs when some lane disagrees. */
-        double best = fabs(AL(k, k));
+        double akk = AL(k, k);
+        double best = fabs(akk);
         int bi = k;
         bool beaten = false;
-        double cand[RS];
+        double cand[RS], colv[RS];      /* column k below the diagonal: raw values and magnitudes */
         SFOR(r, 0, RS) {
             const int i = r * G + g.li;
-            cand[r] = (i > k && i < NS) ? fabs(AL(i, k)) : -1.0;
+            colv[r] = (i > k && i < NS) ? AL(i, k) : 0.0;
+            cand[r] = (i > k && i < NS) ? fabs(colv[r]) : -1.0;
             beaten = beaten || (cand[r] > best);
         } SEND
         if (((__builtin_amdgcn_ballot_w64(beaten) >> g.gbase) & GMASK) != 0) {
@@ -654,12 +656,14 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
                 AL(l, c) = x;
             }
             lu_sync();
+            akk = AL(k, k);             /* rows moved: fetch the column again */
+            SFOR(r, 0, RS) { const int i = r * G + g.li; colv[r] = (i > k && i < NS) ? AL(i, k) : 0.0; } SEND
         }
-        const double mult = 1.0 / AL(k, k);
+        const double mult = 1.0 / akk;
         SFOR(r, 0, RS) {
             const int i = r * G + g.li;
             inv_piv[r] = (i == k) ? mult : inv_piv[r];
-            lcol[r] = (i > k && i < NS) ? AL(i, k) * mult : 0.0;
+            lcol[r] = (i > k && i < NS) ? colv[r] * mult : 0.0;
         } SEND
         /* elimination: this wavefront's batches of LU_BATCH columns, all reads of a batch before its writes */
         for (int j = k + 1 + g.wave * LU_BATCH; j < NS; j += LU_BATCH * SA_WAVES) {
