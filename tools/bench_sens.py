@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sunode_amd import SympyProblem  # noqa: E402
 from sunode_amd.solver import Solver  # noqa: E402
-from tools.problems import PROBLEMS, lv_batch, robertson_batch  # noqa: E402
+from tools.problems import PROBLEMS, lv_batch, robertson_batch, seir_batch  # noqa: E402
 
 
 def main():
@@ -19,6 +19,8 @@ def main():
     prob = SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
     if name == "lv":
         d = lv_batch(B); ps, pr = d["params"][:, :2], d["params"][:, 2:]; rt, at = 1e-8, 1e-8
+    elif name == "seir":
+        d = seir_batch(B); ps, pr = d["ps"], d["pr"]; rt, at = 1e-8, 1e-8
     else:
         d = robertson_batch(B); ps, pr = d["params"], np.zeros(0); rt, at = 1e-8, 1e-10
     sol = Solver(prob, abstol=at, reltol=rt, sens_mode=mode)
