@@ -6,7 +6,12 @@
  *
  *   sunode AdjointSolver.solve_forward   /root/reference/sunode/solver.py:682-721
  *   sunode AdjointSolver.solve_backward  /root/reference/sunode/solver.py:723-784
- *   sunode Solver.solve (no sens)        /root/reference/sunode/solver.py:467-527
+ *   sunode Solver.solve                  /root/reference/sunode/solver.py:467-527
+ *   ... with forward sensitivities       /root/reference/sunode/solver.py:360-392 (CVodeSensInit, EE tolerances,
+ *                                        errconS; simultaneous and staggered correctors)
+ *   ... with inequality constraints      /root/reference/sunode/solver.py:230-233, 569-572 (CVodeSetConstraints)
+ *   ... Hermite interpolation            /root/reference/sunode/solver.py:581-582 (CVodeAdjInit, CV_HERMITE)
+ *   ... lamda_all_out / quad_all_out     /root/reference/sunode/solver.py:778-781
  *
  * all of whose arithmetic happens inside SUNDIALS CVODES 5.x (conda-forge
  * `sundials<6.0`, /root/reference/.github/workflows/main.yml:36), a third-party
@@ -23,7 +28,9 @@
  * bit/step level.  This oracle is pinned instead by (tests/test_oracle_*.py):
  *   - scipy's DVODE (the Fortran ancestor of CVODE) step statistics + states,
  *   - tight-tolerance DOP853/Radau truth solutions + finite-difference gradients,
- *   - the reference notebook's printed known-answer (notebooks/from_sympy.ipynb:240-242).
+ *   - the reference notebook's printed known-answer (notebooks/from_sympy.ipynb:240-242),
+ *   - sensitivity-equation truth for the forward sensitivities, analytic cases, the textbook Robertson
+ *     blow-up for the constraints (tests/test_forward_sens.py, tests/test_oracle_pinning.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  *
