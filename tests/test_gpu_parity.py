@@ -576,6 +576,41 @@ def test_reference_test_declare_sens_and_linear_solver_kwarg():
         np.testing.assert_allclose(y[:, 0], np.exp(t), rtol=1e-8)
 
 
+@pytest.mark.parametrize("variant", [None, "wave4", "wave8", "wave", "mem"])
+def test_row_exchanges_in_the_dense_lu(variant, monkeypatch):
+    """A system whose Newton matrix is far from diagonally dominant (rotations at 1000 rad/s far below the
+    tolerances, steps of order 1): the partial-pivoting LU has to exchange rows in the forward and in the
+    backward solve.  Every mapping (cooperative by default, lane groups, workgroup, memory-resident) must
+    follow the oracle's pivot choices bit for bit."""
+    from sunode_amd.solver import AdjointSolver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem("pivoting")
+    B = 21
+    rng = np.random.RandomState(0)
+    ps = np.array([0.5, 0.3]) * np.exp(0.1 * rng.randn(B, 2))
+    pr = np.array([1000.0, 700.0])
+    y0 = np.tile([0.5, 1e-6, 0.0, 1e-6, 2e-6, 0.1], (B, 1))
+    tv = np.linspace(0, 20, 11)
+    grads = np.ones((11, 6)); grads[:, 1:5] = 0.0
+    kw = dict(abstol=1e-4, reltol=1e-5, backward_abstol=1e-4, backward_reltol=1e-5, quad_abstol=1e-4,
+              quad_reltol=1e-5)
+    sol = AdjointSolver(prob, **kw)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, y0, ps, pr)
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("pivoting")
+    cfg = orc.config(rtol=1e-5, atol=1e-4, rtolB=1e-5, atolB=1e-4, rtolQB=1e-5, atolQB=1e-4)
+    yo, so, sto = orc.solve_forward(cfg, y0, ps, pr, 0.0, tv, nthreads=4)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=4)
+    assert (st == 0).all() and (stb == 0).all()
+    assert stats[:, 0].max() < 80                      # steps of order 0.5: gamma * omega >> 1, rows get exchanged
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(statsb[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
     orc = make_oracle(name)
     cfg = orc.config(**cfg_kw)

@@ -69,6 +69,16 @@ def misc_functions(t, y, p):
     }
 
 
+def pivoting(t, y, p):
+    """Fast rotations far below the tolerances next to slow dynamics: once the step grows, I - gamma*J has
+    off-diagonal entries far larger than its diagonal, so the dense LU must exchange rows."""
+    x = y.x
+    return {"x": [-p.k[0] * x[0] + 1.0,
+                  p.w[0] * x[2], -p.w[0] * x[1],
+                  p.w[1] * x[4] - p.k[1] * x[3], -p.w[1] * x[3],
+                  -x[5] + x[0]]}
+
+
 PROBLEMS = {
     "lv": dict(
         params={"alpha": (), "beta": (), "gamma": (), "delta": ()},
@@ -93,6 +103,12 @@ PROBLEMS = {
         states={"x": (8,)},
         rhs=make_network(8),
         derivative_params=[("scale",)],
+    ),
+    "pivoting": dict(
+        params={"k": (2,), "w": (2,)},
+        states={"x": (6,)},
+        rhs=pivoting,
+        derivative_params=[("k",)],
     ),
     "notebook": dict(
         params={"c": {"d": (3,)}, "f": (50,)},
