@@ -2,12 +2,12 @@
 import functools
 
 from sunode_amd import SympyProblem
-from tools.problems import PROBLEMS, network100
+from tools.problems import EXTRA_PROBLEMS, PROBLEMS, network100
 
 
 @functools.lru_cache(maxsize=None)
 def make_problem(name):
-    spec = network100() if name == "network100" else PROBLEMS[name]
+    spec = network100() if name == "network100" else {**PROBLEMS, **EXTRA_PROBLEMS}[name]
     return SympyProblem(spec["params"], spec["states"], spec["rhs"], spec["derivative_params"])
 
 

@@ -104,12 +104,6 @@ PROBLEMS = {
         rhs=make_network(8),
         derivative_params=[("scale",)],
     ),
-    "pivoting": dict(
-        params={"k": (2,), "w": (2,)},
-        states={"x": (6,)},
-        rhs=pivoting,
-        derivative_params=[("k",)],
-    ),
     "notebook": dict(
         params={"c": {"d": (3,)}, "f": (50,)},
         states={"a": (3,), "b": {"c": (2,)}},
@@ -121,6 +115,17 @@ PROBLEMS = {
         states={"u": (), "v": ()},
         rhs=misc_functions,
         derivative_params=[("a",), ("c",)],
+    ),
+}
+
+
+#: test-only problems without reference-generated golden fixtures
+EXTRA_PROBLEMS = {
+    "pivoting": dict(
+        params={"k": (2,), "w": (2,)},
+        states={"x": (6,)},
+        rhs=pivoting,
+        derivative_params=[("k",)],
     ),
 }
 
