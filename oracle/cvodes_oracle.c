@@ -2006,7 +2006,10 @@ int orc_solve_forward_batch(orc_batch *bt, const orc_config *cfg, int B, const d
         double *yo = y_out + (size_t)b * n_t * NS;
         status[b] = solve_forward_one(cfg, y0 + (size_t)b * NS, ps + (size_t)b * NQ,
                                       pr + (size_t)b * rem_stride, t0, tvals, n_t, yo, &bt->traj[b], st);
-        if (status[b] != CV_SUCCESS) fill_nan(yo, (size_t)n_t * NS);
+        if (status[b] != CV_SUCCESS) {
+            fill_nan(yo, (size_t)n_t * NS);
+            bt->traj[b].np = 0;         /* like the device arena: a failed forward pass leaves nothing to run backward on */
+        }
     }
     return 0;
 }

@@ -611,6 +611,37 @@ def test_row_exchanges_in_the_dense_lu(variant, monkeypatch):
     np.testing.assert_array_equal(lam, lo)
 
 
+@pytest.mark.parametrize("variant", [None, "8", "wave", "mem"])
+def test_recoverable_rhs_failures_match_oracle(variant, monkeypatch):
+    """x' = -k sqrt(x): draws that reach x = 0 inside the horizon hit a non-finite right-hand side; CVODES treats
+    that as a recoverable failure (step cut by 4, up to 10 times), then gives up with CV_REPTD_RHSFUNC_ERR.  Same
+    counters, same status, NaN rows, and CV_NO_FWD from the backward pass -- in every mapping."""
+    from sunode_amd.solver import AdjointSolver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem("sqrt_decay")
+    ps = np.array([[1.0], [1.2], [0.5], [2.0], [0.7]])
+    y0 = np.tile([1.0, 1.0], (5, 1))
+    tv = np.linspace(0, 2.5, 6)
+    kw = dict(abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8, quad_abstol=1e-10,
+              quad_reltol=1e-8)
+    sol = AdjointSolver(prob, **kw)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, y0, ps, np.zeros(0))
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, np.ones((6, 2)))
+    orc = make_oracle("sqrt_decay")
+    cfg = orc.config(rtol=1e-8, atol=1e-10, rtolB=1e-8, atolB=1e-10, rtolQB=1e-8, atolQB=1e-10)
+    yo, so, sto = orc.solve_forward(cfg, y0, ps, np.zeros(0), 0.0, tv)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, np.ones((6, 2)))
+    assert st.tolist() == so.tolist() == [-10, -10, 0, -10, 0]
+    assert stb.tolist() == sbo.tolist() == [-102, -102, 0, -102, 0]
+    np.testing.assert_array_equal(stats[:, CMP[:8]], sto[:, CMP[:8]])
+    ok = st == 0
+    np.testing.assert_array_equal(y[ok], yo[ok])
+    np.testing.assert_array_equal(g[ok], go[ok])
+    assert np.isnan(y[~ok]).all() and np.isnan(g[~ok]).all() and np.isnan(lam[~ok]).all()
+    np.testing.assert_allclose(y[2, :, 0], (1 - 0.25 * tv) ** 2, rtol=1e-7)         # x = (1 - k t / 2)^2
+
+
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
     orc = make_oracle(name)
     cfg = orc.config(**cfg_kw)

@@ -119,8 +119,21 @@ PROBLEMS = {
 }
 
 
+def sqrt_decay(t, y, p):
+    """x' = -k sqrt(x), z' = -z: x reaches zero at t = 2 sqrt(x0)/k and the right-hand side stops being real:
+    a recoverable failure (non-finite rhs) the integrator answers with smaller and smaller steps."""
+    import sympy as sym
+    return {"x": -p.k * sym.sqrt(y.x), "z": -y.z}
+
+
 #: test-only problems without reference-generated golden fixtures
 EXTRA_PROBLEMS = {
+    "sqrt_decay": dict(
+        params={"k": ()},
+        states={"x": (), "z": ()},
+        rhs=sqrt_decay,
+        derivative_params=[("k",)],
+    ),
     "pivoting": dict(
         params={"k": (2,), "w": (2,)},
         states={"x": (6,)},
