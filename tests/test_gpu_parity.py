@@ -642,6 +642,37 @@ def test_recoverable_rhs_failures_match_oracle(variant, monkeypatch):
     np.testing.assert_allclose(y[2, :, 0], (1 - 0.25 * tv) ** 2, rtol=1e-7)         # x = (1 - k t / 2)^2
 
 
+@pytest.mark.parametrize("variant", [None, "8", "wave4", "wave", "mem"])
+def test_error_test_failure_paths_match_oracle(variant, monkeypatch):
+    """Discontinuous forcing (two Heaviside switches of growing size): dozens of error-test failures per solve,
+    repeated failures inside one step (order reduction, reload of the derivative column at order 1), forward and
+    backward.  Counters (incl. netf / netfQ) and results bit for bit in every mapping."""
+    from sunode_amd.solver import AdjointSolver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem("switched")
+    ps = np.array([[1.0, 50.0], [2.0, 500.0], [0.5, 5000.0], [3.0, 1e5], [1.5, 1e7]])
+    y0 = np.tile([1.0, 0.0], (5, 1))
+    tv = np.linspace(0, 3, 7)
+    grads = np.ones((7, 2))
+    kw = dict(abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8, quad_abstol=1e-10,
+              quad_reltol=1e-8)
+    sol = AdjointSolver(prob, **kw)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, y0, ps, np.zeros(0))
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("switched")
+    cfg = orc.config(rtol=1e-8, atol=1e-10, rtolB=1e-8, atolB=1e-10, rtolQB=1e-8, atolQB=1e-10)
+    yo, so, sto = orc.solve_forward(cfg, y0, ps, np.zeros(0), 0.0, tv)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads)
+    assert st.tolist() == so.tolist() and stb.tolist() == sbo.tolist() and (st == 0).all() and (stb == 0).all()
+    assert (stats[:, 6] >= 40).all()                      # netf: the switches are hit hard
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(statsb[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
     orc = make_oracle(name)
     cfg = orc.config(**cfg_kw)

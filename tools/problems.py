@@ -126,8 +126,22 @@ def sqrt_decay(t, y, p):
     return {"x": -p.k * sym.sqrt(y.x), "z": -y.z}
 
 
+def switched(t, y, p):
+    """Discontinuous forcing (Heaviside switches): the error test fails repeatedly at every switch, the order
+    drops to 1 and the derivative column is reloaded (cvDoErrorTest's third branch)."""
+    import sympy as sym
+    return {"x": -p.k * y.x + p.a * sym.Heaviside(t - 1) - 3 * p.a * sym.Heaviside(t - 2),
+            "z": y.x - y.z}
+
+
 #: test-only problems without reference-generated golden fixtures
 EXTRA_PROBLEMS = {
+    "switched": dict(
+        params={"k": (), "a": ()},
+        states={"x": (), "z": ()},
+        rhs=switched,
+        derivative_params=[("k",), ("a",)],
+    ),
     "sqrt_decay": dict(
         params={"k": ()},
         states={"x": (), "z": ()},
