@@ -673,6 +673,38 @@ def test_error_test_failure_paths_match_oracle(variant, monkeypatch):
     np.testing.assert_array_equal(lam, lo)
 
 
+@pytest.mark.parametrize("variant", [None, "16", "wave", "mem"])
+def test_vector_abstol_matches_oracle(variant, monkeypatch):
+    """Per-component absolute tolerances (reference solver.py:404-407, 624-635: CVodeSVtolerances) in the
+    forward problem, scalar ones in the backward problem."""
+    from sunode_amd.solver import AdjointSolver, Solver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem("robertson")
+    d = robertson_batch(9)
+    tv = d["tvals"]
+    atol = np.array([1e-8, 1e-13, 1e-7])
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(3)[None, :])
+    sol = AdjointSolver(prob, abstol=atol, reltol=1e-7, backward_abstol=1e-9, backward_reltol=1e-7,
+                        quad_abstol=1e-8, quad_reltol=1e-7)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["params"], np.zeros(0))
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("robertson")
+    cfg = orc.config(rtol=1e-7, atol=atol, rtolB=1e-7, atolB=1e-9, rtolQB=1e-7, atolQB=1e-8)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], d["params"], np.zeros(0), 0.0, tv)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads)
+    assert (st == 0).all() and (stb == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+    plain = Solver(prob, abstol=atol, reltol=1e-7)
+    yp, stp, statsp = plain.solve_batch(0.0, tv, d["y0"], d["params"], np.zeros(0))
+    ypo, spo, stpo = orc.solve(cfg, d["y0"], d["params"], np.zeros(0), 0.0, tv)
+    np.testing.assert_array_equal(yp, ypo)
+    np.testing.assert_array_equal(statsp[:, CMP[:8]], stpo[:, CMP[:8]])
+
+
 def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end=None):
     orc = make_oracle(name)
     cfg = orc.config(**cfg_kw)
