@@ -714,11 +714,14 @@ def _oracle_adjoint(name, cfg_kw, y0, ps, pr, t0, tv, grads, t_start=None, t_end
     return y, st, g, lam, stb
 
 
-def test_edge_cases_match_oracle():
+@pytest.mark.parametrize("variant", [None, "8", "wave4", "wave", "mem"])
+def test_edge_cases_match_oracle(variant, monkeypatch):
     """Ragged / degenerate inputs (reference semantics, solver.py:705-708, 750-776):
     tvals[0] > t0 (extra interval down to tend), a single output time, B = 1, B not a multiple of 64,
-    per-instance cotangents, tvals containing t0 twice."""
+    per-instance cotangents, tvals containing t0 twice -- in every mapping."""
     from sunode_amd.solver import AdjointSolver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
     prob = make_problem("lv")
     tol = dict(abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8, quad_abstol=1e-8, quad_reltol=1e-8)
     okw = dict(rtol=1e-8, atol=1e-8, rtolB=1e-8, atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
