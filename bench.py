@@ -5,12 +5,19 @@ metric : fp64 forward+adjoint ODE solves/sec at rtol=1e-8 (Lotka-Volterra, confi
          rtol=atol=1e-8 for the forward, backward and quadrature problems, grads = ones)
 step   : one forward (sa_solve_forward_batch) + one adjoint (sa_solve_backward_batch) pass over the
          whole batch, inputs and outputs resident in HBM (torch tensors, SA_MEM_DEVICE).
-N > 1  : one process per GPU (torch.distributed / RCCL only for the barrier and the max-reduce of
-         the elapsed time); the batch shards by instance, no data-path collective -> weak scaling.
+N > 1  : `python bench.py --gpus N` starts N ranks itself (re-exec under torch.distributed.run on
+         127.0.0.1) unless it already runs under one (WORLD_SIZE set, as the driver launches it);
+         one process per GPU, RCCL only for the barrier, the max-reduce of the elapsed time and the
+         sum of the failed-instance counts; the batch shards by instance through
+         sunode_amd.parallel.shard_indices, no data-path collective -> weak scaling.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : dominant kernel (sa_k_backward) algorithmic HBM bytes / HIP-event duration vs 8 TB/s
-  cpu_baseline : the CPU oracle (oracle/cvodes_oracle.c, "port") timed on the host cores, bounded sample
+  roofline     : dominant kernel (sa_k_backward): SURVEY 8(d) algorithmic HBM bytes / HIP-event duration vs
+                 8 TB/s, and a `valu` block (the roofline that actually binds: fp64 vector rate)
+  cpu_baseline : the CPU oracle (oracle/cvodes_oracle.c, "port") timed on the host cores, bounded sample,
+                 all-core and 1-core figures, and the libsundials_cvodes probe
+  configs      : (N = 1) the other BASELINE configurations -- Robertson, SEIR, 100-state network -- a few
+                 steps each with kernel times, failed-instance counts and their own bounded CPU baselines
 """
 from __future__ import annotations
 
@@ -26,27 +33,63 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
+FP64_VALU_PEAK_TFLOPS = 78.6          # MI355X_MICROARCH.md: fp64 vector peak
 
 
-def make_problem():
+# ----------------------------------------------------------------------------------------------
+# workloads (BASELINE.json configs 2-5; definitions in tools/problems.py)
+# ----------------------------------------------------------------------------------------------
+WORKLOADS = {
+    "lv": dict(config=2, batch=65536, rtol=1e-8, atol=1e-8,
+               label="BASELINE config 2: Lotka-Volterra forward+adjoint, 2 sens params, n_t=50, "
+                     "rtol=atol=1e-8 (fwd/bwd/quad), grads=ones"),
+    "robertson": dict(config=3, batch=262144, rtol=1e-8, atol=1e-10,
+                      label="BASELINE config 3: Robertson stiff 3-state, rtol=1e-8 atol=1e-10, forward+adjoint "
+                            "(3 sens params), T=4e4, 7 outputs"),
+    "seir": dict(config=4, batch=16384, rtol=1e-8, atol=1e-8,
+                 label="BASELINE config 4 (one GPU's share of 131 072): SEIR 16-state, forward+adjoint w.r.t. 8 "
+                       "params, n_t=51"),
+    "network100": dict(config=5, batch=1024, rtol=1e-8, atol=1e-8,
+                       label="BASELINE config 5 (one GPU's share of 8 192): 100-state dense reaction network, "
+                             "forward+adjoint w.r.t. 4 params, n_t=11"),
+}
+
+
+def make_problem(name="lv"):
     from sunode_amd import SympyProblem
-    from tools.problems import PROBLEMS
-    s = PROBLEMS["lv"]
+    from tools.problems import PROBLEMS, network100
+    s = network100() if name == "network100" else PROBLEMS[name]
     return SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-    this same command (profiles/pmc_traffic.json, collected as MI355X_MICROARCH.md prescribes: separate
-    passes, KiB units, calibrated on the known arena size); None when no such profile is in the tree.
-    Counters cannot be collected from inside the timed run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh)[kernel]
-        return float(rec["fetch"] + rec["write"])
-    except (OSError, KeyError, ValueError):
-        return None
+def make_batch(name, prob, B):
+    """Synthetic batch of B draws of workload `name`: dict(y0, ps, pr, rem_stride, tvals, grads)."""
+    from tools.problems import lv_batch, network_batch, robertson_batch, seir_batch
+    n = prob.n_states
+    if name == "lv":
+        d = lv_batch(B)
+        ps = d["params"][:, prob.params_subset.subset_index]
+        pr = d["params"][:, prob.params_subset.remainder_index]
+        stride = pr.shape[1]
+        grads = np.ones((len(d["tvals"]), n))
+    elif name == "robertson":
+        d = robertson_batch(B)
+        ps, pr, stride = d["params"], np.zeros(1), 0
+        grads = None
+    else:
+        d = seir_batch(B) if name == "seir" else network_batch(B)
+        ps, pr, stride = d["ps"], d["pr"], 0
+        grads = None
+    if prob.n_remainder:          # hoisted fixed-parameter sub-expressions ride at the end of the remainder vector
+        pr = np.asarray(prob.extend_remainder(pr))
+        stride = pr.shape[-1] if stride else 0
+    tv = d["tvals"]
+    if grads is None:
+        k = np.arange(len(tv))[:, None]
+        i = np.arange(n)[None, :]
+        grads = 1.0 + 0.5 * np.cos(1.7 * k + 0.9 * i)
+    return dict(y0=np.ascontiguousarray(d["y0"]), ps=np.ascontiguousarray(ps), pr=np.ascontiguousarray(pr),
+                rem_stride=stride, tvals=np.ascontiguousarray(tv), grads=np.ascontiguousarray(grads))
 
 
 def usable_cores() -> int:
@@ -61,160 +104,361 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(prob, tol, target_seconds=12.0):
-    """Oracle (CPU restatement of the CVODES path) on all host cores, bounded sample."""
-    from oracle.harness import Oracle
-    from tools.problems import lv_batch
-    cores = usable_cores()
-    orc = Oracle(prob, "lv", opt="-O2")
-    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+# ----------------------------------------------------------------------------------------------
+# per-rank engines: the GPU engine (product path) and, for the CPU multi-process test, whatever
+# `make_engine` the test injects.  An engine integrates the rank's shard: step() = forward + adjoint.
+# ----------------------------------------------------------------------------------------------
+class GpuEngine:
+    """libsunode_amd.so on cuda:<local_rank>, device-resident tensors, work enqueued on a torch stream."""
 
-    def run(B):
-        d = lv_batch(B)
-        ps = d["params"][:, prob.params_subset.subset_index]
-        pr = d["params"][:, prob.params_subset.remainder_index]
-        g = np.ones((len(d["tvals"]), 2))
-        t0 = time.perf_counter()
-        _, st, _ = orc.solve_forward(cfg, d["y0"], ps, pr, 0.0, d["tvals"], nthreads=cores)
-        _, _, st2, _ = orc.solve_backward(cfg, d["tvals"][-1], 0.0, d["tvals"], g, nthreads=cores)
-        dt = time.perf_counter() - t0
-        assert (st == 0).all() and (st2 == 0).all()
-        return dt
+    def __init__(self, name, prob, batch, tol, local_rank, arena_bytes=0):
+        import torch
+        from sunode_amd import _native
+        self.torch, self._native = torch, _native
+        self.dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(local_rank)
+        n, p = prob.n_states, prob.n_params
+        self.n, self.p, self.B, self.n_t = n, p, batch["y0"].shape[0], len(batch["tvals"])
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), device=self.dev)          # noqa: E731
+        self.y0, self.ps, self.pr, self.tvals = t(batch["y0"]), t(batch["ps"]), t(batch["pr"]), t(batch["tvals"])
+        self.grads = t(batch["grads"])
+        self.rem_stride = batch["rem_stride"]
+        self.t_end = float(batch["tvals"][-1])
+        B, n_t = self.B, self.n_t
+        f64, dev = torch.float64, self.dev
+        self.y_out = torch.empty((B, n_t, n), dtype=f64, device=dev)
+        self.grad_out = torch.empty((B, max(p, 1)), dtype=f64, device=dev)
+        self.lamda_out = torch.empty((B, n), dtype=f64, device=dev)
+        self.st_f = torch.empty(B, dtype=torch.int32, device=dev)
+        self.st_b = torch.empty(B, dtype=torch.int32, device=dev)
+        self.stats_f = torch.empty((B, 16), dtype=torch.int64, device=dev)
+        self.stats_b = torch.empty((B, 16), dtype=torch.int64, device=dev)
+        source = prob.native_source()
+        if os.environ.get("SA_ABLATE"):          # timing experiments only (kernel results are then wrong)
+            source += "".join("\n#define SA_ABLATE_%s 1\n" % k for k in os.environ["SA_ABLATE"].split(","))
+        rt, at = tol
+        self.eng = _native.NativeSolver(source, device=local_rank, rtol=rt, atol=at, rtolB=rt, atolB=at,
+                                        rtolQB=rt, atolQB=at, n_states=n, arena_bytes=arena_bytes)
+        # stream ordering (include/sunode_amd.h): the solver launches on the torch stream that owns the tensors
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.eng.set_stream(self.stream.cuda_stream)
+        torch.cuda.synchronize()
 
-    probe = 256 * cores
-    dt = run(probe)
-    B = int(min(4 * 65536, max(probe, probe * target_seconds / max(dt, 1e-6))))
-    dt = run(B)
-    return {"value": B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": "%d config-2 draws (same generator), fwd+adjoint, OpenMP over instances, gcc -O2, "
-                      "threads = cgroup CPU quota" % B}
+    def step(self):
+        e, N = self.eng, self._native
+        with self.torch.cuda.stream(self.stream):
+            e.solve(N.SA_MEM_DEVICE, self.B, self.y0, self.ps, self.pr, self.rem_stride, 0.0, self.tvals, self.n_t,
+                    self.y_out, self.st_f, self.stats_f, adjoint=True)
+            e.solve_backward(N.SA_MEM_DEVICE, self.B, self.ps, self.pr, self.rem_stride, self.t_end, 0.0, self.tvals,
+                             self.n_t, self.grads, 0, self.grad_out, self.lamda_out, self.st_b, self.stats_b)
+
+    def kernel_ms(self):
+        return self.eng.last_kernel_ms()          # HIP events on the solver's stream (waits for this step)
+
+    def sync(self):
+        self.eng.synchronize()
+        self.torch.cuda.synchronize()
+
+    def results(self):
+        self.sync()
+        return dict(failed=int((self.st_f != 0).sum().item() + (self.st_b != 0).sum().item()),
+                    stats_f=self.stats_f.double().mean(dim=0).cpu().numpy(),
+                    stats_b=self.stats_b.double().mean(dim=0).cpu().numpy(),
+                    arena=self.eng.arena_info())
+
+    def close(self):
+        self.eng.close()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import torch
+def run_rank(args, *, backend="nccl", make_engine=None):
+    """One rank of the benchmark (rank / world from the torch.distributed.run environment).  Returns the result
+    dict on rank 0, None elsewhere.  `backend` and `make_engine` are injectable so that the world-size-2 CPU
+    test (tests/test_parallel_gloo.py) runs THIS function over gloo with a CPU stand-in for the per-rank solve."""
+    from sunode_amd.parallel import shard_indices
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
-    from sunode_amd import _native
-    from tools.problems import lv_batch
+    name = args.workload
+    prob = make_problem(name)
+    w = WORKLOADS[name]
+    B = args.batch or w["batch"]
+    # weak scaling: the global synthetic batch has B * world draws; every rank integrates its own shard
+    idx = shard_indices(B * world, rank, world)
+    full = make_batch(name, prob, B * world)
+    shard = {k: (v[idx] if (k in ("y0", "ps") or (k == "pr" and full["rem_stride"])) else v) for k, v in full.items()}
+    factory = make_engine or GpuEngine
+    eng = factory(name, prob, shard, (w["rtol"], w["atol"]), local_rank)
 
-    prob = make_problem()
-    tol = 1e-8
-    B = args.batch
-    d = lv_batch(B * world)                       # global synthetic batch; this rank takes a contiguous shard
-    sl = slice(rank * B, (rank + 1) * B)
-    params = d["params"][sl]
-    n, p, n_t = 2, 2, len(d["tvals"])
-    ps = torch.tensor(np.ascontiguousarray(params[:, prob.params_subset.subset_index]), device=dev)
-    pr = torch.tensor(np.ascontiguousarray(params[:, prob.params_subset.remainder_index]), device=dev)
-    y0 = torch.tensor(np.ascontiguousarray(d["y0"][sl]), device=dev)
-    tvals = torch.tensor(d["tvals"], device=dev)
-    grads = torch.ones((n_t, n), dtype=torch.float64, device=dev)
-    y_out = torch.empty((B, n_t, n), dtype=torch.float64, device=dev)
-    grad_out = torch.empty((B, p), dtype=torch.float64, device=dev)
-    lamda_out = torch.empty((B, n), dtype=torch.float64, device=dev)
-    st_f = torch.empty(B, dtype=torch.int32, device=dev)
-    st_b = torch.empty(B, dtype=torch.int32, device=dev)
-    stats_f = torch.empty((B, 16), dtype=torch.int64, device=dev)
-    stats_b = torch.empty((B, 16), dtype=torch.int64, device=dev)
-
-    source = prob.native_source()
-    if os.environ.get("SA_ABLATE"):          # timing experiments only (kernel results are then wrong)
-        source += "".join("\n#define SA_ABLATE_%s 1\n" % k for k in os.environ["SA_ABLATE"].split(","))
-    eng = _native.NativeSolver(source, device=local_rank, rtol=tol, atol=tol, rtolB=tol, atolB=tol,
-                               rtolQB=tol, atolQB=tol, traj_capacity=512, n_states=n)
-    torch.cuda.synchronize()
-
-    def step():
-        eng.solve(_native.SA_MEM_DEVICE, B, y0, ps, pr, 2, 0.0, tvals, n_t, y_out, st_f, stats_f, adjoint=True)
-        eng.solve_backward(_native.SA_MEM_DEVICE, B, ps, pr, 2, float(d["tvals"][-1]), 0.0, tvals, n_t, grads, 0,
-                           grad_out, lamda_out, st_b, stats_b)
+    def all_reduce(value, op):
+        if world == 1:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device=getattr(eng, "dev", "cpu"))
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+        return float(t.item())
 
     for _ in range(args.warmup):
-        step()
-    eng.synchronize()
-    torch.cuda.synchronize()
+        eng.step()
+    eng.sync()
     if world > 1:
         dist.barrier()
     fwd_ms, bwd_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        f, b = eng.last_kernel_ms()               # HIP events on the solver's stream (waits for this step)
+        eng.step()
+        f, b = eng.kernel_ms()
         fwd_ms.append(f)
         bwd_ms.append(b)
-    eng.synchronize()
-    torch.cuda.synchronize()
+    eng.sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    failed = int((st_f != 0).sum().item() + (st_b != 0).sum().item())
-    sf = stats_f.double().mean(dim=0).cpu().numpy()
-    sb = stats_b.double().mean(dim=0).cpu().numpy()
+    elapsed = all_reduce(elapsed, "MAX")
+    res = eng.results()
+    failed = int(all_reduce(float(res["failed"]), "SUM"))
+    out = None
     if rank == 0:
-        value = world * B * args.steps / elapsed
-        # algorithmic HBM bytes per launch (DESIGN.md section 3):
-        #   trajectory record per stored point: 8*(8+6n) B = {order, dt, T[6], Y[6][n]} (built by the forward
-        #   kernel, read once by the backward kernel when the lane's table index moves onto it)
-        #   backward, per instance: params 8*(p+r) + npts*rec + npts/fwd-status 8 + outputs 8*(p+n) + status 4
-        #     + stats 128; shared: grads 8*n_t*n + tvals 8*n_t
-        #   forward, per instance: y0+params 8*(n+p+r) + npts*rec + y_out 8*n_t*n + status 4 + np 4 + stats 128
-        npts = float(sf[8])
-        rec = 8 * (8 + 6 * n)
-        bwd_bytes = B * (8 * 4 + npts * rec + 8 + 8 * (p + n) + 4 + 128) + 8 * n_t * n + 8 * n_t
-        fwd_bytes = B * (8 * (n + 4) + npts * rec + 8 * n_t * n + 4 + 4 + 128) + 8 * n_t
-        bwd_s = float(np.mean(bwd_ms)) * 1e-3
-        fwd_s = float(np.mean(fwd_ms)) * 1e-3
-        achieved = bwd_bytes / bwd_s / 1e9
-        out = {
-            "metric": "fp64 forward+adjoint ODE solves/sec at rtol=1e-8 (Lotka-Volterra, batch 65536/GPU)",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: Lotka-Volterra forward+adjoint, 2 sens params, "
-                                   "n_t=50, rtol=atol=1e-8 (fwd/bwd/quad), grads=ones",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": "instance-sharded x%d" % world,
-                       "failed_instances": failed},
-            "roofline": {"bound": "hbm", "kernel": "sa_k_backward", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("sa_k_backward"),
-                         "algorithmic_bytes_per_launch": bwd_bytes, "kernel_ms": 1e3 * bwd_s,
-                         "forward_kernel_ms": 1e3 * fwd_s, "forward_bytes_per_launch": fwd_bytes,
-                         "note": "path is latency/fp64-VALU bound, not HBM bound (SURVEY 8d)"},
-            "work": {"fwd_steps_mean": float(sf[0]), "bwd_steps_mean": float(sb[0]),
-                     "fwd_attempts_mean": float(sf[14]), "bwd_attempts_mean": float(sb[14]),
-                     "bwd_wave_iterations_mean": float(sb[15]),
-                     "bdf_steps_per_s": world * B * float(sf[0] + sb[0]) * args.steps / elapsed,
-                     "rhs_evals_per_s": world * B * float(sf[1] + sb[1] + sb[9]) * args.steps / elapsed},
-        }
-        if "PROFILE" in os.environ.get("SA_ABLATE", ""):
-            names = ["pre_step+post", "predict+set", "interp", "newton", "errtest+quad", "complete+prepare",
-                     "post_step", "interval_setup"]
-            tot = float(sb[8:16].sum())
-            out["phase_cycles_per_lane"] = {k: [float(v), round(float(v) / tot, 4)] for k, v in zip(names, sb[8:16])}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(prob, tol)
-        print(json.dumps(out), flush=True)
+        out = summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, failed)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+    return out
+
+
+def algorithmic_bytes(prob, n_t, npts, grads_broadcast=True, per_instance_rem=True):
+    """B_alg per solve = 8*[n + P_inst + n_t*n (y_out) + n_t*n (grads; 0 if broadcast) + p + n]
+    + 2 * S_f * (8*(n+1) + 8), split here by kernel: the forward kernel reads y0 + params, writes y_out and the
+    S_f data points (t, y[n], order); the backward kernel reads params + the data points once, writes p + n."""
+    n, p = prob.n_states, prob.n_params
+    p_inst = p + (prob.n_remainder if per_instance_rem else 0)
+    point = 8 * (n + 1) + 8
+    fwd = 8 * (n + p_inst + n_t * n) + npts * point
+    bwd = 8 * (p_inst + (0 if grads_broadcast else n_t * n) + p + n) + npts * point
+    return fwd, bwd
+
+
+def callback_flops(prob):
+    """fp64 operations per call of each generated callback, counted in the generated source (one per
+    + - * / and two per fma): the F_rhs / F_jac of SURVEY.md 8(d) without hand-written constants."""
+    import re
+    src = prob.native_source()
+    cut = src.index("SA_FN int sa_rhs") if "SA_FN int sa_rhs" in src else 0
+    marks = [(m.start(), m.group(1)) for m in re.finditer(r"SA_FN int (sa_[a-z_]+?)(?:_c\d+)?\(", src[cut:])]
+    out = {}
+    for k, (pos, fname) in enumerate(marks):
+        end = marks[k + 1][0] if k + 1 < len(marks) else len(src) - cut
+        body = src[cut + pos:cut + end]
+        if "SA_CHUNK_CALL" in body:
+            continue
+        stmts = [ln for ln in body.splitlines() if "const double" in ln or "SA_STORE" in ln]
+        text = "\n".join(stmts)
+        ops = len(re.findall(r"(?<![eE(,])[-+*/](?![=/*])", text)) + 2 * text.count("fma(")
+        out[fname] = out.get(fname, 0) + ops
+    return out
+
+
+def algorithmic_flops(prob, sf, sb):
+    """SURVEY.md 8(d) F_alg per solve from the kernels' own counters (stats slots: nst 0, nfe 1, nsetups 2, nje 3,
+    nni 4, nfqe 9, ninterp 11): callback calls x their operation counts + triangular solves 2n^2 per Newton
+    iteration + Nordsieck work 6n(q+2) per step + LU 2/3 n^3 per setup + interpolation 2n(q+1) per call."""
+    n, p = prob.n_states, prob.n_params
+    f = callback_flops(prob)
+    q = 4.0
+    lu = (2.0 / 3.0) * n ** 3
+    fwd = (sf[1] * f.get("sa_rhs", 0) + sf[3] * f.get("sa_jac", 0) + sf[4] * 2 * n * n + sf[0] * 6 * n * (q + 2)
+           + sf[2] * lu)
+    bwd = (sb[1] * f.get("sa_adj_rhs", 0) + sb[9] * f.get("sa_quad_rhs", 0) + sb[3] * f.get("sa_adj_jac", 0)
+           + sb[4] * 2 * n * n + sb[0] * 6 * (n + p) * (q + 2) + sb[2] * lu + sb[11] * 2 * n * (q + 1))
+    return float(fwd), float(bwd)
+
+
+def pmc_profile(kernel):
+    """Committed rocprofv3 --pmc results of this command (profiles/pmc_traffic.json; collected in separate
+    passes as MI355X_MICROARCH.md prescribes -- counters cannot be read from inside the timed run)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh)[kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, failed):
+    n, p = prob.n_states, prob.n_params
+    sf, sb = res["stats_f"], res["stats_b"]
+    n_t = {"lv": 50, "robertson": 7, "seir": 51, "network100": 11}[name]
+    value = world * B * args.steps / elapsed
+    npts = float(sf[8])
+    fwd_alg, bwd_alg = algorithmic_bytes(prob, n_t, npts, grads_broadcast=True, per_instance_rem=(name == "lv"))
+    bwd_s, fwd_s = float(np.mean(bwd_ms)) * 1e-3, float(np.mean(fwd_ms)) * 1e-3
+    achieved = B * bwd_alg / bwd_s / 1e9
+    f_fwd, f_bwd = algorithmic_flops(prob, sf, sb)
+    pmc = pmc_profile("sa_k_backward") if name == "lv" else None
+    arena_bytes, tiles, tiled = res.get("arena", (0, 0, False))
+    rec = 8 * (8 + 6 * n)
+    out = {
+        "metric": "fp64 forward+adjoint ODE solves/sec at rtol=1e-8 (%s, batch %d/GPU)"
+                  % ({"lv": "Lotka-Volterra"}.get(name, name), B),
+        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": w["label"], "batch_per_gpu": B, "global_batch": B * world,
+                   "parallelism": "instance-sharded x%d" % world, "failed_instances": failed},
+        "roofline": {
+            # contract figure: HBM.  The path is NOT HBM-bound (SURVEY 8d: thousands of tiny sequential solves);
+            # `valu` below is the roofline that binds.
+            "bound": "hbm", "kernel": "sa_k_backward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": (pmc["fetch"] + pmc["write"]) if pmc else None,
+            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if pmc else None,
+            "algorithmic_bytes_per_launch": B * bwd_alg, "kernel_ms": 1e3 * bwd_s,
+            "forward_kernel_ms": 1e3 * fwd_s, "forward_bytes_per_launch": B * fwd_alg,
+            "algorithmic_bytes_per_solve_8d": fwd_alg + bwd_alg,
+            # what the implementation moves by design: one {order, dt, T[6], Y[6][n]} record per stored point
+            "traffic_model": B * (8 * (p + prob.n_remainder) + npts * rec + 8 * (p + n) + 140),
+            "binding": "fp64 VALU dependent-issue latency (see valu), not HBM",
+            "valu": {"kernel": "sa_k_backward", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
+                     "algorithmic": B * f_bwd / bwd_s / 1e12, "frac_algorithmic": B * f_bwd / bwd_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                     "issued": (pmc["valu_fp64_flops"] / bwd_s / 1e12) if pmc and "valu_fp64_flops" in pmc else None,
+                     "note": "algorithmic = SURVEY 8(d) F_alg from the kernel's own counters; issued = fp64 "
+                             "FMA/MUL/ADD lane-ops of the committed PMC pass (all 64 lanes counted) / this run's "
+                             "kernel time"}},
+        "work": {"fwd_steps_mean": float(sf[0]), "bwd_steps_mean": float(sb[0]),
+                 "fwd_attempts_mean": float(sf[14]), "bwd_attempts_mean": float(sb[14]),
+                 "stored_points_mean": npts,
+                 "bdf_steps_per_s": world * B * float(sf[0] + sb[0]) * args.steps / elapsed,
+                 "rhs_evals_per_s": world * B * float(sf[1] + sb[1] + sb[9]) * args.steps / elapsed,
+                 "arena": {"bytes": arena_bytes, "tiled": bool(tiled), "reintegrated_tiles": tiles}},
+    }
+    if pmc and "valu_fp64_flops" in pmc:
+        out["roofline"]["valu"]["frac_issued"] = out["roofline"]["valu"]["issued"] / FP64_VALU_PEAK_TFLOPS
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU baseline (oracle = "port"); libsundials_cvodes probe
+# ----------------------------------------------------------------------------------------------
+def cvodes_probe():
+    """BASELINE.md section 3 / SURVEY 8(d): time real CVODES when the box has it.  It never has here: the image
+    carries no SUNDIALS (conda-forge `sundials<6.0` is what the reference links), so the row says so."""
+    import ctypes.util
+    lib = ctypes.util.find_library("sundials_cvodes")
+    if not lib:
+        return {"available": False, "note": "libsundials_cvodes not found on this host (ctypes.util.find_library); "
+                                            "the reference's sunode+CVODES path cannot be timed here"}
+    return {"available": True, "library": lib,
+            "note": "found, but no driver for it is shipped: parity and timing use the restated oracle"}
+
+
+def cpu_baseline(name, prob, w, target_seconds=12.0, opt="-O3"):
+    """Oracle (CPU restatement of the CVODES path, oracle/cvodes_oracle.c) on the host cores, bounded sample of the
+    same workload: all usable cores (OpenMP over instances) and one core."""
+    from oracle.harness import Oracle
+    cores = usable_cores()
+    orc = Oracle(prob, name, opt=opt)
+    rt, at = w["rtol"], w["atol"]
+    cfg = orc.config(rtol=rt, atol=at, rtolB=rt, atolB=at, rtolQB=rt, atolQB=at)
+
+    def run(B, threads):
+        d = make_batch(name, prob, B)
+        t0 = time.perf_counter()
+        _, st, _ = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, d["tvals"], nthreads=threads)
+        _, _, st2, _ = orc.solve_backward(cfg, d["tvals"][-1], 0.0, d["tvals"], d["grads"], nthreads=threads)
+        dt = time.perf_counter() - t0
+        assert (st == 0).all() and (st2 == 0).all()
+        return dt
+
+    probe = {"lv": 256, "robertson": 32, "seir": 8, "network100": 1}[name] * cores
+    dt = run(probe, cores)
+    B = int(min(4 * w["batch"], max(probe, probe * target_seconds / max(dt, 1e-6))))
+    dt = run(B, cores) if B > probe else dt
+    B1 = max(1, B // (cores * 6))
+    dt1 = run(B1, 1)
+    return {"value": B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "one_core": {"value": B1 / dt1, "sample": "%d draws" % B1},
+            "sample": "%d %s draws (same generator), fwd+adjoint, OpenMP over instances, gcc %s, threads = cgroup "
+                      "CPU quota; the port mirrors the kernels' arithmetic bit for bit (explicit FMAs, software pow, "
+                      "tree sums): a stated baseline, not a tuned CPU code" % (B, name, opt),
+            "cvodes": cvodes_probe()}
+
+
+def extra_configs(args):
+    """BASELINE configs 3-5 on this GPU: a couple of steps each (N = 1 only; they are parity-test cases, the
+    headline `value` is config 2)."""
+    rows = {}
+    for name in ("robertson", "seir", "network100"):
+        w = WORKLOADS[name]
+        try:
+            prob = make_problem(name)
+            sub = argparse.Namespace(**vars(args))
+            sub.workload, sub.batch, sub.steps, sub.warmup, sub.gpus = name, 0, 2, 1, 1
+            r = run_rank(sub)
+            row = {"workload": w["label"], "batch": w["batch"], "solves_per_s": r["value"],
+                   "ms_per_step": r["ms_per_step"], "forward_kernel_ms": r["roofline"]["forward_kernel_ms"],
+                   "backward_kernel_ms": r["roofline"]["kernel_ms"],
+                   "failed_instances": r["config"]["failed_instances"],
+                   "hbm_frac": r["roofline"]["frac"], "valu_frac_algorithmic": r["roofline"]["valu"]["frac_algorithmic"],
+                   "work": r["work"]}
+            if not args.no_cpu_baseline:
+                row["cpu_baseline"] = cpu_baseline(name, prob, w, target_seconds=6.0)
+            rows[name] = row
+        except Exception as exc:                      # a missing code object must not take the headline line down
+            rows[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    return rows
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's BASELINE batch)")
+    ap.add_argument("--workload", default="lv", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: become `python -m torch.distributed.run ... bench.py ...`."""
+    import socket
+    import torch
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    os.execv(sys.executable, cmd)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, argv)                      # does not return
+    out = run_rank(args)
+    if out is not None:
+        if args.gpus == 1:
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.workload, make_problem(args.workload), WORKLOADS[args.workload])
+            if not args.no_extra_configs and args.workload == "lv":
+                out["configs"] = extra_configs(args)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

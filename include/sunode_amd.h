@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 1
+#define SA_ABI_VERSION 1          /* device ABI (sa_meta[3] of a code object) */
 
 #define SA_MEM_HOST 0
 #define SA_MEM_DEVICE 1
@@ -40,6 +40,11 @@ extern "C" {
 #define SA_ERR_HIP (-1001)        /* a HIP runtime call failed */
 #define SA_ERR_ARG (-1002)        /* invalid argument / call sequence */
 #define SA_ERR_MODULE (-1003)     /* code object missing, wrong arch or ABI mismatch */
+
+/* per-instance status beyond the CVODES codes: the instance's stored trajectory exceeds
+   sa_options.traj_capacity points (or 64 instances of it exceed arena_bytes).  Distinct from
+   CV_TOO_MUCH_WORK (-1), which keeps its CVODES meaning (mxstep x retries of one CVode call). */
+#define SA_STATUS_ARENA_FULL (-9001)
 
 /* statistics slots: stats[b*SA_N_STATS + slot], int64 (CVodeGetNumSteps & friends,
    16_cvodes.h:208-235, 15_cvodes_ls.h:94-106; summed over the backward restarts) */
@@ -75,10 +80,16 @@ typedef struct sa_options {
     int32_t mxstep;            /* internal steps per CVode call (CVODES default 500) */
     int32_t max_retries_fwd;   /* sunode: 5  (solver.py:467) */
     int32_t max_retries_bwd;   /* sunode: 50 (solver.py:724) */
-    int32_t traj_capacity;     /* stored points per instance (CVodeAdjInit steps; arena rows) */
+    int32_t traj_capacity;     /* most stored points per instance the caller allows (the role of CVodeAdjInit's
+                                  steps x check points; sunode: 500 000).  NOT an allocation size: the arena holds
+                                  what the batch needs, see arena_bytes */
     const double *constraints; /* CVodeSetConstraints (solver.py:230-233, 569-572): host pointer to n_states values
                                   in {0, +-1, +-2} or NULL; forward problem only; needs a code object built with
                                   constraint support (SA_CONSTRAINTS), otherwise the vector is ignored */
+    int64_t arena_bytes;       /* budget of the trajectory arena; 0 = default (16 GiB, at most 60 % of the free HBM).
+                                  A batch whose stored steps fit stays resident between sa_solve_forward_batch and
+                                  sa_solve_backward_batch; a larger one is re-integrated tile by tile inside the
+                                  backward call (check-point semantics; results identical, one extra forward pass) */
 } sa_options;
 
 int sa_abi_version(void);
@@ -150,9 +161,21 @@ int sa_eval_callbacks(sa_solver *s, int mem, int32_t npts, const double *t, cons
 int sa_math_probe(sa_solver *s, int32_t n, const double *x, const double *y, double *pow_out,
                   double *sqrt_out, double *div_out);
 
-/* HIP-event durations (ms) of the most recent forward / backward kernel launches. */
+/* Trajectory arena of the last sa_solve_forward_batch / sa_solve_backward_batch pair: bytes of the largest arena
+   allocation used, number of re-integrated tiles so far on this handle, and whether the last forward batch is
+   resident (0) or will be / was re-integrated tile by tile (1).  Any pointer may be NULL. */
+int sa_arena_info(sa_solver *s, int64_t *arena_bytes, int64_t *tiles, int32_t *tiled);
+
+/* HIP-event durations (ms) of the most recent forward / backward kernel launches (tiled batches: the whole
+   sequence of re-integration + adjoint launches of the backward call). */
 int sa_last_kernel_ms(sa_solver *s, float *forward_ms, float *backward_ms);
-int sa_set_stream(sa_solver *s, void *hip_stream);     /* hipStream_t; NULL = library-owned stream */
+/* Stream ordering contract.  A handle launches on ONE stream: its own (created hipStreamNonBlocking, i.e. NOT
+   ordered against the null stream or any caller stream) unless sa_set_stream() hands it the caller's.  With
+   SA_MEM_DEVICE arguments the caller must therefore either (a) pass the stream its producers / consumers run on
+   (e.g. torch.cuda.current_stream().cuda_stream, when that is not the null stream), or (b) synchronise its own
+   stream before the call and call sa_synchronize() before touching the outputs.  SA_MEM_HOST calls return with
+   the results on the host and need neither. */
+int sa_set_stream(sa_solver *s, void *hip_stream);     /* hipStream_t; NULL = back to a library-owned stream */
 int sa_synchronize(sa_solver *s);
 
 #ifdef __cplusplus

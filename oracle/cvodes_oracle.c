@@ -32,6 +32,15 @@
  *   - sensitivity-equation truth for the forward sensitivities, analytic cases, the textbook Robertson
  *     blow-up for the constraints (tests/test_forward_sens.py, tests/test_oracle_pinning.py).
  *
+ *
+ * RULE FOR EDITS (binding): the fixtures under tests/golden/ that come from OTHER codes -- dvode_stats.json
+ * (DVODE's own counters and step traces), truth_*.npz (DOP853/Radau + sensitivity equations), callbacks.json /
+ * layout.json (the reference's own lambdify output) -- are IMMUTABLE.  This file has been edited together with the
+ * kernels for bit-equality (explicit FMAs, balanced-tree WRMS sums, deterministic pow, reciprocal pivots); such
+ * edits may only re-associate or re-round arithmetic.  An edit after which any DVODE counter or trace in
+ * tests/test_oracle_pinning.py changes is WRONG and is rejected -- the fixture is never regenerated to follow
+ * the oracle.  (Division sharing / reciprocal forms in cvSet and friends fall under this rule too.)
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  *
  * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC \

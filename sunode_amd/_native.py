@@ -124,8 +124,10 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
     forced = os.environ.get("SA_FORCE_GROUP")
-    if hermite and not forced and n <= REGISTER_KERNEL_MAX_STATES:
-        forced = "8"          # Hermite interpolation lives in the cooperative / wave / memory kernels only
+    if hermite and not forced and n <= REGISTER_KERNEL_MAX_STATES and max(n, p) <= COOP_KERNEL_MAX_SIZE:
+        # Hermite interpolation lives in the cooperative / wave / memory kernels only; few states with many
+        # differentiated parameters fall through to the bdf_wave.hip group selection below (it carries Hermite too)
+        forced = "8"
     if sens or forced == "mem" or (not forced and max(n, p) > 128):
         return "bdf_mem.hip", 1
     if forced == "wave" or (not forced and max(n, p) > 64):
@@ -252,7 +254,8 @@ class _Options(ctypes.Structure):
                 ("atol", ctypes.POINTER(ctypes.c_double)), ("rtolB", ctypes.c_double), ("atolB", ctypes.c_double),
                 ("rtolQB", ctypes.c_double), ("atolQB", ctypes.c_double), ("mxstep", ctypes.c_int32),
                 ("max_retries_fwd", ctypes.c_int32), ("max_retries_bwd", ctypes.c_int32),
-                ("traj_capacity", ctypes.c_int32), ("constraints", ctypes.POINTER(ctypes.c_double))]
+                ("traj_capacity", ctypes.c_int32), ("constraints", ctypes.POINTER(ctypes.c_double)),
+                ("arena_bytes", ctypes.c_int64)]
 
 
 _LIB: Optional[ctypes.CDLL] = None
@@ -285,12 +288,14 @@ def load_library() -> ctypes.CDLL:
                                               _dp, _dp, _dp, _dp, _dp, _dp]
     L.sa_eval_callbacks.argtypes = [vp, ctypes.c_int, i32] + [_dp] * 11
     L.sa_math_probe.argtypes = [vp, i32] + [_dp] * 5
+    L.sa_arena_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32)]
     L.sa_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.sa_set_stream.argtypes = [vp, vp]
     L.sa_synchronize.argtypes = [vp]
     for name in ("sa_solver_create", "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
                  "sa_solve_forward_batch", "sa_solve_backward_batch", "sa_solve_backward_batch_all",
-                 "sa_eval_callbacks", "sa_math_probe", "sa_last_kernel_ms", "sa_set_stream", "sa_synchronize"):
+                 "sa_eval_callbacks", "sa_math_probe", "sa_last_kernel_ms", "sa_set_stream", "sa_synchronize",
+                 "sa_arena_info"):
         getattr(L, name).restype = ctypes.c_int
     _LIB = L
     return L
@@ -300,7 +305,7 @@ EXPORTED_SYMBOLS = ["sa_abi_version", "sa_last_error", "sa_solver_create", "sa_s
                     "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
                     "sa_solve_forward_batch",
                     "sa_solve_backward_batch", "sa_solve_backward_batch_all", "sa_eval_callbacks", "sa_math_probe",
-                    "sa_last_kernel_ms",
+                    "sa_last_kernel_ms", "sa_arena_info",
                     "sa_set_stream", "sa_synchronize"]
 
 
@@ -326,8 +331,8 @@ class NativeSolver:
 
     def __init__(self, native_source: str, *, device: int = 0, rtol=1e-10, atol=1e-10, rtolB=1e-10,
                  atolB=1e-10, rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
-                 max_retries_bwd=50, traj_capacity=2048, n_states: Optional[int] = None, sens: bool = False,
-                 constraints=None, hermite: bool = False):
+                 max_retries_bwd=50, traj_capacity=500_001, n_states: Optional[int] = None, sens: bool = False,
+                 constraints=None, hermite: bool = False, arena_bytes: int = 0):
         self.L = load_library()
         self.code_object = build_code_object(native_source, sens=sens, constraints=constraints is not None,
                                              hermite=hermite)
@@ -335,7 +340,8 @@ class NativeSolver:
         self._n_hint = n_states
         self._opt_kw = dict(device=device, rtol=rtol, atol=atol, rtolB=rtolB, atolB=atolB, rtolQB=rtolQB,
                             atolQB=atolQB, mxstep=mxstep, max_retries_fwd=max_retries_fwd,
-                            max_retries_bwd=max_retries_bwd, traj_capacity=traj_capacity, constraints=constraints)
+                            max_retries_bwd=max_retries_bwd, traj_capacity=traj_capacity, constraints=constraints,
+                            arena_bytes=arena_bytes)
         opt, keep = self._make_options(n_states if n_states is not None else 64)
         rc = self.L.sa_solver_create(self.code_object.encode(), ctypes.byref(opt), ctypes.byref(self._h))
         self._check(rc)
@@ -356,6 +362,7 @@ class NativeSolver:
         opt.rtolQB, opt.atolQB = float(kw["rtolQB"]), float(kw["atolQB"])
         opt.mxstep, opt.max_retries_fwd = int(kw["mxstep"]), int(kw["max_retries_fwd"])
         opt.max_retries_bwd, opt.traj_capacity = int(kw["max_retries_bwd"]), int(kw["traj_capacity"])
+        opt.arena_bytes = int(kw.get("arena_bytes") or 0)
         cons = None
         if kw.get("constraints") is not None:
             cons = np.ascontiguousarray(np.broadcast_to(np.asarray(kw["constraints"], dtype=np.float64), (max(n, 1),)))
@@ -422,6 +429,12 @@ class NativeSolver:
         f, b = ctypes.c_float(), ctypes.c_float()
         self._check(self.L.sa_last_kernel_ms(self._h, ctypes.byref(f), ctypes.byref(b)))
         return f.value, b.value
+
+    def arena_info(self):
+        """(bytes of the largest trajectory-arena allocation used, tiles re-integrated so far, last batch tiled?)"""
+        b, t, f = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        self._check(self.L.sa_arena_info(self._h, ctypes.byref(b), ctypes.byref(t), ctypes.byref(f)))
+        return b.value, t.value, bool(f.value)
 
     def set_stream(self, stream_ptr):
         self._check(self.L.sa_set_stream(self._h, ctypes.c_void_p(stream_ptr)))

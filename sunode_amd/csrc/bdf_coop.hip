@@ -1162,7 +1162,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     const double y0 = (m.li < NS) ? a.y0[(int64_t)inst * NS + (m.li < NS ? m.li : 0)] : 0.0;
     cv_reinit(m, a.t0, y0, 0.0);
 
-    const bool store = (a.mode == SA_MODE_ADJ_FWD);
+    /* store: CVodeF semantics (every step is a data point, no mxstep budget); wr: the points are written to the
+       arena (SA_MODE_ADJ_COUNT runs the identical pass and only counts them, see sunode_amd.cpp) */
+    const bool store = (a.mode != SA_MODE_PLAIN), wr = (a.mode == SA_MODE_ADJ_FWD);
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
     double *trec = a.traj + (int64_t)inst * TREC;
     const int64_t trow = a.traj_stride * TREC;
@@ -1184,9 +1186,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             hT[0] = m.tn;
             hY[0] = m.zn[0];
 #ifdef SA_HERMITE
-            store_hermite(trec, m.li, m.tn, m.zn[0], m.f0);
+            if (wr) store_hermite(trec, m.li, m.tn, m.zn[0], m.f0);
 #else
-            store_table(trec, m.li, 0, 1.0, hT, hY);
+            if (wr) store_table(trec, m.li, 0, 1.0, hT, hY);
 #endif
             np = 1;
         }
@@ -1209,15 +1211,15 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             else if (r == 1) {
                 nstloc++;
                 if (store) {
-                    if (np >= a.traj_cap) { status = CV_TOO_MUCH_WORK; done = true; }
+                    if (wr && np >= a.traj_cap) { status = SA_TRAJ_FULL; done = true; }
                     else {
                         SFOR_DOWN(j, QMAX, 1) { hT[j] = hT[j - 1]; hY[j] = hY[j - 1]; } SEND
                         hT[0] = m.tn;
                         hY[0] = m.zn[0];
 #ifdef SA_HERMITE
-                        store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], (1.0 / m.h) * m.zn[1]);
+                        if (wr) store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], (1.0 / m.h) * m.zn[1]);
 #else
-                        store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+                        if (wr) store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
 #endif
                         np++;
                     }

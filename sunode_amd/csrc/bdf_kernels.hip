@@ -1220,7 +1220,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     SFOR(i, 0, NS) y0[i] = a.y0[(int64_t)inst * NS + i]; SEND
     cv_reinit(m, a.t0, y0, (const double *)nullptr);
 
-    const bool store = (a.mode == SA_MODE_ADJ_FWD);
+    /* store: CVodeF semantics (every step is a data point, no mxstep budget); wr: the points are written to the
+       arena (SA_MODE_ADJ_COUNT runs the identical pass and only counts them, see sunode_amd.cpp) */
+    const bool store = (a.mode != SA_MODE_PLAIN), wr = (a.mode == SA_MODE_ADJ_FWD);
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
     double *trec = a.traj + (int64_t)inst * TREC;     /* records {order, dt, T[6], Y[6][n]} */
     const int64_t trow = a.traj_stride * TREC;
@@ -1241,7 +1243,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         else if (store) {
             hT[0] = m.tn;
             SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
-            store_table(trec, 0, 1.0, hT, hY);
+            if (wr) store_table(trec, 0, 1.0, hT, hY);
             np = 1;
         }
     }
@@ -1263,7 +1265,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             else if (r == 1) {
                 nstloc++;
                 if (store) {
-                    if (np >= a.traj_cap) { status = CV_TOO_MUCH_WORK; done = true; }
+                    if (wr && np >= a.traj_cap) { status = SA_TRAJ_FULL; done = true; }
                     else {
                         SFOR_DOWN(j, QMAX, 1) {
                             hT[j] = hT[j - 1];
@@ -1271,7 +1273,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                         } SEND
                         hT[0] = m.tn;
                         SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
-                        store_table(trec + (int64_t)np * trow, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+                        if (wr) store_table(trec + (int64_t)np * trow, m.qu, fabs(hT[0] - hT[1]), hT, hY);
                         np++;
                     }
                 }

@@ -1418,7 +1418,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     }
     cv_reinit(m, a.t0);
 
-    const bool store = (a.mode == SA_MODE_ADJ_FWD);
+    /* store: CVodeF semantics (every step is a data point, no mxstep budget); wr: the points are written to the
+       arena (SA_MODE_ADJ_COUNT runs the identical pass and only counts them, see sunode_amd.cpp) */
+    const bool store = (a.mode != SA_MODE_PLAIN), wr = (a.mode == SA_MODE_ADJ_FWD);
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
     double *trec = a.traj + inst;                       /* point s: trec + s*TREC*tS */
     const int64_t tS = a.traj_stride;
@@ -1439,11 +1441,11 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         if (flag != CV_SUCCESS) { status = flag; done = true; }
         else if (store) {
 #ifdef SA_HERMITE
-            store_hermite(m, trec, tS, m.tn, true);
+            if (wr) store_hermite(m, trec, tS, m.tn, true);
 #else
             hT[0] = m.tn;
             for (int i = 0; i < NS; i++) W(m, O_HY, i) = ZN(m, 0, i);
-            store_table(m, trec, tS, 0, 1.0, hT);
+            if (wr) store_table(m, trec, tS, 0, 1.0, hT);
 #endif
             np = 1;
         }
@@ -1466,17 +1468,17 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             else if (r == 1) {
                 nstloc++;
                 if (store) {
-                    if (np >= a.traj_cap) { status = CV_TOO_MUCH_WORK; done = true; }
+                    if (wr && np >= a.traj_cap) { status = SA_TRAJ_FULL; done = true; }
                     else {
 #ifdef SA_HERMITE
-                        store_hermite(m, trec + (int64_t)np * TREC * tS, tS, m.tn, false);
+                        if (wr) store_hermite(m, trec + (int64_t)np * TREC * tS, tS, m.tn, false);
 #else
                         SFOR_DOWN(j, QMAX, 1) hT[j] = hT[j - 1]; SEND
                         hT[0] = m.tn;
                         for (int j = QMAX; j >= 1; j--)
                             for (int i = 0; i < NS; i++) W(m, O_HY, j * NS + i) = W(m, O_HY, (j - 1) * NS + i);
                         for (int i = 0; i < NS; i++) W(m, O_HY, i) = ZN(m, 0, i);
-                        store_table(m, trec + (int64_t)np * TREC * tS, tS, m.qu, fabs(hT[0] - hT[1]), hT);
+                        if (wr) store_table(m, trec + (int64_t)np * TREC * tS, tS, m.qu, fabs(hT[0] - hT[1]), hT);
 #endif
                         np++;
                     }

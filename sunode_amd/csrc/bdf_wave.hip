@@ -74,7 +74,7 @@ static __device__ __forceinline__ int sa_grp()
 #define SA_WAVES 4
 #endif
 static_assert(G == 64 || SA_WAVES == 1, "worker wavefronts need 64 lanes per instance");
-__shared__ int s_cmd, s_nwaves;
+__shared__ int s_cmd, s_nwaves, s_flag;
 __shared__ double s_targ;
 __shared__ int s_rc[SA_WAVES];
 enum { CMD_EXIT = 0, CMD_RHS = 1, CMD_QUAD = 2, CMD_JAC = 3, CMD_GETRF = 4 };
@@ -144,6 +144,57 @@ static __device__ __forceinline__ double sa_touch(const gdouble *p, int n)
 #define SA_STMT_END asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
 #endif
 #endif
+
+/* Dense matrix-vector block of a callback (generated SA_MATVEC, see symode/codegen.py): out[i] = sum_j M[j*NO+i] v[j]
+   with M = a j-major block of the remainder vector (consecutive lanes read consecutive doubles) and v the staged
+   state / adjoint state in LDS.  Lane-parallel over the rows: a lane owns rows li, li + G, ...; the four
+   interleaved accumulators of the generated association are split between the wavefronts of the workgroup
+   (one accumulator each with SA_WAVES = 4), every partial sum goes to LDS and SA_MV(tag, i) adds the four partials
+   of row i in the canonical order (a0 + a1) + (a2 + a3).  Replaces n_out * n_in scalar statements that every lane
+   used to evaluate redundantly. */
+__shared__ double s_mvp[4 * KPW * W_NS];
+#define SA_MV(tag, i) ((s_mvp[(0 * KPW + sa_grp()) * W_NS + (i)] + s_mvp[(1 * KPW + sa_grp()) * W_NS + (i)]) + \
+                       (s_mvp[(2 * KPW + sa_grp()) * W_NS + (i)] + s_mvp[(3 * KPW + sa_grp()) * W_NS + (i)]))
+#define SA_OWNS(slot) (((slot) % s_nwaves) == sa_wave_index())
+template <int NO, int NI>
+static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const double *v)
+{
+    static_assert(NO <= W_NS, "matrix-vector block larger than the state vector");
+    constexpr int RSL = (NO + G - 1) / G;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int li = lane & (G - 1), grp = (KPW == 1) ? 0 : lane / G;
+    const int nw = (SA_WAVES > 1) ? s_nwaves : 1;
+    const int w = (SA_WAVES > 1) ? sa_wave_index() : 0;
+    int row[RSL];
+#pragma unroll
+    for (int r = 0; r < RSL; r++) row[r] = (r * G + li < NO) ? r * G + li : 0;
+    for (int a = w; a < 4; a += nw) {
+        double acc[RSL];
+        if (a < NI) {
+            const double v0 = v[a];
+#pragma unroll
+            for (int r = 0; r < RSL; r++) acc[r] = M[a * NO + row[r]] * v0;
+            for (int j = a + 4; j < NI; j += 4) {
+                const double vj = v[j];
+#pragma unroll
+                for (int r = 0; r < RSL; r++) acc[r] = __builtin_fma(M[j * NO + row[r]], vj, acc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RSL; r++) acc[r] = 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < RSL; r++)
+            if (r * G + li < NO) s_mvp[(a * KPW + grp) * W_NS + r * G + li] = acc[r];
+    }
+    if constexpr (SA_WAVES > 1) __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+#define SA_MATVEC(tag, NO, NI, OFF, VEC) sa_matvec_coop<NO, NI>(prg + (OFF), &VEC(0))
 
 #include SA_PROBLEM_HEADER
 #include "sa_device_abi.h"
@@ -516,6 +567,7 @@ struct Grp {
     int lane, li, gbase, abase, kbase, wave;
 };
 DEV int getrf_coop(const Grp &g, double (&inv_piv)[(W_NS + G - 1) / G], int &nswaps);
+DEV int setup_lu_regs(int wave, int lane, double c, bool from_saved, double *sj, int &nswaps);
 
 template <bool BWD>
 DEV void worker_loop(const double *pr, double *obuf)
@@ -527,11 +579,8 @@ DEV void worker_loop(const double *pr, double *obuf)
         const double t = s_targ;
         if (cmd == CMD_EXIT) break;
         if (cmd == CMD_GETRF) {
-            double inv_piv[RS];
             int nswaps;
-            SFOR(r, 0, RS) inv_piv[r] = 0.0; SEND
-            const Grp g{lane, lane, 0, 0, 0, wave};
-            (void)getrf_coop(g, inv_piv, nswaps);
+            (void)setup_lu_regs(wave, lane, t, s_flag != 0, obuf - WS_OUT + WS_SJ, nswaps);
         } else {
             const int rc = run_callback<BWD>(cmd, t, pr, obuf);
             if (lane == 0) s_rc[wave] = rc;
@@ -690,6 +739,154 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
     return 0;
 }
 
+/* ---- Newton matrix set-up + LU by the whole workgroup, matrix in REGISTERS (SA_WAVES > 1, G = 64) ----
+ * M = I + c*J (c = -gamma) is built and factorised without touching LDS in the elimination: wavefront w owns the
+ * columns j = SA_WAVES*cc + w (cc < LU_NC; 25 columns at n = 100), lane l the rows l, l + 64: 2*LU_NC doubles per lane.
+ * Step k: the OWNER of column k checks the pivot (one ballot; the arg-max butterfly only if some row beats the
+ * diagonal), scales the column and publishes it (LDS, double-buffered) -- one workgroup barrier -- then every
+ * wavefront updates its trailing columns from registers: the pivot-row entry a(k,j) is a v_readlane of its own
+ * column register, the update one FMA per owned entry.  Same operations and order as denseGETRF / getrf_coop
+ * (bit-identical); row exchanges (rare: I - gamma*J is nearly diagonally dominant) swap register rows with
+ * readlane/select and cost one extra barrier.  J comes from the saved copy in the workspace (from_saved) or from
+ * LDS where the Jacobian callback just wrote it (and is saved on the way); the factors end up in LDS (s_A) for
+ * the triangular solves of wavefront 0, the reciprocal pivots in s_invp. */
+#if SA_WAVES > 1
+#define LU_NC ((NS + SA_WAVES - 1) / SA_WAVES)
+static_assert(64 % SA_WAVES == 0, "the columns of one ownership round must share a register slot");
+__shared__ double s_col[2][W_NS];
+__shared__ double s_invp[W_NS];
+__shared__ int s_luier;
+
+DEV int setup_lu_regs(int wave, int lane, double c, bool from_saved, double *sj, int &nswaps)
+{
+    double a[LU_NC][RS];
+    SFOR(cc, 0, LU_NC) {
+        const int j = cc * SA_WAVES + wave;
+        SFOR(r, 0, RS) {
+            const int i = r * 64 + lane;
+            double v = 0.0;
+            if (j < NS && i < NS) {
+                if (from_saved) v = sj[j * NS + i];
+                else { v = s_A[j * NS + i]; sj[j * NS + i] = v; }
+                v = (i == j) ? FMA(c, v, 1.0) : v * c;
+            }
+            a[cc][r] = v;
+        } SEND
+    } SEND
+    if (wave == 0 && lane == 0) s_luier = 0;
+    nswaps = 0;
+    __syncthreads();
+    int ier = 0;
+    SFOR(kc, 0, LU_NC) {
+        constexpr int slot_k = (kc * SA_WAVES) / 64;
+        for (int o = 0; o < SA_WAVES && ier == 0; o++) {
+            const int k = kc * SA_WAVES + o;
+            if (k >= NS) break;
+            const int kl = k & 63, buf = k & 1;
+            int l = k;
+            if (wave == o) {
+                /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF) */
+                const double akk = readlane_d(a[kc][slot_k], kl);
+                double best = fabs(akk);
+                int bi = k;
+                bool beaten = false;
+                double cand[RS];
+                SFOR(r, 0, RS) {
+                    const int i = r * 64 + lane;
+                    cand[r] = (i > k && i < NS) ? fabs(a[kc][r]) : -1.0;
+                    beaten = beaten || (cand[r] > best);
+                } SEND
+                if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
+                    best = -1.0;
+                    bi = 1 << 20;
+                    SFOR(r, 0, RS) {
+                        const int i = r * 64 + lane;
+                        const double v = (i == k) ? fabs(akk) : cand[r];
+                        if (i >= k && i < NS && v > best) { best = v; bi = i; }
+                    } SEND
+                    SFOR(b, 0, 6) {
+                        const double ov = shfl_d(best, lane ^ (1 << b));
+                        const int oi = shfl_i(bi, lane ^ (1 << b));
+                        const bool take = (ov > best) || (ov == best && oi < bi);
+                        best = take ? ov : best;
+                        bi = take ? oi : bi;
+                    } SEND
+                }
+                l = bi;
+                if (best == 0.0) { if (lane == 0) s_luier = k + 1; }
+                else {
+                    if (lane == 0) s_piv[k] = (uint8_t)l;
+                    if (l == k) {
+                        const double mult = 1.0 / akk;
+                        if (lane == 0) s_invp[k] = mult;
+                        SFOR(r, slot_k, RS) {
+                            const int i = r * 64 + lane;
+                            if (i > k && i < NS) { const double lc = a[kc][r] * mult; a[kc][r] = lc; s_col[buf][i] = lc; }
+                        } SEND
+                    }
+                }
+            }
+            __syncthreads();
+            ier = s_luier;
+            if (ier != 0) break;
+            l = s_piv[k];
+            if (l != k) {                   /* exchange rows k and l in every wavefront's columns, then scale */
+                nswaps++;
+                const int ll = l & 63, ls = l >> 6;
+                SFOR(cc, 0, LU_NC) {
+                    const double xk = readlane_d(a[cc][slot_k], kl);
+                    double src = a[cc][0];
+                    SFOR(r, 1, RS) src = (ls == r) ? a[cc][r] : src; SEND
+                    const double xl = readlane_d(src, ll);
+                    SFOR(r, 0, RS) {
+                        const int i = r * 64 + lane;
+                        a[cc][r] = (i == k) ? xl : ((i == l) ? xk : a[cc][r]);
+                    } SEND
+                } SEND
+                if (wave == o) {
+                    const double akk = readlane_d(a[kc][slot_k], kl);
+                    const double mult = 1.0 / akk;
+                    if (lane == 0) s_invp[k] = mult;
+                    SFOR(r, slot_k, RS) {
+                        const int i = r * 64 + lane;
+                        if (i > k && i < NS) { const double lc = a[kc][r] * mult; a[kc][r] = lc; s_col[buf][i] = lc; }
+                    } SEND
+                }
+                __syncthreads();
+            }
+            /* trailing update of this wavefront's columns j > k */
+            double lc[RS];
+            SFOR(r, slot_k, RS) { const int i = r * 64 + lane; lc[r] = (i > k && i < NS) ? s_col[buf][i] : 0.0; } SEND
+            SFOR(cc, kc, LU_NC) {
+                const int j = cc * SA_WAVES + wave;
+                if (j > k && j < NS) {
+                    const double akj = readlane_d(a[cc][slot_k], kl);
+                    if (akj != 0.0) {
+                        SFOR(r, slot_k, RS) {
+                            const int i = r * 64 + lane;
+                            if (i > k && i < NS) a[cc][r] = FMA(-akj, lc[r], a[cc][r]);
+                        } SEND
+                    }
+                }
+            } SEND
+        }
+    } SEND
+    if (ier == 0) {
+        SFOR(cc, 0, LU_NC) {
+            const int j = cc * SA_WAVES + wave;
+            SFOR(r, 0, RS) {
+                const int i = r * 64 + lane;
+                if (j < NS && i < NS) s_A[j * NS + i] = a[cc][r];
+            } SEND
+        } SEND
+    }
+    __syncthreads();
+    return ier;
+}
+#else
+DEV int setup_lu_regs(int, int, double, bool, double *, int &) { return 0; }
+#endif
+
 template <bool BWD>
 DEV int dense_getrf(Cw<BWD> &m)
 {
@@ -705,6 +902,23 @@ DEV int dense_getrf(Cw<BWD> &m)
     PROF_ADD(m, 3)
     return ier;
 }
+
+#if SA_WAVES > 1
+/* wavefront 0's side of setup_lu_regs: publish the command, take part, collect pivots' reciprocals */
+template <bool BWD>
+DEV int setup_lu_workgroup(Cw<BWD> &m, double c, bool from_saved)
+{
+    PROF_T0
+    if (m.li == 0) { s_cmd = CMD_GETRF; s_targ = c; s_flag = from_saved ? 1 : 0; }
+    __syncthreads();
+    const int ier = setup_lu_regs(0, m.lane, c, from_saved, m.sj, m.nswaps);
+    SFOR(r, 0, RS) { const int i = r * 64 + m.lane; m.inv_piv[r] = (i < NS) ? s_invp[i < NS ? i : 0] : 0.0; } SEND
+    __syncthreads();                /* pairs with the barrier that ends every pass of worker_loop */
+    lds_sync();
+    PROF_ADD(m, 3)
+    return ier;
+}
+#endif
 
 /* component k (wave-uniform k) of a lane-distributed vector */
 DEV double bcast_vec(const double (&b)[RS], int k, int gbase)
@@ -1047,6 +1261,21 @@ DEV int cv_lsetup(Cw<BWD> &m, int convfail)
     int jret = 0;
     const double c = -m.gamma;
     lds_sync();
+#if SA_WAVES > 1
+    {   /* whole workgroup: J (saved copy, or fresh from the callback via LDS) -> I - gamma*J -> LU, in registers */
+        if (!jbad) m.jcur = 0;
+        else {
+            m.nje++;
+            m.nstlj = m.nst;
+            m.jcur = 1;
+            jret = cv_jac(m, m.tn, m.y);
+        }
+        if (jret < 0) return -1;
+        if (jret > 0) return 1;
+        const int ier = setup_lu_workgroup(m, c, !jbad);
+        return ier > 0 ? 1 : 0;
+    }
+#endif
     if (!jbad) {
         PROF_T0
         m.jcur = 0;
@@ -1608,7 +1837,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     SFOR(r, 0, RQ) q0[r] = 0.0; SEND
     cv_reinit(m, a.t0, y0, q0);
 
-    const bool store = (a.mode == SA_MODE_ADJ_FWD);
+    /* store: CVodeF semantics (every step is a data point, no mxstep budget); wr: the points are written to the
+       arena (SA_MODE_ADJ_COUNT runs the identical pass and only counts them, see sunode_amd.cpp) */
+    const bool store = (a.mode != SA_MODE_PLAIN), wr = (a.mode == SA_MODE_ADJ_FWD);
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
     double *trec = a.traj + (int64_t)inst * TREC;
     const int64_t trow = a.traj_stride * TREC;
@@ -1630,9 +1861,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
             hT[0] = m.tn;
             SFOR(r, 0, RS) hY[0][r] = m.zn[0][r]; SEND
 #ifdef SA_HERMITE
-            store_hermite(trec, m.li, m.tn, m.zn[0], m.f0);
+            if (wr) store_hermite(trec, m.li, m.tn, m.zn[0], m.f0);
 #else
-            store_table(trec, m.li, 0, 1.0, hT, hY);
+            if (wr) store_table(trec, m.li, 0, 1.0, hT, hY);
 #endif
             np = 1;
         }
@@ -1655,7 +1886,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
             else if (r == 1) {
                 nstloc++;
                 if (store) {
-                    if (np >= a.traj_cap) { status = CV_TOO_MUCH_WORK; done = true; }
+                    if (wr && np >= a.traj_cap) { status = SA_TRAJ_FULL; done = true; }
                     else {
                         SFOR_DOWN(j, QMAX, 1) { hT[j] = hT[j - 1]; SFOR(s, 0, RS) hY[j][s] = hY[j - 1][s]; SEND } SEND
                         hT[0] = m.tn;
@@ -1664,10 +1895,10 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
                         {
                             double ydp[RS];
                             SFOR(s, 0, RS) ydp[s] = (1.0 / m.h) * m.zn[1][s]; SEND
-                            store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], ydp);
+                            if (wr) store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], ydp);
                         }
 #else
-                        store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+                        if (wr) store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
 #endif
                         np++;
                     }

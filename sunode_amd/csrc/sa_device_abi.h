@@ -25,6 +25,14 @@
 
 #define SA_MODE_PLAIN 0      /* Solver.solve: CVode(NORMAL) per tval, mxstep x max_retries budget */
 #define SA_MODE_ADJ_FWD 1    /* AdjointSolver.solve_forward: CVodeF, every step stored */
+#define SA_MODE_ADJ_COUNT 2  /* the same pass without arena writes: y_out / status / stats identical, traj_np = number of
+                                points the instance WOULD store (sizes the arena tiles of the re-integration, see
+                                sunode_amd.cpp "trajectory arena") */
+
+/* status of an instance whose stored trajectory does not fit the rows the arena was launched with.  Internal:
+   the host library catches it and re-integrates with exactly sized tiles; it only reaches the caller
+   (as SA_STATUS_ARENA_FULL) when a single 64-instance tile exceeds sa_options.traj_capacity / arena_bytes. */
+#define SA_TRAJ_FULL (-9001)
 
 #define SA_N_STATS 16
 

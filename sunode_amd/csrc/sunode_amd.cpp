@@ -80,11 +80,20 @@ struct sa_solver {
     std::vector<double> constraints;
     DevBuf d_constraints;
     bool have_constraints = false;
-    /* trajectory arena + forward bookkeeping of the last forward batch */
+    /* trajectory arena + forward bookkeeping of the last forward batch (see "trajectory arena" below) */
     DevBuf traj, traj_np, fwd_status;
     int64_t traj_stride = 0;
+    int32_t traj_rows = 0;         /* rows the resident arena was launched with */
     int32_t fwd_B = 0;
     double fwd_t0 = 0.0;
+    bool tiled = false;            /* the trajectories are NOT resident: the backward call re-integrates tile by tile */
+    std::vector<int32_t> h_np;     /* tiled mode: points per instance, from the counting pass */
+    std::vector<int32_t> h_scratch;
+    DevBuf keep_y0, keep_tvals;    /* tiled mode: the forward call's initial states and output grid */
+    int32_t fwd_n_t = 0;
+    DevBuf t_yout, t_status, t_stats, t_np;   /* outputs of the re-integration (discarded: identical to the forward call's) */
+    int32_t rows_hint = 0;         /* largest per-instance point count seen so far on this handle */
+    int64_t stat_tiles = 0, stat_arena_bytes = 0;
     /* staging for SA_MEM_HOST calls */
     DevBuf s_y0, s_ps, s_pr, s_tvals, s_yout, s_status, s_stats, s_grads, s_gout, s_lout;
     DevBuf s_misc[12];
@@ -110,6 +119,7 @@ static int apply_options(sa_solver *s, const sa_options *opt)
                     opt ? opt->struct_size : -1, sizeof(sa_options));
     if (s->n > 0 && !opt->atol) return fail(SA_ERR_ARG, "sa_options.atol is NULL");
     if (opt->traj_capacity < 2) return fail(SA_ERR_ARG, "traj_capacity must be >= 2");
+    if (opt->arena_bytes < 0) return fail(SA_ERR_ARG, "arena_bytes must be >= 0");
     s->opt = *opt;
     s->atol.assign(opt->atol, opt->atol + s->n);
     s->opt.atol = nullptr;
@@ -195,7 +205,8 @@ extern "C" void sa_solver_destroy(sa_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    DevBuf *bufs[] = {&s->d_atol, &s->traj, &s->traj_np, &s->fwd_status, &s->s_y0,
+    DevBuf *bufs[] = {&s->d_atol, &s->traj, &s->traj_np, &s->fwd_status, &s->keep_y0, &s->keep_tvals,
+                      &s->t_yout, &s->t_status, &s->t_stats, &s->t_np, &s->s_y0,
                       &s->s_ps, &s->s_pr, &s->s_tvals, &s->s_yout, &s->s_status, &s->s_stats, &s->s_grads,
                       &s->s_gout, &s->s_lout, &s->ws, &s->d_constraints};
     for (DevBuf *b : bufs) b->release();
@@ -248,6 +259,15 @@ extern "C" int sa_synchronize(sa_solver *s)
     return SA_OK;
 }
 
+extern "C" int sa_arena_info(sa_solver *s, int64_t *arena_bytes, int64_t *tiles, int32_t *tiled)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    if (arena_bytes) *arena_bytes = s->stat_arena_bytes;
+    if (tiles) *tiles = s->stat_tiles;
+    if (tiled) *tiled = s->tiled ? 1 : 0;
+    return SA_OK;
+}
+
 extern "C" int sa_last_kernel_ms(sa_solver *s, float *fwd, float *bwd)
 {
     if (!s) return fail(SA_ERR_ARG, "null solver");
@@ -287,6 +307,64 @@ static int bind_workspace(sa_solver *s, int32_t B, double **ws, int64_t *stride)
     return SA_OK;
 }
 
+/* ---- trajectory arena ---------------------------------------------------------------------------
+ * CVODES keeps the adjoint "data points" of CVodeF in host memory, check point by check point, and
+ * re-integrates the forward problem segment by segment when the backward pass needs points it no longer
+ * holds (sunode: CVodeAdjInit(checkpoint_n = 500 000), solver.py:533,588 -- in effect unbounded).  Here the
+ * points of a whole batch live in ONE device arena traj[rows][stride][8+6n] and the same two regimes exist:
+ *
+ *  resident   rows x roundup64(B) records fit the budget (sa_options.arena_bytes): the forward call stores
+ *             every step, the backward call reads them.  rows starts at 512 and follows the largest point
+ *             count seen on the handle (x1.25), never more than sa_options.traj_capacity.
+ *  tiled      otherwise, or when an instance ran out of rows (kernel status SA_TRAJ_FULL): the forward call
+ *             runs the identical integration WITHOUT arena writes (SA_MODE_ADJ_COUNT: y_out / status / stats
+ *             as usual, plus the number of points per instance); the backward call then walks the batch in
+ *             contiguous tiles of 64-instance groups sized so that tile_instances x max_points x record fits
+ *             the budget, re-integrates each tile forward with storage (bit-identical: same kernel, same
+ *             inputs) and runs the adjoint on it -- CVODES' check-point re-integration with one check point
+ *             at t0.  Cost: one extra forward pass; memory: the budget, whatever B and the step counts are.
+ * An instance that needs more rows than traj_capacity, or a 64-instance group that alone exceeds the budget,
+ * is reported with status SA_STATUS_ARENA_FULL (never as CV_TOO_MUCH_WORK, which the reference reserves for
+ * the mxstep x retries budget of one CVode call).
+ */
+static const int32_t SA_FIRST_ROWS = 512;
+
+static int64_t round64(int64_t v) { return (v + 63) / 64 * 64; }
+
+static size_t arena_budget(const sa_solver *s)
+{
+    if (s->opt.arena_bytes > 0) return (size_t)s->opt.arena_bytes;
+    size_t free_b = 0, total_b = 0;
+    size_t dflt = (size_t)16 << 30;                            /* default: 16 GiB ... */
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {      /* ... but at most 60 % of what is free (+ what we hold) */
+        size_t avail = (size_t)(0.6 * (double)(free_b + s->traj.cap));
+        if (avail < dflt) dflt = avail;
+    }
+    return dflt;
+}
+
+static size_t record_bytes(const sa_solver *s) { return sizeof(double) * (size_t)(8 + 6 * s->n); }
+
+struct FwdLaunch {
+    int mode; int32_t B, n_t, rem_stride, rows; int64_t stride; double t0;
+    const double *y0, *ps, *pr, *tvals; double *y_out; int32_t *status; int64_t *stats; int32_t *traj_np;
+};
+
+static int launch_forward(sa_solver *s, const FwdLaunch &f)
+{
+    sa_fwd_args a;
+    memset(&a, 0, sizeof a);
+    a.B = f.B; a.n_t = f.n_t; a.mode = f.mode; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_fwd;
+    a.traj_cap = f.rows; a.rem_stride = f.rem_stride;
+    a.t0 = f.t0; a.rtol = s->opt.rtol; a.atol = (const double *)s->d_atol.p;
+    a.y0 = f.y0; a.ps = f.ps; a.pr = f.pr; a.tvals = f.tvals; a.y_out = f.y_out; a.status = f.status; a.stats = f.stats;
+    a.constraints = s->have_constraints ? (const double *)s->d_constraints.p : nullptr;
+    a.traj_stride = f.stride; a.traj = (double *)s->traj.p; a.traj_np = f.traj_np;
+    int rc;
+    if ((rc = bind_workspace(s, f.B, &a.ws, &a.ws_stride))) return rc;
+    return launch(s, s->k_forward, f.B, &a, sizeof a, s->group);
+}
+
 static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const double *y0, const double *ps,
                           const double *pr, int32_t rem_stride, double t0, const double *tvals, int32_t n_t,
                           double *y_out, int32_t *status, int64_t *stats)
@@ -314,32 +392,67 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
     } else if (mem != SA_MEM_DEVICE) {
         return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
     }
-    sa_fwd_args a;
-    memset(&a, 0, sizeof a);
-    a.B = B; a.n_t = n_t; a.mode = mode; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_fwd;
-    a.traj_cap = s->opt.traj_capacity; a.rem_stride = rem_stride;
-    a.t0 = t0; a.rtol = s->opt.rtol; a.atol = (const double *)s->d_atol.p;
-    a.y0 = d_y0; a.ps = d_ps; a.pr = d_pr; a.tvals = d_tv; a.y_out = d_yout; a.status = d_status; a.stats = d_stats;
-    a.constraints = s->have_constraints ? (const double *)s->d_constraints.p : nullptr;
-    if (mode == SA_MODE_ADJ_FWD) {
-        int64_t stride = ((int64_t)B + 63) / 64 * 64;
-        size_t rows = (size_t)s->opt.traj_capacity;
-        if ((rc = s->traj.ensure(sizeof(double) * rows * stride * (size_t)(8 + 6 * s->n)))) return rc;
+    FwdLaunch f{mode, B, n_t, rem_stride, 2, 0, t0, d_y0, d_ps, d_pr, d_tv, d_yout, d_status, d_stats, nullptr};
+    if (mode == SA_MODE_PLAIN) {
+        HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+        if ((rc = launch_forward(s, f))) return rc;
+        HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+        s->have_fwd_time = true;
+    } else {
+        const int64_t stride = round64(B);
+        const size_t rec = record_bytes(s), budget = arena_budget(s);
+        const int64_t fit_rows = (int64_t)(budget / ((size_t)stride * rec));
+        int64_t want = s->rows_hint > 0 ? (int64_t)(1.25 * s->rows_hint) + 8 : SA_FIRST_ROWS;
+        if (want < SA_FIRST_ROWS) want = SA_FIRST_ROWS;
+        if (want > s->opt.traj_capacity) want = s->opt.traj_capacity;
         if ((rc = s->traj_np.ensure(sizeof(int32_t) * stride))) return rc;
         if ((rc = s->fwd_status.ensure(sizeof(int32_t) * stride))) return rc;
-        s->traj_stride = stride;
-        a.traj_stride = stride;
-        a.traj = (double *)s->traj.p; a.traj_np = (int32_t *)s->traj_np.p;
-    }
-    if ((rc = bind_workspace(s, B, &a.ws, &a.ws_stride))) return rc;
-    HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    if ((rc = launch(s, s->k_forward, B, &a, sizeof a, s->group))) return rc;
-    HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    s->have_fwd_time = true;
-    if (mode == SA_MODE_ADJ_FWD) {
+        f.traj_np = (int32_t *)s->traj_np.p;
+        s->h_scratch.resize(nB);
+        bool resident = false;
+        HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+        if (want <= fit_rows) {                       /* resident attempt */
+            if ((rc = s->traj.ensure((size_t)want * (size_t)stride * rec))) return rc;
+            f.mode = SA_MODE_ADJ_FWD; f.rows = (int32_t)want; f.stride = stride;
+            if ((rc = launch_forward(s, f))) return rc;
+            HIP_TRY(hipMemcpyAsync(s->h_scratch.data(), d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            resident = true;
+            for (size_t i = 0; i < nB; i++) if (s->h_scratch[i] == SA_TRAJ_FULL) { resident = false; break; }
+            if (resident) { s->traj_stride = stride; s->traj_rows = (int32_t)want; s->stat_arena_bytes = (int64_t)((size_t)want * stride * rec); }
+        }
+        if (!resident) {                              /* counting pass: same integration, nothing stored */
+            f.mode = SA_MODE_ADJ_COUNT; f.rows = 2; f.stride = stride;
+            if ((rc = launch_forward(s, f))) return rc;
+            s->h_np.resize(nB);
+            HIP_TRY(hipMemcpyAsync(s->h_np.data(), s->traj_np.p, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
+            if ((rc = s->keep_y0.ensure(sizeof(double) * nB * (size_t)(s->n > 0 ? s->n : 1)))) return rc;
+            if ((rc = s->keep_tvals.ensure(sizeof(double) * (size_t)n_t))) return rc;
+            HIP_TRY(hipMemcpyAsync(s->keep_y0.p, d_y0, sizeof(double) * nB * s->n, hipMemcpyDeviceToDevice, s->stream));
+            HIP_TRY(hipMemcpyAsync(s->keep_tvals.p, d_tv, sizeof(double) * (size_t)n_t, hipMemcpyDeviceToDevice, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            /* instances beyond traj_capacity, or whose 64-instance group cannot fit the budget: SA_STATUS_ARENA_FULL */
+            const int64_t group_rows = (int64_t)(budget / ((size_t)64 * rec));
+            const int64_t max_rows = s->opt.traj_capacity < group_rows ? s->opt.traj_capacity : group_rows;
+            int32_t seen = 0;
+            const int32_t full = SA_STATUS_ARENA_FULL;
+            for (size_t i = 0; i < nB; i++) {
+                if (s->h_np[i] > seen) seen = s->h_np[i];
+                if (s->h_np[i] > max_rows) {
+                    s->h_np[i] = 0;
+                    HIP_TRY(hipMemcpyAsync(d_status + i, &full, sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+                    HIP_TRY(hipStreamSynchronize(s->stream));
+                }
+            }
+            if (seen > s->rows_hint) s->rows_hint = seen;
+        }
+        HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+        s->have_fwd_time = true;
+        s->tiled = !resident;
         HIP_TRY(hipMemcpyAsync(s->fwd_status.p, d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToDevice, s->stream));
         s->fwd_B = B;
         s->fwd_t0 = t0;
+        s->fwd_n_t = n_t;
     }
     if (mem == SA_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(y_out, d_yout, sizeof(double) * nB * n_t * s->n, hipMemcpyDeviceToHost, s->stream));
@@ -468,18 +581,62 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
     }
     sa_bwd_args a;
     memset(&a, 0, sizeof a);
-    a.B = B; a.n_t = n_t; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_bwd;
-    a.traj_cap = s->opt.traj_capacity; a.rem_stride = rem_stride;
-    a.traj_stride = s->traj_stride; a.grads_stride = grads_stride;
+    a.n_t = n_t; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_bwd;
+    a.rem_stride = rem_stride; a.grads_stride = grads_stride;
     a.t0 = t0; a.tend = tend; a.tinitial = s->fwd_t0;
     a.rtolB = s->opt.rtolB; a.atolB = s->opt.atolB; a.rtolQB = s->opt.rtolQB; a.atolQB = s->opt.atolQB;
-    a.ps = d_ps; a.pr = d_pr; a.tvals = d_tv; a.grads = d_g; a.grad_out = d_gout; a.lamda_out = d_lout;
-    a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
-    a.traj = (const double *)s->traj.p; a.traj_np = (const int32_t *)s->traj_np.p;
-    a.lamda_all = d_lall; a.quad_all = d_qall;
-    if ((rc = bind_workspace(s, B, &a.ws, &a.ws_stride))) return rc;
+    a.tvals = d_tv;
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
-    if ((rc = launch(s, s->k_backward, B, &a, sizeof a, s->group))) return rc;
+    if (!s->tiled) {
+        a.B = B; a.traj_cap = s->traj_rows; a.traj_stride = s->traj_stride;
+        a.ps = d_ps; a.pr = d_pr; a.grads = d_g; a.grad_out = d_gout; a.lamda_out = d_lout;
+        a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
+        a.traj = (const double *)s->traj.p; a.traj_np = (const int32_t *)s->traj_np.p;
+        a.lamda_all = d_lall; a.quad_all = d_qall;
+        if ((rc = bind_workspace(s, B, &a.ws, &a.ws_stride))) return rc;
+        if ((rc = launch(s, s->k_backward, B, &a, sizeof a, s->group))) return rc;
+    } else {
+        /* tiled: re-integrate the forward problem tile by tile with exactly sized storage, adjoint per tile */
+        const size_t rec = record_bytes(s), budget = arena_budget(s);
+        const size_t np_ = (size_t)s->p, nn = (size_t)s->n;
+        int64_t lo = 0;
+        while (lo < B) {
+            int64_t hi = lo, rows = 2;
+            while (hi < B) {
+                const int64_t nhi = (hi + 64 < B) ? hi + 64 : B;
+                int64_t r2 = rows;
+                for (int64_t i = hi; i < nhi; i++) if (s->h_np[(size_t)i] > r2) r2 = s->h_np[(size_t)i];
+                if (hi > lo && (size_t)round64(nhi - lo) * (size_t)r2 * rec > budget) break;
+                hi = nhi; rows = r2;
+            }
+            const int32_t tB = (int32_t)(hi - lo);
+            const int64_t stride = round64(tB);
+            if ((rc = s->traj.ensure((size_t)rows * (size_t)stride * rec))) return rc;
+            if ((rc = s->t_yout.ensure(sizeof(double) * (size_t)tB * (size_t)s->fwd_n_t * (nn ? nn : 1)))) return rc;
+            if ((rc = s->t_status.ensure(sizeof(int32_t) * (size_t)stride))) return rc;
+            if ((rc = s->t_stats.ensure(sizeof(int64_t) * (size_t)stride * SA_N_STATS))) return rc;
+            if ((rc = s->t_np.ensure(sizeof(int32_t) * (size_t)stride))) return rc;
+            FwdLaunch f{SA_MODE_ADJ_FWD, tB, s->fwd_n_t, rem_stride, (int32_t)rows, stride, s->fwd_t0,
+                        (const double *)s->keep_y0.p + (size_t)lo * nn, d_ps + (size_t)lo * np_,
+                        d_pr + (size_t)lo * (size_t)rem_stride, (const double *)s->keep_tvals.p,
+                        (double *)s->t_yout.p, (int32_t *)s->t_status.p, (int64_t *)s->t_stats.p, (int32_t *)s->t_np.p};
+            if ((rc = launch_forward(s, f))) return rc;
+            a.B = tB; a.traj_cap = (int32_t)rows; a.traj_stride = stride;
+            a.ps = d_ps + (size_t)lo * np_; a.pr = d_pr + (size_t)lo * (size_t)rem_stride;
+            a.grads = d_g + (size_t)lo * (size_t)grads_stride;
+            a.grad_out = d_gout + (size_t)lo * np_; a.lamda_out = d_lout + (size_t)lo * nn;
+            a.status = d_status + lo; a.fwd_status = (const int32_t *)s->fwd_status.p + lo;
+            a.stats = d_stats + (size_t)lo * SA_N_STATS;
+            a.traj = (const double *)s->traj.p; a.traj_np = (const int32_t *)s->t_np.p;
+            a.lamda_all = d_lall ? d_lall + (size_t)lo * (size_t)n_t * nn : nullptr;
+            a.quad_all = d_qall ? d_qall + (size_t)lo * (size_t)n_t * np_ : nullptr;
+            if ((rc = bind_workspace(s, tB, &a.ws, &a.ws_stride))) return rc;
+            if ((rc = launch(s, s->k_backward, tB, &a, sizeof a, s->group))) return rc;
+            s->stat_tiles++;
+            if ((int64_t)((size_t)rows * stride * rec) > s->stat_arena_bytes) s->stat_arena_bytes = (int64_t)((size_t)rows * stride * rec);
+            lo = hi;
+        }
+    }
     HIP_TRY(hipEventRecord(s->ev[3], s->stream));
     s->have_bwd_time = true;
     if (mem == SA_MEM_HOST) {

@@ -35,6 +35,9 @@ ERRORS: Dict[int, str] = {
     -44: "CV_UNREC_SRHSFUNC_ERR", -45: "CV_BAD_IS",
     -101: "CV_NO_ADJ", -102: "CV_NO_FWD", -103: "CV_NO_BCK", -104: "CV_BAD_TB0",
     -105: "CV_REIFWD_FAIL", -106: "CV_FWD_FAIL", -107: "CV_GETY_BADT",
+    # not a CVODES code: the stored forward trajectory of the instance exceeds max_steps points (or 64 such
+    # instances exceed the arena budget) -- raise AdjointSolver(max_steps=..., arena_gib=...)
+    -9001: "SA_STATUS_ARENA_FULL",
 }
 
 
@@ -325,14 +328,18 @@ class AdjointSolver(_EngineMixin):
     Extra keyword arguments (not in the reference): ``backward_abstol/backward_reltol`` and
     ``quad_abstol/quad_reltol`` expose what the reference hard-codes to 1e-10
     (solver.py:599,614 -- there one has to poke ``lib.CVodeSStolerancesB`` by hand,
-    README.md:245-247); ``max_steps`` bounds the stored trajectory per instance (the
-    device-side equivalent of ``checkpoint_n``, which stays accepted for compatibility).
+    README.md:245-247); ``max_steps`` is the most stored forward steps one instance may take
+    (default ``checkpoint_n + 1``, i.e. as unbounded as the reference) and ``arena_gib`` the HBM
+    budget of the stored trajectories (default 16 GiB, at most 60 % of the free memory): batches
+    that fit stay resident between ``solve_forward`` and ``solve_backward``, larger ones are
+    re-integrated tile by tile inside ``solve_backward`` -- CVODES' check-point scheme, same
+    results (csrc/sunode_amd.cpp, "trajectory arena").
     """
 
     def __init__(self, problem, *, abstol=1e-10, reltol=1e-10, checkpoint_n=500_000, interpolation="polynomial",
                  constraints=None, solver="BDF", adjoint_solver="BDF", backward_abstol=1e-10,
                  backward_reltol=1e-10, quad_abstol=1e-10, quad_reltol=1e-10, mxsteps: int = 500,
-                 max_steps: int = 4096, device: int = 0):
+                 max_steps: Optional[int] = None, arena_gib: Optional[float] = None, device: int = 0):
         if solver not in ("BDF", "ADAMS"):
             raise ValueError(f"Unknown solver {solver}.")
         if adjoint_solver not in ("BDF", "ADAMS"):
@@ -352,7 +359,9 @@ class AdjointSolver(_EngineMixin):
         self._set_tolerances(abstol, reltol)
         self._tolB = (float(backward_reltol), float(backward_abstol), float(quad_reltol), float(quad_abstol))
         self._mxsteps = mxsteps
-        self._max_steps = int(min(max_steps, checkpoint_n + 1))
+        self._max_steps = int(min(max_steps if max_steps is not None else checkpoint_n + 1, checkpoint_n + 1,
+                                  2**31 - 1))
+        self._arena_bytes = int(arena_gib * 2**30) if arena_gib else 0
         self._device = device
         self._source = problem.native_source()
         _native.build_code_object(self._source, constraints=self._constraints is not None, hermite=self._hermite)
@@ -377,7 +386,8 @@ class AdjointSolver(_EngineMixin):
     def _native_kwargs(self):
         rB, aB, rQ, aQ = self._tolB
         return dict(device=self._device, rtol=float(self._rtol), atol=self._atol, rtolB=rB, atolB=aB,
-                    rtolQB=rQ, atolQB=aQ, mxstep=self._mxsteps, traj_capacity=self._max_steps)
+                    rtolQB=rQ, atolQB=aQ, mxstep=self._mxsteps, traj_capacity=self._max_steps,
+                    arena_bytes=self._arena_bytes)
 
     def make_output_buffers(self, tvals):
         y_vals = np.zeros((len(tvals), self._problem.n_states))
@@ -387,11 +397,19 @@ class AdjointSolver(_EngineMixin):
 
     # -- scalar API (B = 1) ----------------------------------------------------------------
     def solve_forward(self, t0, tvals, y0, y_out, *, max_retries=5):
+        """``max_retries`` is accepted and forwarded like in the reference (solver.py:682,710-719); note that it can
+        never take effect there either: CVodeF drives CVode in CV_ONE_STEP mode, whose per-call step counter
+        never reaches mxstep, so CV_TOO_MUCH_WORK is not produced on this path."""
         y0 = _flat_state(self._problem, y0)
         ps, pr = self._problem.flat_params(self._user_data)
-        yo, status, _ = self.solve_forward_batch(t0, tvals, y0[None], ps[None], pr)
+        yo, status, _ = self.solve_forward_batch(t0, tvals, y0[None], ps[None], pr, max_retries=max_retries)
         if status[0] != 0:
             code = int(status[0])
+            if code == -1:
+                raise SolverError("Too many solver retries.")
+            if code == -9001:
+                raise SolverError(f"Solving ode failed: more than max_steps={self._max_steps} stored forward steps "
+                                  "(SA_STATUS_ARENA_FULL); raise max_steps / arena_gib")
             raise SolverError(f"Solving ode failed: {ERRORS.get(code, 'unknown')} ({code})")
         y_out[...] = yo[0]
 
@@ -414,9 +432,11 @@ class AdjointSolver(_EngineMixin):
             quad_all_out[...] = res[5][0]
 
     # -- batch API -------------------------------------------------------------------------
-    def solve_forward_batch(self, t0, tvals, y0, params_sub, params_rem):
+    def solve_forward_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5):
         """B forward solves with stored trajectories: (y_out [B,n_t,n], status [B], stats [B,16])."""
         eng = self._engine()
+        if max_retries != eng._opt_kw["max_retries_fwd"]:
+            eng.set_options(max_retries_fwd=max_retries)
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         y_out = np.zeros((B, len(tvals), self._problem.n_states))

@@ -97,6 +97,30 @@ HELPERS_C = r"""
 #ifndef SA_TEMPLATE
 #define SA_TEMPLATE
 #endif
+/* Dense matrix-vector block of a callback (symode/problem.py extract_matvec):
+     SA_MATVEC(tag, NO, NI, OFF, VEC)   computes  mv[i] = sum_j M[j*NO + i] * VEC(j),  i < NO, j < NI,
+   with M = the j-major block of the remainder vector starting at slot OFF, in THIS association (part of the
+   generated arithmetic, identical in every kernel and in the oracle): four interleaved accumulators
+   a_w = M[w][i]*v[w], then a_w = fma(M[j][i], v[j], a_w) for j = w+4, w+8, ...; mv[i] = (a_0 + a_1) + (a_2 + a_3)
+   (accumulators without a term are +0.0).  SA_MV(tag, i) reads mv[i]; SA_OWNS(slot) lets a multi-wavefront kernel
+   give every wavefront its share of the output statements that follow. */
+#ifndef SA_MATVEC
+#define SA_MATVEC(tag, NO, NI, OFF, VEC) \
+    double sa_mv_##tag[NO]; \
+    for (int i_ = 0; i_ < (NO); i_++) { \
+        double a_[4] = {0.0, 0.0, 0.0, 0.0}; \
+        for (int w_ = 0; w_ < 4 && w_ < (NI); w_++) { \
+            double acc_ = SA_PR((OFF) + w_ * (NO) + i_) * VEC(w_); \
+            for (int j_ = w_ + 4; j_ < (NI); j_ += 4) acc_ = fma(SA_PR((OFF) + j_ * (NO) + i_), VEC(j_), acc_); \
+            a_[w_] = acc_; \
+        } \
+        sa_mv_##tag[i_] = (a_[0] + a_[1]) + (a_[2] + a_[3]); \
+    }
+#define SA_MV(tag, i) sa_mv_##tag[i]
+#endif
+#ifndef SA_OWNS
+#define SA_OWNS(slot) 1
+#endif
 SA_FN double sa_logaddexp(double a, double b) {
     double lo = fmin(a, b), hi = fmax(a, b);
     return hi + log1p(exp(lo - hi));
@@ -257,9 +281,13 @@ def emit_function(
     n_out: int,
     symbol_map: Dict[str, str],
     prefix: str,
+    matvec: Optional[Dict[str, object]] = None,
 ) -> str:
     """One callback.  ``expr`` is ravelled; ``out_index[k]`` is the flat output
-    slot of ``expr.ravel()[k]`` (lets the caller pick column-major storage)."""
+    slot of ``expr.ravel()[k]`` (lets the caller pick column-major storage).
+    ``matvec`` (tag, n_out, n_in, offset, vec): the expressions refer to ``SA_MV(tag, i)``, the results of one
+    dense matrix-vector product evaluated up front by ``SA_MATVEC``; the function is then emitted as ONE body whose
+    output statements carry ``SA_OWNS(slot)`` guards (the kernels split those between wavefronts)."""
     flat = [sym.sympify(e) for e in np.asarray(expr, dtype=object).ravel()]
     names = (sym.Symbol("%s%d" % (prefix, i)) for i in count())
     if flat:
@@ -284,6 +312,9 @@ def emit_function(
     # straight-line on purpose (constant subscripts only, see bdf_kernels.hip on scalar replacement).
     def body(slots, temps, prefetch=False):
         lines = ["    SA_PROLOGUE"]
+        if matvec is not None:
+            lines.append("    SA_MATVEC(%s, %d, %d, %d, %s);" % (matvec["tag"], matvec["n_out"], matvec["n_in"],
+                                                                matvec["offset"], matvec["vec"]))
         stmts = ["    const double %s = %s; SA_STMT_END" % (tname, temp_text[tname]) for tname in temps]
         if prefetch:
             # remaining-parameter slots this chunk reads, as a few contiguous ranges: a kernel may touch them
@@ -310,6 +341,9 @@ def emit_function(
             text = written.get(slot, "0.0")
             if text == "0.0":
                 lines.append("    SA_STORE(%d, 0.0);" % slot)
+            elif matvec is not None:
+                lines.append("    if (SA_OWNS(%d)) { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; } SA_STMT_END"
+                             % (slot, text, slot))
             else:
                 lines.append("    { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; } SA_STMT_END"
                              % (text, slot))
@@ -331,7 +365,7 @@ def emit_function(
     n_chunks = -(-n_out // CHUNK_STATEMENTS)
     if total > CHUNK_COST:
         n_chunks = max(n_chunks, min(MAX_COST_CHUNKS, -(-total // CHUNK_COST), n_out))
-    if n_chunks <= 1:
+    if n_chunks <= 1 or matvec is not None:
         lines = ["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature)]
         lines += body(range(n_out), temp_order)
         lines.append("}")
@@ -372,10 +406,15 @@ def generate_problem_source(
     quad: np.ndarray,
     dydp_t: Optional[np.ndarray] = None,
     description: str = "",
+    matvec: Optional[Dict[str, Dict[str, object]]] = None,
 ) -> str:
     """Full generated header: sizes + helpers + the five callbacks of the adjoint path and the
     parameter derivative of the right-hand side (forward sensitivities)."""
     n = n_states
+    matvec = matvec or {}
+
+    def mv(tag):
+        return dict(matvec[tag], tag=tag) if tag in matvec else None
     # column-major slot of J[i, j] is j*n + i (reference problem.py:345,377 numba.farray)
     col_major = [j * n + i for i in range(n) for j in range(n)]
     jac = np.asarray(jac, dtype=object).reshape(n, n) if n else np.zeros((0, 0), object)
@@ -392,10 +431,10 @@ def generate_problem_source(
         "#define SA_N_REM %d" % n_rem,
         HELPERS_C,
         emit_function("sa_rhs", base, np.asarray(dydt, dtype=object).ravel(),
-                      list(range(n)), n, symbol_map, "r_"),
+                      list(range(n)), n, symbol_map, "r_", matvec=mv("f")),
         emit_function("sa_jac", base, jac, col_major, n * n, symbol_map, "j_"),
         emit_function("sa_adj_rhs", adj, np.asarray(dlamdadt, dtype=object).ravel(),
-                      list(range(n)), n, symbol_map, "a_").replace(
+                      list(range(n)), n, symbol_map, "a_", matvec=mv("a")).replace(
                           "(void)pr;", "(void)pr; (void)lam;"),
         emit_function("sa_quad_rhs", adj, np.asarray(quad, dtype=object).ravel(),
                       list(range(n_sub)), n_sub, symbol_map, "q_").replace(

@@ -14,6 +14,8 @@ conveniences, not part of the device path.
 """
 from __future__ import annotations
 
+import os
+
 from itertools import product
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
@@ -30,6 +32,10 @@ Shape = Tuple[int, ...]
 HOIST_MIN_OPS = 8
 #: a callback touching at least this many fixed parameters in a scattered order gets an access-order copy
 PACK_MIN_SYMBOLS = 256
+#: a callback whose outputs contain a dense (fixed parameter) x (state | adjoint state) product block with at least
+#: this many entries gets it emitted as ONE lane-parallel matrix-vector product (codegen.SA_MATVEC)
+MATVEC_MIN_ENTRIES = 256
+MATVEC_MIN_FILL = 0.5
 
 data_dtype = np.dtype(np.float64)
 
@@ -42,6 +48,78 @@ def _scalarize(item: np.ndarray) -> Any:
     if hasattr(item, "shape") and item.shape == ():
         return item.item()
     return item
+
+
+def extract_matvec(exprs, vsyms, fixed, tag):
+    """Split the outputs ``e_i`` of a vector callback as ``e_i = sum_j M_ij v_j + S + r_i``:
+
+    * ``M_ij = +-(one fixed-parameter symbol)``: a dense constant block -- becomes one matrix-vector product
+      evaluated lane-parallel by the kernels (``SA_MATVEC``) instead of ``n_out * n_in`` scalar statements;
+    * ``S = sum_j v_j u_j``: the part of the remaining coefficient of ``v_j`` that is the same for (nearly) all
+      outputs (the rank-one ``1 (u . v)`` term a dense Jacobian transpose produces), computed once;
+    * ``r_i``: whatever is left, as ordinary straight-line code.
+
+    ``v`` is the state vector (right-hand side) or the adjoint state (adjoint right-hand side).  Pure term
+    re-grouping: the value of every output is unchanged up to rounding.  Returns None when there is no block worth
+    it, else ``(new_exprs, mv_symbols, entries)`` with ``entries[j][i] = (sign, fixed symbol) | None`` and
+    ``mv_symbols[i]`` standing for the i-th product in ``new_exprs``."""
+    n_out = len(exprs)
+    vidx = {sy: j for j, sy in enumerate(vsyms)}
+    vset = set(vsyms)
+    n_in = len(vsyms)
+    if n_out * n_in < MATVEC_MIN_ENTRIES:
+        return None
+    M: Dict[Tuple[int, int], Tuple[int, Any]] = {}
+    rest: List[Dict[int, List[Any]]] = [dict() for _ in range(n_out)]
+    other: List[List[Any]] = [[] for _ in range(n_out)]
+    for i, e in enumerate(exprs):
+        for term in sym.Add.make_args(sym.sympify(e)):
+            c, factors = term.as_coeff_mul()
+            vf = [f for f in factors if f in vset]
+            others = [f for f in factors if f not in vset]
+            if len(vf) != 1 or any(f.free_symbols & vset for f in others):
+                other[i].append(term)
+                continue
+            j = vidx[vf[0]]
+            coef = c * sym.Mul(*others)            # a numeric factor distributes over a sum here
+            for a in sym.Add.make_args(coef):
+                ca, fa = a.as_coeff_mul()
+                if len(fa) == 1 and fa[0] in fixed and (ca == 1 or ca == -1) and (i, j) not in M:
+                    M[(i, j)] = (int(ca), fa[0])
+                else:
+                    rest[i].setdefault(j, []).append(a)
+    cols = sorted({j for (_, j) in M})
+    if not cols or len(M) < MATVEC_MIN_ENTRIES or len(M) < MATVEC_MIN_FILL * n_out * len(cols):
+        return None
+    # S: coefficient terms of v_j shared by (nearly) all outputs
+    shared_terms = []
+    for j in range(n_in):
+        count: Dict[Any, int] = {}
+        for i in range(n_out):
+            for a in rest[i].get(j, ()):
+                count[a] = count.get(a, 0) + 1
+        uj = [a for a, k in count.items() if k >= 0.75 * n_out and k >= 4]
+        if not uj:
+            continue
+        ujset = set(uj)
+        for i in range(n_out):
+            have = rest[i].get(j, [])
+            kept = [a for a in have if a not in ujset]
+            missing = [a for a in uj if a not in have]
+            kept += [-a for a in missing]
+            if kept:
+                rest[i][j] = kept
+            else:
+                rest[i].pop(j, None)
+        shared_terms.append(vsyms[j] * sym.Add(*uj))
+    S = sym.Add(*shared_terms) if shared_terms else sym.Integer(0)
+    mv = [sym.Symbol("sa_mv%s_%d" % (tag, i), real=True) for i in range(n_out)]
+    new = []
+    for i in range(n_out):
+        pieces = [mv[i], S] + [vsyms[j] * sym.Add(*terms) for j, terms in sorted(rest[i].items())] + other[i]
+        new.append(sym.Add(*pieces))
+    entries = [[M.get((i, j)) for i in range(n_out)] for j in range(n_in)]
+    return np.array(new, dtype=object), mv, entries
 
 
 class SympyProblem:
@@ -131,6 +209,9 @@ class SympyProblem:
         self._native_cache = None
         self._hoisted: List[Any] = []
         self._packed: List[int] = []
+        self._matvec: Dict[str, Dict[str, Any]] = {}
+        self._mv_index: List[int] = []
+        self._mv_sign: List[float] = []
         self._hoist_fn = None
         self._host_funcs: Dict[str, Any] = {}
 
@@ -261,40 +342,49 @@ class SympyProblem:
             views[path] = solution[:, self.state_subset.flat_slices[path]].reshape(shape)
         return dtypesubset.as_nested(views)
 
+    def solution_variables(self, tvals, solution, user_data, *, unstack_state=True, unstack_params=True):
+        """The labelled arrays of a solution: ``{name: (dim names, values)}`` -- ``time``, then one entry per
+        state leaf (``solution_<path>``, leading ``time`` axis) and one per parameter leaf
+        (``parameters_<path>``), or the packed record arrays ``solution`` / ``parameters`` when not
+        unstacked.  Built from the flat leaf tables (``flat_slices`` / ``flat_shapes`` / dim names); this is the
+        content of the reference's ``solution_to_xarray`` (problem.py:100-145) without the xarray dependency."""
+        tvals = np.asarray(tvals)
+        solution = np.ascontiguousarray(solution, dtype=np.float64).reshape(len(tvals), self.n_states)
+        flat_params = np.array(self.extract_params(user_data)).reshape(1).view(np.float64) \
+            if self.params_dtype.itemsize else np.zeros(0)
+        out: Dict[str, Tuple[Tuple[str, ...], np.ndarray]] = {"time": (("time",), tvals)}
+
+        def add(name, dims, values):
+            if name in out or name in self.coords:
+                raise ValueError(f"Variable {name} is not unique.")
+            out[name] = (tuple(dims), values)
+
+        def leaves(subset, prefix, flat, lead_dims):
+            for leaf in subset._leaves:
+                block = flat[..., leaf.start:leaf.start + leaf.size]
+                add("_".join((prefix,) + leaf.path), lead_dims + leaf.dim_names,
+                    block.reshape(block.shape[:-1] + leaf.shape))
+
+        if unstack_state:
+            leaves(self.state_subset, "solution", solution, ("time",))
+        else:
+            add("solution", ("time",), solution.view(self.state_dtype)[..., 0])
+        if unstack_params:
+            leaves(self.params_subset, "parameters", flat_params, ())
+        else:
+            add("parameters", (), self.extract_params(user_data))
+        return out
+
     def solution_to_xarray(self, tvals, solution, user_data, sensitivity=None,
                            *, unstack_state=True, unstack_params=True):
-        """Reference problem.py:100-145 (needs xarray, which is optional here)."""
+        """``xarray.Dataset`` of a solution (reference problem.py:100-145; xarray is optional here)."""
+        if sensitivity is not None:
+            raise NotImplementedError("sensitivities are not converted (neither does the reference, problem.py:106)")
         import xarray as xr
-
-        assert sensitivity is None, "TODO"
-        solution = solution.view(self.state_dtype)[..., 0]
-        params = self.extract_params(user_data)
-
-        def unpack(array, dims, prefix):
-            out = {}
-            for name in array.dtype.names:
-                if array[name].dtype == np.float64:
-                    out["_".join(prefix + [name])] = (tuple(dims[name][1]), array[name])
-                else:
-                    out.update(unpack(array[name], dims[name], prefix + [name]))
-            return out
-
         data = xr.Dataset(coords=self.coords)
-        data["time"] = ("time", tvals)
-        if unstack_state:
-            for name, (dims, vals) in unpack(solution, self.state_subset.dims, ["solution"]).items():
-                if name in data:
-                    raise ValueError(f"Variable {name} is not unique.")
-                data[name] = (("time",) + dims, vals)
-        else:
-            data["solution"] = ("time", solution)
-        if unstack_params:
-            for name, (dims, vals) in unpack(params, self.params_subset.dims, ["parameters"]).items():
-                if name in data:
-                    raise ValueError(f"Variable {name} is not unique.")
-                data[name] = (dims, vals)
-        else:
-            data["parameters"] = params
+        for name, (dims, values) in self.solution_variables(
+                tvals, solution, user_data, unstack_state=unstack_state, unstack_params=unstack_params).items():
+            data[name] = (dims, values) if dims else values
         return data
 
     # ------------------------------------------------------------------
@@ -344,6 +434,34 @@ class SympyProblem:
             for k, symbol in enumerate(table.values()):
                 slots[symbol.name] = "SA_PR(%d)" % (self.n_remainder + k)
 
+            # Dense (fixed parameter) x (state | adjoint state) blocks -> one matrix-vector product per callback,
+            # reading a j-major, sign-folded copy of the block appended to the remainder vector (coalesced loads:
+            # consecutive lanes own consecutive outputs).  Block k of callback `tag` starts at remainder slot
+            # self._matvec[tag]["offset"]; entry (j, i) is sign * fixed parameter `index` (index -1: structural zero).
+            self._matvec: Dict[str, Dict[str, Any]] = {}
+            self._mv_index: List[int] = []
+            self._mv_sign: List[float] = []
+            fixed_or_hoisted = set(self._sym_fixed_paramsvec) | set(table.values())
+            index_of_fixed = {sy: k for k, sy in enumerate(self._sym_fixed_paramsvec)}
+            index_of_fixed.update({sy: self.n_remainder + k for k, sy in enumerate(table.values())})
+            arrays = list(arrays)
+            for pos, tag, vsyms in ((0, "f", list(self._sym_statevec)), (2, "a", list(self._sym_lamda))):
+                if not len(fixed) or os.environ.get("SA_NO_MATVEC"):
+                    continue
+                found = extract_matvec(list(arrays[pos].ravel()), vsyms, fixed_or_hoisted, tag)
+                if found is None:
+                    continue
+                new, mv, entries = found
+                arrays[pos] = new.reshape(arrays[pos].shape)
+                self._matvec[tag] = dict(n_out=len(mv), n_in=len(entries), offset=None, start=len(self._mv_index),
+                                         vec="SA_Y" if tag == "f" else "SA_LAM")
+                for col in entries:
+                    for ent in col:
+                        self._mv_index.append(-1 if ent is None else index_of_fixed[ent[1]])
+                        self._mv_sign.append(0.0 if ent is None else float(ent[0]))
+                for i, symbol in enumerate(mv):
+                    slots[symbol.name] = "SA_MV(%s, %d)" % (tag, i)
+
             # Access-order copies: a callback that walks a big block of fixed parameters with a large
             # stride (the adjoint right-hand side reads the rate matrix by columns) gets its own copy
             # of those parameters in the order it uses them, appended to the remainder vector by
@@ -375,6 +493,9 @@ class SympyProblem:
                         sub[sy] = new
                     a = np.array([sym.sympify(x).xreplace(sub) for x in a.ravel()], dtype=object).reshape(a.shape)
                 packed_arrays.append(a)
+            mv_base = base + len(self._packed)
+            for info in self._matvec.values():
+                info["offset"] = mv_base + info.pop("start")
             self._native_cache = (packed_arrays, slots)
         return self._native_cache
 
@@ -382,14 +503,14 @@ class SympyProblem:
     def n_remainder_native(self) -> int:
         """Length of the remainder vector the native code reads (user part + hoisted values)."""
         self._native_exprs()
-        return self.n_remainder + len(self._hoisted) + len(self._packed)
+        return self.n_remainder + len(self._hoisted) + len(self._packed) + len(self._mv_index)
 
     def extend_remainder(self, pr: np.ndarray) -> np.ndarray:
         """[..., n_remainder] -> [..., n_remainder_native]: append the hoisted fixed-parameter
         sub-expressions (evaluated here, once per call, in float64)."""
         self._native_exprs()
         pr = np.asarray(pr, dtype=np.float64)
-        if not self._hoisted and not self._packed:
+        if not self._hoisted and not self._packed and not self._mv_index:
             return pr
         lead = pr.shape[:-1]
         flat = pr.reshape(-1, self.n_remainder)
@@ -403,6 +524,11 @@ class SympyProblem:
             pieces.append(extra.reshape(len(flat), -1))
         if self._packed:
             pieces.append(flat[:, np.asarray(self._packed, dtype=np.int64)])
+        if self._mv_index:          # j-major, sign-folded copies of the matrix-vector blocks (may read hoisted values)
+            src = np.concatenate(pieces[:2], axis=1) if self._hoisted else flat
+            idx = np.asarray(self._mv_index, dtype=np.int64)
+            sign = np.asarray(self._mv_sign, dtype=np.float64)
+            pieces.append(np.where(idx >= 0, src[:, np.maximum(idx, 0)], 0.0) * sign)
         return np.concatenate(pieces, axis=1).reshape(lead + (-1,))
 
     def native_source(self) -> str:
@@ -413,12 +539,13 @@ class SympyProblem:
                 [".".join(p) for p in self.params_subset.paths],
                 [".".join(p) for p in self.params_subset.subset_paths])
             (dydt, jac, dlamdadt, quad, dydp_t), slots = self._native_exprs()
-            if self._hoisted or self._packed:
-                desc += " hoisted=%d packed=%d" % (len(self._hoisted), len(self._packed))
+            if self._hoisted or self._packed or self._matvec:
+                desc += " hoisted=%d packed=%d matvec=%s" % (len(self._hoisted), len(self._packed),
+                                                              {k: (v["n_out"], v["n_in"]) for k, v in self._matvec.items()})
             self._native_source = codegen.generate_problem_source(
                 n_states=self.n_states, n_sub=self.n_params, n_rem=self.n_remainder_native,
                 symbol_map=slots, dydt=dydt, jac=jac, dlamdadt=dlamdadt, quad=quad, dydp_t=dydp_t,
-                description=desc,
+                description=desc, matvec=self._matvec,
             )
         return self._native_source
 

@@ -145,6 +145,10 @@ class SolveODE(Op):
     def grad(self, inputs, g):
         g, g_sens = g
         _, params, params_fixed, t0, tvals = inputs
+        # as the reference (:253): a loss that depends on the sensitivity output would need second-order
+        # sensitivities; fail loudly instead of returning an incomplete gradient
+        if type(getattr(g_sens, "type", g_sens)).__name__ != "DisconnectedType" and str(g_sens) != "<DisconnectedType>":
+            raise NotImplementedError("SolveODE: gradients through the sensitivity output are not implemented")
         solution, sens = self(*inputs)
         return [
             pt.zeros_like(inputs[0]),

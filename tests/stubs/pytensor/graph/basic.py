@@ -1,6 +1,96 @@
+import numpy as np
+
+
+class TensorType:
+    def __init__(self, ndim, shape=None):
+        self.ndim = ndim
+        self.shape = tuple(shape) if shape is not None else (None,) * ndim
+
+    def __call__(self, name=None):
+        return Variable(self, name=name)
+
+
+class Apply:
+    def __init__(self, op, inputs, n_out, out_types):
+        self.op, self.inputs = op, list(inputs)
+        self.outputs = [Variable(out_types[i], owner=self, index=i) for i in range(n_out)]
+
+
 class Variable:
-    pass
+    def __init__(self, type_, owner=None, index=0, name=None):
+        self.type, self.owner, self.index, self.name = type_, owner, index, name
+
+    @property
+    def ndim(self):
+        return self.type.ndim
+
+    # the operator vocabulary the wrapper module uses
+    def _lift(self, fn, *others, ndim=None):
+        from pytensor.tensor import as_tensor_variable, _Lambda
+        ins = [self] + [as_tensor_variable(o) for o in others]
+        return _Lambda(fn, ndim if ndim is not None else max(v.ndim for v in ins))(*ins)
+
+    def __neg__(self):
+        return self._lift(lambda a: -a)
+
+    def __mul__(self, o):
+        return self._lift(lambda a, b: a * b, o)
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        return self._lift(lambda a, b: a + b, o)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._lift(lambda a, b: a - b, o)
+
+    def sum(self, axis=None):
+        nd = 0 if axis is None else self.ndim - (len(axis) if isinstance(axis, (tuple, list)) else 1)
+        return self._lift(lambda a: np.sum(a, axis=tuple(axis) if isinstance(axis, list) else axis), ndim=nd)
+
+    def reshape(self, shape):
+        shape = tuple(shape) if isinstance(shape, (tuple, list)) else (shape,)
+        return self._lift(lambda a: np.reshape(a, shape), ndim=len(shape))
+
+    def __getitem__(self, key):
+        probe = np.zeros((1,) * self.ndim)[key] if self.ndim else np.zeros(())
+        return self._lift(lambda a: a[key], ndim=probe.ndim)
 
 
 class Constant(Variable):
-    pass
+    def __init__(self, value):
+        value = np.asarray(value)
+        super().__init__(TensorType(value.ndim, value.shape))
+        self.data = value
+
+
+def evaluate(outputs, givens=None):
+    """Numeric value of graph variable(s): walk owners, call Op.perform (the part of pytensor.function needed here)."""
+    givens = dict(givens or {})
+    memo = {}
+
+    def val(v):
+        if id(v) in memo:
+            return memo[id(v)]
+        if v in givens:
+            r = np.asarray(givens[v], dtype=np.float64)
+        elif isinstance(v, Constant):
+            r = v.data
+        elif v.owner is None:
+            raise KeyError("no value for graph input %r" % (v.name,))
+        else:
+            node = v.owner
+            key = ("node", id(node))
+            if key not in memo:
+                storage = [[None] for _ in node.outputs]
+                node.op.perform(node, [val(i) for i in node.inputs], storage)
+                memo[key] = [s[0] for s in storage]
+            r = memo[key][v.index]
+        memo[id(v)] = r
+        return r
+
+    if isinstance(outputs, (list, tuple)):
+        return [val(o) for o in outputs]
+    return val(outputs)

@@ -47,7 +47,7 @@ def test_device_arithmetic_matches_host_bitwise():
     np.testing.assert_array_equal(pw, ref)
 
 
-@pytest.mark.parametrize("name", ["lv", "robertson", "seir", "misc", "notebook"])
+@pytest.mark.parametrize("name", ["lv", "robertson", "seir", "network8", "misc", "notebook"])
 def test_device_callbacks_match_golden(name, golden_dir):
     """Generated device functions vs the reference's own lambdify output (golden vectors)."""
     import json
@@ -760,19 +760,30 @@ def test_empty_batch_and_no_derivative_params():
     np.testing.assert_allclose(-lam[:, 0], np.exp(-2.0 * tv).sum(), rtol=1e-7)      # dL/dy0, L = sum_k y(t_k)
 
 
-def test_backward_reports_failed_forward_and_budget():
-    """Instances whose forward pass failed come back CV_NO_FWD (-102) with NaN gradients; a backward
-    step budget that is too small gives CV_TOO_MUCH_WORK for that instance only."""
+def test_backward_reports_failed_forward_and_arena_limit():
+    """Instances whose stored trajectory exceeds max_steps come back SA_STATUS_ARENA_FULL (-9001, NOT
+    CV_TOO_MUCH_WORK) from the forward call -- their forward solution itself is complete -- and CV_NO_FWD (-102)
+    with NaN gradients from the backward call; the other instances of the batch are unaffected."""
     from sunode_amd.solver import AdjointSolver
     prob = make_problem("robertson")
     d = robertson_batch(8)
     tv = d["tvals"]
     params = d["params"].copy()
-    sol = AdjointSolver(prob, abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8,
-                        quad_abstol=1e-10, quad_reltol=1e-8, max_steps=600)     # arena too small for most
+    kw = dict(abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8, quad_abstol=1e-10,
+              quad_reltol=1e-8)
+    ref = AdjointSolver(prob, **kw)
+    yr, sr, statr = ref.solve_forward_batch(0.0, tv, d["y0"], params, np.zeros(0))
+    gr, lr, sbr, _ = ref.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 3)))
+    assert (sr == 0).all() and (sbr == 0).all()
+    cap = int(np.sort(statr[:, 8])[3])                      # the four shortest trajectories fit
+    sol = AdjointSolver(prob, max_steps=cap, **kw)
     y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], params, np.zeros(0))
     g, lam, stb, _ = sol.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 3)))
-    assert set(st.tolist()) <= {0, -1} and (st == -1).any()
-    assert ((stb == -102) == (st == -1)).all()
-    assert np.isnan(g[st == -1]).all() and np.isnan(y[st == -1]).all()
-    assert np.isfinite(g[st == 0]).all()
+    full = statr[:, 8] > cap
+    assert full.any() and not full.all()
+    assert (st[full] == -9001).all() and (st[~full] == 0).all()
+    assert ((stb == -102) == full).all() and (stb[~full] == 0).all()
+    np.testing.assert_array_equal(y, yr)                    # the forward solution does not depend on the arena
+    assert np.isnan(g[full]).all() and np.isnan(lam[full]).all()
+    np.testing.assert_array_equal(g[~full], gr[~full])
+    np.testing.assert_array_equal(lam[~full], lr[~full])

@@ -146,3 +146,53 @@ def test_pytensor_wrapper_is_import_guarded():
     else:
         with pytest.raises(ImportError, match="pytensor"):
             importlib.import_module("sunode_amd.wrappers.as_pytensor")
+
+
+def test_sunode_import_surface_is_the_engine():
+    """`import sunode...` as user code written for pymc-devs/sunode does (reference sunode/__init__.py:3-7):
+    the names resolve to the sunode_amd modules themselves."""
+    import sunode
+    import sunode.solver
+    import sunode.symode
+    import sunode.symode.problem
+    import sunode_amd.solver
+    from sunode.symode import SympyProblem as P1
+    from sunode_amd import SympyProblem as P2
+    assert P1 is P2 and sunode.SympyProblem is P2
+    assert sunode.solver.Solver is sunode_amd.solver.Solver
+    assert sunode.solver.AdjointSolver is sunode_amd.solver.AdjointSolver
+    assert issubclass(sunode.solver.SolverError, RuntimeError)
+    assert sunode.symode.problem.SympyProblem is P2
+    import sunode.wrappers                      # pytensor itself stays optional
+    assert sunode.wrappers.__name__ == "sunode_amd.wrappers"
+
+
+def test_solution_variables_follow_the_leaf_table():
+    """Content of the reference's solution_to_xarray (problem.py:100-145) without xarray: names, dims, values."""
+    from tests.helpers import make_problem
+    prob = make_problem("seir")
+    ud = prob.make_user_data()
+    vals = np.arange(24.0)
+    prob.update_params(ud, vals.view(prob.params_dtype)[0])
+    sol = np.arange(3 * 16.0).reshape(3, 16)
+    v = prob.solution_variables([0.0, 1.0, 2.0], sol, ud)
+    assert list(v)[:5] == ["time", "solution_S", "solution_E", "solution_I", "solution_R"]
+    assert v["solution_I"][0] == ("time", "_I_dim0__") and np.array_equal(v["solution_I"][1], sol[:, 8:12])
+    assert v["parameters_C"][0] == ("_C_dim0__", "_C_dim1__")
+    assert np.array_equal(v["parameters_C"][1], vals[4:20].reshape(4, 4))
+    assert v["parameters_rates_gamma"][0] == () and float(v["parameters_rates_gamma"][1]) == 21.0
+    packed = prob.solution_variables([0.0, 1.0, 2.0], sol, ud, unstack_state=False, unstack_params=False)
+    assert packed["solution"][1].dtype == prob.state_dtype and packed["solution"][1].shape == (3,)
+    assert packed["parameters"][1].dtype == prob.params_dtype
+
+
+def test_hermite_kernel_selection_with_many_parameters():
+    """Few states but more differentiated parameters than the cooperative kernels carry: the Hermite build must
+    fall through to the lane-group kernel instead of failing (kernel_variant)."""
+    from sunode_amd import _native
+    src = "#define SA_N_STATES 3\n#define SA_N_SUB 10\n#define SA_N_REM 0\n"
+    assert _native.kernel_variant(src, hermite=True) == ("bdf_wave.hip", 8)
+    assert _native.kernel_variant(src, hermite=False)[0] == "bdf_wave.hip"
+    small = "#define SA_N_STATES 3\n#define SA_N_SUB 3\n#define SA_N_REM 0\n"
+    assert _native.kernel_variant(small, hermite=True) == ("bdf_coop.hip", 8)
+    assert _native.kernel_variant(small) == ("bdf_kernels.hip", 1)

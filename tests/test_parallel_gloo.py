@@ -74,6 +74,85 @@ def test_two_rank_sharded_solve_equals_single_process(tmp_path, interleaved):
     assert (got["st"] == 0).all()
 
 
+class _OracleEngine:
+    """CPU stand-in for bench.GpuEngine (same interface): the rank's shard integrated by the oracle."""
+
+    def __init__(self, name, prob, batch, tol, local_rank, arena_bytes=0):
+        from tests.helpers import make_oracle
+        self.orc = make_oracle(name)
+        rt, at = tol
+        self.cfg = self.orc.config(rtol=rt, atol=at, rtolB=rt, atolB=at, rtolQB=rt, atolQB=at)
+        self.b = batch
+        self.out = None
+
+    def step(self):
+        b = self.b
+        y, st, sf = self.orc.solve_forward(self.cfg, b["y0"], b["ps"], b["pr"], 0.0, b["tvals"])
+        g, lam, st2, sb = self.orc.solve_backward(self.cfg, b["tvals"][-1], 0.0, b["tvals"], b["grads"])
+        self.out = (y, g, lam, st, st2, sf, sb)
+
+    def kernel_ms(self):
+        return 1.0, 1.0
+
+    def sync(self):
+        pass
+
+    def results(self):
+        y, g, lam, st, st2, sf, sb = self.out
+        return dict(failed=int((st != 0).sum() + (st2 != 0).sum()), stats_f=sf.astype(float).mean(axis=0),
+                    stats_b=sb.astype(float).mean(axis=0), arena=(0, 0, False), grad_sum=float(g.sum()))
+
+    def close(self):
+        pass
+
+
+def _bench_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import json
+    import bench
+    args = bench.parse_args(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--batch", "24"])
+    out = bench.run_rank(args, backend="gloo", make_engine=_OracleEngine)
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            json.dump(out, fh)
+    else:
+        assert out is None
+
+
+def test_bench_rank_function_two_ranks_gloo(tmp_path):
+    """bench.py's own per-rank function (the code `python bench.py --gpus 2` runs under torch.distributed.run),
+    world size 2 over gloo, the per-rank solve played by the CPU oracle: sharding through
+    sunode_amd.parallel.shard_indices, barrier, max-reduce of the time, sum-reduce of the failed count."""
+    import json
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "bench.json")
+    mp.spawn(_bench_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    line = json.load(open(out))
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 48 and line["config"]["batch_per_gpu"] == 24
+    assert line["config"]["failed_instances"] == 0
+    assert line["value"] > 0 and line["unit"] == "solves/s"
+    assert abs(line["value"] - 48 * 1 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    # rank 0 integrated draws 0..23 of the global 48-draw batch (contiguous shards)
+    import bench
+    from tests.helpers import make_oracle, make_problem
+    prob = make_problem("lv")
+    full = bench.make_batch("lv", prob, 48)
+    orc = make_oracle("lv")
+    cfg = orc.config(rtol=1e-8, atol=1e-8, rtolB=1e-8, atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
+    _, _, sf = orc.solve_forward(cfg, full["y0"][:24], full["ps"][:24], full["pr"][:24], 0.0, full["tvals"])
+    assert line["work"]["fwd_steps_mean"] == float(sf[:, 0].mean())
+
+
+def test_bench_gpus_flag_must_match_world(monkeypatch):
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit):
+        bench.run_rank(bench.parse_args(["--gpus", "2"]))
+
+
 def test_shard_bounds_cover_and_balance():
     from sunode_amd.parallel import shard_bounds, shard_indices
     for n in (0, 1, 7, 64, 65536, 65537):

@@ -1,8 +1,9 @@
-"""The numeric halves (``perform``) of the pytensor Ops against the solvers they wrap.
+"""The pytensor Ops: numeric halves (``perform``) against the solvers they wrap, and graph construction
+(``solve_ivp``) + ``grad`` wiring executed end to end against the CPU oracle's gradients.
 
-pytensor is not installed in this image, so a stub package (tests/stubs/pytensor: just the names the wrapper
-module touches) stands in for it; with the real pytensor installed the same test runs against it.  Graph
-construction and ``grad`` wiring need the real package and are not covered here."""
+pytensor is not installed in this image, so a stub package (tests/stubs/pytensor: a tiny lazy graph with the
+tensor vocabulary the wrapper module uses) stands in for it; with the real pytensor installed the ``perform``
+tests run against it unchanged (the graph tests use the stub's ``evaluate`` and skip otherwise)."""
 import importlib
 import os
 import sys
@@ -83,3 +84,93 @@ def test_forward_sensitivity_op_perform(ops):
     np.testing.assert_array_equal(y, yd[0])
     np.testing.assert_array_equal(sens, sd[0])
     assert sens.shape == (21, 2, 2) and np.abs(sens[-1]).max() > 0.1
+
+
+def _lv_rhs(t, y, p):
+    return {"hares": p.alpha * y.hares - p.beta * y.lynx * y.hares,
+            "lynx": p.delta * y.hares * y.lynx - p.gamma * y.lynx}
+
+
+def _oracle_gradients(tv, y0, params, grads, tol):
+    """dL/dy0, dL/d(alpha, beta), y(t) for L = sum(grads * y) from the CPU oracle (forward + adjoint)."""
+    from tests.helpers import make_oracle
+    prob = make_problem("lv")
+    orc = make_oracle("lv")
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    y, st, _ = orc.solve_forward(cfg, y0[None], params[None, :2], params[None, 2:], 0.0, tv)
+    g, lam, st2, _ = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads)
+    assert st[0] == 0 and st2[0] == 0
+    return y[0], -lam[0], g[0]
+
+
+def test_solve_ivp_graph_and_adjoint_grad_chain_vs_oracle(ops):
+    """``solve_ivp`` builds the graph, ``SolveODEAdjoint.grad`` wires forward Op -> SolveODEAdjointBackward ->
+    EvalRhs; evaluating that graph must give the ORACLE's states and gradients (bit for bit: same arithmetic)
+    and d/dtvals = (rhs(y(t_i)) * g_i).sum(-1)  (reference wrappers/as_pytensor.py:294-308)."""
+    pytensor = pytest.importorskip("pytensor")
+    if not hasattr(pytensor, "evaluate"):
+        pytest.skip("graph evaluation helper of the stub only")
+    pt = importlib.import_module("pytensor.tensor")
+    tol = 1e-9
+    alpha, beta = pt.dscalar("alpha"), pt.dscalar("beta")
+    hares0 = pt.dscalar("hares0")
+    tv = np.linspace(0, 10, 21)
+    sol, flat, problem, solver, y0_flat, ps_flat = ops.solve_ivp(
+        t0=0.0, y0={"hares": (hares0, ()), "lynx": np.array(0.1)},
+        params={"alpha": (alpha, ()), "beta": (beta, ()), "gamma": np.array(0.3), "delta": np.array(0.4)},
+        tvals=tv, rhs=_lv_rhs, derivatives="adjoint",
+        solver_kwargs=dict(abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol, quad_abstol=tol,
+                           quad_reltol=tol))
+    assert [".".join(p) for p in problem.params_subset.subset_paths] == ["alpha", "beta"]
+    givens = {alpha: 0.1, beta: 0.2, hares0: 1.0}
+    y = pytensor.evaluate(flat, givens)
+    assert y.shape == (21, 2)
+    np.testing.assert_array_equal(pytensor.evaluate(sol["lynx"], givens), y[:, 1])
+    # cotangent of L = sum(w * y): hand it to the Op's grad() exactly as pytensor.grad would
+    w = np.cos(np.arange(42.0)).reshape(21, 2)
+    node = flat.owner
+    assert type(node.op).__name__ == "SolveODEAdjoint"
+    gl = node.op.grad(node.inputs, [pt.as_tensor_variable(w)])
+    assert len(gl) == 5
+    assert type(gl[2]).__name__ == "NotImplementedGrad" and type(gl[3]).__name__ == "NotImplementedGrad"
+    d_y0, d_params, d_tvals = pytensor.evaluate([gl[0], gl[1], gl[4]], givens)
+    yo, dy0_o, dp_o = _oracle_gradients(tv, np.array([1.0, 0.1]), np.array([0.1, 0.2, 0.3, 0.4]), w, tol)
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(d_params, dp_o)
+    np.testing.assert_array_equal(d_y0, dy0_o)
+    rhs = np.stack([0.1 * yo[:, 0] - 0.2 * yo[:, 1] * yo[:, 0], 0.4 * yo[:, 0] * yo[:, 1] - 0.3 * yo[:, 1]], axis=1)
+    np.testing.assert_allclose(d_tvals, (rhs * w).sum(-1), rtol=1e-12)
+    # finite-difference check of one entry through the graph itself (independent of the adjoint machinery)
+    eps = 1e-6
+    lp = (pytensor.evaluate(flat, {**givens, alpha: 0.1 + eps}) * w).sum()
+    lm = (pytensor.evaluate(flat, {**givens, alpha: 0.1 - eps}) * w).sum()
+    assert abs((lp - lm) / (2 * eps) - d_params[0]) < 2e-5 * max(1.0, abs(d_params[0]))
+
+
+def test_solve_ivp_forward_sensitivity_grad_chain(ops):
+    """derivatives='forward': SolveODE.grad contracts the sensitivities; a cotangent on the sensitivity output
+    is refused like in the reference (:253)."""
+    pytensor = pytest.importorskip("pytensor")
+    if not hasattr(pytensor, "evaluate"):
+        pytest.skip("graph evaluation helper of the stub only")
+    pt = importlib.import_module("pytensor.tensor")
+    grad_mod = importlib.import_module("pytensor.gradient")
+    tol = 1e-9
+    alpha, beta = pt.dscalar("alpha"), pt.dscalar("beta")
+    tv = np.linspace(0, 10, 21)
+    out = ops.solve_ivp(t0=0.0, y0={"hares": np.array(1.0), "lynx": np.array(0.1)},
+                        params={"alpha": (alpha, ()), "beta": (beta, ()), "gamma": np.array(0.3),
+                                "delta": np.array(0.4)},
+                        tvals=tv, rhs=_lv_rhs, derivatives="forward",
+                        solver_kwargs=dict(abstol=tol, reltol=tol, sens_mode="simultaneous"))
+    flat, flat_sens = out[1], out[6]
+    givens = {alpha: 0.1, beta: 0.2}
+    w = np.cos(np.arange(42.0)).reshape(21, 2)
+    node = flat.owner
+    gl = node.op.grad(node.inputs, [pt.as_tensor_variable(w), grad_mod.DisconnectedType()])
+    d_params = pytensor.evaluate(gl[1], givens)
+    _, _, dp_o = _oracle_gradients(tv, np.array([1.0, 0.1]), np.array([0.1, 0.2, 0.3, 0.4]), w, tol)
+    np.testing.assert_allclose(d_params, dp_o, rtol=2e-6)          # two different gradient methods at tol 1e-9
+    assert pytensor.evaluate(flat_sens, givens).shape == (21, 2, 2)
+    with pytest.raises(NotImplementedError):
+        node.op.grad(node.inputs, [pt.as_tensor_variable(w), pt.as_tensor_variable(np.zeros((21, 2, 2)))])
