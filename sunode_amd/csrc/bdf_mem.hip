@@ -27,6 +27,7 @@
 #define SA_TEMPLATE template <class SinkT>
 #define SA_OUT_T SinkT
 #define SA_STORE(slot, value) out.template put<(slot)>(value)
+#define SA_STORE_DYN(slot, value) out.put_dyn(slot, value)
 #define SA_Y(i) y[(int64_t)(i) * sa_ystride]
 #define SA_LAM(i) lam[(int64_t)(i) * sa_ystride]
 /* the state views handed to the generated functions have the stride of their output sink */
@@ -85,6 +86,7 @@ struct StrideSink {
     double *p;
     int64_t stride;
     template <int S> __device__ __forceinline__ void put(double x) const { p[(int64_t)S * stride] = x; }
+    __device__ __forceinline__ void put_dyn(int slot, double x) const { p[(int64_t)slot * stride] = x; }
 };
 
 template <bool BWD>

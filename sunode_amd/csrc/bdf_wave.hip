@@ -59,6 +59,8 @@ __shared__ double s_y[KPW * W_NS];                  /* callback input: state (ba
 __shared__ double s_lam[KPW * W_NS];                /* callback input: adjoint state; scratch for the LU solves */
 __shared__ double s_ps[KPW * W_NQD];                /* differentiated parameters of the instance */
 __shared__ uint8_t s_piv[KPW * W_PIV];              /* pivot rows (n <= 128 fits a byte) */
+#define W_NOUT (W_NS > W_NQD ? W_NS : W_NQD)
+__shared__ double s_out[KPW * W_NOUT];              /* output vector of the vector-valued callbacks */
 /* index of the calling lane's instance within its wavefront */
 static __device__ __forceinline__ int sa_grp()
 {
@@ -196,6 +198,124 @@ static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const do
 }
 #define SA_MATVEC(tag, NO, NI, OFF, VEC) sa_matvec_coop<NO, NI>(prg + (OFF), &VEC(0))
 
+/* Structured matrix callbacks (generated SA_MATFILL): entry(slot) = M[slot] + u[line(slot)].  The N line values are
+   evaluated as ordinary statements (split between the wavefronts by SA_OWNS) into LDS; the N*N entries are then
+   written by ALL lanes of the instance's lane group / workgroup (coalesced reads of the constant block) instead of
+   N*N scalar statements evaluated by every lane; a barrier on either side orders the fill against the line values
+   before it and the exception statements after it. */
+#define SA_UVEC_BEGIN(tag, N)
+#define SA_UVEC_SET(tag, k, v) s_mvp[sa_grp() * W_NS + (k)] = (v)
+#define SA_UVEC(tag, k) s_mvp[sa_grp() * W_NS + (k)]
+#define SA_STORE_DYN(slot, value) out.put_dyn(slot, value)
+static __device__ __forceinline__ void sa_group_sync()
+{
+    if constexpr (SA_WAVES > 1) __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+template <int N, int AXIS, class SinkT>
+static __device__ __forceinline__ double sa_matfill_coop(const gdouble *M, const SinkT &out)
+{
+    static_assert(N <= W_NS, "matrix block larger than the state vector");
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int li = lane & (G - 1), grp = (KPW == 1) ? 0 : lane / G;
+    const int nw = (SA_WAVES > 1) ? s_nwaves : 1;
+    const int w = (SA_WAVES > 1) ? sa_wave_index() : 0;
+    sa_group_sync();
+    const double *uv = s_mvp + grp * W_NS;
+    bool bad = false;
+    for (int slot = w * G + li; slot < N * N; slot += nw * G) {
+        const double f = M[slot] + uv[AXIS ? slot / N : slot % N];
+        out.put_dyn(slot, f);
+        bad = bad || (f * 0.0 != 0.0);
+    }
+    sa_group_sync();
+    const uint64_t any = __builtin_amdgcn_ballot_w64(bad);
+    const uint64_t mask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << (lane & ~(G - 1)));
+    return (any & mask) ? __builtin_nan("") : 0.0;
+}
+#define SA_MATFILL(tag, N, OFF, AXIS) chk += sa_matfill_coop<N, AXIS>(prg + (OFF), out)
+
+/* Butterfly step: the value of lane (lane ^ 2^B).  Strides 1 and 2 are DPP quad permutes, strides 4 and 8 the DPP
+   row_half_mirror / row_mirror patterns (lane 7-i / 15-i instead of i^4 / i^8: inside a SUM or MAX butterfly every
+   lane of the partner block already holds that block's total, so any lane of it serves -- same value, same
+   association), strides 16 and 32 go through ds_bpermute.  Two VALU moves instead of two LDS-crossbar round trips
+   for the four inner stages. */
+template <int B>
+static __device__ __forceinline__ double sa_xor_lane(double v, int lane)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
+    if constexpr (B == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); }
+    else if constexpr (B == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); }
+    else if constexpr (B == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); }
+    else if constexpr (B == 3) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); }
+    else {
+        lo = __builtin_amdgcn_ds_bpermute((lane ^ (1 << B)) << 2, lo);
+        hi = __builtin_amdgcn_ds_bpermute((lane ^ (1 << B)) << 2, hi);
+    }
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+constexpr int sa_ilog2(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
+constexpr int sa_pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+template <int B, int E>
+static __device__ __forceinline__ double sa_butterfly_sum(double x, int lane)
+{
+    if constexpr (B < E) { x = x + sa_xor_lane<B>(x, lane); return sa_butterfly_sum<B + 1, E>(x, lane); }
+    else return x;
+}
+template <int P>
+static __device__ __forceinline__ double sa_pair_tree(const double *s)
+{
+    if constexpr (P == 1) return s[0];
+    else return sa_pair_tree<P / 2>(s) + sa_pair_tree<P / 2>(s + P / 2);
+}
+
+/* Re-rolled sums / outputs of the generated callbacks (codegen.Roller): one term (output) per lane and register
+   slot instead of N scalar statements per lane.  SA_SUM is the balanced tree over next_pow2(N) leaves in index
+   order: leaf j lives in lane j % G of slot j / G, butterfly over the G lanes of a slot, then the slots pairwise. */
+template <int N, class F>
+static __device__ __forceinline__ double sa_sum_coop(F term)
+{
+    constexpr int NSLOT = (N + G - 1) / G, P = sa_pow2_ge(NSLOT);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int li = lane & (G - 1);
+    double s[P];
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+        if (r < NSLOT) {
+            const int j = r * G + li;
+            const double x = term(j < N ? j : N - 1);
+            s[r] = sa_butterfly_sum<0, sa_ilog2(G)>(j < N ? x : 0.0, lane);
+        } else s[r] = 0.0;
+    }
+    return sa_pair_tree<P>(s);
+}
+#define SA_SUM(N, term) sa_sum_coop<N>([&](int j_) -> double { return (term); })
+template <int N, class F>
+static __device__ __forceinline__ double sa_rolled_coop(F body)      /* body(i) evaluates AND stores output i */
+{
+    constexpr int NSLOT = (N + G - 1) / G;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int li = lane & (G - 1);
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < NSLOT; r++) {
+        const int i = r * G + li;
+        if (i < N) { const double v = body(i); bad = bad || (v * 0.0 != 0.0); }
+    }
+    const uint64_t any = __builtin_amdgcn_ballot_w64(bad);
+    const uint64_t mask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << (lane & ~(G - 1)));
+    return (any & mask) ? __builtin_nan("") : 0.0;
+}
+#define SA_ROLLED(N, S0, S1, expr) \
+    chk += sa_rolled_coop<N>([&](int i_) -> double { const double v_ = (expr); out.put_dyn((S0) + (S1) * i_, v_); return v_; })
+#define SA_UVEC_ROLLED(tag, N, expr) \
+    chk += sa_rolled_coop<N>([&](int i_) -> double { const double v_ = (expr); SA_UVEC_SET(tag, i_, v_); return v_; })
+
 #include SA_PROBLEM_HEADER
 #include "sa_device_abi.h"
 #include "sa_common.h"
@@ -245,13 +365,15 @@ DEV void lds_sync()
 }
 
 /* output sinks of the generated callbacks (all lanes hold the same value) */
-struct VecOut {             /* vector-valued callbacks -> workspace vector */
-    gdouble *p;
-    template <int S> __device__ __forceinline__ void put(double x) const { p[S] = x; }
+struct VecOut {             /* vector-valued callbacks -> the instance's LDS output vector */
+    int base;
+    template <int S> __device__ __forceinline__ void put(double x) const { s_out[base + S] = x; }
+    __device__ __forceinline__ void put_dyn(int slot, double x) const { s_out[base + slot] = x; }
 };
 struct MatOut {             /* n x n callbacks -> the instance's LDS matrix (slot = col * n + row) */
     int base;
     template <int S> __device__ __forceinline__ void put(double x) const { s_A[base + S] = x; }
+    __device__ __forceinline__ void put_dyn(int slot, double x) const { s_A[base + slot] = x; }
 };
 
 /* ------------------------------------------------------------------------------------ */
@@ -259,7 +381,7 @@ template <bool BWD>
 struct Cw {
     int lane;                         /* lane in the wavefront */
     int li, gbase;                    /* lane within its instance's group, first lane of the group */
-    int abase, vbase, pbase, kbase;   /* the group's slices of s_A / s_y,s_lam / s_ps / s_piv */
+    int abase, vbase, pbase, kbase, obase;   /* the group's slices of s_A / s_y,s_lam / s_ps / s_piv / s_out */
     double zn[QMAX + 1][RS], znQ[QMAX + 1][RQ], zsave[RS], zsaveQ[RQ];
     double ewt[RS], acor[RS], tempv[RS], ftemp[RS], y[RS], ytmp[RS], atol[RS];
 #ifdef SA_CONSTRAINTS
@@ -327,9 +449,7 @@ DEV double wave_sum(int lane, const double (&v)[NSLOT])
     double s[P];
     SFOR(r, 0, P) {
         if constexpr (r < NSLOT) {
-            double x = v[r];
-            SFOR(b, 0, LOG2G) x = x + shfl_d(x, lane ^ (1 << b)); SEND
-            s[r] = x;
+            s[r] = sa_butterfly_sum<0, LOG2G>(v[r], lane);
         } else {
             s[r] = 0.0;
         }
@@ -339,7 +459,7 @@ DEV double wave_sum(int lane, const double (&v)[NSLOT])
 
 DEV double wave_max(int lane, double x)
 {
-    SFOR(b, 0, LOG2G) { const double o = shfl_d(x, lane ^ (1 << b)); x = x > o ? x : o; } SEND
+    SFOR(b, 0, LOG2G) { const double o = sa_xor_lane<b>(x, lane); x = x > o ? x : o; } SEND
     return x;
 }
 
@@ -527,9 +647,9 @@ DEV void stage_inputs(const Cw<BWD> &m, const double (&ymine)[RS])
 template <bool BWD, int NSLOT, int N>
 DEV void fetch_output(const Cw<BWD> &m, double (&out)[NSLOT])
 {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    SFOR(r, 0, NSLOT) out[r] = (IDX(m, r) < N) ? m.obuf[IDX(m, r) < N ? IDX(m, r) : 0] : 0.0; SEND
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    lds_sync();
+    SFOR(r, 0, NSLOT) out[r] = (IDX(m, r) < N) ? s_out[m.obase + (IDX(m, r) < N ? IDX(m, r) : 0)] : 0.0; SEND
+    lds_sync();
 }
 
 /* every wavefront of the workgroup runs this for the same command; SA_CHUNK_CALL picks its chunks */
@@ -537,10 +657,10 @@ template <bool BWD>
 DEV int run_callback(int cmd, double t, const double *pr, double *obuf)
 {
     if (cmd == CMD_RHS) {
-        if constexpr (BWD) return sa_adj_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{(gdouble *)obuf});
-        else return sa_rhs(t, nullptr, nullptr, pr, VecOut{(gdouble *)obuf});
+        if constexpr (BWD) return sa_adj_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUT});
+        else return sa_rhs(t, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUT});
     }
-    if (cmd == CMD_QUAD) return sa_quad_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{(gdouble *)obuf});
+    if (cmd == CMD_QUAD) return sa_quad_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUT});
     if constexpr (BWD) return sa_adj_jac(t, nullptr, nullptr, pr, MatOut{sa_grp() * NS * NS});
     else return sa_jac(t, nullptr, nullptr, pr, MatOut{sa_grp() * NS * NS});
 }
@@ -567,7 +687,7 @@ struct Grp {
     int lane, li, gbase, abase, kbase, wave;
 };
 DEV int getrf_coop(const Grp &g, double (&inv_piv)[(W_NS + G - 1) / G], int &nswaps);
-DEV int setup_lu_regs(int wave, int lane, double c, bool from_saved, double *sj, int &nswaps);
+static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj);
 
 template <bool BWD>
 DEV void worker_loop(const double *pr, double *obuf)
@@ -579,8 +699,7 @@ DEV void worker_loop(const double *pr, double *obuf)
         const double t = s_targ;
         if (cmd == CMD_EXIT) break;
         if (cmd == CMD_GETRF) {
-            int nswaps;
-            (void)setup_lu_regs(wave, lane, t, s_flag != 0, obuf - WS_OUT + WS_SJ, nswaps);
+            setup_lu_regs(wave, lane, t, s_flag, obuf - WS_OUT + WS_SJ);
         } else {
             const int rc = run_callback<BWD>(cmd, t, pr, obuf);
             if (lane == 0) s_rc[wave] = rc;
@@ -743,23 +862,30 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
  * M = I + c*J (c = -gamma) is built and factorised without touching LDS in the elimination: wavefront w owns the
  * columns j = SA_WAVES*cc + w (cc < LU_NC; 25 columns at n = 100), lane l the rows l, l + 64: 2*LU_NC doubles per lane.
  * Step k: the OWNER of column k checks the pivot (one ballot; the arg-max butterfly only if some row beats the
- * diagonal), scales the column and publishes it (LDS, double-buffered) -- one workgroup barrier -- then every
- * wavefront updates its trailing columns from registers: the pivot-row entry a(k,j) is a v_readlane of its own
- * column register, the update one FMA per owned entry.  Same operations and order as denseGETRF / getrf_coop
- * (bit-identical); row exchanges (rare: I - gamma*J is nearly diagonally dominant) swap register rows with
- * readlane/select and cost one extra barrier.  J comes from the saved copy in the workspace (from_saved) or from
- * LDS where the Jacobian callback just wrote it (and is saved on the way); the factors end up in LDS (s_A) for
- * the triangular solves of wavefront 0, the reciprocal pivots in s_invp. */
+ * diagonal), scales the column and publishes the multipliers (LDS, double-buffered) -- one workgroup barrier --
+ * then every wavefront updates its trailing columns from registers: the pivot-row entry a(k,j) is a v_readlane of
+ * its own column register, the update one FMA per owned entry.
+ * Rows are never moved: a row exchange only relabels -- every lane keeps the LOGICAL index (the row position
+ * denseGETRF's explicit swaps would give) of its rows, masks and pivot ties use logical indices, and the factors
+ * are written back to LDS at their logical rows.  Same operations on the same values in the same order as
+ * denseGETRF / getrf_coop, hence bit-identical; and the step is ONE piece of code in a run-time loop (the owner's
+ * column is selected by a short compare chain): ~1 K instructions, where the fully unrolled form was 60 K and
+ * lived in the instruction cache's miss path.
+ * J comes from the saved copy in the workspace (from_saved) or from LDS where the Jacobian callback just wrote it
+ * (and is saved on the way); the factors end up in LDS (s_A) for the triangular solves of wavefront 0, the
+ * reciprocal pivots in s_invp. */
 #if SA_WAVES > 1
 #define LU_NC ((NS + SA_WAVES - 1) / SA_WAVES)
-static_assert(64 % SA_WAVES == 0, "the columns of one ownership round must share a register slot");
-__shared__ double s_col[2][W_NS];
+__shared__ double s_col[2][RS * 64];
 __shared__ double s_invp[W_NS];
-__shared__ int s_luier;
+__shared__ int s_luier, s_lunswaps;
 
-DEV int setup_lu_regs(int wave, int lane, double c, bool from_saved, double *sj, int &nswaps)
+/* noinline on purpose: the 2*LU_NC matrix registers of a lane must not compete with the integrator state of
+   wavefront 0 (inlined, the pair spilled ~1.6 KB per lane to scratch); results come back through LDS */
+static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj)
 {
     double a[LU_NC][RS];
+    int logpos[RS];
     SFOR(cc, 0, LU_NC) {
         const int j = cc * SA_WAVES + wave;
         SFOR(r, 0, RS) {
@@ -773,118 +899,114 @@ DEV int setup_lu_regs(int wave, int lane, double c, bool from_saved, double *sj,
             a[cc][r] = v;
         } SEND
     } SEND
+    SFOR(r, 0, RS) logpos[r] = (r * 64 + lane < NS) ? r * 64 + lane : -1; SEND
     if (wave == 0 && lane == 0) s_luier = 0;
-    nswaps = 0;
+    int nswaps = 0, ier = 0;
     __syncthreads();
-    int ier = 0;
-    SFOR(kc, 0, LU_NC) {
-        constexpr int slot_k = (kc * SA_WAVES) / 64;
-        for (int o = 0; o < SA_WAVES && ier == 0; o++) {
-            const int k = kc * SA_WAVES + o;
-            if (k >= NS) break;
-            const int kl = k & 63, buf = k & 1;
-            int l = k;
-            if (wave == o) {
-                /* pivot: first row i >= k with the largest |a(i,k)| (strict '>' scan order of denseGETRF) */
-                const double akk = readlane_d(a[kc][slot_k], kl);
-                double best = fabs(akk);
-                int bi = k;
-                bool beaten = false;
-                double cand[RS];
+#pragma nounroll
+    for (int k = 0; k < NS; k++) {
+        const int o = k % SA_WAVES, kcr = k / SA_WAVES, buf = k & 1;
+        int prow_lane = 0, prow_slot = 0;           /* physical home of logical row k */
+        SFOR(r, 0, RS) {
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == k);
+            if (bal != 0) { prow_slot = r; prow_lane = __builtin_ctzll(bal); }
+        } SEND
+        if (wave == o) {
+            double colv[RS];
+            SFOR(r, 0, RS) colv[r] = 0.0; SEND
+            SFOR(cc, 0, LU_NC) { if (cc == kcr) { SFOR(r, 0, RS) colv[r] = a[cc][r]; SEND } } SEND
+            double dsel = colv[0];
+            SFOR(r, 1, RS) dsel = (prow_slot == r) ? colv[r] : dsel; SEND
+            const double akk = readlane_d(dsel, prow_lane);
+            /* pivot: first (lowest logical index) row i >= k with the largest |a(i,k)| */
+            double best = fabs(akk);
+            int bi = k;
+            bool beaten = false;
+            double cand[RS];
+            SFOR(r, 0, RS) {
+                cand[r] = (logpos[r] > k) ? fabs(colv[r]) : -1.0;
+                beaten = beaten || (cand[r] > best);
+            } SEND
+            if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
+                best = -1.0;
+                bi = 1 << 20;
                 SFOR(r, 0, RS) {
-                    const int i = r * 64 + lane;
-                    cand[r] = (i > k && i < NS) ? fabs(a[kc][r]) : -1.0;
-                    beaten = beaten || (cand[r] > best);
+                    const double v = (logpos[r] == k) ? fabs(akk) : cand[r];
+                    if (logpos[r] >= k && (v > best || (v == best && logpos[r] < bi))) { best = v; bi = logpos[r]; }
                 } SEND
-                if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
-                    best = -1.0;
-                    bi = 1 << 20;
-                    SFOR(r, 0, RS) {
-                        const int i = r * 64 + lane;
-                        const double v = (i == k) ? fabs(akk) : cand[r];
-                        if (i >= k && i < NS && v > best) { best = v; bi = i; }
-                    } SEND
-                    SFOR(b, 0, 6) {
-                        const double ov = shfl_d(best, lane ^ (1 << b));
-                        const int oi = shfl_i(bi, lane ^ (1 << b));
-                        const bool take = (ov > best) || (ov == best && oi < bi);
-                        best = take ? ov : best;
-                        bi = take ? oi : bi;
-                    } SEND
-                }
-                l = bi;
-                if (best == 0.0) { if (lane == 0) s_luier = k + 1; }
-                else {
-                    if (lane == 0) s_piv[k] = (uint8_t)l;
-                    if (l == k) {
-                        const double mult = 1.0 / akk;
-                        if (lane == 0) s_invp[k] = mult;
-                        SFOR(r, slot_k, RS) {
-                            const int i = r * 64 + lane;
-                            if (i > k && i < NS) { const double lc = a[kc][r] * mult; a[kc][r] = lc; s_col[buf][i] = lc; }
-                        } SEND
-                    }
-                }
-            }
-            __syncthreads();
-            ier = s_luier;
-            if (ier != 0) break;
-            l = s_piv[k];
-            if (l != k) {                   /* exchange rows k and l in every wavefront's columns, then scale */
-                nswaps++;
-                const int ll = l & 63, ls = l >> 6;
-                SFOR(cc, 0, LU_NC) {
-                    const double xk = readlane_d(a[cc][slot_k], kl);
-                    double src = a[cc][0];
-                    SFOR(r, 1, RS) src = (ls == r) ? a[cc][r] : src; SEND
-                    const double xl = readlane_d(src, ll);
-                    SFOR(r, 0, RS) {
-                        const int i = r * 64 + lane;
-                        a[cc][r] = (i == k) ? xl : ((i == l) ? xk : a[cc][r]);
-                    } SEND
+                SFOR(b, 0, 6) {
+                    const double ov = shfl_d(best, lane ^ (1 << b));
+                    const int oi = shfl_i(bi, lane ^ (1 << b));
+                    const bool take = (ov > best) || (ov == best && oi < bi);
+                    best = take ? ov : best;
+                    bi = take ? oi : bi;
                 } SEND
-                if (wave == o) {
-                    const double akk = readlane_d(a[kc][slot_k], kl);
-                    const double mult = 1.0 / akk;
-                    if (lane == 0) s_invp[k] = mult;
-                    SFOR(r, slot_k, RS) {
-                        const int i = r * 64 + lane;
-                        if (i > k && i < NS) { const double lc = a[kc][r] * mult; a[kc][r] = lc; s_col[buf][i] = lc; }
-                    } SEND
-                }
-                __syncthreads();
             }
-            /* trailing update of this wavefront's columns j > k */
-            double lc[RS];
-            SFOR(r, slot_k, RS) { const int i = r * 64 + lane; lc[r] = (i > k && i < NS) ? s_col[buf][i] : 0.0; } SEND
-            SFOR(cc, kc, LU_NC) {
-                const int j = cc * SA_WAVES + wave;
-                if (j > k && j < NS) {
-                    const double akj = readlane_d(a[cc][slot_k], kl);
-                    if (akj != 0.0) {
-                        SFOR(r, slot_k, RS) {
-                            const int i = r * 64 + lane;
-                            if (i > k && i < NS) a[cc][r] = FMA(-akj, lc[r], a[cc][r]);
-                        } SEND
-                    }
+            const int l = bi;
+            if (best == 0.0) { if (lane == 0) s_luier = k + 1; }
+            else {
+                double apiv = akk;
+                if (l != k) {
+                    int ls = 0, ll = 0;
+                    SFOR(r, 0, RS) {
+                        const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == l);
+                        if (bal != 0) { ls = r; ll = __builtin_ctzll(bal); }
+                    } SEND
+                    double psel = colv[0];
+                    SFOR(r, 1, RS) psel = (ls == r) ? colv[r] : psel; SEND
+                    apiv = readlane_d(psel, ll);
                 }
+                const double mult = 1.0 / apiv;
+                if (lane == 0) { s_piv[k] = (uint8_t)l; s_invp[k] = mult; }
+                /* multipliers of the rows still to be eliminated: every unused row except the pivot row */
+                SFOR(r, 0, RS) {
+                    const bool rem = (logpos[r] >= k) && (logpos[r] != l);
+                    const double lc = colv[r] * mult;
+                    colv[r] = rem ? lc : colv[r];
+                    if (rem) s_col[buf][r * 64 + lane] = lc;
+                } SEND
+                SFOR(cc, 0, LU_NC) { if (cc == kcr) { SFOR(r, 0, RS) a[cc][r] = colv[r]; SEND } } SEND
+            }
+        }
+        __syncthreads();
+        ier = s_luier;
+        if (ier != 0) break;
+        const int l = s_piv[k];
+        if (l != k) {                       /* row exchange = relabelling */
+            nswaps++;
+            SFOR(r, 0, RS) { const int lp = logpos[r]; logpos[r] = (lp == l) ? k : ((lp == k) ? l : lp); } SEND
+            SFOR(r, 0, RS) {
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == k);
+                if (bal != 0) { prow_slot = r; prow_lane = __builtin_ctzll(bal); }
             } SEND
         }
-    } SEND
+        /* trailing update of this wavefront's columns j > k: pivot-row entries first (v_readlane -> SGPRs), then
+           one masked block of FMAs per register slot */
+        double akj[LU_NC];
+        SFOR(cc, 0, LU_NC) {
+            const int j = cc * SA_WAVES + wave;
+            double src = a[cc][0];
+            SFOR(r, 1, RS) src = (prow_slot == r) ? a[cc][r] : src; SEND
+            akj[cc] = (j > k && j < NS) ? readlane_d(src, prow_lane) : 0.0;         /* 0: column not updated */
+        } SEND
+        SFOR(r, 0, RS) {
+            if (logpos[r] > k) {
+                const double lc = s_col[buf][r * 64 + lane];
+                SFOR(cc, 0, LU_NC) { if (akj[cc] != 0.0) a[cc][r] = FMA(-akj[cc], lc, a[cc][r]); } SEND
+            }
+        } SEND
+    }
     if (ier == 0) {
         SFOR(cc, 0, LU_NC) {
             const int j = cc * SA_WAVES + wave;
-            SFOR(r, 0, RS) {
-                const int i = r * 64 + lane;
-                if (j < NS && i < NS) s_A[j * NS + i] = a[cc][r];
-            } SEND
+            SFOR(r, 0, RS) { if (j < NS && logpos[r] >= 0) s_A[j * NS + logpos[r]] = a[cc][r]; } SEND
         } SEND
     }
+    if (wave == 0 && lane == 0) s_lunswaps = nswaps;
     __syncthreads();
-    return ier;
 }
 #else
-DEV int setup_lu_regs(int, int, double, bool, double *, int &) { return 0; }
+static __device__ void setup_lu_regs(int, int, double, int, double *) {}
 #endif
 
 template <bool BWD>
@@ -911,7 +1033,9 @@ DEV int setup_lu_workgroup(Cw<BWD> &m, double c, bool from_saved)
     PROF_T0
     if (m.li == 0) { s_cmd = CMD_GETRF; s_targ = c; s_flag = from_saved ? 1 : 0; }
     __syncthreads();
-    const int ier = setup_lu_regs(0, m.lane, c, from_saved, m.sj, m.nswaps);
+    setup_lu_regs(0, m.lane, c, from_saved ? 1 : 0, m.sj);
+    const int ier = s_luier;
+    m.nswaps = s_lunswaps;
     SFOR(r, 0, RS) { const int i = r * 64 + m.lane; m.inv_piv[r] = (i < NS) ? s_invp[i < NS ? i : 0] : 0.0; } SEND
     __syncthreads();                /* pairs with the barrier that ends every pass of worker_loop */
     lds_sync();
@@ -927,6 +1051,72 @@ DEV double bcast_vec(const double (&b)[RS], int k, int gbase)
     SFOR(r, 1, RS) v = ((k / G) == r) ? b[r] : v; SEND
     if constexpr (G == 64) return readlane_d(v, k & 63);        /* k is wave-uniform */
     else return shfl_d(v, gbase + (k & (G - 1)));               /* k is uniform within the group only */
+}
+
+/* Triangular solves for the whole-wavefront mapping (G = 64): the chain through b is inherently serial
+   (broadcast b_k, one FMA per owned row); everything else is taken out of it -- the loops are split by the
+   register slot that holds b_k (no slot selects), rows that need no mask get none (components beyond n carry
+   don't-care values and are zeroed at the end), and the matrix columns are fetched from LDS a block of
+   GETRS_BLOCK columns ahead (double-buffered) so that no LDS latency sits in the chain. */
+#define GETRS_BLOCK 4
+template <bool BWD>
+DEV void dense_getrs64(Cw<BWD> &m, double (&b)[RS])
+{
+    const int lane = m.lane;
+    const double *A = s_A + m.abase;
+    /* forward substitution with the unit lower factor */
+    SFOR(sk, 0, RS) {
+        constexpr int k_lo = sk * 64;
+        constexpr int k_hi = (NS - 1 < k_lo + 64) ? NS - 1 : k_lo + 64;
+        if constexpr (k_lo < k_hi) {
+            double nxt[GETRS_BLOCK][RS], cur[GETRS_BLOCK][RS];
+            SFOR(d, 0, GETRS_BLOCK) { SFOR(r, sk, RS) nxt[d][r] = A[(k_lo + d < NS ? k_lo + d : 0) * NS + r * 64 + lane]; SEND } SEND
+            for (int k0 = k_lo; k0 < k_hi; k0 += GETRS_BLOCK) {
+                SFOR(d, 0, GETRS_BLOCK) { SFOR(r, sk, RS) cur[d][r] = nxt[d][r]; SEND } SEND
+                SFOR(d, 0, GETRS_BLOCK) {
+                    const int kn = k0 + GETRS_BLOCK + d;
+                    SFOR(r, sk, RS) nxt[d][r] = A[(kn < NS ? kn : 0) * NS + r * 64 + lane]; SEND
+                } SEND
+                SFOR(d, 0, GETRS_BLOCK) {
+                    const int k = k0 + d;
+                    if (k < k_hi) {
+                        const double bk = readlane_d(b[sk], k - k_lo);
+                        if (lane > k - k_lo) b[sk] = FMA(-cur[d][sk], bk, b[sk]);
+                        SFOR(r, sk + 1, RS) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
+                    }
+                } SEND
+            }
+        }
+    } SEND
+    /* back substitution with the upper factor (reciprocal pivots) */
+    SFOR_DOWN(sk, RS - 1, 0) {
+        constexpr int k_lo = sk * 64 > 1 ? sk * 64 : 1;                 /* k = NS-1 ... 1 */
+        constexpr int k_hi = (NS - 1 < sk * 64 + 63) ? NS - 1 : sk * 64 + 63;
+        if constexpr (k_lo <= k_hi) {
+            double nxt[GETRS_BLOCK][RS], cur[GETRS_BLOCK][RS];
+            SFOR(d, 0, GETRS_BLOCK) { SFOR(r, 0, sk + 1) nxt[d][r] = A[(k_hi - d > 0 ? k_hi - d : 0) * NS + r * 64 + lane]; SEND } SEND
+            for (int k0 = k_hi; k0 >= k_lo; k0 -= GETRS_BLOCK) {
+                SFOR(d, 0, GETRS_BLOCK) { SFOR(r, 0, sk + 1) cur[d][r] = nxt[d][r]; SEND } SEND
+                SFOR(d, 0, GETRS_BLOCK) {
+                    const int kn = k0 - GETRS_BLOCK - d;
+                    SFOR(r, 0, sk + 1) nxt[d][r] = A[(kn > 0 ? kn : 0) * NS + r * 64 + lane]; SEND
+                } SEND
+                SFOR(d, 0, GETRS_BLOCK) {
+                    const int k = k0 - d;
+                    if (k >= k_lo) {
+                        const int kl = k - sk * 64;
+                        const double scaled = b[sk] * m.inv_piv[sk];
+                        b[sk] = (lane == kl) ? scaled : b[sk];
+                        const double bk = readlane_d(scaled, kl);
+                        if (lane < kl) b[sk] = FMA(-cur[d][sk], bk, b[sk]);
+                        SFOR(r, 0, sk) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
+                    }
+                } SEND
+            }
+        }
+    } SEND
+    if (lane == 0) b[0] *= m.inv_piv[0];
+    SFOR(r, 0, RS) { if (r * 64 + lane >= NS) b[r] = 0.0; } SEND
 }
 
 template <bool BWD>
@@ -949,6 +1139,11 @@ DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
         }
         SFOR(r, 0, RS) { if (IDX(m, r) < NS) b[r] = s_lam[m.vbase + IDX(m, r)]; } SEND
         lds_sync();
+    }
+    if constexpr (G == 64) {
+        dense_getrs64(m, b);
+        PROF_ADD(m, 4)
+        return;
     }
     /* The chain through b is inherently serial (one broadcast + one FMA per step); the matrix column of the
        NEXT step does not depend on it, so it is fetched from LDS one step ahead (GETRS_DEPTH columns in
@@ -1753,6 +1948,7 @@ DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_st
     {
         const int grp = m.lane / G;
         m.abase = grp * NS * NS; m.vbase = grp * NS; m.pbase = grp * W_NQD; m.kbase = grp * W_PIV;
+        m.obase = grp * W_NOUT;
     }
     m.pr = pr + (int64_t)inst * rem_stride;
     m.sj = ws + (int64_t)inst * WS_DOUBLES + WS_SJ;
@@ -2072,6 +2268,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
 struct ArrayOut {
     gdouble *p;
     template <int S> __device__ __forceinline__ void put(double x) const { p[S] = x; }
+    __device__ __forceinline__ void put_dyn(int slot, double x) const { p[slot] = x; }
 };
 
 extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)

@@ -313,7 +313,7 @@ static int bind_workspace(sa_solver *s, int32_t B, double **ws, int64_t *stride)
  * holds (sunode: CVodeAdjInit(checkpoint_n = 500 000), solver.py:533,588 -- in effect unbounded).  Here the
  * points of a whole batch live in ONE device arena traj[rows][stride][8+6n] and the same two regimes exist:
  *
- *  resident   rows x roundup64(B) records fit the budget (sa_options.arena_bytes): the forward call stores
+ *  resident   rows x roundup64(B) records fit the budget (sa_options.arena_bytes, default 64 GiB): the forward call stores
  *             every step, the backward call reads them.  rows starts at 512 and follows the largest point
  *             count seen on the handle (x1.25), never more than sa_options.traj_capacity.
  *  tiled      otherwise, or when an instance ran out of rows (kernel status SA_TRAJ_FULL): the forward call
@@ -335,7 +335,7 @@ static size_t arena_budget(const sa_solver *s)
 {
     if (s->opt.arena_bytes > 0) return (size_t)s->opt.arena_bytes;
     size_t free_b = 0, total_b = 0;
-    size_t dflt = (size_t)16 << 30;                            /* default: 16 GiB ... */
+    size_t dflt = (size_t)64 << 30;                            /* default: 64 GiB of the 288 GB ... */
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {      /* ... but at most 60 % of what is free (+ what we hold) */
         size_t avail = (size_t)(0.6 * (double)(free_b + s->traj.cap));
         if (avail < dflt) dflt = avail;
@@ -599,16 +599,41 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
         /* tiled: re-integrate the forward problem tile by tile with exactly sized storage, adjoint per tile */
         const size_t rec = record_bytes(s), budget = arena_budget(s);
         const size_t np_ = (size_t)s->p, nn = (size_t)s->n;
-        int64_t lo = 0;
-        while (lo < B) {
-            int64_t hi = lo, rows = 2;
-            while (hi < B) {
-                const int64_t nhi = (hi + 64 < B) ? hi + 64 : B;
-                int64_t r2 = rows;
-                for (int64_t i = hi; i < nhi; i++) if (s->h_np[(size_t)i] > r2) r2 = s->h_np[(size_t)i];
-                if (hi > lo && (size_t)round64(nhi - lo) * (size_t)r2 * rec > budget) break;
-                hi = nhi; rows = r2;
+        /* tile boundaries: as few tiles as the budget allows (greedy over 64-instance groups), then balanced --
+           equal-sized tiles keep every launch wide enough to fill the chip -- as long as each still fits */
+        auto fits = [&](int64_t lo_, int64_t hi_, int64_t *rows_out) {
+            int64_t r2 = 2;
+            for (int64_t i = lo_; i < hi_; i++) if (s->h_np[(size_t)i] > r2) r2 = s->h_np[(size_t)i];
+            if (rows_out) *rows_out = r2;
+            return (size_t)round64(hi_ - lo_) * (size_t)r2 * rec <= budget;
+        };
+        std::vector<int64_t> cuts;                  /* greedy */
+        for (int64_t lo_ = 0; lo_ < B;) {
+            int64_t hi_ = (lo_ + 64 < B) ? lo_ + 64 : B;
+            while (hi_ < B) {
+                const int64_t nhi = (hi_ + 64 < B) ? hi_ + 64 : B;
+                if (!fits(lo_, nhi, nullptr)) break;
+                hi_ = nhi;
             }
+            cuts.push_back(hi_);
+            lo_ = hi_;
+        }
+        if (cuts.size() > 1) {                      /* balanced alternative with the same number of tiles */
+            const int64_t per = round64((B + (int64_t)cuts.size() - 1) / (int64_t)cuts.size());
+            std::vector<int64_t> even;
+            bool ok = true;
+            for (int64_t lo_ = 0; lo_ < B && ok; lo_ += per) {
+                const int64_t hi_ = (lo_ + per < B) ? lo_ + per : B;
+                ok = fits(lo_, hi_, nullptr);
+                even.push_back(hi_);
+            }
+            if (ok && even.size() <= cuts.size()) cuts.swap(even);
+        }
+        int64_t lo = 0;
+        for (size_t ti = 0; ti < cuts.size(); ti++) {
+            const int64_t hi = cuts[ti];
+            int64_t rows = 2;
+            (void)fits(lo, hi, &rows);
             const int32_t tB = (int32_t)(hi - lo);
             const int64_t stride = round64(tB);
             if ((rc = s->traj.ensure((size_t)rows * (size_t)stride * rec))) return rc;

@@ -121,6 +121,51 @@ HELPERS_C = r"""
 #ifndef SA_OWNS
 #define SA_OWNS(slot) 1
 #endif
+/* Matrix callbacks with structure (symode/problem.py extract_matfill): entry(slot) = M[slot] + u[line(slot)] (+ an
+   exception term for few slots), M = the block of the remainder vector at slot OFF, u = N line values set by
+   SA_UVEC_SET, line(slot) = slot % N (AXIS 0: the row of a column-major matrix) or slot / N (AXIS 1: the column).
+   SA_MATFILL stores all N*N entries (SA_STORE_DYN: run-time slot) and folds their finiteness into chk;
+   SA_MF(tag, slot, line, OFF) is the filled value of one slot (exceptions add their term to it). */
+#ifndef SA_MATFILL
+#define SA_UVEC_BEGIN(tag, N) double sa_uv_##tag[N];
+#define SA_UVEC_SET(tag, k, v) sa_uv_##tag[k] = (v)
+#define SA_UVEC(tag, k) sa_uv_##tag[k]
+#define SA_MATFILL(tag, N, OFF, AXIS) \
+    for (int s_ = 0; s_ < (N) * (N); s_++) { \
+        const double f_ = SA_PR((OFF) + s_) + sa_uv_##tag[(AXIS) ? s_ / (N) : s_ % (N)]; \
+        SA_STORE_DYN(s_, f_); chk += f_ * 0.0; \
+    }
+#endif
+#ifndef SA_STORE_DYN
+#define SA_STORE_DYN(slot, value) out[slot] = (value)
+#endif
+#ifndef SA_UVEC_ROLLED       /* the N line values from one expression in i_ */
+#define SA_UVEC_ROLLED(tag, N, expr) \
+    for (int i_ = 0; i_ < (N); i_++) { const double v_ = (expr); SA_UVEC_SET(tag, i_, v_); chk += v_ * 0.0; }
+#endif
+#define SA_MF(tag, slot, line, OFF) (SA_PR((OFF) + (slot)) + SA_UVEC(tag, line))
+/* Re-rolled loops (codegen.Roller): sympy hands over fully unrolled expressions; N isomorphic terms of a sum, or N
+   isomorphic output statements, that differ only by a unit-stride index are emitted ONCE with a loop index.
+     SA_SUM(N, term)       sum over j_ = 0..N-1 of `term` (an expression in j_), associated as the balanced binary
+                           tree over next_pow2(N) leaves in index order (zeros beyond N): the association of a
+                           cross-lane butterfly, so a kernel may evaluate one term per lane;
+     SA_ROLLED(N, S0, S1, expr)   for i_ = 0..N-1: slot S0 + S1*i_ <- `expr` (an expression in i_), with the usual
+                           finiteness check folded into chk.
+   Defaults: plain loops (oracle, thread-per-instance kernels). */
+#ifndef SA_SUM
+#define SA_SUM(N, term) __extension__({ \
+    double s_[(N) <= 1 ? 1 : (N) <= 2 ? 2 : (N) <= 4 ? 4 : (N) <= 8 ? 8 : (N) <= 16 ? 16 : (N) <= 32 ? 32 : (N) <= 64 ? 64 : \
+              (N) <= 128 ? 128 : (N) <= 256 ? 256 : (N) <= 512 ? 512 : 1024]; \
+    const int p_ = (int)(sizeof(s_) / sizeof(s_[0])); \
+    for (int j_ = 0; j_ < p_; j_++) s_[j_] = 0.0; \
+    for (int j_ = 0; j_ < (N); j_++) s_[j_] = (term); \
+    for (int w_ = 1; w_ < p_; w_ *= 2) for (int q_ = 0; q_ < p_; q_ += 2 * w_) s_[q_] = s_[q_] + s_[q_ + w_]; \
+    s_[0]; })
+#endif
+#ifndef SA_ROLLED
+#define SA_ROLLED(N, S0, S1, expr) \
+    for (int i_ = 0; i_ < (N); i_++) { const double v_ = (expr); SA_STORE_DYN((S0) + (S1) * i_, v_); chk += v_ * 0.0; }
+#endif
 SA_FN double sa_logaddexp(double a, double b) {
     double lo = fmin(a, b), hi = fmax(a, b);
     return hi + log1p(exp(lo - hi));
@@ -260,6 +305,181 @@ PREFETCH_MAX_RANGES = 8
 PREFETCH_PIECE = 1024          # doubles covered by one touch (64 lanes x one 128-byte line)
 
 
+#: sums / output families with at least this many isomorphic members are re-rolled
+ROLL_MIN = 16
+ROLL_MAX = 1024
+_LEAF_RE = re.compile(r"^(SA_Y|SA_LAM|SA_PS|SA_PR)\((\d+)\)$")
+_MV_RE = re.compile(r"^SA_MV\((\w+), (\d+)\)$")
+
+
+class Roller:
+    """Recovers loops from unrolled expressions: members of a family (terms of a long sum, or the outputs of a
+    callback) are *isomorphic with unit stride* when replacing every indexed leaf ``ARR(k)`` of member j by the
+    placeholder ``ARR(j + (k - j))`` makes them one and the same expression (leaves shared by ALL members stay
+    as they are: loop invariants)."""
+
+    def __init__(self, symbol_map: Dict[str, str], prefix: str):
+        self.symbol_map = dict(symbol_map)
+        self.prefix = prefix
+        self.leaf: Dict[str, Tuple[str, int]] = {}
+        for name, text in symbol_map.items():
+            m = _LEAF_RE.match(text)
+            if m:
+                self.leaf[name] = (m.group(1), int(m.group(2)))
+                continue
+            m = _MV_RE.match(text)
+            if m:
+                self.leaf[name] = ("SA_MV:" + m.group(1), int(m.group(2)))
+        self.sums: List[Tuple[sym.Symbol, int, sym.Expr]] = []      # (symbol, N, skeleton) in dependency order
+        self._sum_of: Dict[Tuple[int, sym.Expr], sym.Symbol] = {}
+        self._ph: Dict[Tuple[str, int, str], sym.Symbol] = {}
+        self._memo: Dict[sym.Basic, sym.Basic] = {}
+
+    def placeholder(self, arr: str, off: int, var: str) -> sym.Symbol:
+        key = (arr, off, var)
+        if key not in self._ph:
+            s = sym.Symbol("sa_ph%d_%s" % (len(self._ph), var), real=True)
+            self._ph[key] = s
+            idx = var if off == 0 else "%s %s %d" % (var, "+" if off > 0 else "-", abs(off))
+            self.symbol_map[s.name] = ("SA_MV(%s, %s)" % (arr[6:], idx)) if arr.startswith("SA_MV:") else "%s(%s)" % (arr, idx)
+        return self._ph[key]
+
+    def _leaves(self, e):
+        return {sy: self.leaf[sy.name] for sy in e.free_symbols if sy.name in self.leaf}
+
+    def try_roll(self, members: Sequence[sym.Expr], var: str):
+        """-> (skeleton, order) with members[order[j]] == skeleton at index j for j = 0..N-1, or None."""
+        n = len(members)
+        if n < ROLL_MIN or n > ROLL_MAX:
+            return None
+        leaves = [self._leaves(e) for e in members]
+        common = set(leaves[0])
+        for lv in leaves[1:]:
+            common &= set(lv)
+        variable = [{sy: al for sy, al in lv.items() if sy not in common} for lv in leaves]
+        if any(not v for v in variable):
+            return None
+
+        def skeleton(k, j):
+            return members[k].xreplace({sy: self.placeholder(arr, idx - j, var) for sy, (arr, idx) in variable[k].items()})
+
+        cands = sorted({idx for (_, idx) in variable[0].values()})
+        for j0 in cands:
+            skel = skeleton(0, j0)
+            slots = {ph: key for key, ph in self._ph.items() if ph in skel.free_symbols}
+            offs = sorted({(arr, off) for (arr, off, _) in slots.values()})
+            assign = {0: j0}
+            ok = True
+            for k in range(1, n):
+                found = None
+                tried = set()
+                for (arr, idx) in variable[k].values():
+                    for (arr2, off) in offs:
+                        j = idx - off
+                        if arr2 != arr or j in tried:
+                            continue
+                        tried.add(j)
+                        if skeleton(k, j) == skel:
+                            found = j
+                            break
+                    if found is not None:
+                        break
+                if found is None:
+                    ok = False
+                    break
+                assign[k] = found
+            if not ok:
+                continue
+            js = sorted(assign.values())
+            if len(set(js)) != n or js[-1] - js[0] != n - 1:
+                continue
+            base = js[0]
+            if base != 0:            # re-base the loop index to 0
+                skel = skel.xreplace({ph: self.placeholder(key[0], key[1] + base, var)
+                                      for ph, key in slots.items()})
+            order = [None] * n
+            for k, j in assign.items():
+                order[j - base] = k
+            return skel, order
+        return None
+
+    # -- sums --------------------------------------------------------------------------------------
+    def roll_sums(self, e):
+        """Replace every rollable long sum inside ``e`` (bottom-up) by a fresh scalar symbol."""
+        e = sym.sympify(e)
+        if e.is_Atom:
+            return e
+        if e in self._memo:
+            return self._memo[e]
+        args = [self.roll_sums(a) for a in e.args]
+        new = e.func(*args) if any(a is not b for a, b in zip(args, e.args)) else e
+        if new.is_Add and len(new.args) >= ROLL_MIN:
+            new = self._roll_add(new)
+        self._memo[e] = new
+        return new
+
+    def _roll_add(self, add):
+        terms = list(sym.Add.make_args(add))
+        buckets: Dict[Tuple, List[sym.Expr]] = {}
+        for term in terms:
+            key = (tuple(sorted(arr for arr, _ in self._leaves(term).values())), term.count_ops())
+            buckets.setdefault(key, []).append(term)
+        rest, out = [], []
+        for key, group in buckets.items():
+            got = self.try_roll(group, "j_") if key[0] else None
+            if got is None:
+                rest += group
+                continue
+            skel, _ = got
+            # loop-invariant factors leave the sum: sum_j c*t_j is emitted as c * SUM(t_j) (our own definition of
+            # the arithmetic: the oracle compiles the same source), which also lets different sums share one SUM
+            ph = {p_ for p_ in skel.free_symbols if p_ in set(self._ph.values())}
+            coeff, core = skel.as_independent(*ph, as_Add=False) if ph else (sym.Integer(1), skel)
+            if core == 1 or not (core.free_symbols & ph):
+                coeff, core = sym.Integer(1), skel
+            sign = -1 if core.could_extract_minus_sign() else 1
+            core, coeff = sign * core, sign * coeff
+            keyc = (len(group), core)
+            if keyc not in self._sum_of:
+                symbol = sym.Symbol("%ssum%d" % (self.prefix, len(self.sums)), real=True)
+                self.sums.append((symbol, len(group), core))
+                self._sum_of[keyc] = symbol
+            out.append(coeff * self._sum_of[keyc])
+        if not out:
+            return add
+        return sym.Add(*(out + rest))
+
+    def split_invariants(self, skel, names):
+        """Loop-invariant sub-expressions of a skeleton (everything that does not depend on the loop index) become
+        assignments to emit in front of the loop; returns (assignments, skeleton over those temporaries)."""
+        ph = set(self._ph.values())
+        keep: List[Tuple[sym.Symbol, sym.Expr]] = []
+        made: Dict[sym.Expr, sym.Symbol] = {}
+
+        def temp_for(e):
+            if e.is_Atom or (e.is_Mul and len(e.args) == 2 and e.args[0].is_Number and e.args[1].is_Atom):
+                return e
+            if e not in made:
+                made[e] = next(names)
+                keep.append((made[e], e))
+            return made[e]
+
+        def hoist(e):
+            if e.is_Atom:
+                return e
+            if not (e.free_symbols & ph):
+                return temp_for(e)
+            if e.is_Mul or e.is_Add:
+                inv = [a for a in e.args if not (a.free_symbols & ph)]
+                var = [hoist(a) for a in e.args if a.free_symbols & ph]
+                if len(inv) >= 2 or (len(inv) == 1 and not inv[0].is_Atom):
+                    return e.func(temp_for(e.func(*inv)), *var)
+                return e.func(*(inv + var))
+            return e.func(*[hoist(a) for a in e.args])
+
+        return keep, hoist(sym.sympify(skel))
+
+
 def _closure(needed, deps, order):
     """CSE temporaries (in definition order) that the expressions using ``needed`` depend on."""
     seen = set()
@@ -271,6 +491,39 @@ def _closure(needed, deps, order):
         seen.add(name)
         stack.extend(deps[name])
     return [name for name in order if name in seen]
+
+
+def _emit_rolled(name, signature, rolled, out_index, n_out, roller, names, matvec, fam):
+    """Body of a callback whose sums (SA_SUM) and / or outputs (SA_ROLLED) were re-rolled."""
+    printer = HipExprPrinter(roller.symbol_map)
+    lines = ["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature), "    SA_PROLOGUE"]
+    if matvec is not None:
+        lines.append("    SA_MATVEC(%s, %d, %d, %d, %s);" % (matvec["tag"], matvec["n_out"], matvec["n_in"],
+                                                            matvec["offset"], matvec["vec"]))
+    lines.append("    double chk = 0.0;")
+    for symbol, n_terms, skel in roller.sums:
+        keep, body = roller.split_invariants(skel, names)
+        lines += ["    const double %s = %s; SA_STMT_END" % (v.name, printer.doprint(val)) for v, val in keep]
+        lines.append("    const double %s = SA_SUM(%d, %s); SA_STMT_END" % (symbol.name, n_terms, printer.doprint(body)))
+    if fam is not None:
+        keep, body = roller.split_invariants(fam[0], names)
+        lines += ["    const double %s = %s; SA_STMT_END" % (v.name, printer.doprint(val)) for v, val in keep]
+        lines.append("    SA_ROLLED(%d, 0, 1, %s); SA_STMT_END" % (n_out, printer.doprint(body)))
+    else:
+        assigns, reduced = sym.cse(rolled, symbols=names, order="canonical") if rolled else ([], [])
+        lines += ["    const double %s = %s; SA_STMT_END" % (v.name, printer.doprint(val)) for v, val in assigns]
+        for k, value in enumerate(reduced):
+            slot = int(out_index[k])
+            if value == 0:
+                lines.append("    SA_STORE(%d, 0.0);" % slot)
+            else:
+                lines.append("    if (SA_OWNS(%d)) { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; } SA_STMT_END"
+                             % (slot, printer.doprint(value), slot))
+    lines.append("    (void)t; (void)y; (void)ps; (void)pr; (void)out;")
+    lines.append("    SA_EPILOGUE")
+    lines.append("    return (chk == 0.0) ? 0 : 1;")
+    lines.append("}")
+    return "\n".join(lines)
 
 
 def emit_function(
@@ -290,6 +543,18 @@ def emit_function(
     output statements carry ``SA_OWNS(slot)`` guards (the kernels split those between wavefronts)."""
     flat = [sym.sympify(e) for e in np.asarray(expr, dtype=object).ravel()]
     names = (sym.Symbol("%s%d" % (prefix, i)) for i in count())
+    # re-rolling (Roller): long sums of isomorphic terms -> SA_SUM, isomorphic outputs -> SA_ROLLED
+    if len(flat) * max((len(sym.Add.make_args(e)) for e in flat), default=0) >= ROLL_MIN and any(
+            len(sym.Add.make_args(a)) >= ROLL_MIN for e in flat for a in sym.preorder_traversal(e) if a.is_Add) \
+            or len(flat) >= ROLL_MIN:
+        roller = Roller(symbol_map, prefix)
+        rolled = [roller.roll_sums(e) for e in flat]
+        identity = list(out_index) == list(range(n_out))
+        fam = roller.try_roll(rolled, "i_") if identity else None
+        if fam is not None and fam[1] != list(range(n_out)):
+            fam = None
+        if roller.sums or fam is not None:
+            return _emit_rolled(name, signature, rolled, out_index, n_out, roller, names, matvec, fam)
     if flat:
         assigns, reduced = sym.cse(flat, symbols=names, order="canonical")
     else:
@@ -394,6 +659,63 @@ def emit_function(
     return "\n".join(parts)
 
 
+def emit_matfill_function(name: str, signature: str, n: int, info: Dict[str, object], symbol_map: Dict[str, str],
+                          prefix: str, tag: str) -> str:
+    """Matrix callback in the structured form (see HELPERS_C, SA_MATFILL): N line-vector statements, one fill,
+    then one statement per exception slot."""
+    axis, u, exceptions, offset = info["axis"], info["u"], info["exceptions"], info["offset"]
+    keys = sorted(exceptions)
+    names = (sym.Symbol("%s%d" % (prefix, i)) for i in count())
+    roller = Roller(symbol_map, prefix)
+    u_r = [roller.roll_sums(e) for e in u]
+    x_r = [roller.roll_sums(exceptions[k]) for k in keys]
+    printer = HipExprPrinter(roller.symbol_map)
+    lines = ["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature), "    SA_PROLOGUE", "    double chk = 0.0;"]
+    for symbol, n_terms, skel in roller.sums:
+        keep, body = roller.split_invariants(skel, names)
+        lines += ["    const double %s = %s; SA_STMT_END" % (v.name, printer.doprint(val)) for v, val in keep]
+        lines.append("    const double %s = SA_SUM(%d, %s); SA_STMT_END" % (symbol.name, n_terms, printer.doprint(body)))
+    lines.append("    SA_UVEC_BEGIN(%s, %d)" % (tag, n))
+    fam_u = roller.try_roll(u_r, "i_")
+    if fam_u is not None and fam_u[1] != list(range(n)):
+        fam_u = None
+    # the exceptions as a family: entries (i, i) of the diagonal, slot (n + 1) * i, line i
+    diag = keys == [(i, i) for i in range(n)]
+    fam_x = roller.try_roll(x_r, "i_") if diag else None
+    if fam_x is not None and fam_x[1] != list(range(n)):
+        fam_x = None
+    rest = ([] if fam_u is not None else u_r) + ([] if fam_x is not None else x_r)
+    assigns, reduced = sym.cse(rest, symbols=names, order="canonical") if rest else ([], [])
+    lines += ["    const double %s = %s; SA_STMT_END" % (v.name, printer.doprint(val)) for v, val in assigns]
+    if fam_u is not None:
+        keep, body = roller.split_invariants(fam_u[0], names)
+        lines += ["    const double %s = %s; SA_STMT_END" % (v.name, printer.doprint(val)) for v, val in keep]
+        lines.append("    SA_UVEC_ROLLED(%s, %d, %s); SA_STMT_END" % (tag, n, printer.doprint(body)))
+        red_x = reduced
+    else:
+        for k in range(n):
+            lines.append("    if (SA_OWNS(%d)) { const double v_ = %s; SA_UVEC_SET(%s, %d, v_); chk += v_ * 0.0; } SA_STMT_END"
+                         % (k, printer.doprint(reduced[k]), tag, k))
+        red_x = reduced[n:]
+    lines.append("    SA_MATFILL(%s, %d, %d, %d);" % (tag, n, offset, axis))
+    if fam_x is not None:
+        keep, body = roller.split_invariants(fam_x[0], names)
+        lines += ["    const double %s = %s; SA_STMT_END" % (v.name, printer.doprint(val)) for v, val in keep]
+        lines.append("    SA_ROLLED(%d, 0, %d, SA_MF(%s, %d * i_, i_, %d) + (%s)); SA_STMT_END"
+                     % (n, n + 1, tag, n + 1, offset, printer.doprint(body)))
+    else:
+        for q, (i, j) in enumerate(keys):
+            slot = j * n + i
+            line = i if axis == 0 else j
+            lines.append("    if (SA_OWNS(%d)) { const double v_ = SA_MF(%s, %d, %d, %d) + (%s); SA_STORE(%d, v_); "
+                         "chk += v_ * 0.0; } SA_STMT_END" % (q, tag, slot, line, offset, printer.doprint(red_x[q]), slot))
+    lines.append("    (void)t; (void)y; (void)ps; (void)pr; (void)out;")
+    lines.append("    SA_EPILOGUE")
+    lines.append("    return (chk == 0.0) ? 0 : 1;")
+    lines.append("}")
+    return "\n".join(lines)
+
+
 def generate_problem_source(
     *,
     n_states: int,
@@ -407,11 +729,13 @@ def generate_problem_source(
     dydp_t: Optional[np.ndarray] = None,
     description: str = "",
     matvec: Optional[Dict[str, Dict[str, object]]] = None,
+    matfill: Optional[Dict[str, Dict[str, object]]] = None,
 ) -> str:
     """Full generated header: sizes + helpers + the five callbacks of the adjoint path and the
     parameter derivative of the right-hand side (forward sensitivities)."""
     n = n_states
     matvec = matvec or {}
+    matfill = matfill or {}
 
     def mv(tag):
         return dict(matvec[tag], tag=tag) if tag in matvec else None
@@ -432,14 +756,16 @@ def generate_problem_source(
         HELPERS_C,
         emit_function("sa_rhs", base, np.asarray(dydt, dtype=object).ravel(),
                       list(range(n)), n, symbol_map, "r_", matvec=mv("f")),
-        emit_function("sa_jac", base, jac, col_major, n * n, symbol_map, "j_"),
+        (emit_matfill_function("sa_jac", base, n, matfill["j"], symbol_map, "j_", "j") if "j" in matfill else
+         emit_function("sa_jac", base, jac, col_major, n * n, symbol_map, "j_")),
         emit_function("sa_adj_rhs", adj, np.asarray(dlamdadt, dtype=object).ravel(),
                       list(range(n)), n, symbol_map, "a_", matvec=mv("a")).replace(
                           "(void)pr;", "(void)pr; (void)lam;"),
         emit_function("sa_quad_rhs", adj, np.asarray(quad, dtype=object).ravel(),
                       list(range(n_sub)), n_sub, symbol_map, "q_").replace(
                           "(void)pr;", "(void)pr; (void)lam;"),
-        emit_function("sa_adj_jac", base, adj_jac, col_major, n * n, symbol_map, "b_"),
+        (emit_matfill_function("sa_adj_jac", base, n, matfill["b"], symbol_map, "b_", "b") if "b" in matfill else
+         emit_function("sa_adj_jac", base, adj_jac, col_major, n * n, symbol_map, "b_")),
         # d f / d p, stored [n_sub][n_states] (row `is` = derivative w.r.t. differentiated parameter `is`):
         # the explicit part of the sensitivity right-hand side yS' = J yS + df/dp (reference
         # symode/problem.py:557-583)

@@ -122,6 +122,56 @@ def extract_matvec(exprs, vsyms, fixed, tag):
     return np.array(new, dtype=object), mv, entries
 
 
+def extract_matfill(mat, fixed, tag):
+    """Split the entries of a matrix callback (n x n, entry (i, j) stored column-major at slot j*n + i) as
+    ``e_ij = M_ij + u_k + x_ij`` with ``M_ij = +-(one fixed-parameter symbol)`` (a constant block, zero where the
+    entry has none), ``u_k`` a vector indexed by the row (axis 0) or the column (axis 1) -- the part shared by a
+    whole line of the matrix, e.g. the rank-one term of a dense Jacobian -- and ``x_ij`` non-zero for few entries
+    only (the diagonal).  The kernels then fill the matrix lane-parallel (``SA_MATFILL``: constant block + line
+    vector) and evaluate straight-line code only for the exceptions, instead of n*n scalar statements.
+    Returns None if there is no such structure, else ``(axis, u [n], exceptions {(i, j): x_ij}, entries)`` with
+    ``entries[slot] = (sign, symbol) | None``."""
+    from collections import Counter
+    n = mat.shape[0]
+    if n * n < MATVEC_MIN_ENTRIES or mat.shape != (n, n):
+        return None
+    m: Dict[Tuple[int, int], Tuple[int, Any]] = {}
+    rest: Dict[Tuple[int, int], Any] = {}
+    for i in range(n):
+        for j in range(n):
+            others = []
+            for a in sym.Add.make_args(sym.sympify(mat[i, j])):
+                ca, fa = a.as_coeff_mul()
+                if (i, j) not in m and len(fa) == 1 and fa[0] in fixed and (ca == 1 or ca == -1):
+                    m[(i, j)] = (int(ca), fa[0])
+                else:
+                    others.append(a)
+            rest[(i, j)] = sym.Add(*others)
+    if len(m) < MATVEC_MIN_FILL * n * n:
+        return None
+    best = None
+    for axis in (0, 1):
+        u, cover = [], 0
+        for k in range(n):
+            line = [rest[(k, q)] if axis == 0 else rest[(q, k)] for q in range(n)]
+            expr, cnt = Counter(line).most_common(1)[0]
+            u.append(expr)
+            cover += cnt
+        if best is None or cover > best[0]:
+            best = (cover, axis, u)
+    cover, axis, u = best
+    if cover < 0.75 * n * n:
+        return None
+    exceptions = {}
+    for i in range(n):
+        for j in range(n):
+            k = i if axis == 0 else j
+            if rest[(i, j)] != u[k]:
+                exceptions[(i, j)] = rest[(i, j)] - u[k]
+    entries = [m.get((slot % n, slot // n)) for slot in range(n * n)]
+    return axis, u, exceptions, entries
+
+
 class SympyProblem:
     def __init__(
         self,
@@ -210,6 +260,7 @@ class SympyProblem:
         self._hoisted: List[Any] = []
         self._packed: List[int] = []
         self._matvec: Dict[str, Dict[str, Any]] = {}
+        self._matfill: Dict[str, Dict[str, Any]] = {}
         self._mv_index: List[int] = []
         self._mv_sign: List[float] = []
         self._hoist_fn = None
@@ -461,6 +512,22 @@ class SympyProblem:
                         self._mv_sign.append(0.0 if ent is None else float(ent[0]))
                 for i, symbol in enumerate(mv):
                     slots[symbol.name] = "SA_MV(%s, %d)" % (tag, i)
+            # Matrix callbacks (Jacobian, adjoint Jacobian) = constant block + line vector + few exceptions
+            self._matfill: Dict[str, Dict[str, Any]] = {}
+            n_st = self.n_states
+            if len(fixed) and n_st and not os.environ.get("SA_NO_MATVEC"):
+                jac_m = np.array(arrays[1], dtype=object).reshape(n_st, n_st)
+                adj_m = np.array([[-jac_m[j, i] for j in range(n_st)] for i in range(n_st)], dtype=object)
+                for tag, mat in (("j", jac_m), ("b", adj_m)):
+                    found = extract_matfill(mat, fixed_or_hoisted, tag)
+                    if found is None:
+                        continue
+                    axis, u, exceptions, entries = found
+                    self._matfill[tag] = dict(n=n_st, axis=axis, u=u, exceptions=exceptions, offset=None,
+                                              start=len(self._mv_index))
+                    for ent in entries:
+                        self._mv_index.append(-1 if ent is None else index_of_fixed[ent[1]])
+                        self._mv_sign.append(0.0 if ent is None else float(ent[0]))
 
             # Access-order copies: a callback that walks a big block of fixed parameters with a large
             # stride (the adjoint right-hand side reads the rate matrix by columns) gets its own copy
@@ -494,7 +561,7 @@ class SympyProblem:
                     a = np.array([sym.sympify(x).xreplace(sub) for x in a.ravel()], dtype=object).reshape(a.shape)
                 packed_arrays.append(a)
             mv_base = base + len(self._packed)
-            for info in self._matvec.values():
+            for info in list(self._matvec.values()) + list(self._matfill.values()):
                 info["offset"] = mv_base + info.pop("start")
             self._native_cache = (packed_arrays, slots)
         return self._native_cache
@@ -540,12 +607,14 @@ class SympyProblem:
                 [".".join(p) for p in self.params_subset.subset_paths])
             (dydt, jac, dlamdadt, quad, dydp_t), slots = self._native_exprs()
             if self._hoisted or self._packed or self._matvec:
-                desc += " hoisted=%d packed=%d matvec=%s" % (len(self._hoisted), len(self._packed),
-                                                              {k: (v["n_out"], v["n_in"]) for k, v in self._matvec.items()})
+                desc += " hoisted=%d packed=%d matvec=%s matfill=%s" % (
+                    len(self._hoisted), len(self._packed),
+                    {k: (v["n_out"], v["n_in"]) for k, v in self._matvec.items()},
+                    {k: (v["axis"], len(v["exceptions"])) for k, v in self._matfill.items()})
             self._native_source = codegen.generate_problem_source(
                 n_states=self.n_states, n_sub=self.n_params, n_rem=self.n_remainder_native,
                 symbol_map=slots, dydt=dydt, jac=jac, dlamdadt=dlamdadt, quad=quad, dydp_t=dydp_t,
-                description=desc, matvec=self._matvec,
+                description=desc, matvec=self._matvec, matfill=self._matfill,
             )
         return self._native_source
 

@@ -123,13 +123,14 @@ def test_tiled_reintegration_equals_resident_arena(name, B, small):
         sol = _solver(name, w["rtol"], w["atol"], arena_gib=arena_gib)
         y, st, sf = sol.solve_forward_batch(0.0, b["tvals"], b["y0"], b["ps"], pr_user)
         g, lam, stb, sb = sol.solve_backward_batch(b["tvals"][-1], 0.0, b["tvals"], b["grads"])
-        info = sol._engine().arena_info()
-        outs.append((y, st, sf, g, lam, stb, sb, info))
-        # a second pass on the same handle (the row hint has been learnt) must give the same answer
+        # a second pass on the same handle must give the same answer; by then the handle has learnt how many rows
+        # the batch needs (the first call starts with 512 and falls back to counting + re-integration)
         y2, st2, _ = sol.solve_forward_batch(0.0, b["tvals"], b["y0"], b["ps"], pr_user)
         g2, lam2, stb2, _ = sol.solve_backward_batch(b["tvals"][-1], 0.0, b["tvals"], b["grads"])
         np.testing.assert_array_equal(y2, y)
         np.testing.assert_array_equal(g2, g)
+        info = sol._engine().arena_info()
+        outs.append((y, st, sf, g, lam, stb, sb, info))
     res, til = outs
     assert not res[7][2] and til[7][2] and til[7][1] >= 2, (res[7], til[7])      # resident vs tiled, >= 2 tiles
     assert til[7][0] <= small * 2**30

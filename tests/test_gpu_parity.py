@@ -355,6 +355,51 @@ def test_network100_forward_adjoint_vs_oracle(variant, monkeypatch):
     np.testing.assert_array_equal(lam, lo)
 
 
+@pytest.mark.parametrize("variant", [None, "wave8", "wave32", "wave", "mem"])
+def test_matvec_callbacks_in_every_mapping(variant, monkeypatch):
+    """network24: the right-hand side and the adjoint right-hand side contain a dense 24 x 24 fixed-parameter block
+    that is generated as one lane-parallel matrix-vector product (SA_MATVEC).  Lane groups of 8 / 16 (engine
+    choice) / 32, the workgroup-per-instance build (matrix-vector split over four wavefronts, register-resident
+    LU) and the memory-resident build must all reproduce the oracle bit for bit."""
+    from sunode_amd import _native
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("network24")
+    assert _native.kernel_variant(prob.native_source()) == ("bdf_wave.hip", 16)
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    B, n = 40, 24
+    d = network_batch(B, n=n)
+    tv = d["tvals"][:6]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(n)[None, :])
+    tol = 1e-8
+    sol = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol,
+                        quad_abstol=tol, quad_reltol=tol)
+    eng = sol._engine()
+    rng = np.random.RandomState(5)
+    pts = 7
+    tt = np.linspace(0, 1, pts)
+    yy = d["y0"][:pts] * np.exp(0.1 * rng.randn(pts, n))
+    ll = rng.randn(pts, n)
+    pr_native = prob.extend_remainder(d["pr"])
+    ev = eng.eval_callbacks(tt, yy, ll, d["ps"][:pts], np.tile(pr_native, (pts, 1)))
+    orc = make_oracle("network24")
+    for i in range(pts):
+        host = orc.eval(tt[i], yy[i], ll[i], d["ps"][i], pr_native)
+        for key in ("rhs", "adj", "quad", "jac", "adjjac"):
+            np.testing.assert_array_equal(ev[key][i], host[key].reshape(ev[key][i].shape))
+    y, status, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], d["pr"])
+    g, lam, status_b, stats_b = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (status == 0).all() and (status_b == 0).all() and (so == 0).all() and (sbo == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(stats_b[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
 @pytest.mark.parametrize("variant", [None, "16", "wave", "mem"])
 def test_lamda_all_out_and_quad_all_out(variant, monkeypatch):
     """Optional per-output-time results of solve_backward (reference solver.py:778-781) from every

@@ -102,3 +102,49 @@ def test_nonfinite_is_recoverable_error():
     orc = make_oracle("misc")
     got = orc.eval(0.1, [-1.0, 0.5], [1.0, 1.0], [1.0, 1.0, 1.0], [1.0])   # sqrt(-1), log(0)
     assert got["codes"][0] == 1
+
+
+def test_matvec_form_of_dense_linear_blocks():
+    """A dense (fixed parameter) x (state | adjoint state) block is emitted as ONE matrix-vector product
+    (SA_MATVEC) + a shared dot product + short residues.  Pure re-grouping: the generated C (compiled into the
+    oracle) must equal sympy's evaluation of the ORIGINAL expressions to rounding."""
+    from oracle.harness import Oracle
+    from tests.helpers import make_problem
+    prob = make_problem("network24")
+    src = prob.native_source()
+    assert set(prob._matvec) == {"f", "a"} and prob._matvec["a"]["n_in"] == 24
+    assert "SA_MATVEC(a, 24, 24," in src and "SA_MATVEC(f, 24, 24," in src and "SA_OWNS(23)" in src
+    assert {k: (v["axis"], len(v["exceptions"])) for k, v in prob._matfill.items()} == {"j": (0, 24), "b": (1, 24)}
+    assert "SA_MATFILL(j, 24," in src and "SA_MATFILL(b, 24," in src
+    assert prob.n_remainder_native == prob.n_remainder + len(prob._hoisted) + len(prob._packed) + 4 * 24 * 24
+    orc = Oracle(prob, "network24")
+    rng = np.random.RandomState(3)
+    n = 24
+    for _ in range(4):
+        K = np.abs(rng.randn(n, n)) / n
+        sc = np.array([1.0, 0.5, 10.0, 0.1]) * np.exp(0.1 * rng.randn(4))
+        y = np.exp(0.3 * rng.randn(n))
+        lam = rng.randn(n)
+        pr = prob.extend_remainder(K.ravel())
+        # block (j, i) of the j-major copies: K[i, j] for the right-hand side, -K[j, i] for the adjoint
+        off_f, off_a = prob._matvec["f"]["offset"], prob._matvec["a"]["offset"]
+        np.testing.assert_array_equal(pr[off_f:off_f + n * n].reshape(n, n), K.T)
+        np.testing.assert_array_equal(pr[off_a:off_a + n * n].reshape(n, n), -K)
+        got = orc.eval(0.3, y, lam, sc, pr)
+        ud = prob.make_user_data()
+        prob.update_params(ud, np.concatenate([K.ravel(), sc]).view(prob.params_dtype)[0])
+        ys = y.view(prob.state_dtype)[0]
+        want = np.zeros(n); prob.make_rhs()(want, 0.3, ys, ud)
+        np.testing.assert_allclose(got["rhs"], want, rtol=1e-13, atol=1e-15)
+        want = np.zeros(n); prob.make_adjoint_rhs()(want, 0.3, ys, lam, ud)
+        np.testing.assert_allclose(got["adj"], want, rtol=1e-12, atol=1e-14)
+        want = np.zeros(4); prob.make_adjoint_quad_rhs()(want, 0.3, ys, lam, ud)
+        np.testing.assert_allclose(got["quad"], want, rtol=1e-12, atol=1e-14)
+        # matrix callbacks: constant block + line vector + diagonal exceptions (SA_MATFILL)
+        want = np.zeros((n, n)); prob.make_jac_dense()(want, 0.3, ys, None, ud)
+        np.testing.assert_allclose(got["jac"], want, rtol=1e-13, atol=1e-15)
+        want = np.zeros((n, n)); prob.make_adjoint_jac_dense()(want, 0.3, ys, lam, None, ud)
+        np.testing.assert_allclose(got["adjjac"], want, rtol=1e-13, atol=1e-15)
+        assert got["codes"].tolist() == [0, 0, 0, 0, 0]
+    # a problem without such a block keeps the plain form
+    assert not make_problem("seir")._matvec and "SA_MATVEC(" not in make_problem("seir").native_source().split("sa_logaddexp")[1]

@@ -148,6 +148,14 @@ EXTRA_PROBLEMS = {
         rhs=sqrt_decay,
         derivative_params=[("k",)],
     ),
+    # dense fixed rate matrix x state: large enough (24 x 24) for the matrix-vector form of the callbacks
+    # (symode/problem.py extract_matvec), small enough for every lane-group mapping
+    "network24": dict(
+        params={"K": (24, 24), "scale": (4,)},
+        states={"x": (24,)},
+        rhs=make_network(24),
+        derivative_params=[("scale",)],
+    ),
     "pivoting": dict(
         params={"k": (2,), "w": (2,)},
         states={"x": (6,)},
