@@ -61,6 +61,12 @@ __shared__ double s_ps[KPW * W_NQD];                /* differentiated parameters
 __shared__ uint8_t s_piv[KPW * W_PIV];              /* pivot rows (n <= 128 fits a byte) */
 #define W_NOUT (W_NS > W_NQD ? W_NS : W_NQD)
 __shared__ double s_out[KPW * W_NOUT];              /* output vector of the vector-valued callbacks */
+/* Workgroup barrier as ONE inline instruction sequence.  In this build pipeline (clang -O0 -> always-inline -> -O3)
+   HIP's __syncthreads() stays a real function call: every call site spilled the caller's live VGPRs to scratch and
+   reloaded them (140 scratch instructions around the single barrier of the LU's elimination loop -- 14 000 scratch
+   accesses per factorisation, the reason a 100 x 100 LU took 190 us). */
+#define sa_barrier() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); \
+                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 /* index of the calling lane's instance within its wavefront */
 static __device__ __forceinline__ int sa_grp()
 {
@@ -167,29 +173,50 @@ static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const do
     const int li = lane & (G - 1), grp = (KPW == 1) ? 0 : lane / G;
     const int nw = (SA_WAVES > 1) ? s_nwaves : 1;
     const int w = (SA_WAVES > 1) ? sa_wave_index() : 0;
+    /* work split: with nw >= 4 wavefronts, wavefront w takes accumulator w % 4 and the row slots r with
+       r % (nw / 4) == w / 4; with fewer, its accumulators w, w + nw, ... of every slot */
+    const int astep = nw >= 4 ? 4 : nw, sgroups = nw >= 4 ? nw / 4 : 1, sgrp = nw >= 4 ? w / 4 : 0;
     int row[RSL];
 #pragma unroll
     for (int r = 0; r < RSL; r++) row[r] = (r * G + li < NO) ? r * G + li : 0;
-    for (int a = w; a < 4; a += nw) {
+    for (int a = w % astep; a < 4; a += astep) {
         double acc[RSL];
+#pragma unroll
+        for (int r = 0; r < RSL; r++) acc[r] = 0.0;
         if (a < NI) {
-            const double v0 = v[a];
+            /* the matrix entries come from L2 (hundreds of cycles each): fetch a batch of MVB columns for every
+               owned row BEFORE the dependent FMA chain consumes them, instead of one load per chain link */
+            constexpr int MVB = 13;
+            constexpr int NT = (NI + 3) / 4;                 /* terms of one accumulator (at most) */
 #pragma unroll
-            for (int r = 0; r < RSL; r++) acc[r] = M[a * NO + row[r]] * v0;
-            for (int j = a + 4; j < NI; j += 4) {
-                const double vj = v[j];
+            for (int t0 = 0; t0 < NT; t0 += MVB) {
+                double mm[MVB][RSL], vv[MVB];
 #pragma unroll
-                for (int r = 0; r < RSL; r++) acc[r] = __builtin_fma(M[j * NO + row[r]], vj, acc[r]);
+                for (int u = 0; u < MVB; u++) {
+                    const int j = a + 4 * (t0 + u);
+                    const int jc = (t0 + u < NT && j < NI) ? j : a;
+                    vv[u] = v[jc];
+#pragma unroll
+                    for (int r = 0; r < RSL; r++) if (r % sgroups == sgrp) mm[u][r] = M[jc * NO + row[r]];
+                }
+#pragma unroll
+                for (int u = 0; u < MVB; u++) {
+                    const int j = a + 4 * (t0 + u);
+                    if (t0 + u < NT && j < NI) {
+#pragma unroll
+                        for (int r = 0; r < RSL; r++) {
+                            if (r % sgroups == sgrp)
+                                acc[r] = (t0 + u == 0) ? mm[u][r] * vv[u] : __builtin_fma(mm[u][r], vv[u], acc[r]);
+                        }
+                    }
+                }
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < RSL; r++) acc[r] = 0.0;
         }
 #pragma unroll
         for (int r = 0; r < RSL; r++)
-            if (r * G + li < NO) s_mvp[(a * KPW + grp) * W_NS + r * G + li] = acc[r];
+            if (r % sgroups == sgrp && r * G + li < NO) s_mvp[(a * KPW + grp) * W_NS + r * G + li] = acc[r];
     }
-    if constexpr (SA_WAVES > 1) __syncthreads();
+    if constexpr (SA_WAVES > 1) sa_barrier();
     else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -209,7 +236,7 @@ static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const do
 #define SA_STORE_DYN(slot, value) out.put_dyn(slot, value)
 static __device__ __forceinline__ void sa_group_sync()
 {
-    if constexpr (SA_WAVES > 1) __syncthreads();
+    if constexpr (SA_WAVES > 1) sa_barrier();
     else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -419,12 +446,22 @@ struct Cw {
 #endif
 };
 
-#ifdef SA_WAVE_PROFILE                /* tuning builds only: section timers overwrite stats slots 9..15 */
+#if defined(SA_WAVE_PROFILE) && !defined(SA_WAVE_PROFILE_PHASES)   /* tuning builds: section timers -> stats 9..15 */
 #define PROF_T0 const int64_t prof_t0 = (int64_t)wall_clock64();
 #define PROF_ADD(m, k) (m).prof[k] += (int64_t)wall_clock64() - prof_t0;
 #else
 #define PROF_T0
 #define PROF_ADD(m, k)
+#endif
+/* -DSA_WAVE_PROFILE -DSA_WAVE_PROFILE_PHASES: the same slots time the phases of a step attempt instead:
+   0 pre-step (weights, norm), 1 adjust + predict + cvSet, 2 interpolation, 3 Newton pass (callbacks, LU and solves
+   included), 4 error test + quadrature, 5 complete + prepare next step */
+#if defined(SA_WAVE_PROFILE) && defined(SA_WAVE_PROFILE_PHASES)
+#define PH_T0 int64_t ph_t0 = (int64_t)wall_clock64();
+#define PH_ADD(m, k) { const int64_t now_ = (int64_t)wall_clock64(); (m).prof[k] += now_ - ph_t0; ph_t0 = now_; }
+#else
+#define PH_T0
+#define PH_ADD(m, k)
 #endif
 
 #define IDX(m, r) ((r) * G + (m).li)
@@ -671,12 +708,12 @@ DEV int dispatch(Cw<BWD> &m, int cmd, double t)
 {
     if constexpr (SA_WAVES > 1) {
         if (m.li == 0) { s_cmd = cmd; s_targ = t; }
-        __syncthreads();
+        sa_barrier();
     }
     int rc = run_callback<BWD>(cmd, t, m.pr, m.obuf);
     if constexpr (SA_WAVES > 1) {
         if (m.li == 0) s_rc[0] = rc;
-        __syncthreads();
+        sa_barrier();
         SFOR(w, 1, SA_WAVES) rc |= s_rc[w]; SEND
     }
     return rc;
@@ -694,7 +731,7 @@ DEV void worker_loop(const double *pr, double *obuf)
 {
     const int lane = lane_id(), wave = sa_wave_index();
     for (;;) {
-        __syncthreads();
+        sa_barrier();
         const int cmd = s_cmd;
         const double t = s_targ;
         if (cmd == CMD_EXIT) break;
@@ -704,7 +741,7 @@ DEV void worker_loop(const double *pr, double *obuf)
             const int rc = run_callback<BWD>(cmd, t, pr, obuf);
             if (lane == 0) s_rc[wave] = rc;
         }
-        __syncthreads();
+        sa_barrier();
     }
 }
 
@@ -713,7 +750,7 @@ DEV void release_workers(const Cw<BWD> &m)
 {
     if constexpr (SA_WAVES > 1) {
         if (m.li == 0) s_cmd = CMD_EXIT;
-        __syncthreads();
+        sa_barrier();
     }
 }
 
@@ -763,7 +800,7 @@ DEV int cv_jac(Cw<BWD> &m, double t, const double (&ymine)[RS])        /* Jacobi
    otherwise the LDS ordering of the (possibly diverged) wavefront */
 DEV void lu_sync()
 {
-    if constexpr (SA_WAVES > 1) __syncthreads();
+    if constexpr (SA_WAVES > 1) sa_barrier();
     else lds_sync();
 }
 
@@ -868,9 +905,8 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
  * Rows are never moved: a row exchange only relabels -- every lane keeps the LOGICAL index (the row position
  * denseGETRF's explicit swaps would give) of its rows, masks and pivot ties use logical indices, and the factors
  * are written back to LDS at their logical rows.  Same operations on the same values in the same order as
- * denseGETRF / getrf_coop, hence bit-identical; and the step is ONE piece of code in a run-time loop (the owner's
- * column is selected by a short compare chain): ~1 K instructions, where the fully unrolled form was 60 K and
- * lived in the instruction cache's miss path.
+ * denseGETRF / getrf_coop, hence bit-identical.  The ownership round (which register column the owner works on) is
+ * unrolled, the steps inside a round are a run-time loop.
  * J comes from the saved copy in the workspace (from_saved) or from LDS where the Jacobian callback just wrote it
  * (and is saved on the way); the factors end up in LDS (s_A) for the triangular solves of wavefront 0, the
  * reciprocal pivots in s_invp. */
@@ -879,6 +915,14 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
 __shared__ double s_col[2][RS * 64];
 __shared__ double s_invp[W_NS];
 __shared__ int s_luier, s_lunswaps;
+#ifdef SA_WAVE_PROFILE
+__shared__ int64_t s_luprof[3];           /* wavefront 0: cycles before the barrier, in the barrier, in the update */
+#define LUP_T(x) const int64_t x = (int64_t)__builtin_readcyclecounter();
+#define LUP_ADD(k, a, b) if (wave == 0 && lane == 0) s_luprof[k] += (b) - (a);
+#else
+#define LUP_T(x)
+#define LUP_ADD(k, a, b)
+#endif
 
 /* noinline on purpose: the 2*LU_NC matrix registers of a lane must not compete with the integrator state of
    wavefront 0 (inlined, the pair spilled ~1.6 KB per lane to scratch); results come back through LDS */
@@ -902,100 +946,111 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
     SFOR(r, 0, RS) logpos[r] = (r * 64 + lane < NS) ? r * 64 + lane : -1; SEND
     if (wave == 0 && lane == 0) s_luier = 0;
     int nswaps = 0, ier = 0;
-    __syncthreads();
+    sa_barrier();
+    /* kcr (the owner's register column) is a compile-time index: the ownership round is unrolled (LU_NC copies of
+       the step), the SA_WAVES steps inside a round are a run-time loop.  (Measured alternatives that were slower:
+       one run-time loop over k with compare-chain column selects; branch-free FMA blocks with scalar zero
+       detection; ds_bpermute broadcasts of the pivot row -- each adds register-array copies at control-flow joins
+       that cost more than the v_readlane hazards they remove.) */
+    SFOR(kcr, 0, LU_NC) {
 #pragma nounroll
-    for (int k = 0; k < NS; k++) {
-        const int o = k % SA_WAVES, kcr = k / SA_WAVES, buf = k & 1;
-        int prow_lane = 0, prow_slot = 0;           /* physical home of logical row k */
-        SFOR(r, 0, RS) {
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == k);
-            if (bal != 0) { prow_slot = r; prow_lane = __builtin_ctzll(bal); }
-        } SEND
-        if (wave == o) {
-            double colv[RS];
-            SFOR(r, 0, RS) colv[r] = 0.0; SEND
-            SFOR(cc, 0, LU_NC) { if (cc == kcr) { SFOR(r, 0, RS) colv[r] = a[cc][r]; SEND } } SEND
-            double dsel = colv[0];
-            SFOR(r, 1, RS) dsel = (prow_slot == r) ? colv[r] : dsel; SEND
-            const double akk = readlane_d(dsel, prow_lane);
-            /* pivot: first (lowest logical index) row i >= k with the largest |a(i,k)| */
-            double best = fabs(akk);
-            int bi = k;
-            bool beaten = false;
-            double cand[RS];
-            SFOR(r, 0, RS) {
-                cand[r] = (logpos[r] > k) ? fabs(colv[r]) : -1.0;
-                beaten = beaten || (cand[r] > best);
-            } SEND
-            if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
-                best = -1.0;
-                bi = 1 << 20;
-                SFOR(r, 0, RS) {
-                    const double v = (logpos[r] == k) ? fabs(akk) : cand[r];
-                    if (logpos[r] >= k && (v > best || (v == best && logpos[r] < bi))) { best = v; bi = logpos[r]; }
-                } SEND
-                SFOR(b, 0, 6) {
-                    const double ov = shfl_d(best, lane ^ (1 << b));
-                    const int oi = shfl_i(bi, lane ^ (1 << b));
-                    const bool take = (ov > best) || (ov == best && oi < bi);
-                    best = take ? ov : best;
-                    bi = take ? oi : bi;
-                } SEND
-            }
-            const int l = bi;
-            if (best == 0.0) { if (lane == 0) s_luier = k + 1; }
-            else {
-                double apiv = akk;
-                if (l != k) {
-                    int ls = 0, ll = 0;
-                    SFOR(r, 0, RS) {
-                        const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == l);
-                        if (bal != 0) { ls = r; ll = __builtin_ctzll(bal); }
-                    } SEND
-                    double psel = colv[0];
-                    SFOR(r, 1, RS) psel = (ls == r) ? colv[r] : psel; SEND
-                    apiv = readlane_d(psel, ll);
-                }
-                const double mult = 1.0 / apiv;
-                if (lane == 0) { s_piv[k] = (uint8_t)l; s_invp[k] = mult; }
-                /* multipliers of the rows still to be eliminated: every unused row except the pivot row */
-                SFOR(r, 0, RS) {
-                    const bool rem = (logpos[r] >= k) && (logpos[r] != l);
-                    const double lc = colv[r] * mult;
-                    colv[r] = rem ? lc : colv[r];
-                    if (rem) s_col[buf][r * 64 + lane] = lc;
-                } SEND
-                SFOR(cc, 0, LU_NC) { if (cc == kcr) { SFOR(r, 0, RS) a[cc][r] = colv[r]; SEND } } SEND
-            }
-        }
-        __syncthreads();
-        ier = s_luier;
-        if (ier != 0) break;
-        const int l = s_piv[k];
-        if (l != k) {                       /* row exchange = relabelling */
-            nswaps++;
-            SFOR(r, 0, RS) { const int lp = logpos[r]; logpos[r] = (lp == l) ? k : ((lp == k) ? l : lp); } SEND
+        for (int o = 0; o < SA_WAVES; o++) {
+            const int k = kcr * SA_WAVES + o, buf = k & 1;
+            if (k >= NS || ier != 0) break;
+            LUP_T(t_a)
+            int prow_lane = 0, prow_slot = 0;           /* physical home of logical row k */
             SFOR(r, 0, RS) {
                 const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == k);
                 if (bal != 0) { prow_slot = r; prow_lane = __builtin_ctzll(bal); }
             } SEND
-        }
-        /* trailing update of this wavefront's columns j > k: pivot-row entries first (v_readlane -> SGPRs), then
-           one masked block of FMAs per register slot */
-        double akj[LU_NC];
-        SFOR(cc, 0, LU_NC) {
-            const int j = cc * SA_WAVES + wave;
-            double src = a[cc][0];
-            SFOR(r, 1, RS) src = (prow_slot == r) ? a[cc][r] : src; SEND
-            akj[cc] = (j > k && j < NS) ? readlane_d(src, prow_lane) : 0.0;         /* 0: column not updated */
-        } SEND
-        SFOR(r, 0, RS) {
-            if (logpos[r] > k) {
-                const double lc = s_col[buf][r * 64 + lane];
-                SFOR(cc, 0, LU_NC) { if (akj[cc] != 0.0) a[cc][r] = FMA(-akj[cc], lc, a[cc][r]); } SEND
+            if (wave == o) {
+                double dsel = a[kcr][0];
+                SFOR(r, 1, RS) dsel = (prow_slot == r) ? a[kcr][r] : dsel; SEND
+                const double akk = readlane_d(dsel, prow_lane);
+                /* pivot: first (lowest logical index) row i >= k with the largest |a(i,k)| */
+                double best = fabs(akk);
+                int bi = k;
+                bool beaten = false;
+                double cand[RS];
+                SFOR(r, 0, RS) {
+                    cand[r] = (logpos[r] > k) ? fabs(a[kcr][r]) : -1.0;
+                    beaten = beaten || (cand[r] > best);
+                } SEND
+                if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
+                    best = -1.0;
+                    bi = 1 << 20;
+                    SFOR(r, 0, RS) {
+                        const double v = (logpos[r] == k) ? fabs(akk) : cand[r];
+                        if (logpos[r] >= k && (v > best || (v == best && logpos[r] < bi))) { best = v; bi = logpos[r]; }
+                    } SEND
+                    SFOR(b, 0, 6) {
+                        const double ov = shfl_d(best, lane ^ (1 << b));
+                        const int oi = shfl_i(bi, lane ^ (1 << b));
+                        const bool take = (ov > best) || (ov == best && oi < bi);
+                        best = take ? ov : best;
+                        bi = take ? oi : bi;
+                    } SEND
+                }
+                const int l = bi;
+                if (best == 0.0) { if (lane == 0) s_luier = k + 1; }
+                else {
+                    double apiv = akk;
+                    if (l != k) {
+                        int ls = 0, ll = 0;
+                        SFOR(r, 0, RS) {
+                            const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == l);
+                            if (bal != 0) { ls = r; ll = __builtin_ctzll(bal); }
+                        } SEND
+                        double psel = a[kcr][0];
+                        SFOR(r, 1, RS) psel = (ls == r) ? a[kcr][r] : psel; SEND
+                        apiv = readlane_d(psel, ll);
+                    }
+                    const double mult = 1.0 / apiv;
+                    if (lane == 0) { s_piv[k] = (uint8_t)l; s_invp[k] = mult; }
+                    /* multipliers of the rows still to be eliminated: every unused row except the pivot row */
+                    SFOR(r, 0, RS) {
+                        if ((logpos[r] >= k) && (logpos[r] != l)) {
+                            const double lc = a[kcr][r] * mult;
+                            a[kcr][r] = lc;
+                            s_col[buf][r * 64 + lane] = lc;
+                        }
+                    } SEND
+                }
             }
-        } SEND
-    }
+            LUP_T(t_b)
+            sa_barrier();
+            LUP_T(t_c)
+            ier = s_luier;
+            if (ier != 0) break;
+            const int l = s_piv[k];
+            if (l != k) {                       /* row exchange = relabelling */
+                nswaps++;
+                SFOR(r, 0, RS) { const int lp = logpos[r]; logpos[r] = (lp == l) ? k : ((lp == k) ? l : lp); } SEND
+                SFOR(r, 0, RS) {
+                    const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == k);
+                    if (bal != 0) { prow_slot = r; prow_lane = __builtin_ctzll(bal); }
+                } SEND
+            }
+            /* trailing update of this wavefront's columns j > k (register columns cc > kcr, and cc == kcr for the
+               wavefronts behind the owner): pivot-row entries first (v_readlane -> SGPRs), then one masked block of
+               FMAs per register slot */
+            double akj[LU_NC];
+            SFOR(cc, kcr, LU_NC) {
+                const int j = cc * SA_WAVES + wave;
+                double src = a[cc][0];
+                SFOR(r, 1, RS) src = (prow_slot == r) ? a[cc][r] : src; SEND
+                akj[cc] = (j > k && j < NS) ? readlane_d(src, prow_lane) : 0.0;         /* 0: column not updated */
+            } SEND
+            SFOR(r, 0, RS) {
+                if (logpos[r] > k) {
+                    const double lc = s_col[buf][r * 64 + lane];
+                    SFOR(cc, kcr, LU_NC) { if (akj[cc] != 0.0) a[cc][r] = FMA(-akj[cc], lc, a[cc][r]); } SEND
+                }
+            } SEND
+            LUP_T(t_d)
+            LUP_ADD(0, t_a, t_b) LUP_ADD(1, t_b, t_c) LUP_ADD(2, t_c, t_d)
+        }
+    } SEND
     if (ier == 0) {
         SFOR(cc, 0, LU_NC) {
             const int j = cc * SA_WAVES + wave;
@@ -1003,7 +1058,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
         } SEND
     }
     if (wave == 0 && lane == 0) s_lunswaps = nswaps;
-    __syncthreads();
+    sa_barrier();
 }
 #else
 static __device__ void setup_lu_regs(int, int, double, int, double *) {}
@@ -1015,11 +1070,11 @@ DEV int dense_getrf(Cw<BWD> &m)
     PROF_T0
     if constexpr (SA_WAVES > 1) {
         if (m.li == 0) s_cmd = CMD_GETRF;
-        __syncthreads();
+        sa_barrier();
     }
     const Grp g{m.lane, m.li, m.gbase, m.abase, m.kbase, 0};
     const int ier = getrf_coop(g, m.inv_piv, m.nswaps);
-    if constexpr (SA_WAVES > 1) __syncthreads();
+    if constexpr (SA_WAVES > 1) sa_barrier();
     lds_sync();
     PROF_ADD(m, 3)
     return ier;
@@ -1032,12 +1087,12 @@ DEV int setup_lu_workgroup(Cw<BWD> &m, double c, bool from_saved)
 {
     PROF_T0
     if (m.li == 0) { s_cmd = CMD_GETRF; s_targ = c; s_flag = from_saved ? 1 : 0; }
-    __syncthreads();
+    sa_barrier();
     setup_lu_regs(0, m.lane, c, from_saved ? 1 : 0, m.sj);
     const int ier = s_luier;
     m.nswaps = s_lunswaps;
     SFOR(r, 0, RS) { const int i = r * 64 + m.lane; m.inv_piv[r] = (i < NS) ? s_invp[i < NS ? i : 0] : 0.0; } SEND
-    __syncthreads();                /* pairs with the barrier that ends every pass of worker_loop */
+    sa_barrier();                /* pairs with the barrier that ends every pass of worker_loop */
     lds_sync();
     PROF_ADD(m, 3)
     return ier;
@@ -1846,10 +1901,13 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
         c.in_step = 1;
     }
     int callSetup, jbad;
+    PH_T0
     if (!c.redo) {
         cv_predict(m);
         cv_set(m);
+        PH_ADD(m, 1)
         if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
+        PH_ADD(m, 2)
         c.convfail = ((c.nflag == FIRST_CALL) || (c.nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
         callSetup = (c.nflag == PREV_CONV_FAIL) || (c.nflag == PREV_ERR_FAIL) || (m.nst == 0) ||
                     (m.nst >= m.nstlp + MSBP) || (fabs(m.gamrat - 1.0) > DGMAX);
@@ -1860,6 +1918,7 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
     }
     int in_loop;
     int nls = cv_newton_pass(m, callSetup, jbad, c.convfail, in_loop);
+    PH_ADD(m, 3)
     if ((nls > 0) && in_loop && !m.nls_jcur) {
         c.redo = 1;
         return 0;
@@ -1922,12 +1981,14 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
         }
         if (dsmQ > dsm) dsm = dsmQ;
     }
+    PH_ADD(m, 4)
     cv_complete_step(m);
     cv_prepare_next_step(m, dsm);
     m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
     SFOR(r, 0, RS) m.acor[r] = m.tq[2] * m.acor[r]; SEND
     if (BWD) { SFOR(r, 0, RQ) m.acorQ[r] = m.tq[2] * m.acorQ[r]; SEND }
     c.in_step = 0;
+    PH_ADD(m, 5)
     return 1;
 }
 
@@ -2066,7 +2127,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     }
     while (!done) {
         if (!c.in_step) {
+            PH_T0
             int ier = cv_pre_step(m);
+            PH_ADD(m, 0)
             if (ier == CV_ILL_INPUT) { status = ier; done = true; }
             else if (!store && a.mxstep > 0 && nstloc >= a.mxstep) {
                 retries++; total_retries++;
@@ -2140,6 +2203,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     const int inst = blockIdx.x * KPW + sa_grp();
     if (inst >= a.B) return;
     if (threadIdx.x == 0) s_nwaves = SA_WAVES;
+#if defined(SA_WAVE_PROFILE) && SA_WAVES > 1
+    if (threadIdx.x == 0) { s_luprof[0] = 0; s_luprof[1] = 0; s_luprof[2] = 0; }
+#endif
     if (sa_wave_index() != 0) {
         worker_loop<true>(a.pr + (int64_t)inst * a.rem_stride, a.ws + (int64_t)inst * WS_DOUBLES + WS_OUT);
         return;
@@ -2198,7 +2264,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
             bool idone = (status != CV_SUCCESS);
             while (!idone) {
                 if (!c.in_step) {
+                    PH_T0
                     int ier = cv_pre_step(m);
+                    PH_ADD(m, 0)
                     if (ier == CV_ILL_INPUT) { status = ier; idone = true; }
                     else if (a.mxstep > 0 && nstloc >= a.mxstep) {
                         retries++; total_retries++;
@@ -2258,6 +2326,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
 #ifdef SA_WAVE_PROFILE
         SFOR(i, 0, 6) st[9 + i] = m.prof[i]; SEND
         st[15] = m.prof[7] + (int64_t)wall_clock64();
+#if SA_WAVES > 1
+        st[5] = s_luprof[0]; st[6] = s_luprof[1]; st[7] = s_luprof[2];      /* LU: cycles pre-barrier / barrier / update */
+#endif
 #endif
         SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
     }

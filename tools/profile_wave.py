@@ -37,9 +37,14 @@ def main():
     f, b = sol._engine().last_kernel_ms()
     print("B=%d fwd %.1f ms bwd %.1f ms -> %.0f solves/s" % (B, f, b, B / ((f + b) * 1e-3)))
     names = ["rhs", "quad", "jac", "getrf", "getrs", "copy"]
+    if "PROFILE_PHASES" in os.environ.get("SA_KERNEL_DEFINES", ""):
+        names = ["pre_step", "predict+set", "interp", "newton", "errtest+quad", "complete+prepare"]
     for tag, stt in (("fwd", stats), ("bwd", statsb)):
         tot = stt[:, 15].mean() * 1e-5
         parts = ", ".join("%s %.1f" % (n, stt[:, 9 + i].mean() * 1e-5) for i, n in enumerate(names))
+        if tag == "bwd" and stt[:, 5:8].sum() > 0:
+            print("    LU of wavefront 0, kilo-cycles per factorisation: before barrier %.1f, in barrier %.1f, update %.1f"
+                  % tuple(stt[:, 5 + i].mean() / max(stt[:, 2].mean(), 1) / 1e3 for i in range(3)))
         print("%s per-instance ms: total %.1f | %s | nst %.0f nfe %.0f nsetups %.0f nje %.0f nni %.0f"
               % (tag, tot, parts, stt[:, 0].mean(), stt[:, 1].mean(), stt[:, 2].mean(), stt[:, 3].mean(),
                  stt[:, 4].mean()))
