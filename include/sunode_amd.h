@@ -86,7 +86,7 @@ typedef struct sa_options {
     const double *constraints; /* CVodeSetConstraints (solver.py:230-233, 569-572): host pointer to n_states values
                                   in {0, +-1, +-2} or NULL; forward problem only; needs a code object built with
                                   constraint support (SA_CONSTRAINTS), otherwise the vector is ignored */
-    int64_t arena_bytes;       /* budget of the trajectory arena; 0 = default (64 GiB, at most 60 % of the free HBM).
+    int64_t arena_bytes;       /* budget of the trajectory arena; 0 = default (96 GiB, at most 60 % of the free HBM).
                                   A batch whose stored steps fit stays resident between sa_solve_forward_batch and
                                   sa_solve_backward_batch; a larger one is re-integrated tile by tile inside the
                                   backward call (check-point semantics; results identical, one extra forward pass) */

@@ -313,7 +313,7 @@ static int bind_workspace(sa_solver *s, int32_t B, double **ws, int64_t *stride)
  * holds (sunode: CVodeAdjInit(checkpoint_n = 500 000), solver.py:533,588 -- in effect unbounded).  Here the
  * points of a whole batch live in ONE device arena traj[rows][stride][8+6n] and the same two regimes exist:
  *
- *  resident   rows x roundup64(B) records fit the budget (sa_options.arena_bytes, default 64 GiB): the forward call stores
+ *  resident   rows x roundup64(B) records fit the budget (sa_options.arena_bytes, default 96 GiB): the forward call stores
  *             every step, the backward call reads them.  rows starts at 512 and follows the largest point
  *             count seen on the handle (x1.25), never more than sa_options.traj_capacity.
  *  tiled      otherwise, or when an instance ran out of rows (kernel status SA_TRAJ_FULL): the forward call
@@ -335,7 +335,7 @@ static size_t arena_budget(const sa_solver *s)
 {
     if (s->opt.arena_bytes > 0) return (size_t)s->opt.arena_bytes;
     size_t free_b = 0, total_b = 0;
-    size_t dflt = (size_t)64 << 30;                            /* default: 64 GiB of the 288 GB ... */
+    size_t dflt = (size_t)96 << 30;                            /* default: 96 GiB, a third of the 288 GB ... */
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {      /* ... but at most 60 % of what is free (+ what we hold) */
         size_t avail = (size_t)(0.6 * (double)(free_b + s->traj.cap));
         if (avail < dflt) dflt = avail;
@@ -601,19 +601,29 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
         const size_t np_ = (size_t)s->p, nn = (size_t)s->n;
         /* tile boundaries: as few tiles as the budget allows (greedy over 64-instance groups), then balanced --
            equal-sized tiles keep every launch wide enough to fill the chip -- as long as each still fits */
-        auto fits = [&](int64_t lo_, int64_t hi_, int64_t *rows_out) {
+        const int64_t n_groups = (B + 63) / 64;
+        std::vector<int32_t> gmax((size_t)n_groups, 2);            /* largest point count of every 64-instance group */
+        for (int64_t i = 0; i < B; i++)
+            if (s->h_np[(size_t)i] > gmax[(size_t)(i / 64)]) gmax[(size_t)(i / 64)] = s->h_np[(size_t)i];
+        auto rows_of = [&](int64_t lo_, int64_t hi_) {             /* lo_, hi_ on group boundaries (hi_ may be B) */
             int64_t r2 = 2;
-            for (int64_t i = lo_; i < hi_; i++) if (s->h_np[(size_t)i] > r2) r2 = s->h_np[(size_t)i];
+            for (int64_t g = lo_ / 64; g < (hi_ + 63) / 64; g++) if (gmax[(size_t)g] > r2) r2 = gmax[(size_t)g];
+            return r2;
+        };
+        auto fits = [&](int64_t lo_, int64_t hi_, int64_t *rows_out) {
+            const int64_t r2 = rows_of(lo_, hi_);
             if (rows_out) *rows_out = r2;
             return (size_t)round64(hi_ - lo_) * (size_t)r2 * rec <= budget;
         };
-        std::vector<int64_t> cuts;                  /* greedy */
+        std::vector<int64_t> cuts;                  /* greedy, one pass with a running maximum */
         for (int64_t lo_ = 0; lo_ < B;) {
             int64_t hi_ = (lo_ + 64 < B) ? lo_ + 64 : B;
+            int64_t r2 = gmax[(size_t)(lo_ / 64)];
             while (hi_ < B) {
                 const int64_t nhi = (hi_ + 64 < B) ? hi_ + 64 : B;
-                if (!fits(lo_, nhi, nullptr)) break;
-                hi_ = nhi;
+                const int64_t rn = gmax[(size_t)(hi_ / 64)] > r2 ? gmax[(size_t)(hi_ / 64)] : r2;
+                if ((size_t)round64(nhi - lo_) * (size_t)rn * rec > budget) break;
+                hi_ = nhi; r2 = rn;
             }
             cuts.push_back(hi_);
             lo_ = hi_;

@@ -330,7 +330,7 @@ class AdjointSolver(_EngineMixin):
     (solver.py:599,614 -- there one has to poke ``lib.CVodeSStolerancesB`` by hand,
     README.md:245-247); ``max_steps`` is the most stored forward steps one instance may take
     (default ``checkpoint_n + 1``, i.e. as unbounded as the reference) and ``arena_gib`` the HBM
-    budget of the stored trajectories (default 64 GiB, at most 60 % of the free memory): batches
+    budget of the stored trajectories (default 96 GiB, at most 60 % of the free memory): batches
     that fit stay resident between ``solve_forward`` and ``solve_backward``, larger ones are
     re-integrated tile by tile inside ``solve_backward`` -- CVODES' check-point scheme, same
     results (csrc/sunode_amd.cpp, "trajectory arena").
