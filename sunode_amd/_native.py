@@ -337,6 +337,7 @@ class NativeSolver:
         self.code_object = build_code_object(native_source, sens=sens, constraints=constraints is not None,
                                              hermite=hermite)
         self._h = ctypes.c_void_p()
+        self._user_stream = False
         self._n_hint = n_states
         self._opt_kw = dict(device=device, rtol=rtol, atol=atol, rtolB=rtolB, atolB=atolB, rtolQB=rtolQB,
                             atolQB=atolQB, mxstep=mxstep, max_retries_fwd=max_retries_fwd,
@@ -389,18 +390,34 @@ class NativeSolver:
         except Exception:
             pass
 
+    # -- stream ordering (include/sunode_amd.h): the handle launches on its own non-blocking stream unless the caller
+    #    hands it one with set_stream().  When torch tensors come in and no stream was set, the safe default is to
+    #    order by synchronising: torch's current stream before the launch, the solver's stream after it.
+    def _torch_guard(self, *arrays):
+        if self._user_stream or not any(getattr(a, "is_cuda", False) for a in arrays):
+            return None
+        import torch
+        torch.cuda.current_stream().synchronize()
+        return self.synchronize
+
     # -- raw entry points (addresses or numpy arrays; shapes are the caller's responsibility) --
     def solve(self, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats, adjoint=False):
+        done = self._torch_guard(y0, ps, pr, tvals, y_out, status, stats)
         fn = self.L.sa_solve_forward_batch if adjoint else self.L.sa_solve_batch
         self._check(fn(self._h, mem, B, _addr(y0), _addr(ps), _addr(pr), rem_stride, float(t0), _addr(tvals),
                        n_t, _addr(y_out), _addr(status), _addr(stats)))
+        if done:
+            done()
 
     def solve_backward(self, mem, B, ps, pr, rem_stride, t0, tend, tvals, n_t, grads, grads_stride, grad_out,
                        lamda_out, status, stats, lamda_all=None, quad_all=None):
+        done = self._torch_guard(ps, pr, tvals, grads, grad_out, lamda_out, status, stats)
         self._check(self.L.sa_solve_backward_batch_all(
             self._h, mem, B, _addr(ps), _addr(pr), rem_stride, float(t0), float(tend), _addr(tvals), n_t,
             _addr(grads), int(grads_stride), _addr(grad_out), _addr(lamda_out), _addr(lamda_all), _addr(quad_all),
             _addr(status), _addr(stats)))
+        if done:
+            done()
 
     def solve_sens(self, mem, ism, scaling, B, y0, ps, pr, rem_stride, sens0, t0, tvals, n_t, y_out, sens_out,
                    status, stats):
@@ -437,7 +454,10 @@ class NativeSolver:
         return b.value, t.value, bool(f.value)
 
     def set_stream(self, stream_ptr):
-        self._check(self.L.sa_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+        """Launch on the caller's HIP stream (e.g. ``torch.cuda.Stream().cuda_stream``); 0 / None: back to the
+        library-owned stream."""
+        self._check(self.L.sa_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+        self._user_stream = bool(stream_ptr)
 
     def synchronize(self):
         self._check(self.L.sa_synchronize(self._h))

@@ -321,7 +321,7 @@ static __device__ __forceinline__ double sa_sum_coop(F term)
     }
     return sa_pair_tree<P>(s);
 }
-#define SA_SUM(N, term) sa_sum_coop<N>([&](int j_) -> double { return (term); })
+#define SA_SUM(N, term) sa_sum_coop<N>([&](int j_) __attribute__((always_inline)) -> double { return (term); })
 template <int N, class F>
 static __device__ __forceinline__ double sa_rolled_coop(F body)      /* body(i) evaluates AND stores output i */
 {
@@ -339,9 +339,9 @@ static __device__ __forceinline__ double sa_rolled_coop(F body)      /* body(i) 
     return (any & mask) ? __builtin_nan("") : 0.0;
 }
 #define SA_ROLLED(N, S0, S1, expr) \
-    chk += sa_rolled_coop<N>([&](int i_) -> double { const double v_ = (expr); out.put_dyn((S0) + (S1) * i_, v_); return v_; })
+    chk += sa_rolled_coop<N>([&](int i_) __attribute__((always_inline)) -> double { const double v_ = (expr); out.put_dyn((S0) + (S1) * i_, v_); return v_; })
 #define SA_UVEC_ROLLED(tag, N, expr) \
-    chk += sa_rolled_coop<N>([&](int i_) -> double { const double v_ = (expr); SA_UVEC_SET(tag, i_, v_); return v_; })
+    chk += sa_rolled_coop<N>([&](int i_) __attribute__((always_inline)) -> double { const double v_ = (expr); SA_UVEC_SET(tag, i_, v_); return v_; })
 
 #include SA_PROBLEM_HEADER
 #include "sa_device_abi.h"
@@ -724,7 +724,22 @@ struct Grp {
     int lane, li, gbase, abase, kbase, wave;
 };
 DEV int getrf_coop(const Grp &g, double (&inv_piv)[(W_NS + G - 1) / G], int &nswaps);
-static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj);
+/* LDS arrays the factorisation works on, as explicit LDS-address-space pointers: inside a noinline function the
+   compiler reaches a __shared__ variable that only such functions use through a per-kernel offset TABLE in global
+   memory -- one dependent global load per access group, several per elimination step.  The kernels (where the
+   addresses are constants) build this block and pass it by value. */
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) int64_t lds_i64;
+struct LuLds {
+    lds_f64 *A, *col, *invp;
+    lds_u8 *piv;
+    lds_i32 *ier, *nswaps;
+    lds_i64 *prof;
+};
+static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L);
+static __device__ __forceinline__ LuLds lu_lds();
 
 template <bool BWD>
 DEV void worker_loop(const double *pr, double *obuf)
@@ -736,7 +751,7 @@ DEV void worker_loop(const double *pr, double *obuf)
         const double t = s_targ;
         if (cmd == CMD_EXIT) break;
         if (cmd == CMD_GETRF) {
-            setup_lu_regs(wave, lane, t, s_flag, obuf - WS_OUT + WS_SJ);
+            setup_lu_regs(wave, lane, t, s_flag, obuf - WS_OUT + WS_SJ, lu_lds());
         } else {
             const int rc = run_callback<BWD>(cmd, t, pr, obuf);
             if (lane == 0) s_rc[wave] = rc;
@@ -918,15 +933,38 @@ __shared__ int s_luier, s_lunswaps;
 #ifdef SA_WAVE_PROFILE
 __shared__ int64_t s_luprof[3];           /* wavefront 0: cycles before the barrier, in the barrier, in the update */
 #define LUP_T(x) const int64_t x = (int64_t)__builtin_readcyclecounter();
-#define LUP_ADD(k, a, b) if (wave == 0 && lane == 0) s_luprof[k] += (b) - (a);
+#define LUP_ADD(k, a, b) if (wave == 0 && lane == 0) L.prof[k] += (b) - (a);
 #else
 #define LUP_T(x)
 #define LUP_ADD(k, a, b)
 #endif
 
+/* the addresses go through an empty asm: otherwise interprocedural constant propagation puts the __shared__ globals
+   back into the callee -- and with them the offset-table loads */
+template <class T>
+static __device__ __forceinline__ T *lds_opaque(T *p)
+{
+    uint32_t a = (uint32_t)(uintptr_t)p;
+    asm volatile("" : "+s"(a));
+    return (T *)(uintptr_t)a;
+}
+static __device__ __forceinline__ LuLds lu_lds()
+{
+    LuLds L;
+    L.A = lds_opaque((lds_f64 *)s_A); L.col = lds_opaque((lds_f64 *)&s_col[0][0]); L.invp = lds_opaque((lds_f64 *)s_invp);
+    L.piv = lds_opaque((lds_u8 *)s_piv);
+    L.ier = lds_opaque((lds_i32 *)&s_luier); L.nswaps = lds_opaque((lds_i32 *)&s_lunswaps);
+#ifdef SA_WAVE_PROFILE
+    L.prof = lds_opaque((lds_i64 *)s_luprof);
+#else
+    L.prof = nullptr;
+#endif
+    return L;
+}
+
 /* noinline on purpose: the 2*LU_NC matrix registers of a lane must not compete with the integrator state of
    wavefront 0 (inlined, the pair spilled ~1.6 KB per lane to scratch); results come back through LDS */
-static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj)
+static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L)
 {
     double a[LU_NC][RS];
     int logpos[RS];
@@ -937,14 +975,14 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
             double v = 0.0;
             if (j < NS && i < NS) {
                 if (from_saved) v = sj[j * NS + i];
-                else { v = s_A[j * NS + i]; sj[j * NS + i] = v; }
+                else { v = L.A[j * NS + i]; sj[j * NS + i] = v; }
                 v = (i == j) ? FMA(c, v, 1.0) : v * c;
             }
             a[cc][r] = v;
         } SEND
     } SEND
     SFOR(r, 0, RS) logpos[r] = (r * 64 + lane < NS) ? r * 64 + lane : -1; SEND
-    if (wave == 0 && lane == 0) s_luier = 0;
+    if (wave == 0 && lane == 0) (*L.ier) = 0;
     int nswaps = 0, ier = 0;
     sa_barrier();
     /* kcr (the owner's register column) is a compile-time index: the ownership round is unrolled (LU_NC copies of
@@ -992,7 +1030,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                     } SEND
                 }
                 const int l = bi;
-                if (best == 0.0) { if (lane == 0) s_luier = k + 1; }
+                if (best == 0.0) { if (lane == 0) (*L.ier) = k + 1; }
                 else {
                     double apiv = akk;
                     if (l != k) {
@@ -1006,13 +1044,13 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                         apiv = readlane_d(psel, ll);
                     }
                     const double mult = 1.0 / apiv;
-                    if (lane == 0) { s_piv[k] = (uint8_t)l; s_invp[k] = mult; }
+                    if (lane == 0) { L.piv[k] = (uint8_t)l; L.invp[k] = mult; }
                     /* multipliers of the rows still to be eliminated: every unused row except the pivot row */
                     SFOR(r, 0, RS) {
                         if ((logpos[r] >= k) && (logpos[r] != l)) {
                             const double lc = a[kcr][r] * mult;
                             a[kcr][r] = lc;
-                            s_col[buf][r * 64 + lane] = lc;
+                            L.col[buf * (RS * 64) + r * 64 + lane] = lc;
                         }
                     } SEND
                 }
@@ -1020,9 +1058,9 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
             LUP_T(t_b)
             sa_barrier();
             LUP_T(t_c)
-            ier = s_luier;
+            ier = (*L.ier);
             if (ier != 0) break;
-            const int l = s_piv[k];
+            const int l = L.piv[k];
             if (l != k) {                       /* row exchange = relabelling */
                 nswaps++;
                 SFOR(r, 0, RS) { const int lp = logpos[r]; logpos[r] = (lp == l) ? k : ((lp == k) ? l : lp); } SEND
@@ -1033,7 +1071,8 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
             }
             /* trailing update of this wavefront's columns j > k (register columns cc > kcr, and cc == kcr for the
                wavefronts behind the owner): pivot-row entries first (v_readlane -> SGPRs), then one masked block of
-               FMAs per register slot */
+               FMAs per register slot.  (Also measured, slower: keeping the multipliers as SGPR halves with scalar
+               branches around plain FMAs.) */
             double akj[LU_NC];
             SFOR(cc, kcr, LU_NC) {
                 const int j = cc * SA_WAVES + wave;
@@ -1043,7 +1082,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
             } SEND
             SFOR(r, 0, RS) {
                 if (logpos[r] > k) {
-                    const double lc = s_col[buf][r * 64 + lane];
+                    const double lc = L.col[buf * (RS * 64) + r * 64 + lane];
                     SFOR(cc, kcr, LU_NC) { if (akj[cc] != 0.0) a[cc][r] = FMA(-akj[cc], lc, a[cc][r]); } SEND
                 }
             } SEND
@@ -1054,14 +1093,16 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
     if (ier == 0) {
         SFOR(cc, 0, LU_NC) {
             const int j = cc * SA_WAVES + wave;
-            SFOR(r, 0, RS) { if (j < NS && logpos[r] >= 0) s_A[j * NS + logpos[r]] = a[cc][r]; } SEND
+            SFOR(r, 0, RS) { if (j < NS && logpos[r] >= 0) L.A[j * NS + logpos[r]] = a[cc][r]; } SEND
         } SEND
     }
-    if (wave == 0 && lane == 0) s_lunswaps = nswaps;
+    if (wave == 0 && lane == 0) (*L.nswaps) = nswaps;
     sa_barrier();
 }
 #else
-static __device__ void setup_lu_regs(int, int, double, int, double *) {}
+struct LuLds { int unused; };
+static __device__ __forceinline__ LuLds lu_lds() { return LuLds{0}; }
+static __device__ void setup_lu_regs(int, int, double, int, double *, LuLds) {}
 #endif
 
 template <bool BWD>
@@ -1088,7 +1129,7 @@ DEV int setup_lu_workgroup(Cw<BWD> &m, double c, bool from_saved)
     PROF_T0
     if (m.li == 0) { s_cmd = CMD_GETRF; s_targ = c; s_flag = from_saved ? 1 : 0; }
     sa_barrier();
-    setup_lu_regs(0, m.lane, c, from_saved ? 1 : 0, m.sj);
+    setup_lu_regs(0, m.lane, c, from_saved ? 1 : 0, m.sj, lu_lds());
     const int ier = s_luier;
     m.nswaps = s_lunswaps;
     SFOR(r, 0, RS) { const int i = r * 64 + m.lane; m.inv_piv[r] = (i < NS) ? s_invp[i < NS ? i : 0] : 0.0; } SEND

@@ -345,7 +345,9 @@ class Roller:
         return self._ph[key]
 
     def _leaves(self, e):
-        return {sy: self.leaf[sy.name] for sy in e.free_symbols if sy.name in self.leaf}
+        # sorted: set iteration order must not leak into placeholder numbering (and from there, through sympy's
+        # canonical argument order, into the association of the generated arithmetic)
+        return {sy: self.leaf[sy.name] for sy in sorted(e.free_symbols, key=lambda q: q.name) if sy.name in self.leaf}
 
     def try_roll(self, members: Sequence[sym.Expr], var: str):
         """-> (skeleton, order) with members[order[j]] == skeleton at index j for j = 0..N-1, or None."""
@@ -433,9 +435,9 @@ class Roller:
             skel, _ = got
             # loop-invariant factors leave the sum: sum_j c*t_j is emitted as c * SUM(t_j) (our own definition of
             # the arithmetic: the oracle compiles the same source), which also lets different sums share one SUM
-            ph = {p_ for p_ in skel.free_symbols if p_ in set(self._ph.values())}
+            ph = sorted((p_ for p_ in skel.free_symbols if p_ in set(self._ph.values())), key=lambda q: q.name)
             coeff, core = skel.as_independent(*ph, as_Add=False) if ph else (sym.Integer(1), skel)
-            if core == 1 or not (core.free_symbols & ph):
+            if core == 1 or not (core.free_symbols & set(ph)):
                 coeff, core = sym.Integer(1), skel
             sign = -1 if core.could_extract_minus_sign() else 1
             core, coeff = sign * core, sign * coeff
