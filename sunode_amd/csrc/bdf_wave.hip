@@ -968,6 +968,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
 {
     double a[LU_NC][RS];
     int logpos[RS];
+    wave = __builtin_amdgcn_readfirstlane(wave);            /* wave-uniform by construction: let the compiler know */
     SFOR(cc, 0, LU_NC) {
         const int j = cc * SA_WAVES + wave;
         SFOR(r, 0, RS) {
@@ -1080,6 +1081,8 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                 SFOR(r, 1, RS) src = (prow_slot == r) ? a[cc][r] : src; SEND
                 akj[cc] = (j > k && j < NS) ? readlane_d(src, prow_lane) : 0.0;         /* 0: column not updated */
             } SEND
+            /* (a zero-free fast path -- test once whether any live multiplier is zero, plain FMAs otherwise -- was
+               measured slower as well: the join of the two paths copies the whole register matrix) */
             SFOR(r, 0, RS) {
                 if (logpos[r] > k) {
                     const double lc = L.col[buf * (RS * 64) + r * 64 + lane];
