@@ -1103,8 +1103,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
     sa_barrier();
 }
 #else
-struct LuLds { int unused; };
-static __device__ __forceinline__ LuLds lu_lds() { return LuLds{0}; }
+static __device__ __forceinline__ LuLds lu_lds() { return LuLds{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
 static __device__ void setup_lu_regs(int, int, double, int, double *, LuLds) {}
 #endif
 
