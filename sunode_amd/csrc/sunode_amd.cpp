@@ -646,7 +646,14 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
             (void)fits(lo, hi, &rows);
             const int32_t tB = (int32_t)(hi - lo);
             const int64_t stride = round64(tB);
-            if ((rc = s->traj.ensure((size_t)rows * (size_t)stride * rec))) return rc;
+            {   /* a batch that turns out to fit as ONE tile will be resident from the next call on: allocate the rows
+                   that call is going to ask for right away (tens of GB are not freed and re-allocated twice) */
+                int64_t alloc_rows = rows;
+                const int64_t next = (int64_t)(1.25 * s->rows_hint) + 8;
+                if (cuts.size() == 1 && next > rows && next <= s->opt.traj_capacity &&
+                    (size_t)next * (size_t)stride * rec <= budget) alloc_rows = next;
+                if ((rc = s->traj.ensure((size_t)alloc_rows * (size_t)stride * rec))) return rc;
+            }
             if ((rc = s->t_yout.ensure(sizeof(double) * (size_t)tB * (size_t)s->fwd_n_t * (nn ? nn : 1)))) return rc;
             if ((rc = s->t_status.ensure(sizeof(int32_t) * (size_t)stride))) return rc;
             if ((rc = s->t_stats.ensure(sizeof(int64_t) * (size_t)stride * SA_N_STATS))) return rc;
