@@ -103,14 +103,16 @@ def _extra_codegen_flags():
 REGISTER_KERNEL_MAX_STATES = 5
 #: ... and above this size (states or differentiated parameters) the LDS-matrix kernel with lane groups
 COOP_KERNEL_MAX_SIZE = 8
+#: forward sensitivities run in registers while n_states * n_sub stays at or below this
+SENS_REGISTER_MAX_NP = 12
 
 
 def kernel_variant(native_source: str, sens: bool = False, constraints: bool = False, hermite: bool = False):
     """(source file, lanes per instance) for a generated problem header.
 
-    ``sens=True`` (forward sensitivities, ``Solver(sens_mode=...)``): the memory-resident kernel
-    built with ``-DSA_SENS`` for every system size -- the only family carrying the sensitivity
-    corrector so far.
+    ``sens=True`` (forward sensitivities, ``Solver(sens_mode=...)``): the register kernel built with
+    ``-DSA_SENS`` while n <= 5 and n * n_sub <= 12, otherwise the memory-resident kernel -- the two
+    families carrying the sensitivity corrector.
 
     n <= 5 states: thread-per-instance, the whole integrator in one lane's registers.
     up to 8: cooperative (bdf_coop.hip), 8 lanes per instance, matrix rows in registers.
@@ -128,7 +130,13 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
         # Hermite interpolation lives in the cooperative / wave / memory kernels only; few states with many
         # differentiated parameters fall through to the bdf_wave.hip group selection below (it carries Hermite too)
         forced = "8"
-    if sens or forced == "mem" or (not forced and max(n, p) > 128):
+    if sens:
+        # forward sensitivities: the register kernel keeps the p sensitivity Nordsieck arrays (14 n p doubles) next
+        # to the state's while they fit one lane's register file; everything larger runs memory-resident
+        if forced in (None, "1") and n <= REGISTER_KERNEL_MAX_STATES and n * p <= SENS_REGISTER_MAX_NP:
+            return "bdf_kernels.hip", 1
+        return "bdf_mem.hip", 1
+    if forced == "mem" or (not forced and max(n, p) > 128):
         return "bdf_mem.hip", 1
     if forced == "wave" or (not forced and max(n, p) > 64):
         if max(n, p) > 128 or n < 1:

@@ -94,8 +94,23 @@ struct Cv {
     double last_t;
     double tlo, thi;                  /* t[ilast-1], t[ilast]: bracketing times kept in registers */
     int n_interp, n_rebuild;
+#ifdef SA_SENS
+    /* forward sensitivities (Solver(sens_mode=...), reference solver.py:360-392): one Nordsieck array per
+       differentiated parameter, kept in registers like the state's (columns above q at zero, the saved correction
+       in zsaveS); only the SA_SENS build of the forward problem carries them */
+    double znS[QMAX + 1][NQD][NSD], zsaveS[NQD][NSD];
+    double ewtS[NQD][NSD], acorS[NQD][NSD], tempvS[NQD][NSD], ftempS[NQD][NSD], yS[NQD][NSD], deltaS[NQD][NSD];
+    double pbar[NQD], crateS, delpS, acnrmS;
+    int sensi, ism, nfSe, nniS, ncfnS, netfS, nsetupsS;
+#endif
     PROF_DECL
 };
+
+#ifdef SA_SENS
+#define SENS_ON(m) (!BWD && (m).sensi)
+#define SFOR_S(is, i) SFOR(is, 0, NQ) SFOR(i, 0, NS)
+#define SEND_S SEND SEND
+#endif
 
 /* ---- stored forward trajectory ------------------------------------------------------------
  * CVODES (CV_POLYNOMIAL) stores (t_n, y_n, q_n) after every forward step and, in the backward
@@ -251,6 +266,28 @@ DEV int cv_jac(Cv<BWD> &m, double t, const double *y, double *J)
     return sa_jac(t, y, m.ps, PR_OF(m), J);
 }
 
+#ifdef SA_SENS
+/* sensitivity right-hand side for all parameters: out[is] = J(t,y) yS[is] + df/dp_is (oracle cv_fS) */
+template <bool BWD>
+DEV int cv_fS(Cv<BWD> &m, double t, const double *y, const double (&ys)[NQD][NSD], double (&out)[NQD][NSD])
+{
+    m.nfSe++;
+    double Jt[NSD * NSD], dp[NQD * NSD];
+    int rc = sa_jac(t, y, m.ps, PR_OF(m), Jt);
+    if (rc != 0) return rc;
+    rc = sa_dydp(t, y, m.ps, PR_OF(m), dp);
+    int bad = 0;
+    SFOR_S(is, i) {
+        double acc = Jt[0 * NS + i] * ys[is][0];
+        SFOR(j, 1, NS) acc = FMA(Jt[j * NS + i], ys[is][j], acc); SEND
+        acc = acc + dp[is * NS + i];
+        out[is][i] = acc;
+        bad |= !(acc * 0.0 == 0.0);
+    } SEND_S
+    return (rc != 0 || bad) ? 1 : 0;
+}
+#endif
+
 /* ---- vector kernels ---- */
 /* balanced-tree sum over P = 2^k leaves (the association of a cross-lane butterfly; see the oracle) */
 template <int P>
@@ -312,6 +349,32 @@ DEV int ewtQ_set(const Cv<BWD> &m, const double *qcur, double *w)
     } SEND
     return bad ? -1 : 0;
 }
+
+#ifdef SA_SENS
+/* cvSensEwtSetEE / cvSensUpdateNorm (see the oracle) */
+template <bool BWD>
+DEV int sens_ewt_set(const Cv<BWD> &m, const double (&ys)[NQD][NSD], double (&w)[NQD][NSD])
+{
+    int bad = 0;
+    SFOR_S(is, i) {
+        const double v = FMA(m.rtol, fabs(m.pbar[is] * ys[is][i]), m.atol[i]);
+        bad |= (v <= 0.0);
+        w[is][i] = m.pbar[is] * (1.0 / v);
+    } SEND_S
+    return bad ? -1 : 0;
+}
+
+template <bool BWD>
+DEV double sens_update_norm(const Cv<BWD> &m, double old_nrm, const double (&x)[NQD][NSD], const double (&w)[NQD][NSD])
+{
+    double nrm = old_nrm;
+    SFOR(is, 0, NQ) {
+        const double snrm = wrms<NS>(x[is], w[is]);
+        nrm = snrm > nrm ? snrm : nrm;
+    } SEND
+    return nrm;
+}
+#endif
 
 /* ---- dense LU with partial pivoting, column-major, fully unrolled (denseGETRF/GETRS) ---- */
 DEV int dense_getrf(double *a, int *p, double *inv_piv)
@@ -398,6 +461,10 @@ DEV void cv_reinit(Cv<BWD> &m, double t0, const double *y0, const double *q0)
     SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
     SFOR(i, 0, NS) { m.acor[i] = 0.0; m.tempv[i] = 0.0; m.ftemp[i] = 0.0; m.y[i] = 0.0; m.zsave[i] = 0.0; } SEND
     SFOR(i, 0, NQ) { m.acorQ[i] = 0.0; m.tempvQ[i] = 0.0; m.zsaveQ[i] = 0.0; } SEND
+#ifdef SA_SENS
+    m.crateS = 1.0; m.delpS = 0.0; m.acnrmS = 0.0;
+    m.nfSe = m.nniS = m.ncfnS = m.netfS = m.nsetupsS = 0;
+#endif
 }
 
 /* ---- cvHin ---- */
@@ -416,6 +483,18 @@ DEV double cv_upper_bound_h0(Cv<BWD> &m, double tdist)
             if (v > hub_inv) hub_inv = v;
         } SEND
     }
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        sens_ewt_set(m, m.znS[0], m.tempvS);
+        SFOR_S(is, i) {
+            const double t2 = fabs(m.znS[0][is][i]);
+            double t1 = 1.0 / m.tempvS[is][i];
+            t1 = FMA(HUB_FACTOR, t2, t1);
+            const double v = fabs(m.znS[1][is][i]) / t1;
+            if (v > hub_inv) hub_inv = v;
+        } SEND_S
+    }
+#endif
     if (BWD) {
         double tempQ[NQD];
         ewtQ_set(m, m.znQ[0], tempQ);
@@ -438,10 +517,20 @@ template <bool BWD>
 DEV int cv_ydd_norm(Cv<BWD> &m, double hg, double *yddnrm)
 {
     SFOR(i, 0, NS) m.y[i] = FMA(hg, m.zn[1][i], m.zn[0][i]); SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) { SFOR_S(is, i) m.yS[is][i] = FMA(hg, m.znS[1][is][i], m.znS[0][is][i]); SEND_S }
+#endif
     if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
     int retval = cv_f(m, m.tn + hg, m.y, m.tempv);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return RHSFUNC_RECVR;
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        retval = cv_fS(m, m.tn + hg, m.y, m.yS, m.tempvS);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return SRHSFUNC_RECVR;
+    }
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn + hg, m.y, m.tempvQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -452,6 +541,15 @@ DEV int cv_ydd_norm(Cv<BWD> &m, double hg, double *yddnrm)
         m.tempv[i] = (1.0 / hg) * m.tempv[i];
     } SEND
     *yddnrm = wrms<NS>(m.tempv, m.ewt);
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        SFOR_S(is, i) {
+            const double v = m.tempvS[is][i] - m.znS[1][is][i];
+            m.tempvS[is][i] = (1.0 / hg) * v;
+        } SEND_S
+        *yddnrm = sens_update_norm(m, *yddnrm, m.tempvS, m.ewtS);
+    }
+#endif
     if (BWD) {
         SFOR(i, 0, NQ) {
             m.tempvQ[i] = m.tempvQ[i] - m.znQ[1][i];
@@ -521,6 +619,9 @@ DEV void cv_rescale(Cv<BWD> &m)
     SFOR(j, 1, (QMAX) + 1) {
         SFOR(i, 0, NS) m.zn[j][i] *= factor; SEND
         if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] *= factor; SEND }
+#ifdef SA_SENS
+        if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j][is][i] *= factor; SEND_S }
+#endif
         factor *= m.eta;
     } SEND
     m.h = m.hscale * m.eta;
@@ -561,6 +662,16 @@ DEV void cv_increase_bdf(Cv<BWD> &m)
             if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(m.l[j], znQL[i], m.znQ[j][i]); SEND }
         }
     } SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        double znLS[NQD][NSD];
+        SFOR_S(is, i) znLS[is][i] = A1 * m.zsaveS[is][i]; SEND_S
+        SFOR(j, 2, (QMAX) + 1) { if (j == L) { SFOR_S(is, i) m.znS[j][is][i] = znLS[is][i]; SEND_S } } SEND
+        SFOR(j, 2, QMAX) {
+            if (j <= m.q) { SFOR_S(is, i) m.znS[j][is][i] = FMA(m.l[j], znLS[is][i], m.znS[j][is][i]); SEND_S }
+        } SEND
+    }
+#endif
 }
 
 template <bool BWD>
@@ -593,6 +704,19 @@ DEV void cv_decrease_bdf(Cv<BWD> &m)
             if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(-m.l[j], znQq[i], m.znQ[j][i]); SEND }
         }
     } SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        double znSq[NQD][NSD];
+        SFOR_S(is, i) {
+            double r = m.znS[2][is][i];
+            SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.znS[k][is][i] : r; SEND
+            znSq[is][i] = r;
+        } SEND_S
+        SFOR(j, 2, QMAX) {
+            if (j < m.q) { SFOR_S(is, i) m.znS[j][is][i] = FMA(-m.l[j], znSq[is][i], m.znS[j][is][i]); SEND_S }
+        } SEND
+    }
+#endif
 }
 
 /* restore the zero-column invariant after the order dropped from q_old to q_old - 1 */
@@ -603,6 +727,9 @@ DEV void cv_clear_column(Cv<BWD> &m, int q_old)
         if (j == q_old) {
             SFOR(i, 0, NS) m.zn[j][i] = 0.0; SEND
             if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = 0.0; SEND }
+#ifdef SA_SENS
+            if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j][is][i] = 0.0; SEND_S }
+#endif
         }
     } SEND
 }
@@ -639,6 +766,9 @@ DEV void cv_predict(Cv<BWD> &m)
         SFOR_DOWN(j, QMAX, k) {
             SFOR(i, 0, NS) m.zn[j - 1][i] = m.zn[j - 1][i] + m.zn[j][i]; SEND
             if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] + m.znQ[j][i]; SEND }
+#ifdef SA_SENS
+            if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j - 1][is][i] = m.znS[j - 1][is][i] + m.znS[j][is][i]; SEND_S }
+#endif
         } SEND
     } SEND
 }
@@ -651,6 +781,9 @@ DEV void cv_restore(Cv<BWD> &m, double saved_t)
         SFOR_DOWN(j, QMAX, k) {
             SFOR(i, 0, NS) m.zn[j - 1][i] = m.zn[j - 1][i] - m.zn[j][i]; SEND
             if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] - m.znQ[j][i]; SEND }
+#ifdef SA_SENS
+            if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j - 1][is][i] = m.znS[j - 1][is][i] - m.znS[j][is][i]; SEND_S }
+#endif
         } SEND
     } SEND
 }
@@ -697,6 +830,9 @@ DEV int cv_nls_lsetup(Cv<BWD> &m, int jbad, int &convfail)
     m.gamrat = 1.0;
     m.gammap = m.gamma;
     m.crate = 1.0;
+#ifdef SA_SENS
+    m.crateS = 1.0;
+#endif
     m.nstlp = m.nst;
     if (retval < 0) return CV_LSETUP_FAIL;
     if (retval > 0) return NLS_CONV_RECVR;
@@ -717,16 +853,60 @@ DEV int cv_nls_residual(Cv<BWD> &m, double *res)
     return CV_SUCCESS;
 }
 
+#ifdef SA_SENS
+/* cvNlsResidualSensSim / cvNlsResidualSensStg: residuals of the sensitivity systems -> m.deltaS (m.y holds the state) */
+template <bool BWD>
+DEV int cv_nls_residual_sens(Cv<BWD> &m)
+{
+    SFOR_S(is, i) m.yS[is][i] = m.znS[0][is][i] + m.acorS[is][i]; SEND_S
+    int retval = cv_fS(m, m.tn, m.y, m.yS, m.ftempS);
+    if (retval < 0) return CV_SRHSFUNC_FAIL;
+    if (retval > 0) return SRHSFUNC_RECVR;
+    SFOR_S(is, i) {
+        const double r = FMA(m.rl1, m.znS[1][is][i], m.acorS[is][i]);
+        m.deltaS[is][i] = FMA(-m.gamma, m.ftempS[is][i], r);
+    } SEND_S
+    return CV_SUCCESS;
+}
+
+/* one Newton update of every sensitivity system with the current factorisation */
+template <bool BWD>
+DEV void cv_sens_newton_update(Cv<BWD> &m)
+{
+    SFOR(is, 0, NQ) {
+        SFOR(i, 0, NS) m.deltaS[is][i] = -1.0 * m.deltaS[is][i]; SEND
+        dense_getrs(m.A, m.piv, m.inv_piv, m.deltaS[is]);
+        if (m.gamrat != 1.0) {
+            double s = 2.0 / (1.0 + m.gamrat);
+            SFOR(i, 0, NS) m.deltaS[is][i] *= s; SEND
+        }
+        SFOR(i, 0, NS) m.acorS[is][i] = m.acorS[is][i] + m.deltaS[is][i]; SEND
+    } SEND
+}
+#endif
+
 /* One pass of SUNNonlinSolSolve_Newton's outer loop (residual, optional setup, <=3 corrector
    iterations).  Returns 0 on convergence, >0 recoverable, <0 fatal. */
 template <bool BWD>
 DEV int cv_newton_pass(Cv<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
 {
     double delta[NSD];
+#ifdef SA_SENS
+    const bool sim = SENS_ON(m) && m.ism == 0;
+#endif
     in_loop = 0;
     SFOR(i, 0, NS) m.acor[i] = 0.0; SEND
+#ifdef SA_SENS
+    if (sim) { SFOR_S(is, i) m.acorS[is][i] = 0.0; SEND_S }
+#endif
     int retval = cv_nls_residual(m, delta);
     if (retval != CV_SUCCESS) return retval;
+#ifdef SA_SENS
+    if (sim) {
+        retval = cv_nls_residual_sens(m);
+        if (retval != CV_SUCCESS) return retval;
+    }
+#endif
     if (callSetup) {
         retval = cv_nls_lsetup(m, jbad, convfail);
         if (retval != CV_SUCCESS) return retval;
@@ -744,10 +924,22 @@ DEV int cv_newton_pass(Cv<BWD> &m, int callSetup, int jbad, int &convfail, int &
         SFOR(i, 0, NS) m.acor[i] = m.acor[i] + delta[i]; SEND
         /* cvNlsConvTest */
         double del = wrms<NS>(delta, m.ewt);
+#ifdef SA_SENS
+        if (sim) {
+            cv_sens_newton_update(m);
+            del = sens_update_norm(m, del, m.deltaS, m.ewtS);
+        }
+#endif
         if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
         double dcon = del * fmin(1.0, m.crate) * m.tq[4];
         if (dcon <= 1.0) {
-            m.acnrm = (curiter == 0) ? del : wrms<NS>(m.acor, m.ewt);
+            if (curiter == 0) m.acnrm = del;
+            else {
+                m.acnrm = wrms<NS>(m.acor, m.ewt);
+#ifdef SA_SENS
+                if (sim) m.acnrm = sens_update_norm(m, m.acnrm, m.acorS, m.ewtS);
+#endif
+            }
             m.nls_jcur = 0;
             return CV_SUCCESS;
         }
@@ -757,8 +949,64 @@ DEV int cv_newton_pass(Cv<BWD> &m, int callSetup, int jbad, int &convfail, int &
         if (curiter >= NLS_MAXCOR) return NLS_CONV_RECVR;
         retval = cv_nls_residual(m, delta);
         if (retval != CV_SUCCESS) return retval;
+#ifdef SA_SENS
+        if (sim) {
+            retval = cv_nls_residual_sens(m);
+            if (retval != CV_SUCCESS) return retval;
+        }
+#endif
     }
 }
+
+#ifdef SA_SENS
+/* cvStgrNls (ism = CV_STAGGERED): Newton on the sensitivity systems with the state fixed */
+template <bool BWD>
+DEV int cv_stgr_nls(Cv<BWD> &m)
+{
+    int callSetup = 0, jbad = 0, convfail = CV_FAIL_OTHER, retval;
+    SFOR_S(is, i) m.acorS[is][i] = 0.0; SEND_S
+    for (;;) {
+        retval = cv_nls_residual_sens(m);
+        if (retval != CV_SUCCESS) break;
+        if (callSetup) {
+            retval = cv_nls_lsetup(m, jbad, convfail);
+            m.nsetupsS++;
+            if (retval != CV_SUCCESS) break;
+        }
+        int curiter = 0;
+        for (;;) {
+            m.nniS++;
+            cv_sens_newton_update(m);
+            double del = sens_update_norm(m, 0.0, m.deltaS, m.ewtS);
+            if (curiter > 0) m.crateS = fmax(CRDOWN * m.crateS, del / m.delpS);
+            double dcon = del * fmin(1.0, m.crateS) * m.tq[4];
+            if (dcon <= 1.0) {
+                m.acnrmS = (curiter == 0) ? del : sens_update_norm(m, 0.0, m.acorS, m.ewtS);
+                retval = CV_SUCCESS;
+                m.nls_jcur = 0;
+                break;
+            }
+            if ((curiter >= 1) && (del > RDIV * m.delpS)) { retval = NLS_CONV_RECVR; break; }
+            m.delpS = del;
+            curiter++;
+            if (curiter >= NLS_MAXCOR) { retval = NLS_CONV_RECVR; break; }
+            retval = cv_nls_residual_sens(m);
+            if (retval != CV_SUCCESS) break;
+        }
+        if (retval == CV_SUCCESS) break;
+        if ((retval > 0) && !m.nls_jcur) {
+            callSetup = 1;
+            jbad = 1;
+            SFOR_S(is, i) m.acorS[is][i] = 0.0; SEND_S
+            continue;
+        }
+        break;
+    }
+    if (retval != CV_SUCCESS) return retval;
+    SFOR_S(is, i) m.yS[is][i] = m.znS[0][is][i] + m.acorS[is][i]; SEND_S
+    return CV_SUCCESS;
+}
+#endif
 
 /* tail of cvDoErrorTest after a failed test; returns 0 = try again, <0 = give up */
 template <bool BWD>
@@ -795,6 +1043,14 @@ DEV int cv_error_test_failed(Cv<BWD> &m, double saved_t, double dsm, int &nef, i
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
     SFOR(i, 0, NS) m.zn[1][i] = m.h * m.tempv[i]; SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        retval = cv_fS(m, m.tn, m.zn[0], m.znS[0], m.tempvS);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return CV_UNREC_SRHSFUNC_ERR;
+        SFOR_S(is, i) m.znS[1][is][i] = m.h * m.tempvS[is][i]; SEND_S
+    }
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, m.zn[0], m.tempvQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -816,10 +1072,16 @@ DEV void cv_complete_step(Cv<BWD> &m)
     SFOR(j, 0, (QMAX) + 1) {                 /* l[j] == 0 for j > q */
         SFOR(i, 0, NS) m.zn[j][i] = FMA(m.l[j], m.acor[i], m.zn[j][i]); SEND
         if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(m.l[j], m.acorQ[i], m.znQ[j][i]); SEND }
+#ifdef SA_SENS
+        if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j][is][i] = FMA(m.l[j], m.acorS[is][i], m.znS[j][is][i]); SEND_S }
+#endif
     } SEND
     m.qwait--;
     {
         const bool sv = (m.qwait == 1) && (m.q != QMAX);
+#ifdef SA_SENS
+        if (SENS_ON(m)) { SFOR_S(is, i) m.zsaveS[is][i] = sv ? m.acorS[is][i] : m.zsaveS[is][i]; SEND_S }
+#endif
         SFOR(i, 0, NS) m.zsave[i] = sv ? m.acor[i] : m.zsave[i]; SEND
         if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = sv ? m.acorQ[i] : m.zsaveQ[i]; SEND }
         m.saved_tq5 = sv ? m.tq[5] : m.saved_tq5;
@@ -874,6 +1136,16 @@ DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
             } SEND
             ddn = quad_update_norm(m, ddn, znQq);
         }
+#ifdef SA_SENS
+        if (SENS_ON(m)) {
+            SFOR_S(is, i) {
+                double r = m.znS[2][is][i];
+                SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.znS[k][is][i] : r; SEND
+                m.tempvS[is][i] = r;
+            } SEND_S
+            ddn = sens_update_norm(m, ddn, m.tempvS, m.ewtS);
+        }
+#endif
         ddn = ddn * m.tq[1];
         m.etaqm1 = 1.0 / (rpower_r(BIAS1 * ddn, inv_int(m.q)) + ADDON);
     }
@@ -891,6 +1163,12 @@ DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
                 SFOR(i, 0, NQ) m.tempvQ[i] = FMA(-cquot, m.zsaveQ[i], m.acorQ[i]); SEND
                 dup = quad_update_norm(m, dup, m.tempvQ);
             }
+#ifdef SA_SENS
+            if (SENS_ON(m)) {
+                SFOR_S(is, i) m.tempvS[is][i] = FMA(-cquot, m.zsaveS[is][i], m.acorS[is][i]); SEND_S
+                dup = sens_update_norm(m, dup, m.tempvS, m.ewtS);
+            }
+#endif
             dup = dup * m.tq[3];
             m.etaqp1 = 1.0 / (rpower_r(BIAS3 * dup, inv_int(m.L + 1)) + ADDON);
         }
@@ -911,6 +1189,9 @@ DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
         m.qprime = m.q + 1;
         SFOR(i, 0, NS) m.zsave[i] = m.acor[i]; SEND
         if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = m.acorQ[i]; SEND }
+#ifdef SA_SENS
+        if (SENS_ON(m)) { SFOR_S(is, i) m.zsaveS[is][i] = m.acorS[is][i]; SEND_S }
+#endif
     }
     cv_set_eta(m);
 }
@@ -943,6 +1224,23 @@ DEV int cv_get_dky0(const Cv<BWD> &m, double t, double *dky, double *dkyQ)
     return CV_SUCCESS;
 }
 
+#ifdef SA_SENS
+/* CVodeGetSensDky, k = 0, all parameters; the caller has validated t with cv_get_dky0 */
+template <bool BWD>
+DEV void cv_get_sens_dky0(const Cv<BWD> &m, double t, double (&dkyS)[NQD][NSD])
+{
+    double s = (t - m.tn) / m.h;
+    double pw[QMAX + 1];
+    pw[0] = 1.0;
+    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
+    SFOR_S(is, i) {
+        double acc = pw[QMAX] * m.znS[QMAX][is][i];
+        SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.znS[j][is][i], acc); SEND
+        dkyS[is][i] = acc;
+    } SEND_S
+}
+#endif
+
 /* first-call block of CVode(): f(t0,y0), h0 from cvHin, scale zn[1] */
 template <bool BWD>
 DEV int cv_first_call(Cv<BWD> &m, double tout)
@@ -956,10 +1254,20 @@ DEV int cv_first_call(Cv<BWD> &m, double tout)
 #endif
     if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { if (sens_ewt_set(m, m.znS[0], m.ewtS) != 0) return CV_ILL_INPUT; }
+#endif
     if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
     int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        retval = cv_fS(m, m.tn, m.zn[0], m.znS[0], m.znS[1]);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return CV_FIRST_SRHSFUNC_ERR;
+    }
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, m.zn[0], m.znQ[1]);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -979,6 +1287,9 @@ DEV int cv_first_call(Cv<BWD> &m, double tout)
     m.hprime = m.h;
     SFOR(i, 0, NS) m.zn[1][i] = m.h * m.zn[1][i]; SEND
     if (BWD) { SFOR(i, 0, NQ) m.znQ[1][i] = m.h * m.znQ[1][i]; SEND }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { SFOR_S(is, i) m.znS[1][is][i] = m.h * m.znS[1][is][i]; SEND_S }
+#endif
     return CV_SUCCESS;
 }
 
@@ -990,30 +1301,37 @@ DEV int cv_pre_step(Cv<BWD> &m)
        same zn[0], so doing it always gives identical values without a per-lane branch */
     if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { if (sens_ewt_set(m, m.znS[0], m.ewtS) != 0) return CV_ILL_INPUT; }
+#endif
     double nrm = wrms<NS>(m.zn[0], m.ewt);
     if (BWD) nrm = quad_update_norm(m, nrm, m.znQ[0]);
+#ifdef SA_SENS
+    if (SENS_ON(m)) nrm = sens_update_norm(m, nrm, m.znS[0], m.ewtS);
+#endif
     if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
     return CV_SUCCESS;
 }
 
 /* Per-lane control state of the attempt loop. */
 struct StepCtl {
-    int in_step, redo, nflag, ncf, nef, nefQ, convfail;
+    int in_step, redo, nflag, ncf, nef, nefQ, convfail, ncfS, nefS;
     double saved_t;
 };
 
 /* cvHandleNFlag for a failed nonlinear (or quadrature) solve; 0 = predict again, <0 = give up */
 template <bool BWD>
-DEV int cv_handle_nflag_failed(Cv<BWD> &m, StepCtl &c, int nflag)
+DEV int cv_handle_nflag_failed(Cv<BWD> &m, StepCtl &c, int nflag, int &ncf, int &ncfn)
 {
-    m.ncfn++;
+    ncfn++;
     cv_restore(m, c.saved_t);
     if (nflag < 0) return nflag;
-    c.ncf++;
+    ncf++;
     m.etamax = 1.0;
-    if (c.ncf == MXNCF) {
+    if (ncf == MXNCF) {
         if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
+        if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
         if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
         return CV_REPTD_QRHSFUNC_ERR;
     }
@@ -1035,6 +1353,7 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
     if (!c.in_step) {
         c.saved_t = m.tn;
         c.ncf = c.nef = c.nefQ = 0;
+        c.ncfS = c.nefS = 0;
         c.nflag = FIRST_CALL;
         c.redo = 0;
         /* cvAdjustParams: the (rare) order change stays a branch, the rescale runs always with
@@ -1053,6 +1372,9 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
             SFOR(j, 1, (QMAX) + 1) {
                 SFOR(i, 0, NS) m.zn[j][i] *= factor; SEND
                 if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] *= factor; SEND }
+#ifdef SA_SENS
+                if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j][is][i] *= factor; SEND_S }
+#endif
                 factor *= eta;
             } SEND
             const double hnew = m.hscale * m.eta;
@@ -1086,7 +1408,7 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
         return 0;
     }
     c.redo = 0;
-    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls);
+    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls, c.ncf, m.ncfn);
 
     SFOR(i, 0, NS) m.y[i] = m.zn[0][i] + m.acor[i]; SEND
 #ifdef SA_CONSTRAINTS
@@ -1112,7 +1434,7 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
                     minq = (d != 0.0 && qv < minq) ? qv : minq;
                 } SEND
                 m.eta = fmax(0.9 * minq, 0.1);
-                return cv_handle_nflag_failed(m, c, CONSTR_RECVR);
+                return cv_handle_nflag_failed(m, c, CONSTR_RECVR, c.ncf, m.ncfn);
             }
         }
     }
@@ -1122,10 +1444,28 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
         c.nflag = PREV_ERR_FAIL;
         return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
     }
+#ifdef SA_SENS
+    if (SENS_ON(m) && m.ism == 0) { SFOR_S(is, i) m.yS[is][i] = m.znS[0][is][i] + m.acorS[is][i]; SEND_S }
+    if (SENS_ON(m) && m.ism == 1) {      /* CV_STAGGERED: sensitivities after the state passed (oracle cv_step) */
+        c.ncf = c.nef = 0;
+        int retval = cv_f(m, m.tn, m.y, m.ftemp);
+        if (retval < 0) return CV_RHSFUNC_FAIL;
+        if (retval > 0) { c.nflag = PREV_CONV_FAIL; return 0; }
+        const int nflagS = cv_stgr_nls(m);
+        if (nflagS != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nflagS, c.ncfS, m.ncfnS);
+        m.acnrmS = sens_update_norm(m, 0.0, m.acorS, m.ewtS);
+        const double dsmS = m.acnrmS * m.tq[2];
+        if (dsmS > 1.0) {
+            c.nflag = PREV_ERR_FAIL;
+            return cv_error_test_failed(m, c.saved_t, dsmS, c.nefS, m.netfS);
+        }
+        if (dsmS > dsm) dsm = dsmS;
+    }
+#endif
     if (BWD) {
         c.ncf = c.nef = 0;
         int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
-        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR);
+        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR, c.ncf, m.ncfn);
         SFOR(i, 0, NQ) {
             m.acorQ[i] = FMA(m.h, m.acorQ[i], -m.znQ[1][i]);
             m.acorQ[i] = m.rl1 * m.acorQ[i];
@@ -1145,6 +1485,9 @@ DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
     m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
     SFOR(i, 0, NS) m.acor[i] = m.tq[2] * m.acor[i]; SEND
     if (BWD) { SFOR(i, 0, NQ) m.acorQ[i] = m.tq[2] * m.acorQ[i]; SEND }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { SFOR_S(is, i) m.acorS[is][i] = m.tq[2] * m.acorS[is][i]; SEND_S }
+#endif
     c.in_step = 0;
     return 1;
 }
@@ -1215,6 +1558,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     m.last_t = 0.0; m.n_interp = 0; m.n_rebuild = 0; m.tlo = 0.0; m.thi = 0.0;
     m.traj = nullptr; m.trow = 0; m.cur_idx = 0; m.tlo2 = 0.0; m.ltab = nullptr;
     m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
+#ifdef SA_SENS
+    m.sensi = 0; m.ism = 0;
+#endif
 
     double y0[NSD];
     SFOR(i, 0, NS) y0[i] = a.y0[(int64_t)inst * NS + i]; SEND
@@ -1305,6 +1651,108 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     st[ST_NPTS] = np; st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
     SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
 }
+
+#ifdef SA_SENS
+/* Solver(sens_mode=...).solve (reference solver.py:360-392, 497-531): the forward problem together with its
+   NQ sensitivity systems, one instance per thread, everything in registers.  Same control flow as sa_k_forward
+   without the trajectory; bit-identical to bdf_mem.hip's sa_k_sens (and to the oracle). */
+extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
+{
+    const int inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= a.B) return;
+    Cv<false> m;
+    load_params(m, a.ps, a.pr, a.rem_stride, inst);
+    m.rtol = a.rtol;
+#ifdef SA_CONSTRAINTS
+    m.constr = false;
+    SFOR(i, 0, NS) m.cons[i] = 0.0; SEND
+#endif
+    SFOR(i, 0, NS) m.atol[i] = a.atol[i]; SEND
+    SFOR(i, 0, NQ) m.pbar[i] = a.pbar[i]; SEND
+    m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
+    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0;
+    m.last_t = 0.0; m.n_interp = 0; m.n_rebuild = 0; m.tlo = 0.0; m.thi = 0.0;
+    m.traj = nullptr; m.trow = 0; m.cur_idx = 0; m.tlo2 = 0.0; m.ltab = nullptr;
+    m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
+    m.sensi = 1; m.ism = a.ism;
+
+    double y0[NSD], s0[NQD][NSD];
+    SFOR(i, 0, NS) y0[i] = a.y0[(int64_t)inst * NS + i]; SEND
+    SFOR_S(is, i) s0[is][i] = a.sens0[((int64_t)inst * NQ + is) * NS + i]; SEND_S
+    cv_reinit(m, a.t0, y0, (const double *)nullptr);
+    SFOR(j, 0, (QMAX) + 1) { SFOR_S(is, i) m.znS[j][is][i] = (j == 0) ? s0[is][i] : 0.0; SEND_S } SEND
+    SFOR_S(is, i) {
+        m.zsaveS[is][i] = 0.0; m.ewtS[is][i] = 0.0; m.acorS[is][i] = 0.0; m.tempvS[is][i] = 0.0;
+        m.ftempS[is][i] = 0.0; m.yS[is][i] = 0.0; m.deltaS[is][i] = 0.0;
+    } SEND_S
+
+    double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
+    double *so = a.sens_out + (int64_t)inst * a.n_t * NQ * NS;
+    int status = CV_SUCCESS, k = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
+    while (k < a.n_t && a.tvals[k] == a.t0) {
+        SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = y0[i]; SEND
+        SFOR_S(is, i) so[((int64_t)k * NQ + is) * NS + i] = s0[is][i]; SEND_S
+        k++;
+    }
+    bool done = (k >= a.n_t);
+    StepCtl c;
+    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.ncfS = c.nefS = 0; c.convfail = 0;
+    c.saved_t = a.t0;
+    if (!done) {
+        int flag = cv_first_call(m, a.tvals[k]);
+        if (flag != CV_SUCCESS) { status = flag; done = true; }
+    }
+    while (!done) {
+        if (!c.in_step) {
+            int ier = cv_pre_step(m);
+            if (ier == CV_ILL_INPUT) { status = ier; done = true; }
+            else if (a.mxstep > 0 && nstloc >= a.mxstep) {
+                retries++; total_retries++;
+                if (retries >= a.max_retries) { status = CV_TOO_MUCH_WORK; done = true; }
+                else nstloc = 0;
+            }
+            if (!done && ier != CV_SUCCESS) { status = ier; done = true; }
+        }
+        if (!done) {
+            attempts++;
+            int r = cv_attempt(m, c);
+            if (r < 0) { status = r; done = true; }
+            else if (r == 1) {
+                nstloc++;
+                while (!done && k < a.n_t) {
+                    double tout = a.tvals[k];
+                    if (tout == a.t0) {
+                        SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = y0[i]; SEND
+                        SFOR_S(is, i) so[((int64_t)k * NQ + is) * NS + i] = s0[is][i]; SEND_S
+                        k++;
+                    } else if ((m.tn - tout) * m.h >= 0.0) {
+                        double dky[NSD], dkyS[NQD][NSD];
+                        cv_get_dky0(m, tout, dky, (double *)nullptr);
+                        cv_get_sens_dky0(m, tout, dkyS);
+                        SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = dky[i]; SEND
+                        SFOR_S(is, i) so[((int64_t)k * NQ + is) * NS + i] = dkyS[is][i]; SEND_S
+                        k++;
+                        nstloc = 0; retries = 0;
+                    } else break;
+                }
+                if (k >= a.n_t) done = true;
+            }
+        }
+    }
+    if (status != CV_SUCCESS) {
+        for (int j = 0; j < a.n_t * NS; j++) yo[j] = SA_NAN;
+        for (int j = 0; j < a.n_t * NQ * NS; j++) so[j] = SA_NAN;
+    }
+    a.status[inst] = status;
+    int64_t st[SA_N_STATS];
+    SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
+    accumulate_stats(m, st);
+    /* sensitivity counters ride in the quadrature / interpolation slots of the adjoint path */
+    st[ST_NFQE] = m.nfSe; st[ST_NETFQ] = m.netfS; st[ST_NINTERP] = m.nniS; st[ST_NREBUILD] = m.ncfnS;
+    st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+    SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
+}
+#endif
 
 /* ------------------------------------------------------------------------------------ */
 /* backward kernel: AdjointSolver.solve_backward (solver.py:723-784) over CVodeB semantics */

@@ -79,7 +79,8 @@ def test_solver_sens_argument_checks():
     with pytest.raises(ValueError):
         Solver(prob, sens_mode="simultaneous", scaling_factors=np.ones(3))
     sol = Solver(prob, sens_mode="staggered")                        # compiles the sensitivity build
-    assert _native.kernel_variant(prob.native_source(), sens=True)[0] == "bdf_mem.hip"
+    assert _native.kernel_variant(prob.native_source(), sens=True)[0] == "bdf_kernels.hip"     # n p = 4: registers
+    assert _native.kernel_variant(make_problem("seir").native_source(), sens=True)[0] == "bdf_mem.hip"
     assert os.path.exists(_native.code_object_path(prob.native_source(), sens=True))
     with pytest.raises(ValueError):
         sol.solve(0.0, np.linspace(0, 1, 3), np.ones(2), np.zeros((3, 2)))      # sens0 / sens_out missing
@@ -115,10 +116,18 @@ def test_initial_value_parameters_seed_the_sensitivities():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["lv", "robertson"])
 @pytest.mark.parametrize("mode", ["simultaneous", "staggered"])
-def test_device_sensitivities_bitexact_vs_oracle(name, mode, golden_dir):
+@pytest.mark.parametrize("mapping", ["registers", "mem"])
+def test_device_sensitivities_bitexact_vs_oracle(name, mode, mapping, golden_dir, monkeypatch):
+    """Both kernel families that carry the sensitivity corrector: thread-per-instance registers (the default for
+    these sizes) and the memory-resident workspace kernel (every size; forced here)."""
+    from sunode_amd import _native
     from sunode_amd.solver import Solver
     from tools.problems import lv_batch, robertson_batch
+    if mapping == "mem":
+        monkeypatch.setenv("SA_FORCE_GROUP", "mem")
     prob = make_problem(name)
+    assert _native.kernel_variant(prob.native_source(), sens=True)[0] == \
+        ("bdf_mem.hip" if mapping == "mem" else "bdf_kernels.hip")
     B = 70                                                           # ragged vs the 64-lane wavefront
     if name == "lv":
         d = lv_batch(B)
