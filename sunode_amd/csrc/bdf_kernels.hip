@@ -35,12 +35,14 @@
 
 #include "sa_common.h"
 
-/* Optional phase timing (build with SA_PROFILE; bench.py SA_ABLATE=PROFILE): s_memtime deltas per
-   phase of the attempt loop, written over stats slots 8..15 of the backward kernel. */
+/* Optional phase timing (SA_KERNEL_DEFINES=-DSA_ABLATE_PROFILE, tools/profile_lv.py): clock deltas per segment of
+   the attempt loop, written over stats slots 8..15 of the backward kernel.  PHASE(m, k) closes the segment that ENDS
+   at mark k (static slot, so the counters stay in registers); a lane idling while its neighbours run a divergent
+   block charges that time to the next mark it reaches. */
 #ifdef SA_ABLATE_PROFILE
 #define PROF_DECL long long prof[8]; long long prof_last; int prof_cur;
-#define PHASE(m, k) do { long long now_ = clock64(); (m).prof[(m).prof_cur] += now_ - (m).prof_last; \
-                         (m).prof_last = now_; (m).prof_cur = (k); } while (0)
+#define PHASE(m, k) do { long long now_ = __builtin_readcyclecounter(); (m).prof[k] += now_ - (m).prof_last; \
+                         (m).prof_last = now_; } while (0)
 #else
 #define PROF_DECL
 #define PHASE(m, k) do { } while (0)
@@ -1782,7 +1784,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
 #ifdef SA_ABLATE_PROFILE
     SFOR(k, 0, 8) m.prof[k] = 0; SEND
-    m.prof_last = clock64(); m.prof_cur = 7;
+    m.prof_last = __builtin_readcyclecounter(); m.prof_cur = 7;
 #endif
     m.ltab = ltab + threadIdx.x;
     SFOR(f, 0, TREC) m.ltab[f * 64] = 0.0; SEND

@@ -1071,23 +1071,23 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                 } SEND
             }
             /* trailing update of this wavefront's columns j > k (register columns cc > kcr, and cc == kcr for the
-               wavefronts behind the owner): pivot-row entries first (v_readlane -> SGPRs), then one masked block of
-               FMAs per register slot.  (Also measured, slower: keeping the multipliers as SGPR halves with scalar
-               branches around plain FMAs.) */
-            double akj[LU_NC];
+               wavefronts behind the owner), branch-free: the multiplier of a row that is not eliminated in this step
+               and the pivot-row entry of a column that is not updated are ZERO, so the FMA leaves the entry alone.
+               denseGETRF skips a column whose pivot-row entry is zero; a - 0*l equals a (only the sign of a zero
+               entry can differ, no finite value ever does), so the factors compare equal and no result changes.
+               Per column: slot select + v_readlane of the pivot-row entry (SGPR pair), one FMA per register slot. */
+            double lcv[RS];
+            SFOR(r, 0, RS) {
+                const double lc = L.col[buf * (RS * 64) + r * 64 + lane];
+                lcv[r] = (logpos[r] > k) ? lc : 0.0;
+            } SEND
             SFOR(cc, kcr, LU_NC) {
                 const int j = cc * SA_WAVES + wave;
                 double src = a[cc][0];
                 SFOR(r, 1, RS) src = (prow_slot == r) ? a[cc][r] : src; SEND
-                akj[cc] = (j > k && j < NS) ? readlane_d(src, prow_lane) : 0.0;         /* 0: column not updated */
-            } SEND
-            /* (a zero-free fast path -- test once whether any live multiplier is zero, plain FMAs otherwise -- was
-               measured slower as well: the join of the two paths copies the whole register matrix) */
-            SFOR(r, 0, RS) {
-                if (logpos[r] > k) {
-                    const double lc = L.col[buf * (RS * 64) + r * 64 + lane];
-                    SFOR(cc, kcr, LU_NC) { if (akj[cc] != 0.0) a[cc][r] = FMA(-akj[cc], lc, a[cc][r]); } SEND
-                }
+                const bool live = (cc > kcr ? true : wave > o) && (j < NS);
+                const double akj = live ? readlane_d(src, prow_lane) : 0.0;
+                SFOR(r, 0, RS) a[cc][r] = FMA(-akj, lcv[r], a[cc][r]); SEND
             } SEND
             LUP_T(t_d)
             LUP_ADD(0, t_a, t_b) LUP_ADD(1, t_b, t_c) LUP_ADD(2, t_c, t_d)
