@@ -735,7 +735,7 @@ typedef __attribute__((address_space(3))) int64_t lds_i64;
 struct LuLds {
     lds_f64 *A, *col, *invp;
     lds_u8 *piv;
-    lds_i32 *ier, *nswaps;
+    lds_i32 *ier, *nswaps, *info;
     lds_i64 *prof;
 };
 static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L);
@@ -929,9 +929,9 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
 #define LU_NC ((NS + SA_WAVES - 1) / SA_WAVES)
 __shared__ double s_col[2][RS * 64];
 __shared__ double s_invp[W_NS];
-__shared__ int s_luier, s_lunswaps;
+__shared__ int s_luier, s_lunswaps, s_luinfo[2];
 #ifdef SA_WAVE_PROFILE
-__shared__ int64_t s_luprof[3];           /* wavefront 0: cycles before the barrier, in the barrier, in the update */
+__shared__ int64_t s_luprof[5];           /* wavefront 0: cycles before the barrier, in the barrier, in the update, prologue, epilogue */
 #define LUP_T(x) const int64_t x = (int64_t)__builtin_readcyclecounter();
 #define LUP_ADD(k, a, b) if (wave == 0 && lane == 0) L.prof[k] += (b) - (a);
 #else
@@ -954,6 +954,7 @@ static __device__ __forceinline__ LuLds lu_lds()
     L.A = lds_opaque((lds_f64 *)s_A); L.col = lds_opaque((lds_f64 *)&s_col[0][0]); L.invp = lds_opaque((lds_f64 *)s_invp);
     L.piv = lds_opaque((lds_u8 *)s_piv);
     L.ier = lds_opaque((lds_i32 *)&s_luier); L.nswaps = lds_opaque((lds_i32 *)&s_lunswaps);
+    L.info = lds_opaque((lds_i32 *)&s_luinfo[0]);
 #ifdef SA_WAVE_PROFILE
     L.prof = lds_opaque((lds_i64 *)s_luprof);
 #else
@@ -968,24 +969,55 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
 {
     double a[LU_NC][RS];
     int logpos[RS];
+    LUP_T(t_in)
+#ifdef SA_WAVE_PROFILE
+    const int64_t w_in = (int64_t)wall_clock64();
+#endif
     wave = __builtin_amdgcn_readfirstlane(wave);            /* wave-uniform by construction: let the compiler know */
+    /* all loads of the matrix are issued back to back (clamped index instead of a branch per entry: with the branch
+       every load waited for the previous one, 50 dependent round trips to the workspace = 50 us per factorisation) */
+    typedef __attribute__((address_space(1))) double glb_f64;
+    glb_f64 *sjg = (glb_f64 *)sj;
+    if (from_saved) {
+        SFOR(cc, 0, LU_NC) {
+            const int j = cc * SA_WAVES + wave;
+            SFOR(r, 0, RS) {
+                const int i = r * 64 + lane;
+                const bool ok = (j < NS && i < NS);
+                a[cc][r] = sjg[ok ? j * NS + i : 0];
+            } SEND
+        } SEND
+    } else {
+        SFOR(cc, 0, LU_NC) {
+            const int j = cc * SA_WAVES + wave;
+            SFOR(r, 0, RS) {
+                const int i = r * 64 + lane;
+                const bool ok = (j < NS && i < NS);
+                a[cc][r] = L.A[ok ? j * NS + i : 0];
+            } SEND
+        } SEND
+        SFOR(cc, 0, LU_NC) {
+            const int j = cc * SA_WAVES + wave;
+            SFOR(r, 0, RS) {
+                const int i = r * 64 + lane;
+                if (j < NS && i < NS) sjg[j * NS + i] = a[cc][r];
+            } SEND
+        } SEND
+    }
     SFOR(cc, 0, LU_NC) {
         const int j = cc * SA_WAVES + wave;
         SFOR(r, 0, RS) {
             const int i = r * 64 + lane;
-            double v = 0.0;
-            if (j < NS && i < NS) {
-                if (from_saved) v = sj[j * NS + i];
-                else { v = L.A[j * NS + i]; sj[j * NS + i] = v; }
-                v = (i == j) ? FMA(c, v, 1.0) : v * c;
-            }
-            a[cc][r] = v;
+            const double v = a[cc][r];
+            const double w = (i == j) ? FMA(c, v, 1.0) : v * c;
+            a[cc][r] = (j < NS && i < NS) ? w : 0.0;
         } SEND
     } SEND
     SFOR(r, 0, RS) logpos[r] = (r * 64 + lane < NS) ? r * 64 + lane : -1; SEND
     if (wave == 0 && lane == 0) (*L.ier) = 0;
     int nswaps = 0, ier = 0;
     sa_barrier();
+    LUP_T(t_loop)
     /* kcr (the owner's register column) is a compile-time index: the ownership round is unrolled (LU_NC copies of
        the step), the SA_WAVES steps inside a round are a run-time loop.  (Measured alternatives that were slower:
        one run-time loop over k with compare-chain column selects; branch-free FMA blocks with scalar zero
@@ -994,15 +1026,18 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
     SFOR(kcr, 0, LU_NC) {
 #pragma nounroll
         for (int o = 0; o < SA_WAVES; o++) {
+            /* no early exits from this loop: an exit edge makes the register allocator copy the whole register
+               matrix on every iteration (measured: 120 of the 420 instructions of a step).  Steps past the end
+               (k >= NS) or after a zero pivot run as no-ops: no owner work, zero multipliers. */
             const int k = kcr * SA_WAVES + o, buf = k & 1;
-            if (k >= NS || ier != 0) break;
+            const bool active = (k < NS) && (ier == 0);
             LUP_T(t_a)
             int prow_lane = 0, prow_slot = 0;           /* physical home of logical row k */
             SFOR(r, 0, RS) {
                 const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == k);
                 if (bal != 0) { prow_slot = r; prow_lane = __builtin_ctzll(bal); }
             } SEND
-            if (wave == o) {
+            if (wave == o && active) {
                 double dsel = a[kcr][0];
                 SFOR(r, 1, RS) dsel = (prow_slot == r) ? a[kcr][r] : dsel; SEND
                 const double akk = readlane_d(dsel, prow_lane);
@@ -1031,6 +1066,9 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                     } SEND
                 }
                 const int l = bi;
+                /* one word per step for the other wavefronts: pivot row, or the singular flag (read together with
+                   the multipliers after the barrier: one LDS round trip per step instead of three) */
+                if (lane == 0) L.info[buf] = (best == 0.0) ? 0x10000 : l;
                 if (best == 0.0) { if (lane == 0) (*L.ier) = k + 1; }
                 else {
                     double apiv = akk;
@@ -1059,9 +1097,11 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
             LUP_T(t_b)
             sa_barrier();
             LUP_T(t_c)
-            ier = (*L.ier);
-            if (ier != 0) break;
-            const int l = L.piv[k];
+            double lcraw[RS];
+            SFOR(r, 0, RS) lcraw[r] = L.col[buf * (RS * 64) + r * 64 + lane]; SEND
+            const int info = active ? __builtin_amdgcn_readfirstlane(L.info[buf]) : k;
+            if (info >= 0x10000) ier = k + 1;
+            const int l = (info >= 0x10000) ? k : info;
             if (l != k) {                       /* row exchange = relabelling */
                 nswaps++;
                 SFOR(r, 0, RS) { const int lp = logpos[r]; logpos[r] = (lp == l) ? k : ((lp == k) ? l : lp); } SEND
@@ -1077,22 +1117,22 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                entry can differ, no finite value ever does), so the factors compare equal and no result changes.
                Per column: slot select + v_readlane of the pivot-row entry (SGPR pair), one FMA per register slot. */
             double lcv[RS];
-            SFOR(r, 0, RS) {
-                const double lc = L.col[buf * (RS * 64) + r * 64 + lane];
-                lcv[r] = (logpos[r] > k) ? lc : 0.0;
-            } SEND
+            SFOR(r, 0, RS) lcv[r] = (logpos[r] > k && ier == 0) ? lcraw[r] : 0.0; SEND
+            const int pl = __builtin_amdgcn_readfirstlane(prow_lane), psl = __builtin_amdgcn_readfirstlane(prow_slot);
             SFOR(cc, kcr, LU_NC) {
-                const int j = cc * SA_WAVES + wave;
                 double src = a[cc][0];
-                SFOR(r, 1, RS) src = (prow_slot == r) ? a[cc][r] : src; SEND
-                const bool live = (cc > kcr ? true : wave > o) && (j < NS);
-                const double akj = live ? readlane_d(src, prow_lane) : 0.0;
+                SFOR(r, 1, RS) src = (psl == r) ? a[cc][r] : src; SEND
+                /* register column kcr is finished (holds factors) in the wavefronts up to the owner; the padding
+                   columns j >= NS are zero and stay zero under the update */
+                double akj = readlane_d(src, pl);
+                if constexpr (cc == kcr) akj = (wave > o) ? akj : 0.0;
                 SFOR(r, 0, RS) a[cc][r] = FMA(-akj, lcv[r], a[cc][r]); SEND
             } SEND
             LUP_T(t_d)
             LUP_ADD(0, t_a, t_b) LUP_ADD(1, t_b, t_c) LUP_ADD(2, t_c, t_d)
         }
     } SEND
+    LUP_T(t_out)
     if (ier == 0) {
         SFOR(cc, 0, LU_NC) {
             const int j = cc * SA_WAVES + wave;
@@ -1101,9 +1141,14 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
     }
     if (wave == 0 && lane == 0) (*L.nswaps) = nswaps;
     sa_barrier();
+    LUP_T(t_end)
+    LUP_ADD(4, t_in, t_end)
+#ifdef SA_WAVE_PROFILE
+    if (wave == 0 && lane == 0) L.prof[3] += (int64_t)wall_clock64() - w_in;        /* 10 ns ticks over the same span */
+#endif
 }
 #else
-static __device__ __forceinline__ LuLds lu_lds() { return LuLds{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
+static __device__ __forceinline__ LuLds lu_lds() { return LuLds{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
 static __device__ void setup_lu_regs(int, int, double, int, double *, LuLds) {}
 #endif
 
@@ -2247,7 +2292,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     if (inst >= a.B) return;
     if (threadIdx.x == 0) s_nwaves = SA_WAVES;
 #if defined(SA_WAVE_PROFILE) && SA_WAVES > 1
-    if (threadIdx.x == 0) { s_luprof[0] = 0; s_luprof[1] = 0; s_luprof[2] = 0; }
+    if (threadIdx.x == 0) { s_luprof[0] = 0; s_luprof[1] = 0; s_luprof[2] = 0; s_luprof[3] = 0; s_luprof[4] = 0; }
 #endif
     if (sa_wave_index() != 0) {
         worker_loop<true>(a.pr + (int64_t)inst * a.rem_stride, a.ws + (int64_t)inst * WS_DOUBLES + WS_OUT);
@@ -2371,6 +2416,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
         st[15] = m.prof[7] + (int64_t)wall_clock64();
 #if SA_WAVES > 1
         st[5] = s_luprof[0]; st[6] = s_luprof[1]; st[7] = s_luprof[2];      /* LU: cycles pre-barrier / barrier / update */
+        st[8] = s_luprof[3] + (s_luprof[4] << 32);                          /* ... prologue | epilogue << 32 */
 #endif
 #endif
         SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND

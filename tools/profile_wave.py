@@ -43,8 +43,11 @@ def main():
         tot = stt[:, 15].mean() * 1e-5
         parts = ", ".join("%s %.1f" % (n, stt[:, 9 + i].mean() * 1e-5) for i, n in enumerate(names))
         if tag == "bwd" and stt[:, 5:8].sum() > 0:
+            nlu = max(stt[:, 2].mean(), 1)
             print("    LU of wavefront 0, kilo-cycles per factorisation: before barrier %.1f, in barrier %.1f, update %.1f"
-                  % tuple(stt[:, 5 + i].mean() / max(stt[:, 2].mean(), 1) / 1e3 for i in range(3)))
+                  % tuple(stt[:, 5 + i].mean() / nlu / 1e3 for i in range(3))
+                  + "; whole function %.1f us = %.1f kilo-cycles" % ((stt[:, 8] & 0xffffffff).mean() / nlu / 1e2,
+                                                                   (stt[:, 8] >> 32).mean() / nlu / 1e3))
         print("%s per-instance ms: total %.1f | %s | nst %.0f nfe %.0f nsetups %.0f nje %.0f nni %.0f"
               % (tag, tot, parts, stt[:, 0].mean(), stt[:, 1].mean(), stt[:, 2].mean(), stt[:, 3].mean(),
                  stt[:, 4].mean()))
