@@ -910,6 +910,104 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
     return 0;
 }
 
+/* ---- LU of a lane group with the matrix in REGISTERS (G < 64, small systems: config 4) ----
+ * The 64/G instances of a wavefront factorise at different times, so the wavefront pays for a factorisation in
+ * nearly every iteration of its attempt loop even though an instance needs one in a third of its steps (SEIR: the
+ * LDS version's 43 k cycles per call were the largest single item of the backward kernel).  Here lane li of the
+ * group loads rows li, li + G of all columns (NS*RS doubles), eliminates without touching LDS -- the pivot-row entry
+ * of a column is a ds_bpermute from its home lane, every lane scales its own rows' multipliers (the reciprocal of
+ * the pivot is recomputed per lane: no publication, no barrier) -- and writes the factors back for the triangular
+ * solves.  Rows are never moved: an exchange relabels (logical index per register slot, as in setup_lu_regs).  The
+ * steps are unrolled (k is a compile-time index).  Branch-free trailing update: multipliers of finished rows are
+ * zero; denseGETRF's skip of columns with a zero pivot-row entry is dropped (a - 0*l == a).  Same operations on the
+ * same values as getrf_coop / denseGETRF otherwise, hence the same factors (test_row_exchanges_in_the_dense_lu). */
+#ifndef LU_GROUP_REGS_MAX
+#define LU_GROUP_REGS_MAX 40                   /* NS*RS doubles per lane up to which the register version is used */
+#endif
+DEV int getrf_group_regs(const Grp &g, double (&inv_piv)[RS], int &nswaps)
+{
+    double a[NS][RS];
+    int logpos[RS];
+    SFOR(j, 0, NS) {
+        SFOR(r, 0, RS) { const int i = r * G + g.li; a[j][r] = AL(i < NS ? i : 0, j); } SEND
+    } SEND
+    SFOR(r, 0, RS) {
+        const int i = r * G + g.li;
+        logpos[r] = (i < NS) ? i : -1;
+        if (i >= NS) { SFOR(j, 0, NS) a[j][r] = 0.0; SEND }
+    } SEND
+    nswaps = 0;
+    int ier = 0;
+    /* home (lane of the group, register slot) of logical row K, identical in every lane of the group */
+#define LUG_HOME(K, HL, HS) do { HL = 0; HS = 0;                                                                \
+        SFOR(r, 0, RS) {                                                                                        \
+            const uint32_t grp = (uint32_t)((__builtin_amdgcn_ballot_w64(logpos[r] == (K)) >> g.gbase) & GMASK); \
+            if (grp != 0) { HS = r; HL = __builtin_ctz(grp); }                                                  \
+        } SEND } while (0)
+    SFOR(k, 0, NS) {
+        int hl, hs;
+        LUG_HOME(k, hl, hs);
+        double dsel = a[k][0];
+        SFOR(r, 1, RS) dsel = (hs == r) ? a[k][r] : dsel; SEND
+        const double akk = shfl_d(dsel, g.gbase + hl);
+        /* pivot: first (lowest logical index) row i >= k with the largest |a(i,k)| */
+        double best = fabs(akk);
+        int bi = k;
+        bool beaten = false;
+        double cand[RS];
+        SFOR(r, 0, RS) {
+            cand[r] = (logpos[r] > k) ? fabs(a[k][r]) : -1.0;
+            beaten = beaten || (cand[r] > best);
+        } SEND
+        if (((__builtin_amdgcn_ballot_w64(beaten) >> g.gbase) & GMASK) != 0) {
+            best = -1.0;
+            bi = 1 << 20;
+            SFOR(r, 0, RS) {
+                const double v = (logpos[r] == k) ? fabs(akk) : cand[r];
+                if (logpos[r] >= k && (v > best || (v == best && logpos[r] < bi))) { best = v; bi = logpos[r]; }
+            } SEND
+            SFOR(b, 0, LOG2G) {
+                const double ov = shfl_d(best, g.lane ^ (1 << b));
+                const int oi = shfl_i(bi, g.lane ^ (1 << b));
+                const bool take = (ov > best) || (ov == best && oi < bi);
+                best = take ? ov : best;
+                bi = take ? oi : bi;
+            } SEND
+        }
+        const int l = bi;                   /* identical in every lane of the group */
+        if (g.li == 0) s_piv[g.kbase + k] = (uint8_t)l;
+        ier = (ier == 0 && best == 0.0) ? k + 1 : ier;          /* keep going (results unused): no exit edges */
+        double apiv = akk;
+        if (l != k) {                       /* row exchange = relabelling */
+            nswaps++;
+            SFOR(r, 0, RS) { const int lp = logpos[r]; logpos[r] = (lp == l) ? k : ((lp == k) ? l : lp); } SEND
+            LUG_HOME(k, hl, hs);
+            double psel = a[k][0];
+            SFOR(r, 1, RS) psel = (hs == r) ? a[k][r] : psel; SEND
+            apiv = shfl_d(psel, g.gbase + hl);
+        }
+        const double mult = 1.0 / apiv;
+        double lc[RS];
+        SFOR(r, 0, RS) {
+            inv_piv[r] = (r * G + g.li == k) ? mult : inv_piv[r];
+            const bool below = logpos[r] > k;
+            lc[r] = below ? a[k][r] * mult : 0.0;
+            a[k][r] = below ? lc[r] : a[k][r];
+        } SEND
+        SFOR(j, k + 1, NS) {
+            double src = a[j][0];
+            SFOR(r, 1, RS) src = (hs == r) ? a[j][r] : src; SEND
+            const double akj = shfl_d(src, g.gbase + hl);
+            SFOR(r, 0, RS) a[j][r] = FMA(-akj, lc[r], a[j][r]); SEND
+        } SEND
+    } SEND
+#undef LUG_HOME
+    SFOR(j, 0, NS) {
+        SFOR(r, 0, RS) { if (logpos[r] >= 0) AL(logpos[r], j) = a[j][r]; } SEND
+    } SEND
+    return ier;
+}
+
 /* ---- Newton matrix set-up + LU by the whole workgroup, matrix in REGISTERS (SA_WAVES > 1, G = 64) ----
  * M = I + c*J (c = -gamma) is built and factorised without touching LDS in the elimination: wavefront w owns the
  * columns j = SA_WAVES*cc + w (cc < LU_NC; 25 columns at n = 100), lane l the rows l, l + 64: 2*LU_NC doubles per lane.
@@ -1161,7 +1259,9 @@ DEV int dense_getrf(Cw<BWD> &m)
         sa_barrier();
     }
     const Grp g{m.lane, m.li, m.gbase, m.abase, m.kbase, 0};
-    const int ier = getrf_coop(g, m.inv_piv, m.nswaps);
+    int ier;
+    if constexpr (SA_WAVES == 1 && G < 64 && NS * RS <= LU_GROUP_REGS_MAX) ier = getrf_group_regs(g, m.inv_piv, m.nswaps);
+    else ier = getrf_coop(g, m.inv_piv, m.nswaps);
     if constexpr (SA_WAVES > 1) sa_barrier();
     lds_sync();
     PROF_ADD(m, 3)
