@@ -832,3 +832,32 @@ def test_backward_reports_failed_forward_and_arena_limit():
     assert np.isnan(g[full]).all() and np.isnan(lam[full]).all()
     np.testing.assert_array_equal(g[~full], gr[~full])
     np.testing.assert_array_equal(lam[~full], lr[~full])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [None, "16", "wave16", "wave4"])
+def test_seir_device_counters_equal_dvode(group, golden_dir, monkeypatch):
+    """an independent counter oracle for the mid-size mappings.  SEIR (n = 16) forward through the
+    default lane-group kernel (8 lanes, LU in registers), the cooperative kernel (16 lanes), and the lane-group
+    kernel with 16 / 4 lanes (LDS LU at 4 lanes: 4 register slots): every step counter equals Fortran DVODE's
+    (tests/golden/dvode_seir.json), states to round-off."""
+    import json
+    from sunode_amd.solver import AdjointSolver
+    with open(os.path.join(golden_dir, "dvode_seir.json")) as fh:
+        dv = json.load(fh)
+    if group:
+        monkeypatch.setenv("SA_FORCE_GROUP", group)
+    prob = make_problem("seir")
+    cases = [dv["seir_batch_%d" % b] for b in range(4)]
+    tv = np.array(cases[0]["tvals"])
+    sol = AdjointSolver(prob, abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8,
+                        quad_abstol=1e-8, quad_reltol=1e-8)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, np.array([c["y0"] for c in cases]),
+                                           np.array([c["ps"] for c in cases]), np.array(cases[0]["pr"]))
+    assert (st == 0).all()
+    for b, c in enumerate(cases):
+        got = [int(v) for v in stats[b][:8]]
+        assert got == [c["nst"], c["nfe"], c["nlu"], c["nje"], c["nni"], c["ncfn"], c["netf"], c["qlast"]]
+        assert stats[b][8] == c["nst"] + 1                      # stored data points
+        ref = np.array(c["y"])
+        np.testing.assert_allclose(y[b], ref, rtol=0, atol=1e-12 * np.abs(ref).max())

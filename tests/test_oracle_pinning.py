@@ -89,6 +89,43 @@ def test_robertson_stiff_transient_trace_equals_dvode(dvode):
                        nni=case["nni"], ncfn=case["ncfn"], netf=case["netf"])
 
 
+@pytest.fixture(scope="module")
+def dvode_seir(golden_dir):
+    with open(os.path.join(golden_dir, "dvode_seir.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("b", range(4))
+@pytest.mark.parametrize("mode", ["plain", "adjoint_forward"])
+def test_seir_forward_statistics_equal_dvode(dvode_seir, b, mode):
+    """n = 16 (BASELINE config 4): every counter of the restated controller equals Fortran DVODE's on four draws
+    (tools/make_golden_dvode_seir.py; rhs and Jacobian there are numpy restatements of the model, independent of the
+    code generator), states agree to round-off."""
+    case = dvode_seir["seir_batch_%d" % b]
+    orc = make_oracle("seir")
+    cfg = orc.config(rtol=case["rtol"], atol=case["atol"])
+    fn = orc.solve if mode == "plain" else orc.solve_forward
+    y, status, stats = fn(cfg, [case["y0"]], [case["ps"]], np.array(case["pr"]), 0.0, np.array(case["tvals"]))
+    assert status[0] == 0
+    got = {k: int(stats[0][i]) for k, i in STAT.items()}
+    assert got == dict(nst=case["nst"], nfe=case["nfe"], nsetups=case["nlu"], nje=case["nje"], nni=case["nni"],
+                       ncfn=case["ncfn"], netf=case["netf"], qlast=case["qlast"])
+    ref = np.array(case["y"])
+    np.testing.assert_allclose(y[0], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+def test_seir_step_trace_equals_dvode(dvode_seir):
+    """All 344 steps to t = 100: step times (to the round-off level of the error estimate) and step orders."""
+    case = dvode_seir["seir_trace_T100"]
+    orc = make_oracle("seir")
+    cfg = orc.config(rtol=1e-8, atol=1e-8)
+    _, st, stats = orc.solve_forward(cfg, [case["y0"]], [case["ps"]], np.array(case["pr"]), 0.0, np.array([0.0, 100.0]))
+    t, _, order = orc.trajectory(0)
+    assert st[0] == 0 and len(t) - 1 == case["nst"] == len(case["t"])
+    np.testing.assert_allclose(t[1:], case["t"], rtol=1e-7)
+    assert order[1:].tolist() == case["q"]
+
+
 @pytest.mark.parametrize("name,rtol,atol,tol_y,tol_g", [
     ("lv", 1e-8, 1e-8, 1e-5, 4e-6),
     ("lv", 1e-10, 1e-10, 2e-7, 1e-7),
