@@ -117,6 +117,23 @@ DEV void sfor_down(F &&f)          /* B, B-1, ..., E (inclusive) */
 enum { ST_NST, ST_NFE, ST_NSETUPS, ST_NJE, ST_NNI, ST_NCFN, ST_NETF, ST_QLAST,
        ST_NPTS, ST_NFQE, ST_NETFQ, ST_NINTERP, ST_NREBUILD, ST_RETRIES, ST_ATTEMPTS, ST_RESERVED1 };
 
+/* a / b for operands far from the exponent limits (cvSet's step-size ratios and BDF coefficients, det_log's reduced argument: all O(1)): the
+   instruction sequence of the compiler's IEEE division (v_rcp_f64, two Newton steps on the reciprocal, quotient,
+   residual correction) without its range scaling -- v_div_scale leaves such operands unscaled, v_div_fmas then is a
+   plain FMA and v_div_fixup passes the result through, so this IS the correctly rounded a / b, bit for bit
+   (tests/test_gpu_parity.py::test_device_arithmetic checks it against numpy on the device). */
+DEV double fdiv(double a, double b)
+{
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e0 = FMA(-b, r0, 1.0);
+    const double r1 = FMA(r0, e0, r0);
+    const double e1 = FMA(-b, r1, 1.0);
+    const double r2 = FMA(r1, e1, r1);
+    const double q0 = a * r2;
+    const double rem = FMA(-b, q0, a);
+    return FMA(rem, r2, q0);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* deterministic pow (pure +,-,*,/): same operation sequence as the CPU restatement       */
 /* ------------------------------------------------------------------------------------ */
@@ -133,7 +150,7 @@ DEV double det_log(double x)
     double m = __builtin_bit_cast(double, u);
     if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
     double f = m - 1.0;
-    double s = f / (2.0 + f);
+    double s = fdiv(f, 2.0 + f);         /* |f| < 0.42: far from every exponent limit */
     double z = s * s;
     double p = 1.0 / 23.0;
     p = FMA(p, z, 1.0 / 21.0);
@@ -228,7 +245,7 @@ DEV void cv_set(M &m)
     SFOR(j, 2, QMAX) {
         const bool on = j < q;
         hsum = on ? hsum + m.tau[j - 1] : hsum;
-        const double xi = m.h / hsum;
+        const double xi = fdiv(m.h, hsum);
         xi_inv = on ? xi : xi_inv;
         alpha0 = on ? alpha0 - 1.0 / j : alpha0;
         SFOR_DOWN(i, j, 1) { const double v = FMA(m.l[i - 1], xi_inv, m.l[i]); m.l[i] = on ? v : m.l[i]; } SEND
@@ -240,7 +257,7 @@ DEV void cv_set(M &m)
         xistar_inv = gt1 ? xs : xistar_inv;
         const double hs = hsum + pick(m.tau, q - 1);
         hsum = gt1 ? hs : hsum;
-        const double xi = m.h / hsum;
+        const double xi = fdiv(m.h, hsum);
         xi_inv = gt1 ? xi : xi_inv;
         const double ah = -m.l[1] - xi_inv;
         alpha0_hat = gt1 ? ah : alpha0_hat;
@@ -253,30 +270,30 @@ DEV void cv_set(M &m)
         const double lq = pick(m.l, q);
         const double A1 = 1.0 - alpha0_hat + alpha0;
         const double A2 = FMA((double)q, A1, 1.0);
-        m.tq[2] = fabs(A1 / (alpha0 * A2));
-        m.tq[5] = fabs(A2 * xistar_inv / (lq * xi_inv));
+        m.tq[2] = fabs(fdiv(A1, alpha0 * A2));
+        m.tq[5] = fabs(fdiv(A2 * xistar_inv, lq * xi_inv));
         {
             const bool w1 = (m.qwait == 1);
-            const double C = xistar_inv / lq;
+            const double C = fdiv(xistar_inv, lq);
             const double A3 = alpha0 + inv_int(q);
             const double A4 = alpha0_hat + xi_inv;
-            const double Cpinv = (1.0 - A4 + A3) / A3;
+            const double Cpinv = fdiv(1.0 - A4 + A3, A3);
             const double tq1 = gt1 ? fabs(C * Cpinv) : 1.0;
             m.tq[1] = w1 ? tq1 : m.tq[1];
             const double hs = hsum + pick(m.tau, q);
-            const double xi3 = m.h / hs;
+            const double xi3 = fdiv(m.h, hs);
             const double A5 = alpha0 - inv_int(q + 1);
             const double A6 = alpha0_hat - xi3;
-            const double Cppinv = (1.0 - A6 + A5) / A2;
-            const double tq3 = fabs(Cppinv / (xi3 * (q + 2) * A5));
+            const double Cppinv = fdiv(1.0 - A6 + A5, A2);
+            const double tq3 = fabs(fdiv(Cppinv, xi3 * (q + 2) * A5));
             m.tq[3] = w1 ? tq3 : m.tq[3];
         }
         m.tq[4] = m.tq[2] * 10.0;       /* 1/tq[4] of CVODES (= tq[2]/nlscoef): the test multiplies */
     }
-    m.rl1 = 1.0 / m.l[1];
+    m.rl1 = fdiv(1.0, m.l[1]);
     m.gamma = m.h * m.rl1;
     m.gammap = (m.nst == 0) ? m.gamma : m.gammap;
-    const double gr = m.gamma / m.gammap;
+    const double gr = fdiv(m.gamma, m.gammap);
     m.gamrat = (m.nst > 0) ? gr : 1.0;
 }
 
