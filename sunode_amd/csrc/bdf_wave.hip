@@ -910,6 +910,15 @@ DEV int getrf_coop(const Grp &g, double (&inv_piv)[RS], int &nswaps)
     return 0;
 }
 
+/* the addresses go through an empty asm: otherwise interprocedural constant propagation puts the __shared__ globals
+   back into the callee -- and with them the offset-table loads */
+template <class T>
+static __device__ __forceinline__ T *lds_opaque(T *p)
+{
+    uint32_t a = (uint32_t)(uintptr_t)p;
+    asm volatile("" : "+s"(a));
+    return (T *)(uintptr_t)a;
+}
 /* ---- LU of a lane group with the matrix in REGISTERS (G < 64, small systems: config 4) ----
  * The 64/G instances of a wavefront factorise at different times, so the wavefront pays for a factorisation in
  * nearly every iteration of its attempt loop even though an instance needs one in a third of its steps (SEIR: the
@@ -1037,15 +1046,6 @@ __shared__ int64_t s_luprof[5];           /* wavefront 0: cycles before the barr
 #define LUP_ADD(k, a, b)
 #endif
 
-/* the addresses go through an empty asm: otherwise interprocedural constant propagation puts the __shared__ globals
-   back into the callee -- and with them the offset-table loads */
-template <class T>
-static __device__ __forceinline__ T *lds_opaque(T *p)
-{
-    uint32_t a = (uint32_t)(uintptr_t)p;
-    asm volatile("" : "+s"(a));
-    return (T *)(uintptr_t)a;
-}
 static __device__ __forceinline__ LuLds lu_lds()
 {
     LuLds L;
@@ -1307,6 +1307,7 @@ DEV void dense_getrs64(Cw<BWD> &m, double (&b)[RS])
 {
     const int lane = m.lane;
     const double *A = s_A + m.abase;
+    const double (&inv_piv)[RS] = m.inv_piv;
     /* forward substitution with the unit lower factor */
     SFOR(sk, 0, RS) {
         constexpr int k_lo = sk * 64;
@@ -1314,21 +1315,25 @@ DEV void dense_getrs64(Cw<BWD> &m, double (&b)[RS])
         if constexpr (k_lo < k_hi) {
             double nxt[GETRS_BLOCK][RS], cur[GETRS_BLOCK][RS];
             SFOR(d, 0, GETRS_BLOCK) { SFOR(r, sk, RS) nxt[d][r] = A[(k_lo + d < NS ? k_lo + d : 0) * NS + r * 64 + lane]; SEND } SEND
-            for (int k0 = k_lo; k0 < k_hi; k0 += GETRS_BLOCK) {
+            /* the steps are unrolled (k is a compile-time index: immediate lane selects, no loop or bounds
+               bookkeeping, no register copies between the prefetch buffers) */
+            SFOR(kb, 0, (k_hi - k_lo + GETRS_BLOCK - 1) / GETRS_BLOCK) {
+                constexpr int k0 = k_lo + kb * GETRS_BLOCK;
+                __builtin_amdgcn_sched_barrier(0);      /* keep the scheduler from pulling later blocks' loads up */
                 SFOR(d, 0, GETRS_BLOCK) { SFOR(r, sk, RS) cur[d][r] = nxt[d][r]; SEND } SEND
                 SFOR(d, 0, GETRS_BLOCK) {
-                    const int kn = k0 + GETRS_BLOCK + d;
-                    SFOR(r, sk, RS) nxt[d][r] = A[(kn < NS ? kn : 0) * NS + r * 64 + lane]; SEND
+                    constexpr int kn = k0 + GETRS_BLOCK + d;
+                    if constexpr (kn < k_hi) { SFOR(r, sk, RS) nxt[d][r] = A[kn * NS + r * 64 + lane]; SEND }
                 } SEND
                 SFOR(d, 0, GETRS_BLOCK) {
-                    const int k = k0 + d;
-                    if (k < k_hi) {
+                    constexpr int k = k0 + d;
+                    if constexpr (k < k_hi) {
                         const double bk = readlane_d(b[sk], k - k_lo);
                         if (lane > k - k_lo) b[sk] = FMA(-cur[d][sk], bk, b[sk]);
                         SFOR(r, sk + 1, RS) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
                     }
                 } SEND
-            }
+            } SEND
         }
     } SEND
     /* back substitution with the upper factor (reciprocal pivots) */
@@ -1338,27 +1343,29 @@ DEV void dense_getrs64(Cw<BWD> &m, double (&b)[RS])
         if constexpr (k_lo <= k_hi) {
             double nxt[GETRS_BLOCK][RS], cur[GETRS_BLOCK][RS];
             SFOR(d, 0, GETRS_BLOCK) { SFOR(r, 0, sk + 1) nxt[d][r] = A[(k_hi - d > 0 ? k_hi - d : 0) * NS + r * 64 + lane]; SEND } SEND
-            for (int k0 = k_hi; k0 >= k_lo; k0 -= GETRS_BLOCK) {
+            SFOR(kb, 0, (k_hi - k_lo + GETRS_BLOCK) / GETRS_BLOCK) {
+                constexpr int k0 = k_hi - kb * GETRS_BLOCK;
+                __builtin_amdgcn_sched_barrier(0);
                 SFOR(d, 0, GETRS_BLOCK) { SFOR(r, 0, sk + 1) cur[d][r] = nxt[d][r]; SEND } SEND
                 SFOR(d, 0, GETRS_BLOCK) {
-                    const int kn = k0 - GETRS_BLOCK - d;
-                    SFOR(r, 0, sk + 1) nxt[d][r] = A[(kn > 0 ? kn : 0) * NS + r * 64 + lane]; SEND
+                    constexpr int kn = k0 - GETRS_BLOCK - d;
+                    if constexpr (kn >= k_lo) { SFOR(r, 0, sk + 1) nxt[d][r] = A[kn * NS + r * 64 + lane]; SEND }
                 } SEND
                 SFOR(d, 0, GETRS_BLOCK) {
-                    const int k = k0 - d;
-                    if (k >= k_lo) {
-                        const int kl = k - sk * 64;
-                        const double scaled = b[sk] * m.inv_piv[sk];
+                    constexpr int k = k0 - d;
+                    if constexpr (k >= k_lo) {
+                        constexpr int kl = k - sk * 64;
+                        const double scaled = b[sk] * inv_piv[sk];
                         b[sk] = (lane == kl) ? scaled : b[sk];
                         const double bk = readlane_d(scaled, kl);
                         if (lane < kl) b[sk] = FMA(-cur[d][sk], bk, b[sk]);
                         SFOR(r, 0, sk) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
                     }
                 } SEND
-            }
+            } SEND
         }
     } SEND
-    if (lane == 0) b[0] *= m.inv_piv[0];
+    if (lane == 0) b[0] *= inv_piv[0];
     SFOR(r, 0, RS) { if (r * 64 + lane >= NS) b[r] = 0.0; } SEND
 }
 
