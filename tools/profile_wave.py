@@ -42,8 +42,9 @@ def main():
     for tag, stt in (("fwd", stats), ("bwd", statsb)):
         tot = stt[:, 15].mean() * 1e-5
         parts = ", ".join("%s %.1f" % (n, stt[:, 9 + i].mean() * 1e-5) for i, n in enumerate(names))
-        if tag == "bwd" and stt[:, 5:8].sum() > 0:
+        if tag == "bwd" and (stt[:, 8] >> 32).sum() > 0 and (stt[:, 8] >> 32).max() < (1 << 30):   # workgroup-LU builds only
             nlu = max(stt[:, 2].mean(), 1)
+            # the three partial counters are s_memtime reads the compiler may move across VALU work: indicative only
             print("    LU of wavefront 0, kilo-cycles per factorisation: before barrier %.1f, in barrier %.1f, update %.1f"
                   % tuple(stt[:, 5 + i].mean() / nlu / 1e3 for i in range(3))
                   + "; whole function %.1f us = %.1f kilo-cycles" % ((stt[:, 8] & 0xffffffff).mean() / nlu / 1e2,
