@@ -140,6 +140,14 @@ static __device__ __forceinline__ double sa_touch(const gdouble *p, int n)
 #define SA_PROLOGUE SA_LDS_VIEWS const gdouble *prg = (const gdouble *)pr;
 #endif
 #endif
+/* Small systems (config 4: n = 16): NO per-statement barriers.  With them every LDS / parameter load of a statement
+   is waited for on the spot -- the SEIR adjoint right-hand side was 94 dependent memory round trips (32 of them
+   global loads of the contact matrix), 11 k cycles per call; without them the scheduler batches the loads (8 global
+   loads, one wait) and the whole SEIR solve is 21 % faster.  The barriers are for the thousands of statements of the
+   n = 100 callbacks (below). */
+#if W_NS <= 32 && !defined(SA_WAVE_SCHED_BARRIER)
+#define SA_WAVE_NO_SCHED_BARRIER 1
+#endif
 #ifndef SA_WAVE_NO_SCHED_BARRIER
 /* keep the instruction scheduler from hoisting the loads of later statements over earlier ones:
    with thousands of independent statements that ends in tens of KB of spills */
