@@ -220,15 +220,20 @@ DEV int interp_y(Cv<BWD> &m, double t)
         if (indx == m.ilast) m.tlo2 = m.ltab[4 * 64];        /* T[2] = t[ilast-2] for the next move */
     }
     {
+        /* every LDS read of the record up front, in ONE batch: with the reads inside the conditional expressions
+           the compiler built a branch chain around them -- seven dependent LDS round trips per interpolation */
         const double *lt = m.ltab;
-        const int order = (int)lt[0];
-        const double inv_dt = 1.0 / lt[64];
+        double hdr[8], Yt[QMAX + 1][NSD];
+        SFOR(f, 0, 8) hdr[f] = lt[f * 64]; SEND
+        SFOR(i, 0, (QMAX) + 1) { SFOR(k, 0, NS) Yt[i][k] = lt[(8 + i * NS + k) * 64]; SEND } SEND
+        const int order = (int)hdr[0];
+        const double inv_dt = 1.0 / hdr[1];
         double cvals[QMAX + 1];
         cvals[0] = 1.0;
-        SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - lt[(2 + i) * 64]) * inv_dt : 0.0; SEND
+        SFOR(i, 0, QMAX) { const double v = cvals[i] * (t - hdr[2 + i]) * inv_dt; cvals[i + 1] = (i < order) ? v : 0.0; } SEND
         SFOR(k, 0, NS) {
-            double acc = cvals[0] * lt[(8 + k) * 64];
-            SFOR(i, 1, (QMAX) + 1) acc = FMA(cvals[i], lt[(8 + i * NS + k) * 64], acc); SEND
+            double acc = cvals[0] * Yt[0][k];
+            SFOR(i, 1, (QMAX) + 1) acc = FMA(cvals[i], Yt[i][k], acc); SEND
             m.ytmp[k] = acc;
         } SEND
     }
