@@ -1377,6 +1377,89 @@ DEV void dense_getrs64(Cw<BWD> &m, double (&b)[RS])
     SFOR(r, 0, RS) { if (r * 64 + lane >= NS) b[r] = 0.0; } SEND
 }
 
+/* ---- triangular solves of an 8-lane group, unrolled (small systems: config 4) ----
+ * The chain through b is serial: broadcast b_k, one FMA per owned row, next k.  With k a compile-time index the
+ * source lane of the broadcast (k mod 8 of every group) is static, so it is two DPP moves per 32-bit half -- a
+ * quad-permute that fills the source quad, a row_half_mirror under a bank mask that copies it into the other quad
+ * of the group -- ~30 cycles of VALU latency in the chain instead of the ~150 of a ds_bpermute round trip.  The
+ * row masks (i > k, i < k) are folded into the matrix entries (zero where the row takes no part), matrix columns come
+ * from LDS a block of GETRS_BLOCK8 columns ahead.  Same operations on the same values as the generic loop. */
+#define GETRS_BLOCK8 4
+template <int C>
+static __device__ __forceinline__ double sa_bcast8(double v)
+{
+    static_assert(C >= 0 && C < 8, "lane of an 8-lane group");
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
+    constexpr int c4 = C & 3, qp = c4 | (c4 << 2) | (c4 << 4) | (c4 << 6);
+    constexpr int bank = (C < 4) ? 0xA : 0x5;           /* banks (quads of a 16-lane row) to overwrite */
+    lo = __builtin_amdgcn_update_dpp(lo, lo, qp, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, qp, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, bank, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, bank, false);
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+
+template <bool BWD>
+DEV void dense_getrs_group8(Cw<BWD> &m, double (&b)[RS])
+{
+    const Grp g{m.lane, m.li, m.gbase, m.abase, m.kbase, 0};
+    /* forward substitution with the unit lower factor: columns 0 .. NS-2 */
+    {
+        double nxt[GETRS_BLOCK8][RS], cur[GETRS_BLOCK8][RS];
+        SFOR(d, 0, GETRS_BLOCK8) {
+            SFOR(r, 0, RS) { const int i = r * 8 + g.li; nxt[d][r] = (d < NS - 1 && i > d && i < NS) ? AL(i < NS ? i : 0, d < NS ? d : 0) : 0.0; } SEND
+        } SEND
+        SFOR(kb, 0, (NS - 1 + GETRS_BLOCK8 - 1) / GETRS_BLOCK8) {
+            constexpr int k0 = kb * GETRS_BLOCK8;
+            __builtin_amdgcn_sched_barrier(0);
+            SFOR(d, 0, GETRS_BLOCK8) { SFOR(r, 0, RS) cur[d][r] = nxt[d][r]; SEND } SEND
+            SFOR(d, 0, GETRS_BLOCK8) {
+                constexpr int kn = k0 + GETRS_BLOCK8 + d;
+                if constexpr (kn < NS - 1) {
+                    SFOR(r, 0, RS) { const int i = r * 8 + g.li; nxt[d][r] = (i > kn && i < NS) ? AL(i < NS ? i : 0, kn) : 0.0; } SEND
+                }
+            } SEND
+            SFOR(d, 0, GETRS_BLOCK8) {
+                constexpr int k = k0 + d;
+                if constexpr (k < NS - 1) {
+                    const double bk = sa_bcast8<(k & 7)>(b[k / 8]);
+                    SFOR(r, k / 8, RS) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
+                }
+            } SEND
+        } SEND
+    }
+    /* back substitution with the upper factor (reciprocal pivots): columns NS-1 .. 1 */
+    {
+        double nxt[GETRS_BLOCK8][RS], cur[GETRS_BLOCK8][RS];
+        SFOR(d, 0, GETRS_BLOCK8) {
+            SFOR(r, 0, RS) { const int i = r * 8 + g.li; nxt[d][r] = (NS - 1 - d > 0 && i < NS - 1 - d) ? AL(i, NS - 1 - d > 0 ? NS - 1 - d : 0) : 0.0; } SEND
+        } SEND
+        SFOR(kb, 0, (NS - 1 + GETRS_BLOCK8 - 1) / GETRS_BLOCK8) {
+            constexpr int k0 = NS - 1 - kb * GETRS_BLOCK8;
+            __builtin_amdgcn_sched_barrier(0);
+            SFOR(d, 0, GETRS_BLOCK8) { SFOR(r, 0, RS) cur[d][r] = nxt[d][r]; SEND } SEND
+            SFOR(d, 0, GETRS_BLOCK8) {
+                constexpr int kn = k0 - GETRS_BLOCK8 - d;
+                if constexpr (kn > 0) {
+                    SFOR(r, 0, RS) { const int i = r * 8 + g.li; nxt[d][r] = (i < kn) ? AL(i, kn) : 0.0; } SEND
+                }
+            } SEND
+            SFOR(d, 0, GETRS_BLOCK8) {
+                constexpr int k = k0 - d;
+                if constexpr (k > 0) {
+                    constexpr int sk = k / 8;
+                    const double scaled = b[sk] * m.inv_piv[sk];
+                    b[sk] = (g.li == (k & 7)) ? scaled : b[sk];
+                    const double bk = sa_bcast8<(k & 7)>(b[sk]);
+                    SFOR(r, 0, sk + 1) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
+                }
+            } SEND
+        } SEND
+    }
+    if (m.li == 0) b[0] *= m.inv_piv[0];
+}
+
 template <bool BWD>
 DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
 {
@@ -1400,6 +1483,11 @@ DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
     }
     if constexpr (G == 64) {
         dense_getrs64(m, b);
+        PROF_ADD(m, 4)
+        return;
+    }
+    if constexpr (G == 8 && SA_WAVES == 1 && NS <= 32) {
+        dense_getrs_group8(m, b);
         PROF_ADD(m, 4)
         return;
     }
