@@ -1107,16 +1107,11 @@ DEV void cv_set_eta(Cv<BWD> &m)
     }
 }
 
+#ifdef SA_SENS
+/* the branching form of cvPrepareNextStep's order decision (sensitivity builds: the sensitivity norms take part) */
 template <bool BWD>
-DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
+DEV void cv_prepare_next_step_branchy(Cv<BWD> &m, double dsm)
 {
-    if (m.etamax == 1.0) {
-        m.qwait = m.qwait > 2 ? m.qwait : 2;
-        m.qprime = m.q;
-        m.hprime = m.h;
-        m.eta = 1.0;
-        return;
-    }
     m.etaq = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
     if (m.qwait != 0) {
         m.eta = m.etaq;
@@ -1201,6 +1196,83 @@ DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
 #endif
     }
     cv_set_eta(m);
+}
+#endif
+
+template <bool BWD>
+DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
+{
+    if (m.etamax == 1.0) {
+        m.qwait = m.qwait > 2 ? m.qwait : 2;
+        m.qprime = m.q;
+        m.hprime = m.h;
+        m.eta = 1.0;
+        return;
+    }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { cv_prepare_next_step_branchy(m, dsm); return; }
+#endif
+    /* cvComputeEtaqm1 / cvComputeEtaqp1 / cvChooseEta as ONE straight-line block (values identical to the
+       branching form below, which the sensitivity builds keep): in a wavefront some lane is at qwait == 0 in nearly
+       every iteration, so the full path runs anyway -- but as three serial power evaluations (~60 dependent
+       instructions each) behind data-dependent branches.  Here the two norms and the three powers are independent
+       chains of one basic block (the scheduler interleaves them), lanes that are not at an order decision
+       (qwait != 0) or whose candidate is not defined (q == 1, q == qmax, no saved correction) discard the values
+       through selects; no field is written that the branching form would not write. */
+    const bool full = (m.qwait == 0);
+    double znq[NSD], znQq[NQD], tv[NSD], tvQ[NQD];
+    SFOR(i, 0, NS) {
+        double r = m.zn[2][i];
+        SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.zn[k][i] : r; SEND
+        znq[i] = r;
+    } SEND
+    double ddn = wrms<NS>(znq, m.ewt);
+    if (BWD) {
+        SFOR(i, 0, NQ) {
+            double r = m.znQ[2][i];
+            SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.znQ[k][i] : r; SEND
+            znQq[i] = r;
+        } SEND
+        ddn = quad_update_norm(m, ddn, znQq);
+    }
+    ddn = ddn * m.tq[1];
+    const double base = m.h / m.tau[2];
+    double pw = 1.0;
+    SFOR(i, 1, (QMAX + 1) + 1) { pw = (i <= m.L) ? pw * base : pw; } SEND
+    const double cquot = (m.tq[5] / m.saved_tq5) * pw;
+    SFOR(i, 0, NS) tv[i] = FMA(-cquot, m.zsave[i], m.acor[i]); SEND
+    double dup = wrms<NS>(tv, m.ewt);
+    if (BWD) {
+        SFOR(i, 0, NQ) tvQ[i] = FMA(-cquot, m.zsaveQ[i], m.acorQ[i]); SEND
+        dup = quad_update_norm(m, dup, tvQ);
+    }
+    dup = dup * m.tq[3];
+    const double p0 = rpower_nb(BIAS2 * dsm, inv_int(m.L));
+    const double p1 = rpower_nb(BIAS1 * ddn, inv_int(m.q));
+    const double p2 = rpower_nb(BIAS3 * dup, inv_int(m.L + 1));
+    const double etaq = 1.0 / (p0 + ADDON), e1 = 1.0 / (p1 + ADDON), e2 = 1.0 / (p2 + ADDON);
+    const double etaqm1 = (m.q > 1) ? e1 : 0.0;
+    const double etaqp1 = ((m.q != QMAX) && (m.saved_tq5 != 0.0)) ? e2 : 0.0;
+    m.etaq = etaq;
+    m.etaqm1 = full ? etaqm1 : m.etaqm1;
+    m.etaqp1 = full ? etaqp1 : m.etaqp1;
+    m.qwait = full ? 2 : m.qwait;
+    /* cvChooseEta (full) or eta = etaq (not at an order decision) */
+    const double etam = fmax(etaqm1, fmax(etaq, etaqp1));
+    const bool c0 = etam < THRESH, c1 = (etam == etaq), c2 = (etam == etaqm1);
+    const double eta_f = c0 ? 1.0 : (c1 ? etaq : (c2 ? etaqm1 : etaqp1));
+    const int qp_f = c0 ? m.q : (c1 ? m.q : (c2 ? m.q - 1 : m.q + 1));
+    const bool up = full && !c0 && !c1 && !c2;
+    m.eta = full ? eta_f : etaq;
+    m.qprime = full ? qp_f : m.q;
+    SFOR(i, 0, NS) m.zsave[i] = up ? m.acor[i] : m.zsave[i]; SEND
+    if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = up ? m.acorQ[i] : m.zsaveQ[i]; SEND }
+    {   /* cvSetEta */
+        const bool small = m.eta < THRESH;
+        const double capped = fmin(m.eta, m.etamax);
+        m.hprime = small ? m.h : m.h * capped;
+        m.eta = small ? 1.0 : capped;
+    }
 }
 
 /* CVodeGetDky, k = 0 (and CVodeGetQuadDky) */

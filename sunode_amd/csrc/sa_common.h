@@ -197,6 +197,15 @@ DEV double rpower_r(double base, double expo)
     return det_exp(expo * det_log(base));
 }
 
+/* the same value without the early return (select instead of branch): independent powers written one after the
+   other stay in one basic block and the scheduler interleaves their dependent chains */
+DEV double rpower_nb(double base, double expo)
+{
+    const bool nonpos = (base <= 0.0);
+    const double r = det_exp(expo * det_log(nonpos ? 1.0 : base));
+    return nonpos ? 0.0 : r;
+}
+
 /* N_VConstrMask entry: true where the inequality constraint c (0, +-1: >= / <= 0, +-2: > / < 0) on x fails */
 DEV bool constr_violated(double c, double x)
 {
