@@ -2012,58 +2012,54 @@ DEV void cv_prepare_next_step(Cw<BWD> &m, double dsm)
         m.eta = 1.0;
         return;
     }
-    m.etaq = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
-    if (m.qwait != 0) {
-        m.eta = m.etaq;
-        m.qprime = m.q;
-        cv_set_eta(m);
-        return;
+    /* cvComputeEtaqm1 / cvComputeEtaqp1 / cvChooseEta as ONE straight-line block (see bdf_kernels.hip): with 64/G
+       instances per wavefront some group is at an order decision in nearly every iteration, so the full path runs
+       anyway; here its two norms and three powers are independent chains of one basic block, groups that are not at
+       a decision (qwait != 0) or whose candidate is not defined discard the values through selects.  Values and
+       written fields identical to the branching form. */
+    const bool full = (m.qwait == 0);
+    double znq[RS], znQq[RQ], tv[RS], tvQ[RQ];
+    SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
+    SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
+    double ddn = wrms_n(m, znq, m.ewt);
+    if (BWD) ddn = quad_update_norm(m, ddn, znQq);
+    ddn = ddn * m.tq[1];
+    const double base = m.h / m.tau[2];
+    double pw = 1.0;
+    SFOR(i, 1, (QMAX + 1) + 1) { pw = (i <= m.L) ? pw * base : pw; } SEND
+    const double cquot = (m.tq[5] / m.saved_tq5) * pw;
+    SFOR(r, 0, RS) tv[r] = FMA(-cquot, m.zsave[r], m.acor[r]); SEND
+    double dup = wrms_n(m, tv, m.ewt);
+    if (BWD) {
+        SFOR(r, 0, RQ) tvQ[r] = FMA(-cquot, m.zsaveQ[r], m.acorQ[r]); SEND
+        dup = quad_update_norm(m, dup, tvQ);
     }
-    m.qwait = 2;
-    m.etaqm1 = 0.0;
-    if (m.q > 1) {
-        double znq[RS], znQq[RQ];
-        SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
-        SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
-        double ddn = wrms_n(m, znq, m.ewt);
-        if (BWD) ddn = quad_update_norm(m, ddn, znQq);
-        ddn = ddn * m.tq[1];
-        m.etaqm1 = 1.0 / (rpower_r(BIAS1 * ddn, inv_int(m.q)) + ADDON);
+    dup = dup * m.tq[3];
+    const double p0 = rpower_nb(BIAS2 * dsm, inv_int(m.L));
+    const double p1 = rpower_nb(BIAS1 * ddn, inv_int(m.q));
+    const double p2 = rpower_nb(BIAS3 * dup, inv_int(m.L + 1));
+    const double etaq = 1.0 / (p0 + ADDON), e1 = 1.0 / (p1 + ADDON), e2 = 1.0 / (p2 + ADDON);
+    const double etaqm1 = (m.q > 1) ? e1 : 0.0;
+    const double etaqp1 = ((m.q != QMAX) && (m.saved_tq5 != 0.0)) ? e2 : 0.0;
+    m.etaq = etaq;
+    m.etaqm1 = full ? etaqm1 : m.etaqm1;
+    m.etaqp1 = full ? etaqp1 : m.etaqp1;
+    m.qwait = full ? 2 : m.qwait;
+    const double etam = fmax(etaqm1, fmax(etaq, etaqp1));
+    const bool c0 = etam < THRESH, c1 = (etam == etaq), c2 = (etam == etaqm1);
+    const double eta_f = c0 ? 1.0 : (c1 ? etaq : (c2 ? etaqm1 : etaqp1));
+    const int qp_f = c0 ? m.q : (c1 ? m.q : (c2 ? m.q - 1 : m.q + 1));
+    const bool up = full && !c0 && !c1 && !c2;
+    m.eta = full ? eta_f : etaq;
+    m.qprime = full ? qp_f : m.q;
+    SFOR(r, 0, RS) m.zsave[r] = up ? m.acor[r] : m.zsave[r]; SEND
+    if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = up ? m.acorQ[r] : m.zsaveQ[r]; SEND }
+    {   /* cvSetEta */
+        const bool small = m.eta < THRESH;
+        const double capped = fmin(m.eta, m.etamax);
+        m.hprime = small ? m.h : m.h * capped;
+        m.eta = small ? 1.0 : capped;
     }
-    m.etaqp1 = 0.0;
-    if (m.q != QMAX) {
-        if (m.saved_tq5 != 0.0) {
-            double base = m.h / m.tau[2];
-            double pw = 1.0;
-            SFOR(i, 1, (QMAX + 1) + 1) { if (i <= m.L) pw *= base; } SEND
-            double cquot = (m.tq[5] / m.saved_tq5) * pw;
-            SFOR(r, 0, RS) m.tempv[r] = FMA(-cquot, m.zsave[r], m.acor[r]); SEND
-            double dup = wrms_n(m, m.tempv, m.ewt);
-            if (BWD) {
-                SFOR(r, 0, RQ) m.tempvQ[r] = FMA(-cquot, m.zsaveQ[r], m.acorQ[r]); SEND
-                dup = quad_update_norm(m, dup, m.tempvQ);
-            }
-            dup = dup * m.tq[3];
-            m.etaqp1 = 1.0 / (rpower_r(BIAS3 * dup, inv_int(m.L + 1)) + ADDON);
-        }
-    }
-    double etam = fmax(m.etaqm1, fmax(m.etaq, m.etaqp1));
-    if (etam < THRESH) {
-        m.eta = 1.0;
-        m.qprime = m.q;
-    } else if (etam == m.etaq) {
-        m.eta = m.etaq;
-        m.qprime = m.q;
-    } else if (etam == m.etaqm1) {
-        m.eta = m.etaqm1;
-        m.qprime = m.q - 1;
-    } else {
-        m.eta = m.etaqp1;
-        m.qprime = m.q + 1;
-        SFOR(r, 0, RS) m.zsave[r] = m.acor[r]; SEND
-        if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = m.acorQ[r]; SEND }
-    }
-    cv_set_eta(m);
 }
 
 template <bool BWD>
