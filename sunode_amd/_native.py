@@ -126,10 +126,7 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
     forced = os.environ.get("SA_FORCE_GROUP")
-    if hermite and not forced and n <= REGISTER_KERNEL_MAX_STATES and max(n, p) <= COOP_KERNEL_MAX_SIZE:
-        # Hermite interpolation lives in the cooperative / wave / memory kernels only; few states with many
-        # differentiated parameters fall through to the bdf_wave.hip group selection below (it carries Hermite too)
-        forced = "8"
+    # (Hermite interpolation: every family carries it -- since round 2 the register kernel too)
     if sens:
         # forward sensitivities: the register kernel keeps the p sensitivity Nordsieck arrays (14 n p doubles) next
         # to the state's while they fit one lane's register file; everything larger runs memory-resident

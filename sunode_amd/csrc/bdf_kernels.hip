@@ -88,6 +88,10 @@ struct Cv {
     int64_t trow;                     /* step pitch in doubles */
     int cur_idx;                      /* index whose divided-difference table is in use */
     double pf[4];                     /* in-flight prefetch touches (never consumed as data) */
+#ifdef SA_HERMITE                     /* CV_HERMITE: cubic on [t0,t1] from y, y' at both ends */
+    double h_t0, h_t1, h_y0[NSD], h_yd0[NSD], h_Y0[NSD], h_Y1[NSD];
+    double f0[NSD];                   /* f(t0, y0) of the first stored point */
+#endif
     double *ltab;                     /* this lane's column of the LDS table copy: ltab[field * 64] */
     double tlo2;                      /* t[ilast-2] */
     int np;
@@ -204,6 +208,37 @@ DEV int interp_y(Cv<BWD> &m, double t)
         SFOR(i, 0, NS) m.ytmp[i] = m.traj[8 + i]; SEND        /* record 0: Y[0] = y(t0) */
         return CV_SUCCESS;
     }
+#ifdef SA_HERMITE
+    {   /* CVAhermiteGetY (see the oracle; same arithmetic as bdf_coop.hip / bdf_mem.hip) */
+        if (newpoint) {
+            m.n_rebuild++;
+            m.cur_idx = indx;
+            const double *r0 = m.traj + (int64_t)(indx - 1) * m.trow, *r1 = m.traj + (int64_t)indx * m.trow;
+            m.h_t0 = r0[2]; m.h_t1 = r1[2];
+            const double delta = m.h_t1 - m.h_t0;
+            SFOR(c, 0, NS) {
+                m.h_y0[c] = r0[8 + c]; m.h_yd0[c] = r0[8 + NS + c];
+                const double y1 = r1[8 + c], yd1 = r1[8 + NS + c];
+                const double dy = y1 - m.h_y0[c];
+                m.h_Y0[c] = FMA(-delta, m.h_yd0[c], dy);
+                m.h_Y1[c] = FMA(delta, yd1 + m.h_yd0[c], -2.0 * dy);
+            } SEND
+            if (indx == m.ilast) m.tlo2 = (indx >= 2) ? point_time(m, indx - 2) : m.tlo;
+        }
+        const double delta = m.h_t1 - m.h_t0;
+        const double factor1 = t - m.h_t0;
+        double factor2 = factor1 / delta;
+        factor2 = factor2 * factor2;
+        const double factor3 = factor2 * (t - m.h_t1) / delta;
+        SFOR(c, 0, NS) {
+            double acc = FMA(factor1, m.h_yd0[c], m.h_y0[c]);
+            acc = FMA(factor2, m.h_Y0[c], acc);
+            acc = FMA(factor3, m.h_Y1[c], acc);
+            m.ytmp[c] = acc;
+        } SEND
+        return CV_SUCCESS;
+    }
+#endif
     if (newpoint) {
         m.n_rebuild++;
         m.cur_idx = indx;                     /* the table CVODES would rebuild now */
@@ -1340,6 +1375,9 @@ DEV int cv_first_call(Cv<BWD> &m, double tout)
     int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
+#ifdef SA_HERMITE
+    if (!BWD) { SFOR(i, 0, NS) m.f0[i] = m.zn[1][i]; SEND }
+#endif
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         retval = cv_fS(m, m.tn, m.zn[0], m.znS[0], m.znS[1]);
@@ -1597,6 +1635,16 @@ DEV void accumulate_stats(const Cv<BWD> &m, int64_t *acc)
 /* Build the CVApolynomialGetY divided-difference table of the newest stored point from the point
    history (T[j], Y[j] = point s-j) and write the trajectory record.  Same operation order as the
    on-demand rebuild in the oracle: factor = dt / (T[j] - T[j-i]), Y[j] = factor * (Y[j] - Y[j-1]). */
+#ifdef SA_HERMITE
+/* CV_HERMITE data point {t, y, y'} in the slots r[2], r[8 + i], r[8 + n + i] of a record; y' = scale * yd
+   (f(t0, y0) with scale 1 for the first point, zn[1] / h afterwards) */
+DEV void store_hermite(double *r, double t, const double (&y)[NSD], const double (&yd)[NSD], double scale)
+{
+    r[0] = 0.0; r[1] = 1.0; r[2] = t;
+    SFOR(i, 0, NS) { r[8 + i] = y[i]; r[8 + NS + i] = (scale == 1.0) ? yd[i] : scale * yd[i]; } SEND
+}
+#endif
+
 DEV void store_table(double *r, int order, double dt, const double (&hT)[QMAX + 1], const double (&hY)[QMAX + 1][NSD])
 {
     double Y[QMAX + 1][NSD];
@@ -1668,7 +1716,11 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         else if (store) {
             hT[0] = m.tn;
             SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
+#ifdef SA_HERMITE
+            if (wr) store_hermite(trec, m.tn, m.zn[0], m.f0, 1.0);
+#else
             if (wr) store_table(trec, 0, 1.0, hT, hY);
+#endif
             np = 1;
         }
     }
@@ -1698,7 +1750,11 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                         } SEND
                         hT[0] = m.tn;
                         SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
+#ifdef SA_HERMITE
+                        if (wr) store_hermite(trec + (int64_t)np * trow, m.tn, m.zn[0], m.zn[1], 1.0 / m.h);
+#else
                         if (wr) store_table(trec + (int64_t)np * trow, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+#endif
                         np++;
                     }
                 }

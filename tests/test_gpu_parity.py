@@ -477,11 +477,11 @@ def test_inequality_constraints_match_oracle(variant, monkeypatch):
     np.testing.assert_array_equal(ya[sta == 0], yao[sao == 0])
 
 
-@pytest.mark.parametrize("name,variant", [("lv", None), ("robertson", "16"), ("seir", None), ("seir", "wave"),
-                                          ("seir", "wave16"), ("seir", "mem")])
+@pytest.mark.parametrize("name,variant", [("lv", None), ("lv", "8"), ("robertson", None), ("robertson", "16"),
+                                          ("seir", None), ("seir", "wave"), ("seir", "wave16"), ("seir", "mem")])
 def test_hermite_interpolation_matches_oracle(name, variant, monkeypatch):
-    """AdjointSolver(interpolation='hermite') (reference solver.py:581-582): Hermite builds of the
-    cooperative / wave / memory kernels (small systems use the cooperative one) against the oracle."""
+    """AdjointSolver(interpolation='hermite') (reference solver.py:581-582): Hermite builds of the register
+    (default for small systems), cooperative, wave and memory kernels against the oracle."""
     from sunode_amd import _native
     from sunode_amd.solver import AdjointSolver
     if variant:
@@ -490,7 +490,8 @@ def test_hermite_interpolation_matches_oracle(name, variant, monkeypatch):
     B = 37
     if name == "lv":
         d = lv_batch(B); ps, pr = d["params"][:, :2], d["params"][:, 2:]; rt, at = 1e-8, 1e-8
-        assert _native.kernel_variant(prob.native_source(), hermite=True) == ("bdf_coop.hip", 8)
+        assert _native.kernel_variant(prob.native_source(), hermite=True) == \
+            (("bdf_coop.hip", 8) if variant == "8" else ("bdf_kernels.hip", 1))
     elif name == "robertson":
         d = robertson_batch(B); ps, pr = d["params"], np.zeros(0); rt, at = 1e-8, 1e-10
     else:

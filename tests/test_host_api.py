@@ -194,5 +194,5 @@ def test_hermite_kernel_selection_with_many_parameters():
     assert _native.kernel_variant(src, hermite=True) == ("bdf_wave.hip", 8)
     assert _native.kernel_variant(src, hermite=False)[0] == "bdf_wave.hip"
     small = "#define SA_N_STATES 3\n#define SA_N_SUB 3\n#define SA_N_REM 0\n"
-    assert _native.kernel_variant(small, hermite=True) == ("bdf_coop.hip", 8)
+    assert _native.kernel_variant(small, hermite=True) == ("bdf_kernels.hip", 1)     # register kernel carries Hermite
     assert _native.kernel_variant(small) == ("bdf_kernels.hip", 1)

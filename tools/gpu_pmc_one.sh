@@ -16,3 +16,4 @@ for pmc in "$@"; do
     { echo "## --pmc $pmc"; summ "$d" --counters | grep -v "at::native\|rocclr"; } >> "$f"
 done
 cat "$f"
+rm -rf "$out"

@@ -31,3 +31,4 @@ for pmc in FETCH_SIZE WRITE_SIZE; do
     { echo "## --pmc $pmc"; summ "$d" --counters; } >> "$root/gpurun_out/${tag}_pmc_calibration.txt"
 done
 cat "$root/gpurun_out/${tag}_pmc_calibration.txt" "$root/gpurun_out/${tag}_lv_pmc.txt"
+rm -rf "$out"      # raw rocprofv3 databases: the summaries above are what is kept (gpurun copies back at most 64 MiB)
