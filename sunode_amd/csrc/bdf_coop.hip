@@ -1166,7 +1166,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
        arena (SA_MODE_ADJ_COUNT runs the identical pass and only counts them, see sunode_amd.cpp) */
     const bool store = (a.mode != SA_MODE_PLAIN), wr = (a.mode == SA_MODE_ADJ_FWD);
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
-    double *trec = a.traj + (int64_t)inst * TREC;
+    double *trec = a.traj + (int64_t)inst * a.traj_istride * TREC;
     const int64_t trow = a.traj_stride * TREC;
     double hT[QMAX + 1], hY[QMAX + 1];
     SFOR(j, 0, (QMAX) + 1) { hT[j] = 0.0; hY[j] = 0.0; } SEND
@@ -1274,7 +1274,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     m.atol = a.atolB;
     m.rtolQ = a.rtolQB; m.atolQ = a.atolQB;
     m.tstop = a.tinitial;
-    m.traj = a.traj + (int64_t)inst * TREC;
+    m.traj = a.traj + (int64_t)inst * a.traj_istride * TREC;
     m.trow = a.traj_stride * TREC;
     m.np = np;
     m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + 2] : a.tinitial;

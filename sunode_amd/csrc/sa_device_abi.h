@@ -37,8 +37,8 @@
 #define SA_N_STATS 16
 
 typedef struct {
-    int32_t B, n_t, mode, mxstep, max_retries, traj_cap, rem_stride, reserved;
-    int64_t traj_stride;
+    int32_t B, n_t, mode, mxstep, max_retries, traj_cap, rem_stride, traj_istride;
+    int64_t traj_stride;      /* record (instance i, point s) at traj + (i * traj_istride + s * traj_stride) * record size */
     double t0, rtol;
     const double *atol;
     const double *y0, *ps, *pr, *tvals;
@@ -53,7 +53,7 @@ typedef struct {
 } sa_fwd_args;
 
 typedef struct {
-    int32_t B, n_t, mxstep, max_retries, traj_cap, rem_stride, reserved0, reserved1;
+    int32_t B, n_t, mxstep, max_retries, traj_cap, rem_stride, traj_istride, reserved1;
     int64_t traj_stride, grads_stride;
     double t0, tend, tinitial;
     double rtolB, atolB, rtolQB, atolQB;

@@ -359,7 +359,12 @@ static int launch_forward(sa_solver *s, const FwdLaunch &f)
     a.t0 = f.t0; a.rtol = s->opt.rtol; a.atol = (const double *)s->d_atol.p;
     a.y0 = f.y0; a.ps = f.ps; a.pr = f.pr; a.tvals = f.tvals; a.y_out = f.y_out; a.status = f.status; a.stats = f.stats;
     a.constraints = s->have_constraints ? (const double *)s->d_constraints.p : nullptr;
-    a.traj_stride = f.stride; a.traj = (double *)s->traj.p; a.traj_np = f.traj_np;
+    /* arena layout: the register / cooperative / wave kernels keep every instance's records contiguous
+       ([instance][point]: the backward pass walks an instance's points in order, so consecutive records share cache
+       lines and DRAM pages); the memory-resident kernel keeps its [point][field][instance] layout */
+    if (s->ws_doubles == 0) { a.traj_istride = f.rows; a.traj_stride = 1; }
+    else { a.traj_istride = 1; a.traj_stride = f.stride; }
+    a.traj = (double *)s->traj.p; a.traj_np = f.traj_np;
     int rc;
     if ((rc = bind_workspace(s, f.B, &a.ws, &a.ws_stride))) return rc;
     return launch(s, s->k_forward, f.B, &a, sizeof a, s->group);
@@ -588,7 +593,9 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
     a.tvals = d_tv;
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     if (!s->tiled) {
-        a.B = B; a.traj_cap = s->traj_rows; a.traj_stride = s->traj_stride;
+        a.B = B; a.traj_cap = s->traj_rows;
+        if (s->ws_doubles == 0) { a.traj_istride = s->traj_rows; a.traj_stride = 1; }
+        else { a.traj_istride = 1; a.traj_stride = s->traj_stride; }
         a.ps = d_ps; a.pr = d_pr; a.grads = d_g; a.grad_out = d_gout; a.lamda_out = d_lout;
         a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
         a.traj = (const double *)s->traj.p; a.traj_np = (const int32_t *)s->traj_np.p;
@@ -663,7 +670,9 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
                         d_pr + (size_t)lo * (size_t)rem_stride, (const double *)s->keep_tvals.p,
                         (double *)s->t_yout.p, (int32_t *)s->t_status.p, (int64_t *)s->t_stats.p, (int32_t *)s->t_np.p};
             if ((rc = launch_forward(s, f))) return rc;
-            a.B = tB; a.traj_cap = (int32_t)rows; a.traj_stride = stride;
+            a.B = tB; a.traj_cap = (int32_t)rows;
+            if (s->ws_doubles == 0) { a.traj_istride = (int32_t)rows; a.traj_stride = 1; }
+            else { a.traj_istride = 1; a.traj_stride = stride; }
             a.ps = d_ps + (size_t)lo * np_; a.pr = d_pr + (size_t)lo * (size_t)rem_stride;
             a.grads = d_g + (size_t)lo * (size_t)grads_stride;
             a.grad_out = d_gout + (size_t)lo * np_; a.lamda_out = d_lout + (size_t)lo * nn;
