@@ -164,3 +164,45 @@ def test_six_thousand_step_instance_at_default_settings():
     np.testing.assert_array_equal(y, yo)
     np.testing.assert_array_equal(g, go)
     np.testing.assert_array_equal(lam, lo)
+
+
+def test_full_size_hermite_and_sensitivities_lv():
+    """The round-2 register-kernel paths at the full LV batch (B = 65 536): Hermite interpolation and forward
+    sensitivities; a strided 1-in-257 sample must equal the oracle bit for bit, every instance must be finite."""
+    import bench
+    from sunode_amd import _native
+    from sunode_amd.solver import Solver
+    w = bench.WORKLOADS["lv"]
+    prob = make_problem("lv")
+    B = w["batch"]
+    b = bench.make_batch("lv", prob, B)
+    rt, at = w["rtol"], w["atol"]
+    idx = np.arange(0, B, 257)
+    n_rem = prob.n_remainder
+    pr_user = b["pr"][..., :n_rem] if n_rem else np.zeros(0)
+    orc = make_oracle("lv")
+    pr_o = b["pr"][idx] if b["rem_stride"] else b["pr"]
+    # Hermite
+    assert _native.kernel_variant(prob.native_source(), hermite=True) == ("bdf_kernels.hip", 1)
+    sol = _solver("lv", rt, at, interpolation="hermite")
+    y, st, sf = sol.solve_forward_batch(0.0, b["tvals"], b["y0"], b["ps"], pr_user)
+    g, lam, stb, sb = sol.solve_backward_batch(b["tvals"][-1], 0.0, b["tvals"], b["grads"])
+    assert (st == 0).all() and (stb == 0).all() and np.isfinite(g).all() and np.isfinite(lam).all()
+    cfg = orc.config(rtol=rt, atol=at, rtolB=rt, atolB=at, rtolQB=rt, atolQB=at, hermite=True)
+    yo, so, _ = orc.solve_forward(cfg, b["y0"][idx], b["ps"][idx], pr_o, 0.0, b["tvals"], nthreads=8)
+    go, lo, sbo, _ = orc.solve_backward(cfg, b["tvals"][-1], 0.0, b["tvals"], b["grads"], nthreads=8)
+    assert (so == 0).all() and (sbo == 0).all()
+    np.testing.assert_array_equal(y[idx], yo)
+    np.testing.assert_array_equal(g[idx], go)
+    np.testing.assert_array_equal(lam[idx], lo)
+    # forward sensitivities
+    assert _native.kernel_variant(prob.native_source(), sens=True) == ("bdf_kernels.hip", 1)
+    ssol = Solver(prob, abstol=at, reltol=rt, sens_mode="simultaneous")
+    sens0 = np.zeros((prob.n_params, prob.n_states))
+    ys, S, sts, _ = ssol.solve_sens_batch(0.0, b["tvals"], b["y0"], b["ps"], pr_user, sens0)
+    assert (sts == 0).all() and np.isfinite(S).all()
+    cfg = orc.config(rtol=rt, atol=at)
+    yso, So, sso, _ = orc.solve_sens(cfg, b["y0"][idx], b["ps"][idx], pr_o, sens0, 0.0, b["tvals"], mode="simultaneous", nthreads=8)
+    assert (sso == 0).all()
+    np.testing.assert_array_equal(ys[idx], yso)
+    np.testing.assert_array_equal(S[idx], So)
