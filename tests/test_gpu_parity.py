@@ -627,7 +627,7 @@ def test_reference_test_declare_sens_and_linear_solver_kwarg():
         np.testing.assert_allclose(y[:, 0], np.exp(t), rtol=1e-8)
 
 
-@pytest.mark.parametrize("variant", [None, "wave4", "wave8", "wave", "mem"])
+@pytest.mark.parametrize("variant", [None, "wave2", "wave4", "wave8", "wave16", "wave", "mem"])
 def test_row_exchanges_in_the_dense_lu(variant, monkeypatch):
     """A system whose Newton matrix is far from diagonally dominant (rotations at 1000 rad/s far below the
     tolerances, steps of order 1): the partial-pivoting LU has to exchange rows in the forward and in the
