@@ -62,22 +62,23 @@ def make_problem(name="lv"):
     return SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
 
 
-def make_batch(name, prob, B):
-    """Synthetic batch of B draws of workload `name`: dict(y0, ps, pr, rem_stride, tvals, grads)."""
+def make_batch(name, prob, B, idx=None):
+    """Synthetic batch of B draws of workload `name`: dict(y0, ps, pr, rem_stride, tvals, grads).
+    ``idx``: only these draws of it (the counter-based generator makes a rank's shard without the global batch)."""
     from tools.problems import lv_batch, network_batch, robertson_batch, seir_batch
     n = prob.n_states
     if name == "lv":
-        d = lv_batch(B)
+        d = lv_batch(B, idx=idx)
         ps = d["params"][:, prob.params_subset.subset_index]
         pr = d["params"][:, prob.params_subset.remainder_index]
         stride = pr.shape[1]
         grads = np.ones((len(d["tvals"]), n))
     elif name == "robertson":
-        d = robertson_batch(B)
+        d = robertson_batch(B, idx=idx)
         ps, pr, stride = d["params"], np.zeros(1), 0
         grads = None
     else:
-        d = seir_batch(B) if name == "seir" else network_batch(B)
+        d = seir_batch(B, idx=idx) if name == "seir" else network_batch(B, idx=idx)
         ps, pr, stride = d["ps"], d["pr"], 0
         grads = None
     if prob.n_remainder:          # hoisted fixed-parameter sub-expressions ride at the end of the remainder vector
@@ -181,7 +182,8 @@ def run_rank(args, *, backend="nccl", make_engine=None):
     if world != max(1, args.gpus):
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or getattr(args, "force_dist", False)   # --force-dist: a world of one still forms its group
+    if use_dist:
         import torch
         import torch.distributed as dist
         if backend == "nccl":
@@ -195,15 +197,15 @@ def run_rank(args, *, backend="nccl", make_engine=None):
     prob = make_problem(name)
     w = WORKLOADS[name]
     B = args.batch or w["batch"]
-    # weak scaling: the global synthetic batch has B * world draws; every rank integrates its own shard
+    # weak scaling: the global synthetic batch has B * world draws; every rank generates and integrates its own shard
+    # (draw i depends only on (seed, i): no rank materialises the global batch)
     idx = shard_indices(B * world, rank, world)
-    full = make_batch(name, prob, B * world)
-    shard = {k: (v[idx] if (k in ("y0", "ps") or (k == "pr" and full["rem_stride"])) else v) for k, v in full.items()}
+    shard = make_batch(name, prob, B * world, idx=idx)
     factory = make_engine or GpuEngine
     eng = factory(name, prob, shard, (w["rtol"], w["atol"]), local_rank)
 
     def all_reduce(value, op):
-        if world == 1:
+        if not use_dist:
             return value
         import torch
         t = torch.tensor([value], dtype=torch.float64, device=getattr(eng, "dev", "cpu"))
@@ -213,7 +215,7 @@ def run_rank(args, *, backend="nccl", make_engine=None):
     for _ in range(args.warmup):
         eng.step()
     eng.sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     fwd_ms, bwd_ms = [], []
     t0 = time.perf_counter()
@@ -224,7 +226,7 @@ def run_rank(args, *, backend="nccl", make_engine=None):
         bwd_ms.append(b)
     eng.sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = all_reduce(elapsed, "MAX")
     res = eng.results()
@@ -233,7 +235,7 @@ def run_rank(args, *, backend="nccl", make_engine=None):
     if rank == 0:
         out = summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, failed)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return out
 
@@ -405,7 +407,7 @@ def extra_configs(args):
             sub = argparse.Namespace(**vars(args))
             # two untimed steps: the first call on a handle sizes the trajectory arena (and may re-integrate), the
             # second allocates its final size; from the third on the allocation is stable
-            sub.workload, sub.batch, sub.steps, sub.warmup, sub.gpus = name, 0, 2, 2, 1
+            sub.workload, sub.batch, sub.steps, sub.warmup, sub.gpus = name, 0, 5, 2, 1
             r = run_rank(sub)
             row = {"workload": w["label"], "batch": w["batch"], "solves_per_s": r["value"],
                    "ms_per_step": r["ms_per_step"], "forward_kernel_ms": r["roofline"]["forward_kernel_ms"],
@@ -430,6 +432,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="lv", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="form the process group (nccl = RCCL), barrier and device all-reduce even with one rank")
     return ap.parse_args(argv)
 
 
@@ -460,6 +464,11 @@ def main(argv=None):
                 out["cpu_baseline"] = cpu_baseline(args.workload, make_problem(args.workload), WORKLOADS[args.workload])
             if not args.no_extra_configs and args.workload == "lv":
                 out["configs"] = extra_configs(args)
+        else:
+            # the contract times the CPU baseline at N = 1 only; keep the pointer so an N > 1 line is self-describing
+            out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": usable_cores(), "kind": "port",
+                                   "sample": "not timed at N > 1 (contract: rank 0, N = 1 only); see the N = 1 line of "
+                                             "the same round (BENCH_rNN.json / profiles/rNN_bench.json)"}
         print(json.dumps(out), flush=True)
 
 

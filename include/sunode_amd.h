@@ -10,7 +10,12 @@
  * Memory spaces: every array argument of one call lives either in host memory
  * (SA_MEM_HOST: the library stages it through its own device buffers and returns after
  * the results are back) or in device memory of the solver's GPU (SA_MEM_DEVICE: the
- * call only enqueues work on the solver's stream; use sa_synchronize()).
+ * call only enqueues work on the solver's stream; use sa_synchronize()).  One exception,
+ * stated here because callers that overlap work care: sa_solve_backward_batch[_all] waits
+ * once, before it launches, for the preceding sa_solve_forward_batch to finish (a 4-byte
+ * read-back that tells it whether every stored trajectory fitted the resident arena; if
+ * not, it also fetches the per-instance point counts and re-integrates tile by tile).
+ * sa_solve_batch, sa_solve_forward_batch and sa_eval_callbacks never synchronise.
  * The caller owns every array; the library owns the handle, the per-instance
  * trajectory arena (CVODES' adjoint "data points") and its staging buffers.
  *
@@ -31,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 1          /* device ABI (sa_meta[3] of a code object) */
+#define SA_ABI_VERSION 2          /* device ABI (sa_meta[3] of a code object) */
 
 #define SA_MEM_HOST 0
 #define SA_MEM_DEVICE 1
@@ -41,9 +46,12 @@ extern "C" {
 #define SA_ERR_ARG (-1002)        /* invalid argument / call sequence */
 #define SA_ERR_MODULE (-1003)     /* code object missing, wrong arch or ABI mismatch */
 
-/* per-instance status beyond the CVODES codes: the instance's stored trajectory exceeds
-   sa_options.traj_capacity points (or 64 instances of it exceed arena_bytes).  Distinct from
-   CV_TOO_MUCH_WORK (-1), which keeps its CVODES meaning (mxstep x retries of one CVode call). */
+/* per-instance status beyond the CVODES codes.  From sa_solve_forward_batch: the instance would store more than
+   sa_options.traj_capacity points -- the integration stops there (bounded work, whatever the inputs) and y_out is
+   NaN like for every other failure; the backward call answers CV_NO_FWD (-102) for it.  From
+   sa_solve_backward_batch: the 64 instances of its group do not fit arena_bytes even alone (forward results are
+   complete and valid; gradients NaN).  Distinct from CV_TOO_MUCH_WORK (-1), which keeps its CVODES meaning
+   (mxstep x retries of one CVode call). */
 #define SA_STATUS_ARENA_FULL (-9001)
 
 /* statistics slots: stats[b*SA_N_STATS + slot], int64 (CVodeGetNumSteps & friends,

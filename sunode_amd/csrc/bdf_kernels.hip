@@ -1742,7 +1742,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             else if (r == 1) {
                 nstloc++;
                 if (store) {
-                    if (wr && np >= a.traj_cap) { status = SA_TRAJ_FULL; done = true; }
+                    if (np >= a.traj_max) { status = SA_TRAJ_FULL; done = true; }    /* bounded in every store mode */
                     else {
                         SFOR_DOWN(j, QMAX, 1) {
                             hT[j] = hT[j - 1];
@@ -1751,9 +1751,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                         hT[0] = m.tn;
                         SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
 #ifdef SA_HERMITE
-                        if (wr) store_hermite(trec + (int64_t)np * trow, m.tn, m.zn[0], m.zn[1], 1.0 / m.h);
+                        if (wr && np < a.traj_cap) store_hermite(trec + (int64_t)np * trow, m.tn, m.zn[0], m.zn[1], 1.0 / m.h);
 #else
-                        if (wr) store_table(trec + (int64_t)np * trow, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+                        if (wr && np < a.traj_cap) store_table(trec + (int64_t)np * trow, m.qu, fabs(hT[0] - hT[1]), hT, hY);
 #endif
                         np++;
                     }
@@ -1779,7 +1779,12 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         for (int j = 0; j < a.n_t * NS; j++) yo[j] = SA_NAN;
     }
     a.status[inst] = status;
-    if (store) a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
+    if (store) {
+        a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
+        /* outgrew the rows of this launch (nothing written beyond them): the host re-integrates exactly sized */
+        if (wr && status == CV_SUCCESS && np > a.traj_cap)
+            (void)__hip_atomic_fetch_max(a.overflow, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     int64_t st[SA_N_STATS];
     SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
     accumulate_stats(m, st);
@@ -2077,4 +2082,4 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 }
 
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance} read back by sa_solver_create() */
-extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, 1, 0};
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, SA_DEVICE_ABI_VERSION, 1, 0};

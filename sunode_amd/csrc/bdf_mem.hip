@@ -1470,17 +1470,17 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             else if (r == 1) {
                 nstloc++;
                 if (store) {
-                    if (wr && np >= a.traj_cap) { status = SA_TRAJ_FULL; done = true; }
+                    if (np >= a.traj_max) { status = SA_TRAJ_FULL; done = true; }    /* bounded in every store mode */
                     else {
 #ifdef SA_HERMITE
-                        if (wr) store_hermite(m, trec + (int64_t)np * TREC * tS, tS, m.tn, false);
+                        if (wr && np < a.traj_cap) store_hermite(m, trec + (int64_t)np * TREC * tS, tS, m.tn, false);
 #else
                         SFOR_DOWN(j, QMAX, 1) hT[j] = hT[j - 1]; SEND
                         hT[0] = m.tn;
                         for (int j = QMAX; j >= 1; j--)
                             for (int i = 0; i < NS; i++) W(m, O_HY, j * NS + i) = W(m, O_HY, (j - 1) * NS + i);
                         for (int i = 0; i < NS; i++) W(m, O_HY, i) = ZN(m, 0, i);
-                        if (wr) store_table(m, trec + (int64_t)np * TREC * tS, tS, m.qu, fabs(hT[0] - hT[1]), hT);
+                        if (wr && np < a.traj_cap) store_table(m, trec + (int64_t)np * TREC * tS, tS, m.qu, fabs(hT[0] - hT[1]), hT);
 #endif
                         np++;
                     }
@@ -1504,7 +1504,12 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
         for (int j = 0; j < a.n_t * NS; j++) yo[j] = SA_NAN;
     }
     a.status[inst] = status;
-    if (store) a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
+    if (store) {
+        a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
+        /* outgrew the rows of this launch (nothing written beyond them): the host re-integrates exactly sized */
+        if (wr && status == CV_SUCCESS && np > a.traj_cap)
+            (void)__hip_atomic_fetch_max(a.overflow, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     int64_t st[SA_N_STATS];
     SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
     accumulate_stats(m, st);
@@ -1792,4 +1797,4 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 }
 
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance, workspace doubles per instance} */
-extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, 1, WS_DOUBLES};
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, SA_DEVICE_ABI_VERSION, 1, WS_DOUBLES};

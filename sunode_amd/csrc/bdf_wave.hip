@@ -2432,7 +2432,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
             else if (r == 1) {
                 nstloc++;
                 if (store) {
-                    if (wr && np >= a.traj_cap) { status = SA_TRAJ_FULL; done = true; }
+                    if (np >= a.traj_max) { status = SA_TRAJ_FULL; done = true; }    /* bounded in every store mode */
                     else {
                         SFOR_DOWN(j, QMAX, 1) { hT[j] = hT[j - 1]; SFOR(s, 0, RS) hY[j][s] = hY[j - 1][s]; SEND } SEND
                         hT[0] = m.tn;
@@ -2441,10 +2441,10 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
                         {
                             double ydp[RS];
                             SFOR(s, 0, RS) ydp[s] = (1.0 / m.h) * m.zn[1][s]; SEND
-                            if (wr) store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], ydp);
+                            if (wr && np < a.traj_cap) store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], ydp);
                         }
 #else
-                        if (wr) store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
+                        if (wr && np < a.traj_cap) store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
 #endif
                         np++;
                     }
@@ -2472,7 +2472,12 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     }
     if (m.li == 0) {
         a.status[inst] = status;
-        if (store) a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
+        if (store) {
+            a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
+            /* outgrew the rows of this launch (nothing written beyond them): the host re-integrates exactly sized */
+            if (wr && status == CV_SUCCESS && np > a.traj_cap)
+                (void)__hip_atomic_fetch_max(a.overflow, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         int64_t st[SA_N_STATS];
         SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
         accumulate_stats(m, st);
@@ -2673,4 +2678,4 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 }
 
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance, workspace doubles per instance} */
-extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, 1, G * SA_WAVES, WS_DOUBLES};
+extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, SA_DEVICE_ABI_VERSION, G * SA_WAVES, WS_DOUBLES};

@@ -29,16 +29,26 @@
                                 points the instance WOULD store (sizes the arena tiles of the re-integration, see
                                 sunode_amd.cpp "trajectory arena") */
 
-/* status of an instance whose stored trajectory does not fit the rows the arena was launched with.  Internal:
-   the host library catches it and re-integrates with exactly sized tiles; it only reaches the caller
-   (as SA_STATUS_ARENA_FULL) when a single 64-instance tile exceeds sa_options.traj_capacity / arena_bytes. */
+/* status of an instance that would store more than traj_max (= sa_options.traj_capacity) points: the integration
+   stops there (no unbounded pass, whatever the mode) and the outputs are NaN like for any other failure; the value is
+   SA_STATUS_ARENA_FULL of include/sunode_amd.h.  An instance that merely outgrows the rows the arena was LAUNCHED
+   with (traj_cap) is not a failure: it keeps integrating without arena writes, reports its full point count in
+   traj_np and raises *overflow (atomic max of such counts); the host library sees that at the start of the backward
+   call and re-integrates with exactly sized tiles (sunode_amd.cpp "trajectory arena"). */
 #define SA_TRAJ_FULL (-9001)
 
 #define SA_N_STATS 16
 
+/* sa_meta[3] of a code object; sa_solver_create() rejects any other value (= SA_ABI_VERSION of sunode_amd.h).
+   2: arena records instance-major (traj_istride), SA_MODE_ADJ_COUNT, traj_max / overflow in sa_fwd_args */
+#define SA_DEVICE_ABI_VERSION 2
+
 typedef struct {
     int32_t B, n_t, mode, mxstep, max_retries, traj_cap, rem_stride, traj_istride;
     int64_t traj_stride;      /* record (instance i, point s) at traj + (i * traj_istride + s * traj_stride) * record size */
+    int32_t traj_max;         /* store modes: most points an instance may produce (SA_TRAJ_FULL beyond) */
+    int32_t reserved0;
+    int32_t *overflow;        /* store modes: atomic max of the point counts of instances with more than traj_cap points */
     double t0, rtol;
     const double *atol;
     const double *y0, *ps, *pr, *tvals;

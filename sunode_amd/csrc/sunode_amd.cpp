@@ -18,6 +18,8 @@
 #include "../../include/sunode_amd.h"
 #include "sa_device_abi.h"
 
+static_assert(SA_DEVICE_ABI_VERSION == SA_ABI_VERSION, "sa_device_abi.h and include/sunode_amd.h disagree on the device ABI");
+
 static thread_local std::string g_err;
 
 static int fail(int code, const char *fmt, ...)
@@ -93,6 +95,13 @@ struct sa_solver {
     int32_t fwd_n_t = 0;
     DevBuf t_yout, t_status, t_stats, t_np;   /* outputs of the re-integration (discarded: identical to the forward call's) */
     int32_t rows_hint = 0;         /* largest per-instance point count seen so far on this handle */
+    /* the forward call only enqueues; whether its trajectories are resident is settled at the start of the backward
+       call (resolve_forward) from the device-side overflow word */
+    bool pending = false;          /* a forward batch was launched and its arena outcome has not been read yet */
+    bool resident_attempt = false; /* ... it was launched with arena writes (rows = traj_rows) */
+    DevBuf d_overflow;             /* int32: max point count of the instances that outgrew traj_rows (0: none) */
+    size_t budget = 0;             /* arena budget of the last forward call (the backward call must use the same) */
+    std::vector<int32_t> full_idx; /* instances whose 64-instance group exceeds the budget: backward status ARENA_FULL */
     int64_t stat_tiles = 0, stat_arena_bytes = 0;
     /* staging for SA_MEM_HOST calls */
     DevBuf s_y0, s_ps, s_pr, s_tvals, s_yout, s_status, s_stats, s_grads, s_gout, s_lout;
@@ -208,7 +217,7 @@ extern "C" void sa_solver_destroy(sa_solver *s)
     DevBuf *bufs[] = {&s->d_atol, &s->traj, &s->traj_np, &s->fwd_status, &s->keep_y0, &s->keep_tvals,
                       &s->t_yout, &s->t_status, &s->t_stats, &s->t_np, &s->s_y0,
                       &s->s_ps, &s->s_pr, &s->s_tvals, &s->s_yout, &s->s_status, &s->s_stats, &s->s_grads,
-                      &s->s_gout, &s->s_lout, &s->ws, &s->d_constraints};
+                      &s->s_gout, &s->s_lout, &s->ws, &s->d_constraints, &s->d_overflow};
     for (DevBuf *b : bufs) b->release();
     for (DevBuf &b : s->s_misc) b.release();
     for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -259,9 +268,16 @@ extern "C" int sa_synchronize(sa_solver *s)
     return SA_OK;
 }
 
+static int resolve_forward(sa_solver *s);
+
 extern "C" int sa_arena_info(sa_solver *s, int64_t *arena_bytes, int64_t *tiles, int32_t *tiled)
 {
     if (!s) return fail(SA_ERR_ARG, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    {
+        int rc0 = resolve_forward(s);
+        if (rc0) return rc0;
+    }
     if (arena_bytes) *arena_bytes = s->stat_arena_bytes;
     if (tiles) *tiles = s->stat_tiles;
     if (tiled) *tiled = s->tiled ? 1 : 0;
@@ -356,6 +372,7 @@ static int launch_forward(sa_solver *s, const FwdLaunch &f)
     memset(&a, 0, sizeof a);
     a.B = f.B; a.n_t = f.n_t; a.mode = f.mode; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_fwd;
     a.traj_cap = f.rows; a.rem_stride = f.rem_stride;
+    a.traj_max = s->opt.traj_capacity; a.overflow = (int32_t *)s->d_overflow.p;
     a.t0 = f.t0; a.rtol = s->opt.rtol; a.atol = (const double *)s->d_atol.p;
     a.y0 = f.y0; a.ps = f.ps; a.pr = f.pr; a.tvals = f.tvals; a.y_out = f.y_out; a.status = f.status; a.stats = f.stats;
     a.constraints = s->have_constraints ? (const double *)s->d_constraints.p : nullptr;
@@ -404,57 +421,42 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
         HIP_TRY(hipEventRecord(s->ev[1], s->stream));
         s->have_fwd_time = true;
     } else {
+        /* Enqueue only (no host synchronisation: SA_MEM_DEVICE callers overlap this with their own work).  Resident
+           attempt when the rows this handle expects fit the budget, otherwise the pass that only counts; either way
+           the kernel delivers y_out / status / stats and the per-instance point counts, and raises *overflow when an
+           instance outgrew the rows.  The backward call reads that word and decides (resolve_forward). */
         const int64_t stride = round64(B);
         const size_t rec = record_bytes(s), budget = arena_budget(s);
+        s->budget = budget;
         const int64_t fit_rows = (int64_t)(budget / ((size_t)stride * rec));
         int64_t want = s->rows_hint > 0 ? (int64_t)(1.25 * s->rows_hint) + 8 : SA_FIRST_ROWS;
         if (want < SA_FIRST_ROWS) want = SA_FIRST_ROWS;
         if (want > s->opt.traj_capacity) want = s->opt.traj_capacity;
         if ((rc = s->traj_np.ensure(sizeof(int32_t) * stride))) return rc;
         if ((rc = s->fwd_status.ensure(sizeof(int32_t) * stride))) return rc;
+        if ((rc = s->d_overflow.ensure(sizeof(int32_t)))) return rc;
+        if ((rc = s->keep_y0.ensure(sizeof(double) * nB * (size_t)(s->n > 0 ? s->n : 1)))) return rc;
+        if ((rc = s->keep_tvals.ensure(sizeof(double) * (size_t)n_t))) return rc;
         f.traj_np = (int32_t *)s->traj_np.p;
-        s->h_scratch.resize(nB);
-        bool resident = false;
+        HIP_TRY(hipMemsetAsync(s->d_overflow.p, 0, sizeof(int32_t), s->stream));
         HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-        if (want <= fit_rows) {                       /* resident attempt */
+        s->resident_attempt = (want <= fit_rows);
+        if (s->resident_attempt) {
             if ((rc = s->traj.ensure((size_t)want * (size_t)stride * rec))) return rc;
             f.mode = SA_MODE_ADJ_FWD; f.rows = (int32_t)want; f.stride = stride;
-            if ((rc = launch_forward(s, f))) return rc;
-            HIP_TRY(hipMemcpyAsync(s->h_scratch.data(), d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
-            resident = true;
-            for (size_t i = 0; i < nB; i++) if (s->h_scratch[i] == SA_TRAJ_FULL) { resident = false; break; }
-            if (resident) { s->traj_stride = stride; s->traj_rows = (int32_t)want; s->stat_arena_bytes = (int64_t)((size_t)want * stride * rec); }
-        }
-        if (!resident) {                              /* counting pass: same integration, nothing stored */
+            s->traj_stride = stride; s->traj_rows = (int32_t)want;
+        } else {
             f.mode = SA_MODE_ADJ_COUNT; f.rows = 2; f.stride = stride;
-            if ((rc = launch_forward(s, f))) return rc;
-            s->h_np.resize(nB);
-            HIP_TRY(hipMemcpyAsync(s->h_np.data(), s->traj_np.p, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
-            if ((rc = s->keep_y0.ensure(sizeof(double) * nB * (size_t)(s->n > 0 ? s->n : 1)))) return rc;
-            if ((rc = s->keep_tvals.ensure(sizeof(double) * (size_t)n_t))) return rc;
-            HIP_TRY(hipMemcpyAsync(s->keep_y0.p, d_y0, sizeof(double) * nB * s->n, hipMemcpyDeviceToDevice, s->stream));
-            HIP_TRY(hipMemcpyAsync(s->keep_tvals.p, d_tv, sizeof(double) * (size_t)n_t, hipMemcpyDeviceToDevice, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
-            /* instances beyond traj_capacity, or whose 64-instance group cannot fit the budget: SA_STATUS_ARENA_FULL */
-            const int64_t group_rows = (int64_t)(budget / ((size_t)64 * rec));
-            const int64_t max_rows = s->opt.traj_capacity < group_rows ? s->opt.traj_capacity : group_rows;
-            int32_t seen = 0;
-            const int32_t full = SA_STATUS_ARENA_FULL;
-            for (size_t i = 0; i < nB; i++) {
-                if (s->h_np[i] > seen) seen = s->h_np[i];
-                if (s->h_np[i] > max_rows) {
-                    s->h_np[i] = 0;
-                    HIP_TRY(hipMemcpyAsync(d_status + i, &full, sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-                    HIP_TRY(hipStreamSynchronize(s->stream));
-                }
-            }
-            if (seen > s->rows_hint) s->rows_hint = seen;
         }
+        if ((rc = launch_forward(s, f))) return rc;
         HIP_TRY(hipEventRecord(s->ev[1], s->stream));
         s->have_fwd_time = true;
-        s->tiled = !resident;
+        /* what a re-integration needs (the caller may reuse its buffers after this call) */
+        HIP_TRY(hipMemcpyAsync(s->keep_y0.p, d_y0, sizeof(double) * nB * s->n, hipMemcpyDeviceToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->keep_tvals.p, d_tv, sizeof(double) * (size_t)n_t, hipMemcpyDeviceToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->fwd_status.p, d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToDevice, s->stream));
+        s->pending = true;
+        s->tiled = !s->resident_attempt;
         s->fwd_B = B;
         s->fwd_t0 = t0;
         s->fwd_n_t = n_t;
@@ -542,6 +544,49 @@ extern "C" int sa_solve_forward_batch(sa_solver *s, int mem, int32_t B, const do
     return forward_common(s, SA_MODE_ADJ_FWD, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats);
 }
 
+/* Settle the arena outcome of the last forward batch (one 4-byte read-back; the only host synchronisation of a
+   device-memory forward + backward pair, and it sits in the backward call).  Resident and nothing overflowed: the
+   backward kernel reads the arena.  Otherwise fetch the point counts and switch to tiled re-integration; a
+   64-instance group that cannot fit the budget even alone is taken out (backward status SA_STATUS_ARENA_FULL). */
+static int resolve_forward(sa_solver *s)
+{
+    if (!s->pending) return SA_OK;
+    s->pending = false;
+    const size_t nB = (size_t)s->fwd_B;
+    const size_t rec = record_bytes(s);
+    s->full_idx.clear();
+    if (s->resident_attempt) {
+        int32_t ov = 0;
+        HIP_TRY(hipMemcpyAsync(&ov, s->d_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (ov == 0) {
+            s->tiled = false;
+            s->stat_arena_bytes = (int64_t)((size_t)s->traj_rows * (size_t)s->traj_stride * rec);
+            return SA_OK;
+        }
+    }
+    s->tiled = true;
+    s->h_np.resize(nB);
+    s->h_scratch.resize(nB);
+    HIP_TRY(hipMemcpyAsync(s->h_np.data(), s->traj_np.p, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_scratch.data(), s->fwd_status.p, sizeof(int32_t) * nB, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int64_t group_rows = (int64_t)(s->budget / ((size_t)64 * rec));
+    int32_t seen = 0;
+    for (size_t i = 0; i < nB; i++) {
+        if (s->h_np[i] > seen) seen = s->h_np[i];
+        if (s->h_np[i] > group_rows) {              /* (more than traj_capacity points: already failed in the kernel) */
+            s->h_np[i] = 0;
+            s->h_scratch[i] = SA_STATUS_ARENA_FULL;
+            s->full_idx.push_back((int32_t)i);
+        }
+    }
+    if (!s->full_idx.empty())                       /* the library-owned copy: the backward kernel answers CV_NO_FWD */
+        HIP_TRY(hipMemcpyAsync(s->fwd_status.p, s->h_scratch.data(), sizeof(int32_t) * nB, hipMemcpyHostToDevice, s->stream));
+    if (seen > s->rows_hint) s->rows_hint = seen;
+    return SA_OK;
+}
+
 extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const double *ps, const double *pr,
                                        int32_t rem_stride, double t0, double tend, const double *tvals,
                                        int32_t n_t, const double *grads, int64_t grads_stride, double *grad_out,
@@ -563,6 +608,10 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
     if (grads_stride != 0 && grads_stride != (int64_t)n_t * s->n) return fail(SA_ERR_ARG, "grads_stride must be 0 or n_t*n");
     HIP_TRY(hipSetDevice(s->device));
     if (B == 0) return SA_OK;
+    {
+        int rc0 = resolve_forward(s);
+        if (rc0) return rc0;
+    }
     const size_t nB = (size_t)B;
     const double *d_ps = ps, *d_pr = pr, *d_tv = tvals, *d_g = grads;
     double *d_gout = grad_out, *d_lout = lamda_out, *d_lall = lamda_all_out, *d_qall = quad_all_out;
@@ -604,7 +653,7 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
         if ((rc = launch(s, s->k_backward, B, &a, sizeof a, s->group))) return rc;
     } else {
         /* tiled: re-integrate the forward problem tile by tile with exactly sized storage, adjoint per tile */
-        const size_t rec = record_bytes(s), budget = arena_budget(s);
+        const size_t rec = record_bytes(s), budget = s->budget;      /* the forward call's (not re-evaluated) */
         const size_t np_ = (size_t)s->p, nn = (size_t)s->n;
         /* tile boundaries: as few tiles as the budget allows (greedy over 64-instance groups), then balanced --
            equal-sized tiles keep every launch wide enough to fill the chip -- as long as each still fits */
@@ -690,6 +739,11 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
     }
     HIP_TRY(hipEventRecord(s->ev[3], s->stream));
     s->have_bwd_time = true;
+    if (!s->full_idx.empty()) {     /* instances taken out by resolve_forward: say why (their gradients are NaN already) */
+        static const int32_t full = SA_STATUS_ARENA_FULL;
+        for (int32_t i : s->full_idx)
+            HIP_TRY(hipMemcpyAsync(d_status + i, &full, sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    }
     if (mem == SA_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(grad_out, d_gout, sizeof(double) * nB * s->p, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipMemcpyAsync(lamda_out, d_lout, sizeof(double) * nB * s->n, hipMemcpyDeviceToHost, s->stream));

@@ -88,6 +88,15 @@ def extract_matvec(exprs, vsyms, fixed, tag):
                     M[(i, j)] = (int(ca), fa[0])
                 else:
                     rest[i].setdefault(j, []).append(a)
+    # one canonical term list per (output, v_j): an unexpanded right-hand side such as y0*(a + b) + a*y0 leaves the same
+    # atom twice in rest[i][j]; merged here (2*a) so that the shared-term bookkeeping below removes and adds whole terms
+    for i in range(n_out):
+        for j in list(rest[i]):
+            terms = [a for a in sym.Add.make_args(sym.Add(*rest[i][j])) if a != 0]
+            if terms:
+                rest[i][j] = terms
+            else:
+                del rest[i][j]
     cols = sorted({j for (_, j) in M})
     if not cols or len(M) < MATVEC_MIN_ENTRIES or len(M) < MATVEC_MIN_FILL * n_out * len(cols):
         return None

@@ -19,7 +19,7 @@ import numpy as np
 
 try:
     import pytensor.tensor as pt
-    from pytensor.gradient import grad_not_implemented
+    from pytensor.gradient import DisconnectedType, grad_not_implemented
     from pytensor.graph.basic import Constant, Variable
     from pytensor.graph.op import Op
 except ImportError as exc:  # pragma: no cover - depends on the environment
@@ -124,6 +124,28 @@ class EvalRhs(Op):
         outputs[0][0] = res["rhs"]
 
 
+class EvalRhsBatch(Op):
+    """rhs(t_i, y_bi) for every draw b and output time i (d/dtvals of the batched Op)."""
+    itypes = [pt.dmatrix, pt.dvector, pt.dtensor3, pt.dvector]      # params [B,p], params_fixed [r], y [B,n_t,n], tvals
+    otypes = [pt.dtensor3]
+    __props__ = ("_solver_id",)
+
+    def __init__(self, solver):
+        self._solver = solver
+        self._solver_id = id(solver)
+
+    def perform(self, node, inputs, outputs):
+        params, params_fixed, y, tvals = inputs
+        eng = self._solver._engine()
+        B, n_t, n = y.shape
+        fixed = self._solver._problem.extend_remainder(params_fixed) if len(params_fixed) else params_fixed
+        res = eng.eval_callbacks(np.tile(tvals, B), y.reshape(B * n_t, n), np.zeros((B * n_t, n)),
+                                 np.repeat(params, n_t, axis=0), np.tile(fixed, (B * n_t, 1)))
+        if res["codes"][:, 0].any():
+            raise ValueError("Bad ode rhs return code: 1")
+        outputs[0][0] = res["rhs"].reshape(B, n_t, n)
+
+
 class SolveODE(Op):
     """Forward solve + forward sensitivities of one draw (reference ``SolveODE``, :186-264)."""
     itypes = [pt.dvector, pt.dvector, pt.dvector, pt.dscalar, pt.dvector]   # y0, params, fixed, t0, tvals
@@ -147,7 +169,7 @@ class SolveODE(Op):
         _, params, params_fixed, t0, tvals = inputs
         # as the reference (:253): a loss that depends on the sensitivity output would need second-order
         # sensitivities; fail loudly instead of returning an incomplete gradient
-        if type(getattr(g_sens, "type", g_sens)).__name__ != "DisconnectedType" and str(g_sens) != "<DisconnectedType>":
+        if not isinstance(getattr(g_sens, "type", None), DisconnectedType):
             raise NotImplementedError("SolveODE: gradients through the sensitivity output are not implemented")
         solution, sens = self(*inputs)
         return [
@@ -224,9 +246,12 @@ class SolveODEAdjointBatch(Op):
     def grad(self, inputs, g):
         g, = g
         y0, params, params_fixed, t0, tvals = inputs
+        solution = self(*inputs)
         lamda, gradient = SolveODEAdjointBatchBackward(self._solver)(y0, params, params_fixed, g, t0, tvals)
+        # the output grid is shared by the draws: its gradient sums over the batch axis (per draw: reference :294-308)
+        d_tvals = (EvalRhsBatch(self._solver)(params, params_fixed, solution, tvals) * g).sum(-1).sum(0)
         return [-lamda, gradient, grad_not_implemented(self, 2, params_fixed),
-                grad_not_implemented(self, 3, t0), grad_not_implemented(self, 4, tvals)]
+                grad_not_implemented(self, 3, t0), d_tvals]
 
 
 class SolveODEAdjointBatchBackward(Op):

@@ -206,3 +206,33 @@ def test_full_size_hermite_and_sensitivities_lv():
     assert (sso == 0).all()
     np.testing.assert_array_equal(ys[idx], yso)
     np.testing.assert_array_equal(S[idx], So)
+
+
+def test_bench_rank_under_an_rccl_process_group_of_one(tmp_path):
+    """the N > 1 branch of bench.py on the one GPU there is -- `run_rank` with the product `GpuEngine`
+    under a world-size-1 `nccl` (= RCCL) process group: init_process_group(device_id=...), the barriers, the device
+    all-reduces of the elapsed time / failed count and destroy_process_group all execute, and the line it prints
+    equals what the same rank computes without a group (same kernels, same shard)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch",
+           "4096", "--no-cpu-baseline", "--no-extra-configs"]
+    lines = {}
+    for tag, extra in (("group", ["--force-dist"]), ("plain", [])):
+        res = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines[tag] = json.loads(res.stdout.strip().splitlines()[-1])
+    g, p = lines["group"], lines["plain"]
+    assert g["n_gpus"] == 1 and g["config"]["failed_instances"] == 0 and g["value"] > 0
+    for key in ("fwd_steps_mean", "bwd_steps_mean", "stored_points_mean"):
+        assert g["work"][key] == p["work"][key]

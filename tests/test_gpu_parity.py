@@ -812,9 +812,10 @@ def test_empty_batch_and_no_derivative_params():
 
 
 def test_backward_reports_failed_forward_and_arena_limit():
-    """Instances whose stored trajectory exceeds max_steps come back SA_STATUS_ARENA_FULL (-9001, NOT
-    CV_TOO_MUCH_WORK) from the forward call -- their forward solution itself is complete -- and CV_NO_FWD (-102)
-    with NaN gradients from the backward call; the other instances of the batch are unaffected."""
+    """Instances that would store more than max_steps points come back SA_STATUS_ARENA_FULL (-9001, NOT
+    CV_TOO_MUCH_WORK) from the forward call -- the integration stops at the bound (no unbounded pass), outputs NaN
+    like every other failure -- and CV_NO_FWD (-102) with NaN gradients from the backward call; the other instances
+    of the batch are unaffected."""
     from sunode_amd.solver import AdjointSolver
     prob = make_problem("robertson")
     d = robertson_batch(8)
@@ -834,7 +835,8 @@ def test_backward_reports_failed_forward_and_arena_limit():
     assert full.any() and not full.all()
     assert (st[full] == -9001).all() and (st[~full] == 0).all()
     assert ((stb == -102) == full).all() and (stb[~full] == 0).all()
-    np.testing.assert_array_equal(y, yr)                    # the forward solution does not depend on the arena
+    np.testing.assert_array_equal(y[~full], yr[~full])
+    assert np.isnan(y[full]).all() and (stats[full, 8] == cap).all()       # stopped at the bound
     assert np.isnan(g[full]).all() and np.isnan(lam[full]).all()
     np.testing.assert_array_equal(g[~full], gr[~full])
     np.testing.assert_array_equal(lam[~full], lr[~full])

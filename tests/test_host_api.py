@@ -23,7 +23,10 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(_native.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sa_abi_version() == 1
+    want = int(re.search(r"#define SA_ABI_VERSION (\d+)", header).group(1))
+    assert L.sa_abi_version() == want == 2         # 2: instance-major arena records, bounded store modes
+    abi = open(os.path.join(ROOT, "sunode_amd", "csrc", "sa_device_abi.h")).read()
+    assert int(re.search(r"#define SA_DEVICE_ABI_VERSION (\d+)", abi).group(1)) == want
 
 
 def test_native_create_fails_loudly_without_gpu_or_code_object():

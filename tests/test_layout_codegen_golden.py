@@ -148,3 +148,27 @@ def test_matvec_form_of_dense_linear_blocks():
         assert got["codes"].tolist() == [0, 0, 0, 0, 0]
     # a problem without such a block keeps the plain form
     assert not make_problem("seir")._matvec and "SA_MATVEC(" not in make_problem("seir").native_source().split("sa_logaddexp")[1]
+
+
+def test_matvec_regrouping_of_an_unexpanded_rhs_is_exact():
+    """the same coefficient atom twice for one (output, v_j) pair -- y_j*(g + b) + g*y_j on every row of a
+    dense 16 x 16 block, nothing expanded -- used to lose one g*y_j per output (both occurrences removed, the shared
+    term added once).  Substituting the matrix-vector symbols back must give the original expressions exactly."""
+    import sympy as sym
+    from sunode_amd.symode.problem import extract_matvec
+    n = 16
+    y = sym.symbols("y0:%d" % n, positive=True)
+    K = [[sym.Symbol("K_%d_%d" % (i, j), real=True) for j in range(n)] for i in range(n)]
+    g, b = sym.symbols("g b", real=True)
+    fixed = {K[i][j] for i in range(n) for j in range(n)}
+    exprs = [sum(K[i][j] * y[j] for j in range(n)) + y[0] * (g + b) + g * y[0] + (i + 1) * b * y[3] - y[i] ** 2
+             for i in range(n)]
+    out = extract_matvec(exprs, list(y), fixed, "t")
+    assert out is not None
+    new, mv, entries = out
+    back = {mv[i]: sum(entries[j][i][0] * entries[j][i][1] * y[j] for j in range(n) if entries[j][i] is not None)
+            for i in range(n)}
+    for i in range(n):
+        assert sym.expand(new[i].subs(back) - exprs[i]) == 0, i
+    # the shared part really was pulled out once (2*g + b multiplies y0 in every output)
+    assert all(sym.expand(new[i]).coeff(y[0]).subs({mv[i]: 0}) == 2 * g + b for i in range(n))

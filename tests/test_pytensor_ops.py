@@ -167,10 +167,53 @@ def test_solve_ivp_forward_sensitivity_grad_chain(ops):
     givens = {alpha: 0.1, beta: 0.2}
     w = np.cos(np.arange(42.0)).reshape(21, 2)
     node = flat.owner
-    gl = node.op.grad(node.inputs, [pt.as_tensor_variable(w), grad_mod.DisconnectedType()])
+    gl = node.op.grad(node.inputs, [pt.as_tensor_variable(w), grad_mod.DisconnectedType()()])
     d_params = pytensor.evaluate(gl[1], givens)
     _, _, dp_o = _oracle_gradients(tv, np.array([1.0, 0.1]), np.array([0.1, 0.2, 0.3, 0.4]), w, tol)
     np.testing.assert_allclose(d_params, dp_o, rtol=2e-6)          # two different gradient methods at tol 1e-9
     assert pytensor.evaluate(flat_sens, givens).shape == (21, 2, 2)
     with pytest.raises(NotImplementedError):
         node.op.grad(node.inputs, [pt.as_tensor_variable(w), pt.as_tensor_variable(np.zeros((21, 2, 2)))])
+
+
+def test_batched_op_grad_chain_vs_oracle(ops):
+    """``SolveODEAdjointBatch.grad``: forward Op -> SolveODEAdjointBatchBackward -> EvalRhsBatch, evaluated through the
+    graph for three draws with per-draw cotangents; every row must equal the ORACLE's gradients of that draw bit for
+    bit, and d/dtvals (the grid is shared by the draws) = sum_b (rhs(y_b(t_i)) * g_bi).sum(-1)."""
+    pytensor = pytest.importorskip("pytensor")
+    if not hasattr(pytensor, "evaluate"):
+        pytest.skip("graph evaluation helper of the stub only")
+    pt = importlib.import_module("pytensor.tensor")
+    from sunode_amd.solver import AdjointSolver
+    tol = 1e-9
+    solver = AdjointSolver(make_problem("lv"), abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol,
+                           quad_abstol=tol, quad_reltol=tol)
+    tv = np.linspace(0, 10, 21)
+    Y0 = np.array([[1.0, 0.1], [1.1, 0.12], [0.9, 0.2]])
+    P = np.array([[0.1, 0.2], [0.12, 0.18], [0.09, 0.25]])
+    fixed = np.array([0.3, 0.4])
+    W = np.cos(np.arange(3 * 42.0)).reshape(3, 21, 2)
+    y0v, pv = pt.dmatrix("y0"), pt.dmatrix("params")
+    flat = ops.SolveODEAdjointBatch(solver)(y0v, pv, fixed, 0.0, tv)
+    node = flat.owner
+    gl = node.op.grad(node.inputs, [pt.as_tensor_variable(W)])
+    assert len(gl) == 5 and type(gl[2]).__name__ == "NotImplementedGrad" and type(gl[3]).__name__ == "NotImplementedGrad"
+    givens = {y0v: Y0, pv: P}
+    y, d_y0, d_params, d_tvals = pytensor.evaluate([flat, gl[0], gl[1], gl[4]], givens)
+    want_tv = np.zeros(len(tv))
+    for b in range(3):
+        yo, dy0_o, dp_o = _oracle_gradients(tv, Y0[b], np.concatenate([P[b], fixed]), W[b], tol)
+        np.testing.assert_array_equal(y[b], yo)
+        np.testing.assert_array_equal(d_params[b], dp_o)
+        np.testing.assert_array_equal(d_y0[b], dy0_o)
+        rhs = np.stack([P[b, 0] * yo[:, 0] - P[b, 1] * yo[:, 1] * yo[:, 0],
+                        0.4 * yo[:, 0] * yo[:, 1] - 0.3 * yo[:, 1]], axis=1)
+        want_tv += (rhs * W[b]).sum(-1)
+    np.testing.assert_allclose(d_tvals, want_tv, rtol=1e-12)
+    # one entry of d/dtvals against a finite difference of the loss through the graph
+    k, eps = 7, 1e-6
+    def loss(tvk):
+        tvp = tv.copy(); tvp[k] = tvk
+        return (pytensor.evaluate(ops.SolveODEAdjointBatch(solver)(y0v, pv, fixed, 0.0, tvp), givens) * W).sum()
+    fd = (loss(tv[k] + eps) - loss(tv[k] - eps)) / (2 * eps)
+    assert abs(fd - d_tvals[k]) < 1e-5 * max(1.0, abs(d_tvals[k]))

@@ -189,9 +189,10 @@ def splitmix64(seed: int, idx: np.ndarray) -> np.ndarray:
         return z ^ (z >> np.uint64(31))
 
 
-def std_normal(seed: int, stream: int, n: int) -> np.ndarray:
-    """n standard normals; element i depends only on (seed, stream, i)."""
-    idx = np.arange(n, dtype=np.uint64)
+def std_normal(seed: int, stream: int, n: int, idx=None) -> np.ndarray:
+    """n standard normals; element i depends only on (seed, stream, i).  ``idx``: only these elements (a rank's
+    shard of a global batch is generated without materialising the batch)."""
+    idx = np.arange(n, dtype=np.uint64) if idx is None else np.asarray(idx, dtype=np.uint64)
     base = np.uint64(stream) << np.uint64(40)
     u1 = (splitmix64(seed, base + np.uint64(2) * idx) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
     u2 = (splitmix64(seed, base + np.uint64(2) * idx + np.uint64(1)) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
@@ -202,29 +203,30 @@ def std_normal(seed: int, stream: int, n: int) -> np.ndarray:
 # --------------------------------------------------------------------------
 # synthetic batches (BASELINE.json configs 2-5)
 # --------------------------------------------------------------------------
-def lv_batch(B: int, seed: int = SEED):
+def lv_batch(B: int, seed: int = SEED, idx=None):
     """Config 2: p = p0*exp(0.25 z), y0 = (1, 0.1)*exp(0.1 z').  Returns full params [B,4]
-    in declaration order (alpha, beta, gamma, delta), y0 [B,2], tvals, t0."""
+    in declaration order (alpha, beta, gamma, delta), y0 [B,2], tvals, t0.
+    ``idx`` (all batch generators): the global draw indices wanted -- rows idx of the B-draw batch."""
     p0 = np.array([0.1, 0.2, 0.3, 0.4])
-    z = np.stack([std_normal(seed, s, B) for s in range(4)], axis=1)
-    zy = np.stack([std_normal(seed, 8 + s, B) for s in range(2)], axis=1)
+    z = np.stack([std_normal(seed, s, B, idx) for s in range(4)], axis=1)
+    zy = np.stack([std_normal(seed, 8 + s, B, idx) for s in range(2)], axis=1)
     params = p0 * np.exp(0.25 * z)
     y0 = np.array([1.0, 0.1]) * np.exp(0.1 * zy)
     return dict(params=params, y0=y0, tvals=np.linspace(0, 10), t0=0.0,
                 rtol=1e-8, atol=1e-8)
 
 
-def robertson_batch(B: int, seed: int = SEED):
+def robertson_batch(B: int, seed: int = SEED, idx=None):
     """Config 3: k = k0*exp(0.1 z), y0 = (1, 0, 0), T = 4e4, rtol 1e-8 / atol 1e-10."""
     k0 = np.array([0.04, 1e4, 3e7])
-    z = np.stack([std_normal(seed, 16 + s, B) for s in range(3)], axis=1)
+    z = np.stack([std_normal(seed, 16 + s, B, idx) for s in range(3)], axis=1)
     params = k0 * np.exp(0.1 * z)
-    y0 = np.tile(np.array([1.0, 0.0, 0.0]), (B, 1))
+    y0 = np.tile(np.array([1.0, 0.0, 0.0]), (len(z), 1))
     tvals = np.array([0.0] + [0.4 * 10.0 ** k for k in range(6)])
     return dict(params=params, y0=y0, tvals=tvals, t0=0.0, rtol=1e-8, atol=1e-10)
 
 
-def seir_batch(B: int, seed: int = SEED):
+def seir_batch(B: int, seed: int = SEED, idx=None):
     """Config 4: 4 groups x (S,E,I,R); beta + 4 rates differentiated, C shared."""
     beta0 = np.array([0.30, 0.25, 0.35, 0.20])
     rates0 = np.array([0.2, 0.1, 0.01, 0.02])          # sigma, gamma, mu, nu
@@ -232,22 +234,22 @@ def seir_batch(B: int, seed: int = SEED):
                   [0.3, 1.0, 0.3, 0.2],
                   [0.2, 0.3, 1.0, 0.3],
                   [0.1, 0.2, 0.3, 1.0]])
-    z = np.stack([std_normal(seed, 32 + s, B) for s in range(8)], axis=1)
+    z = np.stack([std_normal(seed, 32 + s, B, idx) for s in range(8)], axis=1)
     sub = np.concatenate([beta0, rates0]) * np.exp(0.1 * z)          # [B, 8] subset order
     pop = np.array([1000.0, 800.0, 1200.0, 600.0])
     I0 = np.array([1.0, 0.0, 2.0, 0.0])
     y0 = np.concatenate([pop - I0, np.zeros(4), I0, np.zeros(4)])
-    return dict(ps=sub, pr=C.ravel(), y0=np.tile(y0, (B, 1)), tvals=np.linspace(0, 100, 51), t0=0.0,
+    return dict(ps=sub, pr=C.ravel(), y0=np.tile(y0, (len(z), 1)), tvals=np.linspace(0, 100, 51), t0=0.0,
                 rtol=1e-8, atol=1e-8)
 
 
-def network_batch(B: int, n: int = 100, seed: int = SEED):
+def network_batch(B: int, n: int = 100, seed: int = SEED, idx=None):
     """Config 5: dense mass-action network, K (n x n) shared fixed, scale(4) differentiated per draw."""
     u = np.abs(std_normal(seed, 64, n * n)).reshape(n, n)
     K = u / n
     scale0 = np.array([1.0, 0.5, 10.0, 0.1])
-    z = np.stack([std_normal(seed, 65 + s, B) for s in range(4)], axis=1)
+    z = np.stack([std_normal(seed, 65 + s, B, idx) for s in range(4)], axis=1)
     ps = scale0 * np.exp(0.1 * z)
     zx = std_normal(seed, 70, n)
-    y0 = np.tile(np.exp(0.3 * zx), (B, 1))
+    y0 = np.tile(np.exp(0.3 * zx), (len(z), 1))
     return dict(ps=ps, pr=K.ravel(), y0=y0, tvals=np.linspace(0, 10, 11), t0=0.0, rtol=1e-8, atol=1e-8)
