@@ -1711,6 +1711,10 @@ typedef struct {
     int max_traj_points;    /* 0 = unbounded; mirrors the device arena capacity */
     int constraints_set, hermite;   /* hermite: CVodeAdjInit(..., CV_HERMITE) instead of CV_POLYNOMIAL */
     double constraints[NSD];    /* CVodeSetConstraints: 0 none, +-1 (>= / <= 0), +-2 (> / < 0); forward problem only */
+    int no_errconQB;            /* 1: CVodeSetQuadErrConB(false) -- the quadratures ride along without a say in the
+                                   step / order control (sunode sets true, solver.py:615; the DVODE pin of the backward
+                                   controller, tools/make_golden_dvode_backward.py, needs the pure adjoint system) */
+    int reserved_pad;
 } orc_config;
 
 typedef struct {
@@ -1866,7 +1870,7 @@ static int solve_backward_one(const orc_config *cfg, const double *ps, const dou
     cvmem *m = (cvmem *)calloc(1, sizeof(cvmem));
     m->ps = ps; m->pr = pr; m->backward = 1; m->tr = tr;
     m->rtol = cfg->rtolB; for (int i = 0; i < NS; i++) m->atol[i] = cfg->atolB;
-    m->quadr = 1; m->errconQ = 1; m->rtolQ = cfg->rtolQB; m->atolQ = cfg->atolQB;
+    m->quadr = 1; m->errconQ = cfg->no_errconQB ? 0 : 1; m->rtolQ = cfg->rtolQB; m->atolQ = cfg->atolQB;
     m->mxstep = cfg->mxstep; m->tstopset = 0;
     double lam[NSD], quad[NQD], quad_out[NQD], tret;
     for (int i = 0; i < NS; i++) lam[i] = 0.0;

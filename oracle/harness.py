@@ -64,7 +64,7 @@ def build_oracle_library(native_source: str, tag: Optional[str] = None, opt: str
 class OracleConfig:
     def __init__(self, n_states, rtol=1e-10, atol=1e-10, rtolB=1e-10, atolB=1e-10,
                  rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
-                 max_retries_bwd=50, max_traj_points=0, constraints=None, hermite=False):
+                 max_retries_bwd=50, max_traj_points=0, constraints=None, hermite=False, errconQB=True):
         nsd = max(n_states, 1)
 
         class _Cfg(ctypes.Structure):
@@ -74,7 +74,8 @@ class OracleConfig:
                         ("mxstep", ctypes.c_int), ("max_retries_fwd", ctypes.c_int),
                         ("max_retries_bwd", ctypes.c_int), ("max_traj_points", ctypes.c_int),
                         ("constraints_set", ctypes.c_int), ("hermite", ctypes.c_int),
-                        ("constraints", ctypes.c_double * nsd)]
+                        ("constraints", ctypes.c_double * nsd), ("no_errconQB", ctypes.c_int),
+                        ("reserved_pad", ctypes.c_int)]
         c = _Cfg()
         c.rtol = rtol
         av = np.broadcast_to(np.asarray(atol, dtype=float), (n_states,)) if n_states else []
@@ -85,6 +86,7 @@ class OracleConfig:
         c.max_traj_points = max_traj_points
         c.constraints_set = 0 if constraints is None else 1
         c.hermite = 1 if hermite else 0
+        c.no_errconQB = 0 if errconQB else 1
         if constraints is not None:
             for i, v in enumerate(np.broadcast_to(np.asarray(constraints, dtype=float), (n_states,))):
                 c.constraints[i] = float(v)

@@ -54,13 +54,54 @@
 #define KPW (64 / G)
 #define W_NQD (W_NQ > 0 ? W_NQ : 1)
 #define W_PIV ((W_NS + 15) / 16 * 16)
+/* LEAN lane groups (G < 64 and at most 64 matrix doubles per lane, i.e. n <= 16 with four lanes, n <= 21 with eight):
+   the LU factors stay in REGISTERS between factorisation and solves (static DPP broadcasts, no LDS matrix at all --
+   16 instances x 2 KB would not fit next to the rest), the Jacobian callback writes straight to the saved copy in the
+   workspace, and the cold per-instance state (interpolation table) lives in LDS instead of registers. */
+#define W_RS_PRE ((W_NS + G - 1) / G)
+#if SA_GROUP <= 8 && (W_NS * W_RS_PRE) <= 64 && !defined(SA_NO_LEAN)
+#define SA_LEAN 1
+#else
+#define SA_LEAN 0
+#endif
+/* a group's slice of the staging vectors starts at an ODD multiple-free stride (doubles): with a power-of-two n
+   the 64/G groups of a wavefront hit the same few banks when they read "their" element i (16 x 16 states: 8-way
+   conflict on every callback input), with an odd stride every group has its own bank pair */
+#define W_NSP (KPW > 1 ? (W_NS | 1) : W_NS)
+#define W_NQP (KPW > 1 ? (W_NQD | 1) : W_NQD)
+__shared__ double s_y[KPW * W_NSP];                 /* callback input: state (backward: interpolated forward state) */
+#if SA_LEAN && (KPW * W_NSP >= W_NS * W_NS)
+#define s_A s_y                                     /* scratch of the pivoting fall-back: ONE matrix, used a group at a time,
+                                                       between callbacks (every callback stages its inputs afresh) */
+#elif SA_LEAN
+__shared__ double s_A[W_NS * W_NS];
+#else
 __shared__ double s_A[KPW * W_NS * W_NS];           /* Newton matrix / its LU, column-major, per instance */
-__shared__ double s_y[KPW * W_NS];                  /* callback input: state (backward: interpolated forward state) */
-__shared__ double s_lam[KPW * W_NS];                /* callback input: adjoint state; scratch for the LU solves */
-__shared__ double s_ps[KPW * W_NQD];                /* differentiated parameters of the instance */
+#endif
+__shared__ double s_lam[KPW * W_NSP];               /* callback input: adjoint state; scratch for the LU solves */
+__shared__ double s_ps[KPW * W_NQP];                /* differentiated parameters of the instance */
 __shared__ uint8_t s_piv[KPW * W_PIV];              /* pivot rows (n <= 128 fits a byte) */
 #define W_NOUT (W_NS > W_NQD ? W_NS : W_NQD)
-__shared__ double s_out[KPW * W_NOUT];              /* output vector of the vector-valued callbacks */
+#define W_NOUTP (KPW > 1 ? (W_NOUT | 1) : W_NOUT)
+__shared__ double s_out[KPW * W_NOUTP];             /* output vector of the vector-valued callbacks */
+#if SA_LEAN && !defined(SA_HERMITE)
+/* the divided-difference record of the current interpolation index, copied from the arena when the index moves
+   (20 + 6 n/G registers per lane otherwise).  Stride: even (16-byte rows) and not a multiple of 16 doubles. */
+#define SA_TAB_LDS 1
+#define W_TREC (8 + 6 * W_NS)
+#define W_TRECP (W_TREC + 2)
+__shared__ double s_tab[KPW * W_TRECP];
+#else
+#define SA_TAB_LDS 0
+#endif
+#if SA_LEAN
+/* COLD per-lane state, parked in LDS across the Newton pass of a step attempt (callbacks, factorisation, solves): the
+   Nordsieck columns 2..5, the saved correction and the whole quadrature history are only touched by predict / rescale
+   / complete / order changes.  Lane-private slots [slot][lane]: no synchronisation, conflict-free. */
+#define W_RQ_PRE (W_NQ > 0 ? (W_NQ + G - 1) / G : 1)
+#define W_NCOLD (5 * W_RS_PRE + 7 * W_RQ_PRE)
+__shared__ double s_cold[W_NCOLD * 64];
+#endif
 /* Workgroup barrier as ONE inline instruction sequence.  In this build pipeline (clang -O0 -> always-inline -> -O3)
    HIP's __syncthreads() stays a real function call: every call site spilled the caller's live VGPRs to scratch and
    reloaded them (140 scratch instructions around the single barrier of the LU's elimination loop -- 14 000 scratch
@@ -100,8 +141,8 @@ static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_
 #define SA_Y(i) sa_yv[i]
 #define SA_LAM(i) sa_lv[i]
 #define SA_PS(j) sa_pv[j]
-#define SA_LDS_VIEWS const double *sa_yv = s_y + sa_grp() * W_NS; const double *sa_lv = s_lam + sa_grp() * W_NS; \
-    const double *sa_pv = s_ps + sa_grp() * W_NQD; (void)sa_yv; (void)sa_lv; (void)sa_pv;
+#define SA_LDS_VIEWS const double *sa_yv = s_y + sa_grp() * W_NSP; const double *sa_lv = s_lam + sa_grp() * W_NSP; \
+    const double *sa_pv = s_ps + sa_grp() * W_NQP; (void)sa_yv; (void)sa_lv; (void)sa_pv;
 typedef __attribute__((address_space(1))) double gdouble;      /* explicit global pointer: cannot alias LDS */
 #define SA_CONST_AS __attribute__((address_space(4)))
 #ifdef SA_WAVE_PR_SCALAR
@@ -410,6 +451,12 @@ struct MatOut {             /* n x n callbacks -> the instance's LDS matrix (slo
     template <int S> __device__ __forceinline__ void put(double x) const { s_A[base + S] = x; }
     __device__ __forceinline__ void put_dyn(int slot, double x) const { s_A[base + slot] = x; }
 };
+struct GMatOut {            /* lean lane groups: n x n callbacks -> the saved Jacobian in the workspace (every lane of the
+                               group holds the same value and writes it: one transaction per group) */
+    gdouble *p;
+    template <int S> __device__ __forceinline__ void put(double x) const { p[S] = x; }
+    __device__ __forceinline__ void put_dyn(int slot, double x) const { p[slot] = x; }
+};
 
 /* ------------------------------------------------------------------------------------ */
 template <bool BWD>
@@ -443,8 +490,14 @@ struct Cw {
     double tfinal;
     int ilast, newdata, have_last, cur_idx;
     double last_t, tlo, thi, tlo2;
+#if !SA_TAB_LDS
     double tab_hdr[8];                /* order, dt, T[6] */
     double tabY[QMAX + 1][RS];
+#endif
+#if SA_LEAN
+    double lu[NS][RS];                /* LU factors of I - gamma*J, rows IDX(r) of every column: live in registers from
+                                         the factorisation to the next one (no LDS matrix) */
+#endif
 #ifdef SA_HERMITE
     double f0[RS];                    /* f(t0, y0) of the first stored point */
 #endif
@@ -646,6 +699,39 @@ DEV int interp_y(Cw<BWD> &m, double t)
         return CV_SUCCESS;
     }
 #endif
+#if SA_TAB_LDS
+    double *tab = s_tab + (m.lane / G) * W_TRECP;
+    if (newpoint) {
+        m.n_rebuild++;
+        m.cur_idx = indx;
+        const gdouble *r = (const gdouble *)(m.traj + (int64_t)indx * m.trow);
+        /* the group copies the record (8 + 6n doubles) arena -> LDS, all loads in flight before the first store */
+        constexpr int NCP = (W_TREC + G - 1) / G;
+        double cp[NCP];
+        SFOR(u, 0, NCP) { const int f = u * G + m.li; cp[u] = r[f < W_TREC ? f : 0]; } SEND
+        lds_sync();
+        SFOR(u, 0, NCP) { const int f = u * G + m.li; if (f < W_TREC) tab[f] = cp[u]; } SEND
+        lds_sync();
+        if (tab[0] > (double)indx) return CV_GETY_BADT;
+        if (indx == m.ilast) m.tlo2 = tab[4];
+    }
+    {
+        double hdr[8], ty[QMAX + 1][RS];
+        SFOR(f, 0, 8) hdr[f] = tab[f]; SEND
+        SFOR(i, 0, (QMAX) + 1) { SFOR(s, 0, RS) ty[i][s] = tab[8 + i * NS + (IDX(m, s) < NS ? IDX(m, s) : 0)]; SEND } SEND
+        const int order = (int)hdr[0];
+        const double inv_dt = 1.0 / hdr[1];
+        double cvals[QMAX + 1];
+        cvals[0] = 1.0;
+        SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - hdr[2 + i]) * inv_dt : 0.0; SEND
+        SFOR(s, 0, RS) {
+            double acc = cvals[0] * ty[0][s];
+            SFOR(i, 1, (QMAX) + 1) acc = FMA(cvals[i], ty[i][s], acc); SEND
+            m.ytmp[s] = (IDX(m, s) < NS) ? acc : 0.0;
+        } SEND
+    }
+    return CV_SUCCESS;
+#else
     if (newpoint) {
         m.n_rebuild++;
         m.cur_idx = indx;
@@ -673,6 +759,7 @@ DEV int interp_y(Cw<BWD> &m, double t)
         } SEND
     }
     return CV_SUCCESS;
+#endif
 }
 
 /* ---- callbacks: stage the inputs in LDS, evaluate, fetch the owned outputs ---- */
@@ -702,12 +789,18 @@ template <bool BWD>
 DEV int run_callback(int cmd, double t, const double *pr, double *obuf)
 {
     if (cmd == CMD_RHS) {
-        if constexpr (BWD) return sa_adj_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUT});
-        else return sa_rhs(t, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUT});
+        if constexpr (BWD) return sa_adj_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUTP});
+        else return sa_rhs(t, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUTP});
     }
-    if (cmd == CMD_QUAD) return sa_quad_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUT});
-    if constexpr (BWD) return sa_adj_jac(t, nullptr, nullptr, pr, MatOut{sa_grp() * NS * NS});
-    else return sa_jac(t, nullptr, nullptr, pr, MatOut{sa_grp() * NS * NS});
+    if (cmd == CMD_QUAD) return sa_quad_rhs(t, nullptr, nullptr, nullptr, pr, VecOut{sa_grp() * W_NOUTP});
+    if constexpr (SA_LEAN) {
+        gdouble *sjp = (gdouble *)(obuf - WS_OUT + WS_SJ);
+        if constexpr (BWD) return sa_adj_jac(t, nullptr, nullptr, pr, GMatOut{sjp});
+        else return sa_jac(t, nullptr, nullptr, pr, GMatOut{sjp});
+    } else {
+        if constexpr (BWD) return sa_adj_jac(t, nullptr, nullptr, pr, MatOut{sa_grp() * NS * NS});
+        else return sa_jac(t, nullptr, nullptr, pr, MatOut{sa_grp() * NS * NS});
+    }
 }
 
 /* wavefront 0: publish the command (the inputs are already staged), evaluate, collect */
@@ -1460,6 +1553,142 @@ DEV void dense_getrs_group8(Cw<BWD> &m, double (&b)[RS])
     if (m.li == 0) b[0] *= m.inv_piv[0];
 }
 
+#if SA_LEAN
+/* ---- lean lane groups: LU and triangular solves on REGISTER-resident factors (m.lu) -------------------------------
+ * Lane li of a group owns rows li, li + G, ... of every column (NS*RS doubles).  I - gamma*J is close to diagonally
+ * dominant: partial pivoting all but never exchanges rows, so the factorisation runs SPECULATIVELY without exchanges --
+ * every row stays in its home lane and slot, the elimination index k is a compile-time constant, and every broadcast
+ * (pivot, pivot-row entry, b_k of the solves) is a static DPP pattern: quad-permute for four lanes per instance, two
+ * DPP moves for eight (sa_bcast8) -- no ds_bpermute, no LDS, no ballot per step.  Each lane records whether one of
+ * its rows ever beat the pivot (denseGETRF's strict '>' test); a group where that happened -- and only such a group --
+ * is factorised again by getrf_coop (LDS, explicit exchanges, pivots to s_piv) in the one-matrix scratch s_A, one
+ * group at a time, and reloads its factors from there.  Same operations on the same values as denseGETRF / denseGETRS
+ * in both cases (test_row_exchanges_in_the_dense_lu drives the fall-back). */
+template <int C>
+static __device__ __forceinline__ double sa_bcast_grp(double v)
+{
+    static_assert(C >= 0 && C < G, "lane of the group");
+    if constexpr (G == 8) return sa_bcast8<C>(v);
+    else {
+        static_assert(G == 4 || G == 2, "static group broadcasts: 2, 4 or 8 lanes per instance");
+        constexpr int qp = (G == 4) ? (C | (C << 2) | (C << 4) | (C << 6)) : (C | (C << 2) | ((C + 2) << 4) | ((C + 2) << 6));
+        const uint64_t u = __builtin_bit_cast(uint64_t, v);
+        int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, qp, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, qp, 0xF, 0xF, false);
+        return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+    }
+}
+/* row r*G + li is a real row (compile-time true for slots without padding) */
+#define LEAN_REAL(r, li) ((((r) + 1) * G <= NS) ? true : ((r) * G + (li) < NS))
+
+template <bool BWD>
+DEV int getrf_lean(Cw<BWD> &m, bool &beaten)
+{
+    int ier = 0;
+    beaten = false;
+    SFOR(k, 0, NS) {
+        constexpr int sk = k / G, lk = k % G;
+        const double akk = sa_bcast_grp<lk>(m.lu[k][sk]);
+        const double best = fabs(akk);
+        bool below[RS];
+        SFOR(r, sk, RS) {
+            below[r] = (r > sk) ? LEAN_REAL(r, m.li) : (m.li > lk && LEAN_REAL(r, m.li));
+            beaten = beaten || (below[r] && fabs(m.lu[k][r]) > best);
+        } SEND
+        ier = (ier == 0 && akk == 0.0) ? k + 1 : ier;       /* (a zero pivot with a non-zero row below it: beaten) */
+        const double mult = 1.0 / akk;
+        m.inv_piv[sk] = (m.li == lk) ? mult : m.inv_piv[sk];
+        double lc[RS];
+        SFOR(r, sk, RS) {
+            lc[r] = below[r] ? m.lu[k][r] * mult : 0.0;
+            m.lu[k][r] = below[r] ? lc[r] : m.lu[k][r];
+        } SEND
+        SFOR(j, k + 1, NS) {
+            const double akj = sa_bcast_grp<lk>(m.lu[j][sk]);
+            SFOR(r, sk, RS) m.lu[j][r] = FMA(-akj, lc[r], m.lu[j][r]); SEND
+        } SEND
+    } SEND
+    return ier;
+}
+
+/* M = I + c*J (c = -gamma) from the saved Jacobian in the workspace, straight into the factor registers */
+template <bool BWD>
+DEV void lean_load_matrix(Cw<BWD> &m, double c)
+{
+    const gdouble *sjg = (const gdouble *)m.sj;
+    SFOR(j, 0, NS) {
+        SFOR(r, 0, RS) {
+            const int row = r * G + m.li;
+            const double v = sjg[j * NS + (LEAN_REAL(r, m.li) ? row : 0)];
+            const double w = (row == j) ? FMA(c, v, 1.0) : v * c;
+            m.lu[j][r] = LEAN_REAL(r, m.li) ? w : 0.0;
+        } SEND
+    } SEND
+}
+
+template <bool BWD>
+DEV int lean_factor(Cw<BWD> &m, double c)
+{
+    bool beaten;
+    m.nswaps = 0;
+    lean_load_matrix(m, c);
+    int ier = getrf_lean(m, beaten);
+    const uint64_t need = __builtin_amdgcn_ballot_w64(beaten);
+    if (need != 0) {                                    /* rare: some group needs a row exchange */
+        for (int g = 0; g < KPW; g++) {
+            if (((need >> (g * G)) & GMASK) == 0) continue;
+            if (m.lane / G == g) {
+                const gdouble *sjg = (const gdouble *)m.sj;
+                lds_sync();
+                for (int idx = m.li; idx < NS * NS; idx += G) {
+                    const double v = sjg[idx];
+                    s_A[idx] = (idx % NS == idx / NS) ? FMA(c, v, 1.0) : v * c;
+                }
+                lds_sync();
+                const Grp gg{m.lane, m.li, m.gbase, 0, m.kbase, 0};
+                ier = getrf_coop(gg, m.inv_piv, m.nswaps);
+                lds_sync();
+                SFOR(j, 0, NS) {
+                    SFOR(r, 0, RS) {
+                        const int row = r * G + m.li;
+                        m.lu[j][r] = LEAN_REAL(r, m.li) ? s_A[j * NS + (LEAN_REAL(r, m.li) ? row : 0)] : 0.0;
+                    } SEND
+                } SEND
+                lds_sync();
+            }
+        }
+    }
+    return ier;
+}
+
+/* denseGETRS on the register factors (after the row permutation of b, done by the caller through s_piv) */
+template <bool BWD>
+DEV void getrs_lean(Cw<BWD> &m, double (&b)[RS])
+{
+    SFOR(k, 0, NS - 1) {                                /* unit lower factor */
+        constexpr int sk = k / G, lk = k % G;
+        const double bk = sa_bcast_grp<lk>(b[sk]);
+        SFOR(r, sk, RS) {
+            const double l = (r > sk) ? m.lu[k][r] : ((m.li > lk) ? m.lu[k][r] : 0.0);
+            b[r] = FMA(-l, bk, b[r]);
+        } SEND
+    } SEND
+    SFOR_DOWN(k, NS - 1, 1) {                           /* upper factor, reciprocal pivots */
+        constexpr int sk = k / G, lk = k % G;
+        const double scaled = b[sk] * m.inv_piv[sk];
+        b[sk] = (m.li == lk) ? scaled : b[sk];
+        const double bk = sa_bcast_grp<lk>(b[sk]);
+        SFOR(r, 0, sk + 1) {
+            const double u = (r < sk) ? m.lu[k][r] : ((m.li < lk) ? m.lu[k][r] : 0.0);
+            b[r] = FMA(-u, bk, b[r]);
+        } SEND
+    } SEND
+    if (m.li == 0) b[0] *= m.inv_piv[0];
+    SFOR(r, 0, RS) { if (!LEAN_REAL(r, m.li)) b[r] = 0.0; } SEND
+}
+#endif
+
 template <bool BWD>
 DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
 {
@@ -1486,6 +1715,11 @@ DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
         PROF_ADD(m, 4)
         return;
     }
+#if SA_LEAN
+    getrs_lean(m, b);
+    PROF_ADD(m, 4)
+    return;
+#endif
     if constexpr (G == 8 && SA_WAVES == 1 && NS <= 32) {
         dense_getrs_group8(m, b);
         PROF_ADD(m, 4)
@@ -1802,6 +2036,27 @@ DEV int cv_lsetup(Cw<BWD> &m, int convfail)
     int jret = 0;
     const double c = -m.gamma;
     lds_sync();
+#if SA_LEAN
+    {   /* J (fresh: the callback wrote it to the workspace; else the saved copy) -> I - gamma*J -> LU, in registers */
+        if (!jbad) m.jcur = 0;
+        else {
+            m.nje++;
+            m.nstlj = m.nst;
+            m.jcur = 1;
+            jret = cv_jac(m, m.tn, m.y);
+            /* the group's lanes wrote the entries; every lane now reads its rows */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (jret < 0) return -1;
+        if (jret > 0) return 1;
+        PROF_T0
+        const int ier = lean_factor(m, c);
+        PROF_ADD(m, 3)
+        return ier > 0 ? 1 : 0;
+    }
+#endif
 #if SA_WAVES > 1
     {   /* whole workgroup: J (saved copy, or fresh from the callback via LDS) -> I - gamma*J -> LU, in registers */
         if (!jbad) m.jcur = 0;
@@ -2146,6 +2401,36 @@ struct StepCtl {
     double saved_t;
 };
 
+#if SA_LEAN
+template <bool BWD>
+DEV void cold_store(const Cw<BWD> &m)
+{
+    double *c = s_cold + m.lane;
+    SFOR(j, 2, (QMAX) + 1) { SFOR(r, 0, RS) c[((j - 2) * RS + r) * 64] = m.zn[j][r]; SEND } SEND
+    SFOR(r, 0, RS) c[(4 * RS + r) * 64] = m.zsave[r]; SEND
+    if (BWD) {
+        SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) c[(5 * RS + j * RQ + r) * 64] = m.znQ[j][r]; SEND } SEND
+        SFOR(r, 0, RQ) c[(5 * RS + 6 * RQ + r) * 64] = m.zsaveQ[r]; SEND
+    }
+}
+template <bool BWD>
+DEV void cold_load(Cw<BWD> &m)
+{
+    const double *c = s_cold + m.lane;
+    SFOR(j, 2, (QMAX) + 1) { SFOR(r, 0, RS) m.zn[j][r] = c[((j - 2) * RS + r) * 64]; SEND } SEND
+    SFOR(r, 0, RS) m.zsave[r] = c[(4 * RS + r) * 64]; SEND
+    if (BWD) {
+        SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) m.znQ[j][r] = c[(5 * RS + j * RQ + r) * 64]; SEND } SEND
+        SFOR(r, 0, RQ) m.zsaveQ[r] = c[(5 * RS + 6 * RQ + r) * 64]; SEND
+    }
+}
+#define COLD_STORE(m) cold_store(m)
+#define COLD_LOAD(m) cold_load(m)
+#else
+#define COLD_STORE(m)
+#define COLD_LOAD(m)
+#endif
+
 template <bool BWD>
 DEV int cv_handle_nflag_failed(Cw<BWD> &m, StepCtl &c, int nflag)
 {
@@ -2193,6 +2478,7 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
         cv_predict(m);
         cv_set(m);
         PH_ADD(m, 1)
+        COLD_STORE(m);          /* until the Newton pass (and the quadrature callback) are over */
         if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
         PH_ADD(m, 2)
         c.convfail = ((c.nflag == FIRST_CALL) || (c.nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
@@ -2202,16 +2488,18 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
     } else {
         callSetup = 1;
         jbad = 1;
+        COLD_STORE(m);
     }
     int in_loop;
     int nls = cv_newton_pass(m, callSetup, jbad, c.convfail, in_loop);
     PH_ADD(m, 3)
     if ((nls > 0) && in_loop && !m.nls_jcur) {
+        COLD_LOAD(m);
         c.redo = 1;
         return 0;
     }
     c.redo = 0;
-    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls);
+    if (nls != CV_SUCCESS) { COLD_LOAD(m); return cv_handle_nflag_failed(m, c, nls); }
 
     SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
 #ifdef SA_CONSTRAINTS
@@ -2242,6 +2530,7 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
                 } SEND
                 const double minq = -wave_max(m.lane, -q);
                 m.eta = fmax(0.9 * minq, 0.1);
+                COLD_LOAD(m);
                 return cv_handle_nflag_failed(m, c, CONSTR_RECVR);
             }
         }
@@ -2250,11 +2539,13 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
     double dsm = m.acnrm * m.tq[2];
     if (dsm > 1.0) {
         c.nflag = PREV_ERR_FAIL;
+        COLD_LOAD(m);
         return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
     }
     if (BWD) {
         c.ncf = c.nef = 0;
         int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
+        COLD_LOAD(m);
         if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR);
         SFOR(r, 0, RQ) {
             m.acorQ[r] = FMA(m.h, m.acorQ[r], -m.znQ[1][r]);
@@ -2267,6 +2558,8 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
             return cv_error_test_failed(m, c.saved_t, dsmQ, c.nefQ, m.netfQ);
         }
         if (dsmQ > dsm) dsm = dsmQ;
+    } else {
+        COLD_LOAD(m);
     }
     PH_ADD(m, 4)
     cv_complete_step(m);
@@ -2295,8 +2588,8 @@ DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_st
     m.gbase = m.lane & ~(G - 1);
     {
         const int grp = m.lane / G;
-        m.abase = grp * NS * NS; m.vbase = grp * NS; m.pbase = grp * W_NQD; m.kbase = grp * W_PIV;
-        m.obase = grp * W_NOUT;
+        m.abase = SA_LEAN ? 0 : grp * NS * NS; m.vbase = grp * W_NSP; m.pbase = grp * W_NQP; m.kbase = grp * W_PIV;
+        m.obase = grp * W_NOUTP;
     }
     m.pr = pr + (int64_t)inst * rem_stride;
     m.sj = ws + (int64_t)inst * WS_DOUBLES + WS_SJ;
@@ -2305,8 +2598,15 @@ DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_st
     m.nswaps = 0;
     SFOR(r, 0, RS) { m.inv_piv[r] = 0.0; m.ytmp[r] = 0.0; m.ewt[r] = 0.0; } SEND
     SFOR(r, 0, RQ) m.ewtQ[r] = 0.0; SEND
+#if SA_TAB_LDS
+    for (int f = m.li; f < W_TREC; f += G) s_tab[(m.lane / G) * W_TRECP + f] = (f == 1) ? 1.0 : 0.0;
+#else
     SFOR(f, 0, 8) m.tab_hdr[f] = (f == 1) ? 1.0 : 0.0; SEND
     SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) m.tabY[j][r] = 0.0; SEND } SEND
+#endif
+#if SA_LEAN
+    SFOR(j, 0, NS) { SFOR(r, 0, RS) m.lu[j][r] = 0.0; SEND } SEND
+#endif
 #ifdef SA_WAVE_PROFILE
     SFOR(i, 0, 8) m.prof[i] = 0; SEND
     m.prof[7] = -(int64_t)wall_clock64();
@@ -2644,10 +2944,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_eval(sa_eval_args a)
         if (i >= a.npts) break;
         lds_sync();
         for (int k = li; k < NS; k += G) {
-            s_y[grp * NS + k] = a.y[(int64_t)i * NS + k];
-            s_lam[grp * NS + k] = a.lam[(int64_t)i * NS + k];
+            s_y[grp * W_NSP + k] = a.y[(int64_t)i * NS + k];
+            s_lam[grp * W_NSP + k] = a.lam[(int64_t)i * NS + k];
         }
-        for (int k = li; k < NQ; k += G) s_ps[grp * W_NQD + k] = a.ps[(int64_t)i * NQ + k];
+        for (int k = li; k < NQ; k += G) s_ps[grp * W_NQP + k] = a.ps[(int64_t)i * NQ + k];
         lds_sync();
         const double *prp = a.pr + (int64_t)i * NR;
         const double t = a.t[i];

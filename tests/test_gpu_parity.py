@@ -869,3 +869,40 @@ def test_seir_device_counters_equal_dvode(group, golden_dir, monkeypatch):
         assert stats[b][8] == c["nst"] + 1                      # stored data points
         ref = np.array(c["y"])
         np.testing.assert_allclose(y[b], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("group", [None, "wave4"])
+def test_device_backward_controller_equals_dvode(group, golden_dir, monkeypatch):
+    """The adjoint pass ON THE DEVICE against Fortran DVODE (tests/golden/dvode_backward.json, see
+    tests/test_oracle_pinning.py::test_backward_controller_equals_dvode): one interval T -> t_mid per call
+    (solve_backward_batch(t0=T, tend=t_mid)), quadrature tolerances so loose that the built-in quadrature error
+    control never decides anything; every counter equal on the exact rows, lambda(t_mid) to round-off level.
+    All cases of a problem go through one batch per t_mid index."""
+    import json
+    from sunode_amd.solver import AdjointSolver
+    if group:
+        monkeypatch.setenv("SA_FORCE_GROUP", group)
+    with open(os.path.join(golden_dir, "dvode_backward.json")) as fh:
+        gold = json.load(fh)
+    exact = lambda tag, t_mid: not (tag.startswith("robertson") and not (tag == "robertson_0" and t_mid == 30.0))  # noqa: E731
+    n_exact = 0
+    for tag, c in gold.items():
+        if group and c["problem"] != "seir":
+            continue
+        prob = make_problem(c["problem"])
+        sol = AdjointSolver(prob, abstol=c["atol"], reltol=c["rtol"], backward_abstol=c["atol"], backward_reltol=c["rtol"],
+                            quad_abstol=1e30, quad_reltol=0.0)
+        tv = np.array([c["T"]])
+        y, st, sf = sol.solve_forward_batch(0.0, tv, np.array([c["y0"]]), np.array([c["ps"]]), np.array(c["pr"]))
+        assert st[0] == 0 and sf[0][8] == len(c["fwd_t"])
+        for row in c["intervals"]:
+            g, lam, stb, sb = sol.solve_backward_batch(c["T"], row["t_mid"], tv, np.array(c["g"])[None, None, :])
+            assert stb[0] == 0
+            got = [int(v) for v in sb[0][:8]]
+            want = [row[k] for k in ("nst", "nfe", "nlu", "nje", "nni", "ncfn", "netf", "qlast")]
+            ref = np.array(row["lam_mid"])
+            if exact(tag, row["t_mid"]):
+                assert got == want, (tag, row["t_mid"], got, want)
+                np.testing.assert_allclose(lam[0], ref, rtol=0, atol=(1e-8 if tag == "robertson_0" else 5e-12) * np.abs(ref).max())
+                n_exact += 1
+    assert n_exact == (6 if group else 23)
