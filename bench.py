@@ -352,16 +352,52 @@ def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, faile
 # ----------------------------------------------------------------------------------------------
 # CPU baseline (oracle = "port"); libsundials_cvodes probe
 # ----------------------------------------------------------------------------------------------
-def cvodes_probe():
-    """BASELINE.md section 3 / SURVEY 8(d): time real CVODES when the box has it.  It never has here: the image
-    carries no SUNDIALS (conda-forge `sundials<6.0` is what the reference links), so the row says so."""
-    import ctypes.util
-    lib = ctypes.util.find_library("sundials_cvodes")
-    if not lib:
-        return {"available": False, "note": "libsundials_cvodes not found on this host (ctypes.util.find_library); "
-                                            "the reference's sunode+CVODES path cannot be timed here"}
-    return {"available": True, "library": lib,
-            "note": "found, but no driver for it is shipped: parity and timing use the restated oracle"}
+def cvodes_probe(name="lv", prob=None, w=None, seconds=8.0):
+    """BASELINE.md section 3 / SURVEY 8(d): time real CVODES when the box has it -- oracle/cvodes_driver.py drives
+    libsundials_cvodes with the reference's own call sequence (solver.py:565-615, 682-784) and callbacks compiled
+    from the generated C header, one draw at a time on one core like the reference, and reports it next to the
+    restated oracle on the same draws (states / gradients / forward step counters: the one place this repository
+    meets CVODES itself).  The image carries no SUNDIALS (conda-forge `sundials<6.0` is what the reference links),
+    so normally the row just says so."""
+    from oracle import cvodes_driver as drv
+    libs = drv.find_libraries()
+    if not libs:
+        return {"available": False, "note": "libsundials_cvodes (+ nvecserial, sunmatrixdense, sunlinsoldense) not found "
+                                            "on this host (ctypes.util.find_library); the reference's sunode+CVODES path "
+                                            "cannot be timed here"}
+    try:
+        import ctypes
+        from oracle.harness import Oracle
+        prob = prob or make_problem(name)
+        w = w or WORKLOADS[name]
+        rt, at = w["rtol"], w["atol"]
+        cb = ctypes.CDLL(drv.build_callbacks(prob.native_source(), name))
+        d = drv.CvodesDriver(prob.n_states, prob.n_params, cb, drv.load(libs), rtol=rt, atol=at, rtolB=rt, atolB=at,
+                             rtolQB=rt, atolQB=at)
+        b = make_batch(name, prob, 64)
+        ys, gs, ls, cnt, t0, done = [], [], [], [], time.perf_counter(), 0
+        for i in range(64):
+            d.set_params(b["ps"][i], b["pr"][i] if b["rem_stride"] else b["pr"])
+            ys.append(d.solve_forward(0.0, b["tvals"], b["y0"][i]))
+            cnt.append(d.counters())
+            g, lam = d.solve_backward(b["tvals"][-1], 0.0, b["tvals"], b["grads"])
+            gs.append(g); ls.append(lam)
+            done += 1
+            if time.perf_counter() - t0 > seconds:
+                break
+        dt = time.perf_counter() - t0
+        orc = Oracle(prob, name)
+        cfg = orc.config(rtol=rt, atol=at, rtolB=rt, atolB=at, rtolQB=rt, atolQB=at)
+        pr = b["pr"][:done] if b["rem_stride"] else b["pr"]
+        yo, _, so = orc.solve_forward(cfg, b["y0"][:done], b["ps"][:done], pr, 0.0, b["tvals"])
+        go, lo, _, _ = orc.solve_backward(cfg, b["tvals"][-1], 0.0, b["tvals"], b["grads"])
+        rel = lambda a, r: float(np.max(np.abs(np.asarray(a) - r) / np.maximum(np.abs(r).max(axis=-1, keepdims=True), 1e-300)))  # noqa: E731
+        return {"available": True, "libraries": libs, "value": done / dt, "unit": "solves/s", "cores": 1,
+                "kind": "reference", "sample": "%d %s draws, one at a time (the reference's call pattern)" % (done, name),
+                "vs_oracle": {"states_max_rel": rel(ys, yo), "grad_max_rel": rel(gs, go), "lamda_max_rel": rel(ls, lo),
+                              "forward_counters_equal": bool(np.array_equal(np.array(cnt), so[:, :7]))}}
+    except Exception as exc:                          # a half-installed SUNDIALS must not take the bench line down
+        return {"available": True, "libraries": libs, "error": "%s: %s" % (type(exc).__name__, exc)}
 
 
 def cpu_baseline(name, prob, w, target_seconds=12.0, opt="-O3"):
@@ -393,7 +429,7 @@ def cpu_baseline(name, prob, w, target_seconds=12.0, opt="-O3"):
             "sample": "%d %s draws (same generator), fwd+adjoint, OpenMP over instances, gcc %s, threads = cgroup "
                       "CPU quota; the port mirrors the kernels' arithmetic bit for bit (explicit FMAs, software pow, "
                       "tree sums): a stated baseline, not a tuned CPU code" % (B, name, opt),
-            "cvodes": cvodes_probe()}
+            "cvodes": cvodes_probe(name, prob, w)}
 
 
 def extra_configs(args):

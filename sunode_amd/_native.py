@@ -99,10 +99,8 @@ def _extra_codegen_flags():
     return os.environ.get("SA_CLANG_FLAGS", DEFAULT_CODEGEN_FLAGS).split()
 
 
-#: systems with more states than this use the cooperative kernels (bdf_coop.hip): G lanes per instance
+#: systems with more states than this use lane groups (bdf_wave.hip): G lanes per instance
 REGISTER_KERNEL_MAX_STATES = 5
-#: ... and above this size (states or differentiated parameters) the LDS-matrix kernel with lane groups
-COOP_KERNEL_MAX_SIZE = 8
 #: forward sensitivities run in registers while n_states * n_sub stays at or below this
 SENS_REGISTER_MAX_NP = 12
 
@@ -115,13 +113,13 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
     families carrying the sensitivity corrector.
 
     n <= 5 states: thread-per-instance, the whole integrator in one lane's registers.
-    up to 8: cooperative (bdf_coop.hip), 8 lanes per instance, matrix rows in registers.
-    up to 64: bdf_wave.hip with G = 8..32 lanes per instance (two components per lane), matrix in LDS.
+    up to 64: bdf_wave.hip with G lanes per instance (lane_group_size: 4 lanes up to 16 states, 8 up to 21 -- the
+        "lean" groups with the LU factors in registers -- then two components per lane, matrix in LDS).
     up to 128: bdf_wave.hip, one 4-wavefront workgroup per instance, Newton matrix / LU resident in LDS.
     larger: memory-resident thread-per-instance kernel (state in an HBM workspace, [element][instance]).
-    SA_FORCE_GROUP=<G> forces the cooperative build with that group size (tests run small
-    problems through every mapping); SA_FORCE_GROUP=1 forces the register kernel,
-    SA_FORCE_GROUP=wave the wavefront-per-instance one and SA_FORCE_GROUP=mem the memory-resident one."""
+    SA_FORCE_GROUP=<G> or wave<G> forces G lanes per instance (tests run small problems through every mapping);
+    SA_FORCE_GROUP=1 forces the register kernel, SA_FORCE_GROUP=wave the workgroup-per-instance one and
+    SA_FORCE_GROUP=mem the memory-resident one."""
     import re
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
@@ -145,29 +143,34 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
             raise NativeBuildError("bdf_wave.hip group size %d must be a power of two with 8*G >= max(n, p)=%d"
                                    % (g, max(n, p)))
         return "bdf_wave.hip", g
-    if not forced and max(n, p) > COOP_KERNEL_MAX_SIZE:
-        # 9..64: bdf_wave.hip with two components per lane (G = next power of two >= max(n, p)/2, at least 8):
-        # measured on SEIR (n = 16): 96 k solves/s against 70 k/s for the cooperative kernel with 16 lanes --
-        # the generated callbacks are evaluated redundantly by every lane of a group, so fewer lanes per
-        # instance waste less, and the matrix lives in LDS instead of registers
-        g = 8
-        while 2 * g < max(n, p):
-            g *= 2
-        return "bdf_wave.hip", g
-    if forced:
+    if forced:                                       # "8" / "16": that many lanes per instance (same as "wave8" / ...)
         g = int(forced)
-    elif n <= REGISTER_KERNEL_MAX_STATES:
-        g = 1
-    else:
-        g = 8
-        while g < max(n, p):
-            g *= 2
-    if g == 1:
+        if g == 1:
+            return "bdf_kernels.hip", 1
+        if 8 * g < max(n, p) or g > 64 or g & (g - 1) or g < 2:
+            raise NativeBuildError("lane groups need a power of two 2 <= G <= 64 with 8*G >= max(n_states, n_sub) = %d"
+                                   % max(n, p))
+        return "bdf_wave.hip", g
+    if n <= REGISTER_KERNEL_MAX_STATES:
         return "bdf_kernels.hip", 1
-    if g < max(n, p) or g > 64 or g & (g - 1):
-        raise NativeBuildError("cooperative kernels need max(n_states, n_sub) = %d <= group size %d <= 64"
-                               % (max(n, p), g))
-    return "bdf_coop.hip", g
+    return "bdf_wave.hip", lane_group_size(n, p)
+
+
+def lane_group_size(n: int, p: int) -> int:
+    """Lanes per instance of the lane-group kernel for 6 <= max(n, p) <= 64.
+
+    LEAN groups (bdf_wave.hip, SA_LEAN: LU factors in registers, cold state in LDS) exist while a lane's share of the
+    matrix, n * ceil(n / G), is at most 64 doubles: G = 4 up to 16 states (16 instances per wavefront: the control
+    scalars and the generated callbacks, evaluated redundantly by every lane of a group, cost half of what they
+    cost with 8 lanes -- SEIR: 235 k against 191 k solves/s), G = 8 up to 21.  Larger systems keep the matrix in LDS
+    with two components per lane (G = next power of two >= max(n, p) / 2)."""
+    for g in (4, 8):
+        if n * ((n + g - 1) // g) <= 64 and 8 * g >= max(n, p):
+            return g
+    g = 8
+    while 2 * g < max(n, p):
+        g *= 2
+    return g
 
 
 def _size_defines(native_source: str):

@@ -209,7 +209,7 @@ DEV int interp_y(Cv<BWD> &m, double t)
         return CV_SUCCESS;
     }
 #ifdef SA_HERMITE
-    {   /* CVAhermiteGetY (see the oracle; same arithmetic as bdf_coop.hip / bdf_mem.hip) */
+    {   /* CVAhermiteGetY (see the oracle; same arithmetic as bdf_wave.hip / bdf_mem.hip) */
         if (newpoint) {
             m.n_rebuild++;
             m.cur_idx = indx;

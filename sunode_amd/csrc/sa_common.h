@@ -1,6 +1,6 @@
 /*
- * sa_common.h -- pieces shared by the thread-per-instance kernels (bdf_kernels.hip) and the
- * cooperative kernels (bdf_coop.hip): sizes, CVODES constants and return codes, compile-time loops,
+ * sa_common.h -- pieces shared by the thread-per-instance kernels (bdf_kernels.hip, bdf_mem.hip) and the
+ * lane-group / workgroup kernels (bdf_wave.hip): sizes, CVODES constants and return codes, compile-time loops,
  * the deterministic pow, and the scalar BDF coefficient routine cvSet.
  * Included after the generated problem header (SA_N_STATES, SA_N_SUB, SA_N_REM).
  */

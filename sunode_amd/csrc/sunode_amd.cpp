@@ -66,7 +66,7 @@ struct DevBuf {
 struct sa_solver {
     int device = 0;
     int n = 0, p = 0, r = 0;
-    int group = 1;                 /* lanes per instance: 1 = thread-per-instance, 2^k = cooperative build */
+    int group = 1;                 /* lanes per instance: 1 = thread-per-instance, 2^k = lane group / workgroup build */
     int64_t ws_doubles = 0;        /* per-instance workspace of the memory-resident build (0: register builds) */
     DevBuf ws;
     hipModule_t module = nullptr;
@@ -376,7 +376,7 @@ static int launch_forward(sa_solver *s, const FwdLaunch &f)
     a.t0 = f.t0; a.rtol = s->opt.rtol; a.atol = (const double *)s->d_atol.p;
     a.y0 = f.y0; a.ps = f.ps; a.pr = f.pr; a.tvals = f.tvals; a.y_out = f.y_out; a.status = f.status; a.stats = f.stats;
     a.constraints = s->have_constraints ? (const double *)s->d_constraints.p : nullptr;
-    /* arena layout: the register / cooperative / wave kernels keep every instance's records contiguous
+    /* arena layout: the register / lane-group / workgroup kernels keep every instance's records contiguous
        ([instance][point]: the backward pass walks an instance's points in order, so consecutive records share cache
        lines and DRAM pages); the memory-resident kernel keeps its [point][field][instance] layout */
     if (s->ws_doubles == 0) { a.traj_istride = f.rows; a.traj_stride = 1; }

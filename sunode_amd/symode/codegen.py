@@ -574,7 +574,7 @@ def emit_function(
         uses[slot] = [s.name for s in sym.sympify(value).free_symbols if s.name in temp_names]
 
     # Outputs go through SA_STORE(slot, value): plain kernels / the oracle define it as
-    # `out[slot] = value`; the cooperative kernel (one lane per state component) keeps only the
+    # `out[slot] = value`; the lane-group kernels (a few state components per lane) keep only the
     # slots a lane owns.  x*0.0 is (+-)0 for finite x and NaN for inf/nan: the finiteness check is
     # straight-line on purpose (constant subscripts only, see bdf_kernels.hip on scalar replacement).
     def body(slots, temps, prefetch=False):

@@ -61,9 +61,7 @@ def test_full_size_batches(name, arena_gib):
     if name == "lv":
         assert (y > 0).all()
     # strided sample against the oracle, bit for bit (includes the last instance: tail of the last wave)
-    idx = np.unique(np.concatenate([np.arange(0, B, 257), [B - 1]]))
-    if name == "network100":
-        idx = idx[:3]
+    idx = np.unique(np.concatenate([np.arange(0, B, 64 if name == "network100" else 257), [B - 1]]))   # network100: 17 of 1 024
     yo, go, lo, sfo, sbo = _oracle_sample(name, rt, at, b, idx)
     np.testing.assert_array_equal(sf[idx][:, CMP], sfo[:, CMP])
     np.testing.assert_array_equal(sb[idx][:, CMP_B], sbo[:, CMP_B])
@@ -231,7 +229,7 @@ def test_bench_rank_under_an_rccl_process_group_of_one(tmp_path):
     for tag, extra in (("group", ["--force-dist"]), ("plain", [])):
         res = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-3000:]
-        lines[tag] = json.loads(res.stdout.strip().splitlines()[-1])
+        lines[tag] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])   # (RCCL prints too)
     g, p = lines["group"], lines["plain"]
     assert g["n_gpus"] == 1 and g["config"]["failed_instances"] == 0 and g["value"] > 0
     for key in ("fwd_steps_mean", "bwd_steps_mean", "stored_points_mean"):

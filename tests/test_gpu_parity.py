@@ -302,7 +302,7 @@ def test_cooperative_mapping_equals_thread_per_instance(name, group, monkeypatch
 @pytest.mark.parametrize("variant", ["16", "mem", "wave", "wave4", "wave16", "wave32"])
 def test_seir_large_system_mappings_vs_oracle(variant, monkeypatch):
     """SEIR (n = 16, 16 shared fixed parameters; the engine's own choice is bdf_wave.hip with 8 lanes per
-    instance) through the other mappings: cooperative with 16 lanes, memory-resident, wavefront-per-instance,
+    instance) through the other mappings: 16 lanes per instance, memory-resident, wavefront-per-instance,
     4 / 16 / 32 lanes per instance: all bit-exact against the oracle."""
     from sunode_amd.solver import AdjointSolver
     monkeypatch.setenv("SA_FORCE_GROUP", variant)
@@ -481,7 +481,7 @@ def test_inequality_constraints_match_oracle(variant, monkeypatch):
                                           ("seir", None), ("seir", "wave"), ("seir", "wave16"), ("seir", "mem")])
 def test_hermite_interpolation_matches_oracle(name, variant, monkeypatch):
     """AdjointSolver(interpolation='hermite') (reference solver.py:581-582): Hermite builds of the register
-    (default for small systems), cooperative, wave and memory kernels against the oracle."""
+    (default for small systems), lane-group, workgroup and memory kernels against the oracle."""
     from sunode_amd import _native
     from sunode_amd.solver import AdjointSolver
     if variant:
@@ -491,7 +491,7 @@ def test_hermite_interpolation_matches_oracle(name, variant, monkeypatch):
     if name == "lv":
         d = lv_batch(B); ps, pr = d["params"][:, :2], d["params"][:, 2:]; rt, at = 1e-8, 1e-8
         assert _native.kernel_variant(prob.native_source(), hermite=True) == \
-            (("bdf_coop.hip", 8) if variant == "8" else ("bdf_kernels.hip", 1))
+            (("bdf_wave.hip", 8) if variant == "8" else ("bdf_kernels.hip", 1))
     elif name == "robertson":
         d = robertson_batch(B); ps, pr = d["params"], np.zeros(0); rt, at = 1e-8, 1e-10
     else:
@@ -631,7 +631,7 @@ def test_reference_test_declare_sens_and_linear_solver_kwarg():
 def test_row_exchanges_in_the_dense_lu(variant, monkeypatch):
     """A system whose Newton matrix is far from diagonally dominant (rotations at 1000 rad/s far below the
     tolerances, steps of order 1): the partial-pivoting LU has to exchange rows in the forward and in the
-    backward solve.  Every mapping (cooperative by default, lane groups, workgroup, memory-resident) must
+    backward solve.  Every mapping (lean lane groups by default, other group sizes, workgroup, memory-resident) must
     follow the oracle's pivot choices bit for bit."""
     from sunode_amd.solver import AdjointSolver
     if variant:
@@ -843,11 +843,11 @@ def test_backward_reports_failed_forward_and_arena_limit():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("group", [None, "16", "wave16", "wave4"])
+@pytest.mark.parametrize("group", [None, "8", "wave16", "wave32"])
 def test_seir_device_counters_equal_dvode(group, golden_dir, monkeypatch):
     """an independent counter oracle for the mid-size mappings.  SEIR (n = 16) forward through the
-    default lane-group kernel (8 lanes, LU in registers), the cooperative kernel (16 lanes), and the lane-group
-    kernel with 16 / 4 lanes (LDS LU at 4 lanes: 4 register slots): every step counter equals Fortran DVODE's
+    default lane-group kernel (4 lanes per instance, LU factors in registers), the lean build with 8 lanes, 16 lanes
+    and 32 lanes (matrix in LDS): every step counter equals Fortran DVODE's
     (tests/golden/dvode_seir.json), states to round-off."""
     import json
     from sunode_amd.solver import AdjointSolver
@@ -906,3 +906,32 @@ def test_device_backward_controller_equals_dvode(group, golden_dir, monkeypatch)
                 np.testing.assert_allclose(lam[0], ref, rtol=0, atol=(1e-8 if tag == "robertson_0" else 5e-12) * np.abs(ref).max())
                 n_exact += 1
     assert n_exact == (6 if group else 23)
+
+
+@pytest.mark.parametrize("name,variant", [("network24", None), ("network24", "wave32"), ("network24", "wave"),
+                                          ("network24", "mem"), ("network100", None)])
+def test_device_structured_callbacks_match_reference(name, variant, golden_dir, monkeypatch):
+    """The structured (SA_MATVEC / SA_MATFILL / SA_SUM / SA_ROLLED) callbacks ON THE DEVICE, lane-parallel in the
+    lane-group / workgroup mappings, against the reference's own lambdify output
+    (tests/golden/callbacks_network.json) -- and bit-equal to the host build of the same generated source."""
+    from sunode_amd.solver import Solver
+    from tests.helpers import check_matrix_summary, network_golden_points
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem(name)
+    n, pts = network_golden_points(golden_dir, name)
+    eng = Solver(prob)._engine()
+    pr = np.array([prob.extend_remainder(pt["K"]) for pt in pts])
+    got = eng.eval_callbacks([pt["t"] for pt in pts], [pt["y"] for pt in pts], [pt["lam"] for pt in pts],
+                             np.array([pt["scale"] for pt in pts]), pr)
+    orc = make_oracle(name)
+    for i, pt in enumerate(pts):
+        host = orc.eval(pt["t"], pt["y"], pt["lam"], np.array(pt["scale"]), pt["K"])
+        for key in ("rhs", "adj", "quad"):
+            ref = np.array(pt[key])
+            np.testing.assert_allclose(got[key][i], ref, rtol=1e-12, atol=64 * 2.3e-16 * np.abs(ref).max(), err_msg=key)
+            np.testing.assert_array_equal(got[key][i], host[key])
+        for key in ("jac", "adjjac"):
+            check_matrix_summary(got[key][i], pt[key])
+            np.testing.assert_array_equal(got[key][i], host[key])
+        assert got["codes"][i].tolist() == pt["codes"]

@@ -172,3 +172,23 @@ def test_matvec_regrouping_of_an_unexpanded_rhs_is_exact():
         assert sym.expand(new[i].subs(back) - exprs[i]) == 0, i
     # the shared part really was pulled out once (2*g + b multiplies y0 in every output)
     assert all(sym.expand(new[i]).coeff(y[0]).subs({mv[i]: 0}) == 2 * g + b for i in range(n))
+
+
+@pytest.mark.parametrize("name", ["network24", "network100"])
+def test_structured_network_callbacks_match_reference(name, golden_dir):
+    """the callbacks this build emits in STRUCTURED form (SA_MATVEC / SA_MATFILL / SA_SUM / SA_ROLLED) against
+    values produced by the REFERENCE's own lambdify pipeline (tests/golden/callbacks_network.json), not a sympy
+    re-evaluation of our expressions: vectors entry by entry, the n x n Jacobians through two dense projections, the
+    diagonal and a strided sample (n = 100 would be megabytes otherwise).  Generated C compiled into the oracle."""
+    from tests.helpers import check_matrix_summary, network_golden_points
+    prob = make_problem(name)
+    orc = make_oracle(name)
+    n, pts = network_golden_points(golden_dir, name)
+    for pt in pts:
+        got = orc.eval(pt["t"], pt["y"], pt["lam"], np.array(pt["scale"]), pt["K"])
+        for key in ("rhs", "adj", "quad"):
+            ref = np.array(pt[key])
+            np.testing.assert_allclose(got[key], ref, rtol=1e-12, atol=64 * 2.3e-16 * np.abs(ref).max(), err_msg=key)
+        check_matrix_summary(got["jac"], pt["jac"])
+        check_matrix_summary(got["adjjac"], pt["adjjac"])
+        assert got["codes"].tolist() == pt["codes"]
