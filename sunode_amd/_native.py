@@ -27,7 +27,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-_CSRC = os.path.join(_PKG, "csrc")
+_CSRC = os.environ.get("SA_CSRC_DIR") or os.path.join(_PKG, "csrc")      # SA_CSRC_DIR: kernel sources of a scratch tree (tuning)
 _LIBDIR = os.path.join(_PKG, "_lib")
 _CACHE = os.path.join(_PKG, "_cache")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -101,6 +101,8 @@ def _extra_codegen_flags():
 
 #: systems with more states than this use lane groups (bdf_wave.hip): G lanes per instance
 REGISTER_KERNEL_MAX_STATES = 5
+#: ... or more differentiated parameters than this (six quadrature Nordsieck columns per parameter in one lane)
+REGISTER_KERNEL_MAX_SUB = 8
 #: forward sensitivities run in registers while n_states * n_sub stays at or below this
 SENS_REGISTER_MAX_NP = 12
 
@@ -130,6 +132,11 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
         # to the state's while they fit one lane's register file; everything larger runs memory-resident
         if forced in (None, "1") and n <= REGISTER_KERNEL_MAX_STATES and n * p <= SENS_REGISTER_MAX_NP:
             return "bdf_kernels.hip", 1
+        # lean lane groups (sensitivity vectors streamed from the workspace): everything they cover (n <= 21)
+        g = int(forced[4:]) if forced and forced.startswith("wave") and forced != "wave" else \
+            (None if forced else lane_group_size(n, p))
+        if g in (2, 4, 8) and n * ((n + g - 1) // g) <= 64 and 8 * g >= max(n, p) and n >= 1:
+            return "bdf_wave.hip", g
         return "bdf_mem.hip", 1
     if forced == "mem" or (not forced and max(n, p) > 128):
         return "bdf_mem.hip", 1
@@ -139,7 +146,7 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
         return "bdf_wave.hip", 64
     if forced and forced.startswith("wave"):        # "wave16": bdf_wave.hip with 16 lanes per instance
         g = int(forced[4:])
-        if 8 * g < max(n, p) or g > 64 or g & (g - 1) or g < 2:
+        if 8 * g < max(n, p) or g > 64 or g & (g - 1) or g < 1:
             raise NativeBuildError("bdf_wave.hip group size %d must be a power of two with 8*G >= max(n, p)=%d"
                                    % (g, max(n, p)))
         return "bdf_wave.hip", g
@@ -151,7 +158,7 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
             raise NativeBuildError("lane groups need a power of two 2 <= G <= 64 with 8*G >= max(n_states, n_sub) = %d"
                                    % max(n, p))
         return "bdf_wave.hip", g
-    if n <= REGISTER_KERNEL_MAX_STATES:
+    if n <= REGISTER_KERNEL_MAX_STATES and p <= REGISTER_KERNEL_MAX_SUB:
         return "bdf_kernels.hip", 1
     return "bdf_wave.hip", lane_group_size(n, p)
 

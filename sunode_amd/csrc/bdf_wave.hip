@@ -410,7 +410,26 @@ constexpr int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 /* workspace (doubles per instance): saved Jacobian + callback output vector */
 #define WS_SJ 0
 #define WS_OUT (NS * NS)
-#define WS_DOUBLES (NS * NS + ((NS > NQ ? NS : NQ) + 7) / 8 * 8)
+#define WS_SMALL0 (NS * NS + ((NS > NQ ? NS : NQ) + 7) / 8 * 8)
+#ifdef SA_SENS
+/* forward-sensitivity builds (lane groups only): per instance additionally the fresh Jacobian and df/dp of the
+   sensitivity right-hand side; then, per WAVEFRONT, the sensitivity vectors [vector][parameter][slot][lane] */
+#define WS_JS WS_SMALL0
+#define WS_DP (WS_SMALL0 + NS * NS)
+#define WS_SMALL (WS_SMALL0 + NS * NS + NQD_ * NS)
+#define NQD_ (NQ > 0 ? NQ : 1)
+enum { SV_ZN0 = 0, SV_ZSAVE = 6, SV_EWT = 7, SV_ACOR = 8, SV_TEMPV = 9, SV_FTEMP = 10, SV_Y = 11, SV_DELTA = 12, SV_COUNT = 13 };
+#define WS_DOUBLES (WS_SMALL + SV_COUNT * NQD_ * RS * G)
+#else
+#define WS_SMALL WS_SMALL0
+#define WS_DOUBLES WS_SMALL0
+#endif
+/* workspace of instance `inst`: the wavefront's block starts at its first instance, the per-instance parts come
+   first (WS_SMALL doubles each), the wavefront-wide sensitivity block after them */
+static __device__ __forceinline__ double *ws_inst(double *ws, int inst)
+{
+    return ws + (int64_t)(inst / KPW * KPW) * WS_DOUBLES + (int64_t)(inst % KPW) * WS_SMALL;
+}
 
 /* ---- cross-lane primitives (the wave is always converged when these run) ---- */
 DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -502,6 +521,14 @@ struct Cw {
     double f0[RS];                    /* f(t0, y0) of the first stored point */
 #endif
     int n_interp, n_rebuild;
+#ifdef SA_SENS
+    /* forward sensitivities (Solver(sens_mode=...), reference solver.py:360-392): the NQ sensitivity Nordsieck arrays
+       and work vectors live in the workspace (SV(m, vector, parameter, slot)), streamed through registers phase by phase */
+    double *sws;
+    const double *pbar;
+    double crateS, delpS, acnrmS;
+    int sensi, ism, nfSe, nniS, ncfnS, netfS, nsetupsS;
+#endif
 #ifdef SA_WAVE_PROFILE
     int64_t prof[8];                  /* 10 ns ticks: rhs, quad, jac, getrf, getrs, matrix copy */
 #endif
@@ -705,7 +732,10 @@ DEV int interp_y(Cw<BWD> &m, double t)
         m.n_rebuild++;
         m.cur_idx = indx;
         const gdouble *r = (const gdouble *)(m.traj + (int64_t)indx * m.trow);
-        /* the group copies the record (8 + 6n doubles) arena -> LDS, all loads in flight before the first store */
+        /* the group copies the record (8 + 6n doubles) arena -> LDS, all loads in flight before the first store.
+           (Measured and not kept, SEIR: touching the lines of the next-left record ahead of time -- at the move itself
+           every function call then waits for the touch, interp 7.8 -> 10.5 ms; after the attempt's last callback,
+           8 k call-free cycles ahead of the next move: 9.0 ms, the whole backward kernel 63.1 -> 65.3 ms.) */
         constexpr int NCP = (W_TREC + G - 1) / G;
         double cp[NCP];
         SFOR(u, 0, NCP) { const int f = u * G + m.li; cp[u] = r[f < W_TREC ? f : 0]; } SEND
@@ -1570,7 +1600,8 @@ static __device__ __forceinline__ double sa_bcast_grp(double v)
     static_assert(C >= 0 && C < G, "lane of the group");
     if constexpr (G == 8) return sa_bcast8<C>(v);
     else {
-        static_assert(G == 4 || G == 2, "static group broadcasts: 2, 4 or 8 lanes per instance");
+        if constexpr (G == 1) return v;
+        static_assert(G == 4 || G == 2 || G == 1, "static group broadcasts: 1, 2, 4 or 8 lanes per instance");
         constexpr int qp = (G == 4) ? (C | (C << 2) | (C << 4) | (C << 6)) : (C | (C << 2) | ((C + 2) << 4) | ((C + 2) << 6));
         const uint64_t u = __builtin_bit_cast(uint64_t, v);
         int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
@@ -1769,6 +1800,128 @@ DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
     PROF_ADD(m, 4)
 }
 
+
+#ifdef SA_SENS
+/* ---- forward sensitivities in the lean lane groups (Solver(sens_mode=...), reference solver.py:360-392, 483-527;
+ * sensitivity right-hand side symode/problem.py:557-583) -----------------------------------------------------------
+ * Same corrector as the register kernel's -DSA_SENS build / the oracle (simultaneous: the sensitivity systems ride in
+ * the state's Newton iteration; staggered: their own iteration after the state passed), but the NQ x 13 sensitivity
+ * vectors do not fit any on-chip storage at n = 16, p = 8 (416 doubles per lane): they live in the workspace,
+ * [vector][parameter][slot][lane] (a wavefront's 64 lanes touch 64 consecutive doubles), and every operation streams
+ * them through registers.  The right-hand side J(t,y) s_i + df/dp_i takes J and df/dp from the generated callbacks
+ * (written to the workspace by all lanes of the group), each lane then accumulates its rows for all parameters with
+ * the entries of s_i broadcast across the group by static DPP moves -- the association of the oracle's cv_fS. */
+static_assert(SA_LEAN, "the sensitivity corrector of bdf_wave.hip exists in the lean lane-group builds (n <= 21); larger: bdf_mem.hip");
+#define SENS_ON(m) (!BWD && (m).sensi)
+#define SV(m, v, is, r) (m).sws[(int64_t)(((v) * NQ + (is)) * RS + (r)) * 64]
+#define SLOOP(is) for (int is = 0; is < NQ; is++)
+
+/* out[is] = J ys[is] + dp[is] for the rows of this lane; J, dp: workspace copies the callbacks just wrote */
+static __device__ __attribute__((noinline)) int sens_rhs_rows(double *sws, const gdouble *js, const gdouble *dp, int li,
+                                                              int v_in, int v_out)
+{
+    double ys[NQ][RS], acc[NQ][RS];
+    SFOR(is, 0, NQ) { SFOR(r, 0, RS) ys[is][r] = sws[(int64_t)((v_in * NQ + is) * RS + r) * 64]; SEND } SEND
+    SFOR(j, 0, NS) {
+        double jrow[RS];
+        SFOR(r, 0, RS) jrow[r] = js[j * NS + (LEAN_REAL(r, li) ? r * G + li : 0)]; SEND
+        SFOR(is, 0, NQ) {
+            const double yj = sa_bcast_grp<(j % G)>(ys[is][j / G]);
+            SFOR(r, 0, RS) acc[is][r] = (j == 0) ? jrow[r] * yj : FMA(jrow[r], yj, acc[is][r]); SEND
+        } SEND
+    } SEND
+    bool bad = false;
+    SFOR(is, 0, NQ) {
+        SFOR(r, 0, RS) {
+            const double a = acc[is][r] + dp[is * NS + (LEAN_REAL(r, li) ? r * G + li : 0)];
+            sws[(int64_t)((v_out * NQ + is) * RS + r) * 64] = LEAN_REAL(r, li) ? a : 0.0;
+            bad = bad || (LEAN_REAL(r, li) && !(a * 0.0 == 0.0));
+        } SEND
+    } SEND
+    return bad ? 1 : 0;
+}
+
+template <bool BWD>
+DEV int cv_fS(Cw<BWD> &m, double t, const double (&y)[RS], int v_in, int v_out)
+{
+    m.nfSe++;
+    stage_inputs(m, y);
+    gdouble *js = (gdouble *)(m.sj - WS_SJ + WS_JS), *dp = (gdouble *)(m.sj - WS_SJ + WS_DP);
+    int rc = sa_jac(t, nullptr, nullptr, m.pr, GMatOut{js});
+    if (rc != 0) return rc;
+    rc = sa_dydp(t, nullptr, nullptr, m.pr, GMatOut{dp});
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int bad = sens_rhs_rows(m.sws, js, dp, m.li, v_in, v_out);
+    const uint64_t any = __builtin_amdgcn_ballot_w64(bad != 0);
+    return (rc != 0 || ((any >> m.gbase) & GMASK) != 0) ? 1 : 0;
+}
+
+/* cvSensEwtSetEE: w[is] = pbar / (rtol |pbar s| + atol) */
+template <bool BWD>
+DEV int sens_ewt_set(Cw<BWD> &m, int v_in, int v_out)
+{
+    double bad = 0.0;
+    SLOOP(is) {
+        const double pb = m.pbar[is];
+        SFOR(r, 0, RS) {
+            const double v = FMA(m.rtol, fabs(pb * SV(m, v_in, is, r)), m.atol[r]);
+            bad = (IDX(m, r) < NS && v <= 0.0) ? 1.0 : bad;
+            SV(m, v_out, is, r) = pb * (1.0 / v);
+        } SEND
+    }
+    return wave_max(m.lane, bad) > 0.0 ? -1 : 0;
+}
+
+/* cvSensUpdateNorm: max(old, max_is wrms(x[is], w[is])) */
+template <bool BWD>
+DEV double sens_update_norm(const Cw<BWD> &m, double old_nrm, int v_x, int v_w)
+{
+    double nrm = old_nrm;
+    SLOOP(is) {
+        double x[RS], w[RS];
+        SFOR(r, 0, RS) { x[r] = SV(m, v_x, is, r); w[r] = SV(m, v_w, is, r); } SEND
+        const double snrm = wrms_n(m, x, w);
+        nrm = snrm > nrm ? snrm : nrm;
+    }
+    return nrm;
+}
+
+/* cvNlsResidualSensSim / ...Stg: residuals of the sensitivity systems -> DELTA (m.y holds the state) */
+template <bool BWD>
+DEV int cv_nls_residual_sens(Cw<BWD> &m)
+{
+    SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND }
+    int retval = cv_fS(m, m.tn, m.y, SV_Y, SV_FTEMP);
+    if (retval < 0) return CV_SRHSFUNC_FAIL;
+    if (retval > 0) return SRHSFUNC_RECVR;
+    SLOOP(is) {
+        SFOR(r, 0, RS) {
+            const double rr = FMA(m.rl1, SV(m, SV_ZN0 + 1, is, r), SV(m, SV_ACOR, is, r));
+            SV(m, SV_DELTA, is, r) = FMA(-m.gamma, SV(m, SV_FTEMP, is, r), rr);
+        } SEND
+    }
+    return CV_SUCCESS;
+}
+
+/* one Newton update of every sensitivity system with the current factorisation */
+template <bool BWD>
+DEV void cv_sens_newton_update(Cw<BWD> &m)
+{
+    SLOOP(is) {
+        double d[RS];
+        SFOR(r, 0, RS) d[r] = -1.0 * SV(m, SV_DELTA, is, r); SEND
+        dense_getrs(m, d);
+        if (m.gamrat != 1.0) {
+            double sc = 2.0 / (1.0 + m.gamrat);
+            SFOR(r, 0, RS) d[r] *= sc; SEND
+        }
+        SFOR(r, 0, RS) { SV(m, SV_DELTA, is, r) = d[r]; SV(m, SV_ACOR, is, r) = SV(m, SV_ACOR, is, r) + d[r]; } SEND
+    }
+}
+#endif
+
 /* ---- CVodeInit / CVodeReInit ---- */
 template <bool BWD>
 DEV void cv_reinit(Cw<BWD> &m, double t0, const double (&y0)[RS], const double (&q0)[RQ])
@@ -1793,6 +1946,10 @@ DEV void cv_reinit(Cw<BWD> &m, double t0, const double (&y0)[RS], const double (
     SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
     SFOR(r, 0, RS) { m.acor[r] = m.tempv[r] = m.ftemp[r] = m.y[r] = m.zsave[r] = 0.0; } SEND
     SFOR(r, 0, RQ) { m.acorQ[r] = m.tempvQ[r] = m.zsaveQ[r] = 0.0; } SEND
+#ifdef SA_SENS
+    m.crateS = 1.0; m.delpS = 0.0; m.acnrmS = 0.0;
+    m.nfSe = m.nniS = m.ncfnS = m.netfS = m.nsetupsS = 0;
+#endif
 }
 
 /* ---- cvHin ---- */
@@ -1808,6 +1965,23 @@ DEV double cv_upper_bound_h0(Cw<BWD> &m, double tdist)
         loc = v > loc ? v : loc;
     } SEND
     double hub_inv = wave_max(m.lane, loc);
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        sens_ewt_set(m, SV_ZN0, SV_TEMPV);
+        double locS = 0.0;
+        SLOOP(is) {
+            SFOR(r, 0, RS) {
+                const double t2 = fabs(SV(m, SV_ZN0, is, r));
+                double t1 = 1.0 / SV(m, SV_TEMPV, is, r);
+                t1 = FMA(HUB_FACTOR, t2, t1);
+                const double v = (IDX(m, r) < NS) ? fabs(SV(m, SV_ZN0 + 1, is, r)) / t1 : 0.0;
+                locS = v > locS ? v : locS;
+            } SEND
+        }
+        const double hubS = wave_max(m.lane, locS);
+        if (hubS > hub_inv) hub_inv = hubS;
+    }
+#endif
     if (BWD) {
         double wq[RQ];
         ewtQ_set(m, m.znQ[0], wq);
@@ -1829,10 +2003,20 @@ template <bool BWD>
 DEV int cv_ydd_norm(Cw<BWD> &m, double hg, double *yddnrm)
 {
     SFOR(r, 0, RS) m.y[r] = FMA(hg, m.zn[1][r], m.zn[0][r]); SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_Y, is, r) = FMA(hg, SV(m, SV_ZN0 + 1, is, r), SV(m, SV_ZN0, is, r)); SEND } }
+#endif
     if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
     int retval = cv_f(m, m.tn + hg, m.y, m.tempv);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return RHSFUNC_RECVR;
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        retval = cv_fS(m, m.tn + hg, m.y, SV_Y, SV_TEMPV);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return SRHSFUNC_RECVR;
+    }
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn + hg, m.y, m.tempvQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -1843,6 +2027,17 @@ DEV int cv_ydd_norm(Cw<BWD> &m, double hg, double *yddnrm)
         m.tempv[r] = (1.0 / hg) * m.tempv[r];
     } SEND
     *yddnrm = wrms_n(m, m.tempv, m.ewt);
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        SLOOP(is) {
+            SFOR(r, 0, RS) {
+                const double v = SV(m, SV_TEMPV, is, r) - SV(m, SV_ZN0 + 1, is, r);
+                SV(m, SV_TEMPV, is, r) = (1.0 / hg) * v;
+            } SEND
+        }
+        *yddnrm = sens_update_norm(m, *yddnrm, SV_TEMPV, SV_EWT);
+    }
+#endif
     if (BWD) {
         SFOR(r, 0, RQ) {
             m.tempvQ[r] = m.tempvQ[r] - m.znQ[1][r];
@@ -1912,6 +2107,9 @@ DEV void cv_rescale(Cw<BWD> &m)
     SFOR(j, 1, (QMAX) + 1) {
         SFOR(r, 0, RS) m.zn[j][r] *= factor; SEND
         if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] *= factor; SEND }
+#ifdef SA_SENS
+        if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) *= factor; SEND } }
+#endif
         factor *= m.eta;
     } SEND
     m.h = m.hscale * m.eta;
@@ -1952,6 +2150,18 @@ DEV void cv_increase_bdf(Cw<BWD> &m)
             if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(m.l[j], znQL[r], m.znQ[j][r]); SEND }
         }
     } SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        SLOOP(is) {
+            double zl[RS];
+            SFOR(r, 0, RS) zl[r] = A1 * SV(m, SV_ZSAVE, is, r); SEND
+            SFOR(j, 2, (QMAX) + 1) { if (j == L) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = zl[r]; SEND } } SEND
+            SFOR(j, 2, QMAX) {
+                if (j <= m.q) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], zl[r], SV(m, SV_ZN0 + j, is, r)); SEND }
+            } SEND
+        }
+    }
+#endif
 }
 
 template <bool BWD>
@@ -1976,6 +2186,20 @@ DEV void cv_decrease_bdf(Cw<BWD> &m)
             if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(-m.l[j], znQq[r], m.znQ[j][r]); SEND }
         }
     } SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        SLOOP(is) {
+            double zq[RS];
+            SFOR(r, 0, RS) {
+                zq[r] = SV(m, SV_ZN0 + 2, is, r);
+                SFOR(k, 3, (QMAX) + 1) { if (m.q == k) zq[r] = SV(m, SV_ZN0 + k, is, r); } SEND
+            } SEND
+            SFOR(j, 2, QMAX) {
+                if (j < m.q) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(-m.l[j], zq[r], SV(m, SV_ZN0 + j, is, r)); SEND }
+            } SEND
+        }
+    }
+#endif
 }
 
 template <bool BWD>
@@ -1985,6 +2209,9 @@ DEV void cv_clear_column(Cw<BWD> &m, int q_old)
         if (j == q_old) {
             SFOR(r, 0, RS) m.zn[j][r] = 0.0; SEND
             if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = 0.0; SEND }
+#ifdef SA_SENS
+            if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = 0.0; SEND } }
+#endif
         }
     } SEND
 }
@@ -2010,6 +2237,16 @@ DEV void cv_predict(Cw<BWD> &m)
             if (BWD) { SFOR(r, 0, RQ) m.znQ[j - 1][r] = m.znQ[j - 1][r] + m.znQ[j][r]; SEND }
         } SEND
     } SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {           /* the same Pascal-triangle pass, one load and one store per entry */
+        SLOOP(is) {
+            double z[QMAX + 1][RS];
+            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) z[j][r] = SV(m, SV_ZN0 + j, is, r); SEND } SEND
+            SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { SFOR(r, 0, RS) z[j - 1][r] = z[j - 1][r] + z[j][r]; SEND } SEND } SEND
+            SFOR(j, 0, QMAX) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = z[j][r]; SEND } SEND
+        }
+    }
+#endif
 }
 
 template <bool BWD>
@@ -2022,6 +2259,16 @@ DEV void cv_restore(Cw<BWD> &m, double saved_t)
             if (BWD) { SFOR(r, 0, RQ) m.znQ[j - 1][r] = m.znQ[j - 1][r] - m.znQ[j][r]; SEND }
         } SEND
     } SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        SLOOP(is) {
+            double z[QMAX + 1][RS];
+            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) z[j][r] = SV(m, SV_ZN0 + j, is, r); SEND } SEND
+            SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { SFOR(r, 0, RS) z[j - 1][r] = z[j - 1][r] - z[j][r]; SEND } SEND } SEND
+            SFOR(j, 0, QMAX) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = z[j][r]; SEND } SEND
+        }
+    }
+#endif
 }
 
 /* ---- linear solver interface ---- */
@@ -2120,6 +2367,9 @@ DEV int cv_nls_lsetup(Cw<BWD> &m, int jbad, int &convfail)
     m.gamrat = 1.0;
     m.gammap = m.gamma;
     m.crate = 1.0;
+#ifdef SA_SENS
+    m.crateS = 1.0;
+#endif
     m.nstlp = m.nst;
     if (retval < 0) return CV_LSETUP_FAIL;
     if (retval > 0) return NLS_CONV_RECVR;
@@ -2144,10 +2394,22 @@ template <bool BWD>
 DEV int cv_newton_pass(Cw<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
 {
     double delta[RS];
+#ifdef SA_SENS
+    const bool sim = SENS_ON(m) && m.ism == 0;
+#endif
     in_loop = 0;
     SFOR(r, 0, RS) m.acor[r] = 0.0; SEND
+#ifdef SA_SENS
+    if (sim) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND } }
+#endif
     int retval = cv_nls_residual(m, delta);
     if (retval != CV_SUCCESS) return retval;
+#ifdef SA_SENS
+    if (sim) {
+        retval = cv_nls_residual_sens(m);
+        if (retval != CV_SUCCESS) return retval;
+    }
+#endif
     if (callSetup) {
         retval = cv_nls_lsetup(m, jbad, convfail);
         if (retval != CV_SUCCESS) return retval;
@@ -2164,10 +2426,19 @@ DEV int cv_newton_pass(Cw<BWD> &m, int callSetup, int jbad, int &convfail, int &
         }
         SFOR(r, 0, RS) m.acor[r] = m.acor[r] + delta[r]; SEND
         double del = wrms_n(m, delta, m.ewt);
+#ifdef SA_SENS
+        if (sim) {
+            cv_sens_newton_update(m);
+            del = sens_update_norm(m, del, SV_DELTA, SV_EWT);
+        }
+#endif
         if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
         double dcon = del * fmin(1.0, m.crate) * m.tq[4];
         if (dcon <= 1.0) {
             m.acnrm = (curiter == 0) ? del : wrms_n(m, m.acor, m.ewt);
+#ifdef SA_SENS
+            if (sim && curiter != 0) m.acnrm = sens_update_norm(m, m.acnrm, SV_ACOR, SV_EWT);
+#endif
             m.nls_jcur = 0;
             return CV_SUCCESS;
         }
@@ -2177,8 +2448,64 @@ DEV int cv_newton_pass(Cw<BWD> &m, int callSetup, int jbad, int &convfail, int &
         if (curiter >= NLS_MAXCOR) return NLS_CONV_RECVR;
         retval = cv_nls_residual(m, delta);
         if (retval != CV_SUCCESS) return retval;
+#ifdef SA_SENS
+        if (sim) {
+            retval = cv_nls_residual_sens(m);
+            if (retval != CV_SUCCESS) return retval;
+        }
+#endif
     }
 }
+
+#ifdef SA_SENS
+/* cvStgrNls (ism = CV_STAGGERED): Newton on the sensitivity systems with the state fixed */
+template <bool BWD>
+DEV int cv_stgr_nls(Cw<BWD> &m)
+{
+    int callSetup = 0, jbad = 0, convfail = CV_FAIL_OTHER, retval;
+    SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND }
+    for (;;) {
+        retval = cv_nls_residual_sens(m);
+        if (retval != CV_SUCCESS) break;
+        if (callSetup) {
+            retval = cv_nls_lsetup(m, jbad, convfail);
+            m.nsetupsS++;
+            if (retval != CV_SUCCESS) break;
+        }
+        int curiter = 0;
+        for (;;) {
+            m.nniS++;
+            cv_sens_newton_update(m);
+            double del = sens_update_norm(m, 0.0, SV_DELTA, SV_EWT);
+            if (curiter > 0) m.crateS = fmax(CRDOWN * m.crateS, del / m.delpS);
+            double dcon = del * fmin(1.0, m.crateS) * m.tq[4];
+            if (dcon <= 1.0) {
+                m.acnrmS = (curiter == 0) ? del : sens_update_norm(m, 0.0, SV_ACOR, SV_EWT);
+                retval = CV_SUCCESS;
+                m.nls_jcur = 0;
+                break;
+            }
+            if ((curiter >= 1) && (del > RDIV * m.delpS)) { retval = NLS_CONV_RECVR; break; }
+            m.delpS = del;
+            curiter++;
+            if (curiter >= NLS_MAXCOR) { retval = NLS_CONV_RECVR; break; }
+            retval = cv_nls_residual_sens(m);
+            if (retval != CV_SUCCESS) break;
+        }
+        if (retval == CV_SUCCESS) break;
+        if ((retval > 0) && !m.nls_jcur) {
+            callSetup = 1;
+            jbad = 1;
+            SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND }
+            continue;
+        }
+        break;
+    }
+    if (retval != CV_SUCCESS) return retval;
+    SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND }
+    return CV_SUCCESS;
+}
+#endif
 
 template <bool BWD>
 DEV int cv_error_test_failed(Cw<BWD> &m, double saved_t, double dsm, int &nef, int &netf_counter)
@@ -2214,6 +2541,14 @@ DEV int cv_error_test_failed(Cw<BWD> &m, double saved_t, double dsm, int &nef, i
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
     SFOR(r, 0, RS) m.zn[1][r] = m.h * m.tempv[r]; SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        retval = cv_fS(m, m.tn, m.zn[0], SV_ZN0, SV_TEMPV);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return CV_UNREC_SRHSFUNC_ERR;
+        SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZN0 + 1, is, r) = m.h * SV(m, SV_TEMPV, is, r); SEND }
+    }
+#endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, m.zn[0], m.tempvQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
@@ -2236,6 +2571,16 @@ DEV void cv_complete_step(Cw<BWD> &m)
         SFOR(r, 0, RS) m.zn[j][r] = FMA(m.l[j], m.acor[r], m.zn[j][r]); SEND
         if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(m.l[j], m.acorQ[r], m.znQ[j][r]); SEND }
     } SEND
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        SLOOP(is) {
+            double ac[RS];
+            SFOR(r, 0, RS) ac[r] = SV(m, SV_ACOR, is, r); SEND
+            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], ac[r], SV(m, SV_ZN0 + j, is, r)); SEND } SEND
+            if ((m.qwait - 1 == 1) && (m.q != QMAX)) { SFOR(r, 0, RS) SV(m, SV_ZSAVE, is, r) = ac[r]; SEND }
+        }
+    }
+#endif
     m.qwait--;
     {
         const bool sv = (m.qwait == 1) && (m.q != QMAX);
@@ -2278,6 +2623,18 @@ DEV void cv_prepare_next_step(Cw<BWD> &m, double dsm)
     SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
     double ddn = wrms_n(m, znq, m.ewt);
     if (BWD) ddn = quad_update_norm(m, ddn, znQq);
+#ifdef SA_SENS
+    if (SENS_ON(m) && full && m.q > 1) {            /* cvComputeEtaqm1: the sensitivities' column q takes part */
+        SLOOP(is) {
+            SFOR(r, 0, RS) {
+                double v = SV(m, SV_ZN0 + 2, is, r);
+                SFOR(k, 3, (QMAX) + 1) { if (m.q == k) v = SV(m, SV_ZN0 + k, is, r); } SEND
+                SV(m, SV_TEMPV, is, r) = v;
+            } SEND
+        }
+        ddn = sens_update_norm(m, ddn, SV_TEMPV, SV_EWT);
+    }
+#endif
     ddn = ddn * m.tq[1];
     const double base = m.h / m.tau[2];
     double pw = 1.0;
@@ -2289,6 +2646,12 @@ DEV void cv_prepare_next_step(Cw<BWD> &m, double dsm)
         SFOR(r, 0, RQ) tvQ[r] = FMA(-cquot, m.zsaveQ[r], m.acorQ[r]); SEND
         dup = quad_update_norm(m, dup, tvQ);
     }
+#ifdef SA_SENS
+    if (SENS_ON(m) && full && (m.q != QMAX) && (m.saved_tq5 != 0.0)) {     /* cvComputeEtaqp1 */
+        SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_TEMPV, is, r) = FMA(-cquot, SV(m, SV_ZSAVE, is, r), SV(m, SV_ACOR, is, r)); SEND }
+        dup = sens_update_norm(m, dup, SV_TEMPV, SV_EWT);
+    }
+#endif
     dup = dup * m.tq[3];
     const double p0 = rpower_nb(BIAS2 * dsm, inv_int(m.L));
     const double p1 = rpower_nb(BIAS1 * ddn, inv_int(m.q));
@@ -2309,6 +2672,9 @@ DEV void cv_prepare_next_step(Cw<BWD> &m, double dsm)
     m.qprime = full ? qp_f : m.q;
     SFOR(r, 0, RS) m.zsave[r] = up ? m.acor[r] : m.zsave[r]; SEND
     if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = up ? m.acorQ[r] : m.zsaveQ[r]; SEND }
+#ifdef SA_SENS
+    if (SENS_ON(m) && up) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZSAVE, is, r) = SV(m, SV_ACOR, is, r); SEND } }
+#endif
     {   /* cvSetEta */
         const bool small = m.eta < THRESH;
         const double capped = fmin(m.eta, m.etamax);
@@ -2356,6 +2722,9 @@ DEV int cv_first_call(Cw<BWD> &m, double tout)
 #endif
     if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { if (sens_ewt_set(m, SV_ZN0, SV_EWT) != 0) return CV_ILL_INPUT; }
+#endif
     if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
     int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
     if (retval < 0) return CV_RHSFUNC_FAIL;
@@ -2368,6 +2737,13 @@ DEV int cv_first_call(Cw<BWD> &m, double tout)
         if (retval < 0) return CV_QRHSFUNC_FAIL;
         if (retval > 0) return CV_FIRST_QRHSFUNC_ERR;
     }
+#ifdef SA_SENS
+    if (SENS_ON(m)) {
+        retval = cv_fS(m, m.tn, m.zn[0], SV_ZN0, SV_ZN0 + 1);
+        if (retval < 0) return CV_SRHSFUNC_FAIL;
+        if (retval > 0) return CV_FIRST_SRHSFUNC_ERR;
+    }
+#endif
     double tout_hin = tout;
     if (BWD) {
         if ((m.tstop - m.tn) * (tout - m.tn) <= 0.0) return CV_ILL_INPUT;
@@ -2382,6 +2758,9 @@ DEV int cv_first_call(Cw<BWD> &m, double tout)
     m.hprime = m.h;
     SFOR(r, 0, RS) m.zn[1][r] = m.h * m.zn[1][r]; SEND
     if (BWD) { SFOR(r, 0, RQ) m.znQ[1][r] = m.h * m.znQ[1][r]; SEND }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZN0 + 1, is, r) = m.h * SV(m, SV_ZN0 + 1, is, r); SEND } }
+#endif
     return CV_SUCCESS;
 }
 
@@ -2390,14 +2769,20 @@ DEV int cv_pre_step(Cw<BWD> &m)
 {
     if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { if (sens_ewt_set(m, SV_ZN0, SV_EWT) != 0) return CV_ILL_INPUT; }
+#endif
     double nrm = wrms_n(m, m.zn[0], m.ewt);
     if (BWD) nrm = quad_update_norm(m, nrm, m.znQ[0]);
+#ifdef SA_SENS
+    if (SENS_ON(m)) nrm = sens_update_norm(m, nrm, SV_ZN0, SV_EWT);
+#endif
     if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
     return CV_SUCCESS;
 }
 
 struct StepCtl {
-    int in_step, redo, nflag, ncf, nef, nefQ, convfail;
+    int in_step, redo, nflag, ncf, nef, nefQ, convfail, ncfS, nefS;
     double saved_t;
 };
 
@@ -2432,16 +2817,17 @@ DEV void cold_load(Cw<BWD> &m)
 #endif
 
 template <bool BWD>
-DEV int cv_handle_nflag_failed(Cw<BWD> &m, StepCtl &c, int nflag)
+DEV int cv_handle_nflag_failed(Cw<BWD> &m, StepCtl &c, int nflag, int &ncf, int &ncfn)
 {
-    m.ncfn++;
+    ncfn++;
     cv_restore(m, c.saved_t);
     if (nflag < 0) return nflag;
-    c.ncf++;
+    ncf++;
     m.etamax = 1.0;
-    if (c.ncf == MXNCF) {
+    if (ncf == MXNCF) {
         if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
         if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
+        if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
         if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
         return CV_REPTD_QRHSFUNC_ERR;
     }
@@ -2458,6 +2844,7 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
     if (!c.in_step) {
         c.saved_t = m.tn;
         c.ncf = c.nef = c.nefQ = 0;
+        c.ncfS = c.nefS = 0;
         c.nflag = FIRST_CALL;
         c.redo = 0;
         if ((m.nst > 0) && (m.hprime != m.h)) {
@@ -2499,7 +2886,7 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
         return 0;
     }
     c.redo = 0;
-    if (nls != CV_SUCCESS) { COLD_LOAD(m); return cv_handle_nflag_failed(m, c, nls); }
+    if (nls != CV_SUCCESS) { COLD_LOAD(m); return cv_handle_nflag_failed(m, c, nls, c.ncf, m.ncfn); }
 
     SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
 #ifdef SA_CONSTRAINTS
@@ -2531,7 +2918,7 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
                 const double minq = -wave_max(m.lane, -q);
                 m.eta = fmax(0.9 * minq, 0.1);
                 COLD_LOAD(m);
-                return cv_handle_nflag_failed(m, c, CONSTR_RECVR);
+                return cv_handle_nflag_failed(m, c, CONSTR_RECVR, c.ncf, m.ncfn);
             }
         }
     }
@@ -2542,11 +2929,30 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
         COLD_LOAD(m);
         return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
     }
+#ifdef SA_SENS
+    if (SENS_ON(m) && m.ism == 0) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND } }
+    if (SENS_ON(m) && m.ism == 1) {      /* CV_STAGGERED: sensitivities after the state passed (oracle cv_step) */
+        c.ncf = c.nef = 0;
+        int retval = cv_f(m, m.tn, m.y, m.ftemp);
+        if (retval < 0) return CV_RHSFUNC_FAIL;
+        if (retval > 0) { COLD_LOAD(m); c.nflag = PREV_CONV_FAIL; return 0; }
+        const int nflagS = cv_stgr_nls(m);
+        if (nflagS != CV_SUCCESS) { COLD_LOAD(m); return cv_handle_nflag_failed(m, c, nflagS, c.ncfS, m.ncfnS); }
+        m.acnrmS = sens_update_norm(m, 0.0, SV_ACOR, SV_EWT);
+        const double dsmS = m.acnrmS * m.tq[2];
+        if (dsmS > 1.0) {
+            c.nflag = PREV_ERR_FAIL;
+            COLD_LOAD(m);
+            return cv_error_test_failed(m, c.saved_t, dsmS, c.nefS, m.netfS);
+        }
+        if (dsmS > dsm) dsm = dsmS;
+    }
+#endif
     if (BWD) {
         c.ncf = c.nef = 0;
         int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
         COLD_LOAD(m);
-        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR);
+        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR, c.ncf, m.ncfn);
         SFOR(r, 0, RQ) {
             m.acorQ[r] = FMA(m.h, m.acorQ[r], -m.znQ[1][r]);
             m.acorQ[r] = m.rl1 * m.acorQ[r];
@@ -2567,6 +2973,9 @@ DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
     m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
     SFOR(r, 0, RS) m.acor[r] = m.tq[2] * m.acor[r]; SEND
     if (BWD) { SFOR(r, 0, RQ) m.acorQ[r] = m.tq[2] * m.acorQ[r]; SEND }
+#ifdef SA_SENS
+    if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = m.tq[2] * SV(m, SV_ACOR, is, r); SEND } }
+#endif
     c.in_step = 0;
     PH_ADD(m, 5)
     return 1;
@@ -2592,8 +3001,12 @@ DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_st
         m.obase = grp * W_NOUTP;
     }
     m.pr = pr + (int64_t)inst * rem_stride;
-    m.sj = ws + (int64_t)inst * WS_DOUBLES + WS_SJ;
-    m.obuf = ws + (int64_t)inst * WS_DOUBLES + WS_OUT;
+    m.sj = ws_inst(ws, inst) + WS_SJ;
+    m.obuf = ws_inst(ws, inst) + WS_OUT;
+#ifdef SA_SENS
+    m.sws = ws + (int64_t)(inst / KPW * KPW) * WS_DOUBLES + (int64_t)KPW * WS_SMALL + m.lane;
+    m.sensi = 0; m.ism = 0; m.pbar = nullptr;
+#endif
     for (int j = m.li; j < NQ; j += G) s_ps[m.pbase + j] = ps[(int64_t)inst * NQ + j];
     m.nswaps = 0;
     SFOR(r, 0, RS) { m.inv_piv[r] = 0.0; m.ytmp[r] = 0.0; m.ewt[r] = 0.0; } SEND
@@ -2660,7 +3073,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     if (inst >= a.B) return;
     if (threadIdx.x == 0) s_nwaves = SA_WAVES;
     if (sa_wave_index() != 0) {
-        worker_loop<false>(a.pr + (int64_t)inst * a.rem_stride, a.ws + (int64_t)inst * WS_DOUBLES + WS_OUT);
+        worker_loop<false>(a.pr + (int64_t)inst * a.rem_stride, ws_inst(a.ws, inst) + WS_OUT);
         return;
     }
     Cw<false> m;
@@ -2697,7 +3110,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     }
     bool done = (k >= a.n_t);
     StepCtl c;
-    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0; c.saved_t = a.t0;
+    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.ncfS = c.nefS = 0; c.convfail = 0; c.saved_t = a.t0;
     if (!done) {
         int flag = cv_first_call(m, a.tvals[k]);
         if (flag != CV_SUCCESS) { status = flag; done = true; }
@@ -2790,6 +3203,118 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     }
 }
 
+#ifdef SA_SENS
+/* Solver(sens_mode=...).solve (reference solver.py:360-392, 497-531) in the lean lane groups: the forward problem
+   together with its NQ sensitivity systems.  Same control flow as sa_k_forward without the trajectory; bit-identical
+   to the register kernel's / bdf_mem.hip's sa_k_sens (and to the oracle). */
+extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
+{
+    const int inst = blockIdx.x * KPW + sa_grp();
+    if (inst >= a.B) return;
+    if (threadIdx.x == 0) s_nwaves = 1;
+    Cw<false> m;
+    setup_common(m, a.ps, a.pr, a.rem_stride, inst, a.ws);
+    m.rtol = a.rtol;
+#ifdef SA_CONSTRAINTS
+    m.constr = 0;
+    SFOR(r, 0, RS) m.cons[r] = 0.0; SEND
+#endif
+    SFOR(r, 0, RS) m.atol[r] = (IDX(m, r) < NS) ? a.atol[IDX(m, r) < NS ? IDX(m, r) : 0] : 1.0; SEND
+    m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0;
+    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
+    m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
+    m.traj = nullptr; m.trow = 0;
+    m.sensi = 1; m.ism = a.ism; m.pbar = a.pbar;
+
+    double y0[RS], q0[RQ];
+    SFOR(r, 0, RS) y0[r] = (IDX(m, r) < NS) ? a.y0[(int64_t)inst * NS + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND
+    SFOR(r, 0, RQ) q0[r] = 0.0; SEND
+    cv_reinit(m, a.t0, y0, q0);
+    const double *s0 = a.sens0 + (int64_t)inst * NQ * NS;
+    for (int v = 0; v < SV_COUNT; v++)
+        SLOOP(is) { SFOR(r, 0, RS) SV(m, v, is, r) = (v == SV_ZN0 && IDX(m, r) < NS) ? s0[is * NS + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND }
+
+    double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
+    double *so = a.sens_out + (int64_t)inst * a.n_t * NQ * NS;
+    int status = CV_SUCCESS, k = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
+    while (k < a.n_t && a.tvals[k] == a.t0) {
+        SFOR(r, 0, RS) { if (IDX(m, r) < NS) yo[(int64_t)k * NS + IDX(m, r)] = y0[r]; } SEND
+        SLOOP(is) { SFOR(r, 0, RS) { if (IDX(m, r) < NS) so[((int64_t)k * NQ + is) * NS + IDX(m, r)] = s0[is * NS + IDX(m, r)]; } SEND }
+        k++;
+    }
+    bool done = (k >= a.n_t);
+    StepCtl c;
+    c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.ncfS = c.nefS = 0; c.convfail = 0;
+    c.saved_t = a.t0;
+    if (!done) {
+        int flag = cv_first_call(m, a.tvals[k]);
+        if (flag != CV_SUCCESS) { status = flag; done = true; }
+    }
+    while (!done) {
+        if (!c.in_step) {
+            int ier = cv_pre_step(m);
+            if (ier == CV_ILL_INPUT) { status = ier; done = true; }
+            else if (a.mxstep > 0 && nstloc >= a.mxstep) {
+                retries++; total_retries++;
+                if (retries >= a.max_retries) { status = CV_TOO_MUCH_WORK; done = true; }
+                else nstloc = 0;
+            }
+            if (!done && ier != CV_SUCCESS) { status = ier; done = true; }
+        }
+        if (!done) {
+            attempts++;
+            int r = cv_attempt(m, c);
+            if (r < 0) { status = r; done = true; }
+            else if (r == 1) {
+                nstloc++;
+                while (!done && k < a.n_t) {
+                    double tout = a.tvals[k];
+                    if (tout == a.t0) {
+                        SFOR(s, 0, RS) { if (IDX(m, s) < NS) yo[(int64_t)k * NS + IDX(m, s)] = y0[s]; } SEND
+                        SLOOP(is) { SFOR(s, 0, RS) { if (IDX(m, s) < NS) so[((int64_t)k * NQ + is) * NS + IDX(m, s)] = s0[is * NS + IDX(m, s)]; } SEND }
+                        k++;
+                    } else if ((m.tn - tout) * m.h >= 0.0) {
+                        double dky[RS], dq[RQ];
+                        cv_get_dky0(m, tout, dky, dq);
+                        SFOR(s, 0, RS) { if (IDX(m, s) < NS) yo[(int64_t)k * NS + IDX(m, s)] = dky[s]; } SEND
+                        {   /* CVodeGetSensDky, k = 0 (t validated by cv_get_dky0) */
+                            const double sx = (tout - m.tn) / m.h;
+                            double pw[QMAX + 1];
+                            pw[0] = 1.0;
+                            SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * sx; SEND
+                            SLOOP(is) {
+                                SFOR(s, 0, RS) {
+                                    double acc = pw[QMAX] * SV(m, SV_ZN0 + QMAX, is, s);
+                                    SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], SV(m, SV_ZN0 + j, is, s), acc); SEND
+                                    if (IDX(m, s) < NS) so[((int64_t)k * NQ + is) * NS + IDX(m, s)] = acc;
+                                } SEND
+                            }
+                        }
+                        k++;
+                        nstloc = 0; retries = 0;
+                    } else break;
+                }
+                if (k >= a.n_t) done = true;
+            }
+        }
+    }
+    if (status != CV_SUCCESS) {
+        for (int j = m.li; j < a.n_t * NS; j += G) yo[j] = SA_NAN;
+        for (int j = m.li; j < a.n_t * NQ * NS; j += G) so[j] = SA_NAN;
+    }
+    if (m.li == 0) {
+        a.status[inst] = status;
+        int64_t st[SA_N_STATS];
+        SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
+        accumulate_stats(m, st);
+        /* sensitivity counters ride in the quadrature / interpolation slots of the adjoint path */
+        st[ST_NFQE] = m.nfSe; st[ST_NETFQ] = m.netfS; st[ST_NINTERP] = m.nniS; st[ST_NREBUILD] = m.ncfnS;
+        st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+        SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
+    }
+}
+#endif
+
 extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd_args a)
 {
     const int inst = blockIdx.x * KPW + sa_grp();
@@ -2799,7 +3324,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     if (threadIdx.x == 0) { s_luprof[0] = 0; s_luprof[1] = 0; s_luprof[2] = 0; s_luprof[3] = 0; s_luprof[4] = 0; }
 #endif
     if (sa_wave_index() != 0) {
-        worker_loop<true>(a.pr + (int64_t)inst * a.rem_stride, a.ws + (int64_t)inst * WS_DOUBLES + WS_OUT);
+        worker_loop<true>(a.pr + (int64_t)inst * a.rem_stride, ws_inst(a.ws, inst) + WS_OUT);
         return;
     }
     int64_t st[SA_N_STATS];
@@ -2845,13 +3370,15 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
                     if ((t_lower - a.tinitial) < -tfuzz || (m.tfinal - t_lower) < -tfuzz) status = CV_ILL_INPUT;
                 }
                 if (status == CV_SUCCESS) {
+                    PH_T0
                     int flag = cv_first_call(m, t_lower);
+                    PH_ADD(m, 6)
                     if (flag != CV_SUCCESS) status = flag;
                 }
             }
             int nstloc = 0, retries = 0;
             StepCtl c;
-            c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.convfail = 0;
+            c.in_step = 0; c.redo = 0; c.nflag = FIRST_CALL; c.ncf = c.nef = c.nefQ = 0; c.ncfS = c.nefS = 0; c.convfail = 0;
             c.saved_t = t_upper;
             bool idone = (status != CV_SUCCESS);
             while (!idone) {
@@ -2918,6 +3445,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
 #ifdef SA_WAVE_PROFILE
         SFOR(i, 0, 6) st[9 + i] = m.prof[i]; SEND
         st[15] = m.prof[7] + (int64_t)wall_clock64();
+#if defined(SA_WAVE_PROFILE_PHASES) && SA_WAVES == 1
+        st[ST_NPTS] = m.prof[6];            /* phase builds: restarts (cv_first_call: f, fQ, cvHin) in the point-count slot */
+#endif
 #if SA_WAVES > 1
         st[5] = s_luprof[0]; st[6] = s_luprof[1]; st[7] = s_luprof[2];      /* LU: cycles pre-barrier / barrier / update */
         st[8] = s_luprof[3] + (s_luprof[4] << 32);                          /* ... prologue | epilogue << 32 */

@@ -190,11 +190,11 @@ def test_solution_variables_follow_the_leaf_table():
 
 
 def test_hermite_kernel_selection_with_many_parameters():
-    """Few states but more differentiated parameters than the cooperative kernels carry: the Hermite build must
+    """Few states but more differentiated parameters than one lane carries: the build (Hermite or not) must
     fall through to the lane-group kernel instead of failing (kernel_variant)."""
     from sunode_amd import _native
     src = "#define SA_N_STATES 3\n#define SA_N_SUB 10\n#define SA_N_REM 0\n"
-    assert _native.kernel_variant(src, hermite=True) == ("bdf_wave.hip", 8)
+    assert _native.kernel_variant(src, hermite=True) == ("bdf_wave.hip", 4)
     assert _native.kernel_variant(src, hermite=False)[0] == "bdf_wave.hip"
     small = "#define SA_N_STATES 3\n#define SA_N_SUB 3\n#define SA_N_REM 0\n"
     assert _native.kernel_variant(small, hermite=True) == ("bdf_kernels.hip", 1)     # register kernel carries Hermite

@@ -42,6 +42,8 @@ def main():
     for tag, stt in (("fwd", stats), ("bwd", statsb)):
         tot = stt[:, 15].mean() * 1e-5
         parts = ", ".join("%s %.1f" % (n, stt[:, 9 + i].mean() * 1e-5) for i, n in enumerate(names))
+        if tag == "bwd" and "PROFILE_PHASES" in os.environ.get("SA_KERNEL_DEFINES", "") and stt[:, 8].mean() > 1e4:
+            parts += ", restarts %.1f" % (stt[:, 8].mean() * 1e-5)
         if tag == "bwd" and (stt[:, 8] >> 32).sum() > 0 and (stt[:, 8] >> 32).max() < (1 << 30):   # workgroup-LU builds only
             nlu = max(stt[:, 2].mean(), 1)
             # the three partial counters are s_memtime reads the compiler may move across VALU work: indicative only
