@@ -190,26 +190,27 @@ def _size_defines(native_source: str):
 
 
 def code_object_path(native_source: str, sens: bool = False, constraints: bool = False,
-                     hermite: bool = False) -> str:
+                     hermite: bool = False, compact: bool = False) -> str:
     fname, group = kernel_variant(native_source, sens, constraints, hermite)
     kern = os.path.join(_CSRC, fname)
-    deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h")]
+    deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h", "bdf_core.h")]
     deps = [d for d in deps if os.path.exists(d)]
     extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group + fname.encode()
              + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode()
-             + (b"SENS" if sens else b"") + (b"CONSTR" if constraints else b"") + (b"HERMITE" if hermite else b""))
+             + (b"SENS" if sens else b"") + (b"CONSTR" if constraints else b"") + (b"HERMITE" if hermite else b"")
+             + (b"COMPACT" if compact else b""))
     key = _hash_files(*deps, extra=extra) if os.path.exists(kern) else \
         hashlib.sha256(extra).hexdigest()[:16]
     return os.path.join(_CACHE, "sa_%s.hsaco" % key)
 
 
 def build_code_object(native_source: str, force: bool = False, keep_temps: bool = False,
-                      sens: bool = False, constraints: bool = False, hermite: bool = False) -> str:
+                      sens: bool = False, constraints: bool = False, hermite: bool = False, compact: bool = False) -> str:
     """Compile the integrator kernels for one problem to a gfx950 code object (cached).
     ``constraints=True`` builds the variant that enforces CVodeSetConstraints-style inequality
     constraints (a separate code object: the default build carries no trace of them)."""
     os.makedirs(_CACHE, exist_ok=True)
-    out = code_object_path(native_source, sens, constraints, hermite)
+    out = code_object_path(native_source, sens, constraints, hermite, compact)
     if os.path.exists(out) and not force:
         return out
     fname, group = kernel_variant(native_source, sens, constraints, hermite)
@@ -225,7 +226,7 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
               "-Xclang", "-disable-O0-optnone", "-ffp-contract=off", "-std=c++17",
               "-DSA_PROBLEM_HEADER=\"%s\"" % hdr, "-DSA_GROUP=%d" % group] + _size_defines(native_source)
              + (["-DSA_SENS=1"] if sens else []) + (["-DSA_CONSTRAINTS=1"] if constraints else [])
-             + (["-DSA_HERMITE=1"] if hermite else [])
+             + (["-DSA_HERMITE=1"] if hermite else []) + (["-DSA_COMPACT_TRAJ=1"] if compact else [])
              + ["-I" + _CSRC, kern, "-o", bc0])
         _run([os.path.join(LLVM_BIN, "opt"), "-passes=always-inline,sroa", bc0, "-o", bc1])
         occupancy = os.environ.get("SA_WAVES_PER_EU")
@@ -347,10 +348,10 @@ class NativeSolver:
     def __init__(self, native_source: str, *, device: int = 0, rtol=1e-10, atol=1e-10, rtolB=1e-10,
                  atolB=1e-10, rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
                  max_retries_bwd=50, traj_capacity=500_001, n_states: Optional[int] = None, sens: bool = False,
-                 constraints=None, hermite: bool = False, arena_bytes: int = 0):
+                 constraints=None, hermite: bool = False, arena_bytes: int = 0, compact: bool = False):
         self.L = load_library()
         self.code_object = build_code_object(native_source, sens=sens, constraints=constraints is not None,
-                                             hermite=hermite)
+                                             hermite=hermite, compact=compact)
         self._h = ctypes.c_void_p()
         self._user_stream = False
         self._n_hint = n_states

@@ -104,8 +104,7 @@ struct Cv {
     /* forward sensitivities (Solver(sens_mode=...), reference solver.py:360-392): one Nordsieck array per
        differentiated parameter, kept in registers like the state's (columns above q at zero, the saved correction
        in zsaveS); only the SA_SENS build of the forward problem carries them */
-    double znS[QMAX + 1][NQD][NSD], zsaveS[NQD][NSD];
-    double ewtS[NQD][NSD], acorS[NQD][NSD], tempvS[NQD][NSD], ftempS[NQD][NSD], yS[NQD][NSD], deltaS[NQD][NSD];
+    double sv[SV_COUNT][NQD][NSD];    /* SV(m, vector, parameter, component): SV_ZN0..5, SV_ZSAVE, SV_EWT, ... (sa_common.h) */
     double pbar[NQD], crateS, delpS, acnrmS;
     int sensi, ism, nfSe, nniS, ncfnS, netfS, nsetupsS;
 #endif
@@ -139,10 +138,44 @@ struct Cv {
  * common move (one index to the left) needs no load at all (t[idx-1], t[idx-2] ride along in
  * registers).  Same values as CVODES computes on demand, hence bit-identical to the oracle.
  */
+#if defined(SA_COMPACT_TRAJ) && !defined(SA_HERMITE)
+/* -DSA_COMPACT_TRAJ (AdjointSolver(compact_trajectory=True)): the arena holds what CVODES itself stores per step and
+ * SURVEY 8(d) counts -- {order, t, y[n]}, n + 2 doubles instead of 8 + 6n -- and the BACKWARD kernel rebuilds the
+ * divided-difference table into its LDS column when the index moves (the same operations in the same order the forward
+ * kernel performs otherwise: build_table below), from the order + 1 points ending at the index: one contiguous block of
+ * the instance's records.  5.2x (n = 3) ... 5.8x (n = 16) less arena and forward write traffic, no table build and no
+ * point history in the forward kernel; the price is the rebuild in the divergent part of the backward loop (the
+ * reason the table records exist).  Measured A/B: profiles/r03_compact_trajectory.txt. */
+#define SA_COMPACT 1
+#define TREC (NS + 2)
+#define TREC_T 1
+#define TREC_Y 2
+#else
+#define SA_COMPACT 0
 #define TREC (8 + 6 * NS)
+#define TREC_T 2
+#define TREC_Y 8
+#endif
+#define TTAB (8 + 6 * NS)            /* the table in LDS: {order, dt, T[6], Y[6][n]} */
 
 template <bool BWD>
-DEV double point_time(const Cv<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + 2]; }
+DEV double point_time(const Cv<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + TREC_T]; }
+
+/* Newton divided differences of CVApolynomialGetY over the points hT[j], hY[j] (j = 0 newest .. order), scaled by
+   dt^j: factor = dt / (T[j] - T[j-i]), Y[j] = factor * (Y[j] - Y[j-1]) -- the oracle's operation order */
+DEV void build_table(int order, double dt, const double (&hT)[QMAX + 1], double (&Y)[QMAX + 1][NSD])
+{
+    SFOR(i, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, 1) {
+            if constexpr (j >= i) {
+                if (j <= order) {
+                    double factor = dt / (hT[j] - hT[j - i]);
+                    SFOR(k, 0, NS) Y[j][k] = factor * (Y[j][k] - Y[j - 1][k]); SEND
+                }
+            }
+        } SEND
+    } SEND
+}
 
 /* CVAfindIndex + CVApolynomialGetY (forward integration direction), with the wrappers'
    repeated interpolation at an unchanged t evaluated once. */
@@ -205,7 +238,7 @@ DEV int interp_y(Cv<BWD> &m, double t)
     m.have_last = 1;
     m.last_t = t;
     if (indx == 0) {
-        SFOR(i, 0, NS) m.ytmp[i] = m.traj[8 + i]; SEND        /* record 0: Y[0] = y(t0) */
+        SFOR(i, 0, NS) m.ytmp[i] = m.traj[TREC_Y + i]; SEND   /* record 0: Y[0] = y(t0) */
         return CV_SUCCESS;
     }
 #ifdef SA_HERMITE
@@ -246,11 +279,31 @@ DEV int interp_y(Cv<BWD> &m, double t)
         /* the touches issued at the previous move have long landed: retire them (keeps their
            destination registers reserved until now, i.e. the loads were never waited for early) */
         asm volatile("" :: "v"(m.pf[0]), "v"(m.pf[1]), "v"(m.pf[2]), "v"(m.pf[3]));
+#if SA_COMPACT
+        {   /* rebuild: the order + 1 points ending at indx (all loads in flight together; unused columns zero) */
+            const int order = (int)r[0];
+            double hT[QMAX + 1], Y[QMAX + 1][NSD];
+            SFOR(j, 0, (QMAX) + 1) {
+                const double *rj = m.traj + (int64_t)(indx - j > 0 ? indx - j : 0) * m.trow;
+                hT[j] = rj[TREC_T];
+                SFOR(k, 0, NS) { const double v = rj[TREC_Y + k]; Y[j][k] = (j <= order) ? v : 0.0; } SEND
+            } SEND
+            const double dt = fabs(hT[0] - hT[1]);
+            build_table(order, dt, hT, Y);
+            m.ltab[0] = (double)order;
+            m.ltab[64] = dt;
+            SFOR(j, 0, (QMAX) + 1) m.ltab[(2 + j) * 64] = hT[j]; SEND
+            SFOR(j, 0, (QMAX) + 1) { SFOR(k, 0, NS) m.ltab[(8 + j * NS + k) * 64] = Y[j][k]; SEND } SEND
+            const double *rn = r - (indx > QMAX + 1 ? (QMAX + 1) * m.trow : 0);     /* the point the next move adds */
+            m.pf[0] = rn[0]; m.pf[1] = rn[TREC - 1]; m.pf[2] = m.pf[0]; m.pf[3] = m.pf[1];
+        }
+#else
         SFOR(f, 0, TREC) m.ltab[f * 64] = r[f]; SEND
         {   /* touch the record of the next index to the left so that it is L2-resident when needed */
             const double *rn = r - (indx > 0 ? m.trow : 0);
             m.pf[0] = rn[0]; m.pf[1] = rn[TREC / 3]; m.pf[2] = rn[2 * TREC / 3]; m.pf[3] = rn[TREC - 1];
         }
+#endif
         if (m.ltab[0] > (double)indx) return CV_GETY_BADT;   /* CVODES would shift the base; cannot occur */
         if (indx == m.ilast) m.tlo2 = m.ltab[4 * 64];        /* T[2] = t[ilast-2] for the next move */
     }
@@ -309,9 +362,9 @@ DEV int cv_jac(Cv<BWD> &m, double t, const double *y, double *J)
 }
 
 #ifdef SA_SENS
-/* sensitivity right-hand side for all parameters: out[is] = J(t,y) yS[is] + df/dp_is (oracle cv_fS) */
-template <bool BWD>
-DEV int cv_fS(Cv<BWD> &m, double t, const double *y, const double (&ys)[NQD][NSD], double (&out)[NQD][NSD])
+/* sensitivity right-hand side for all parameters: SV(v_out)[is] = J(t,y) SV(v_in)[is] + df/dp_is (oracle cv_fS) */
+template <int v_in, int v_out, bool BWD>
+DEV int cv_fS(Cv<BWD> &m, double t, const double *y)
 {
     m.nfSe++;
     double Jt[NSD * NSD], dp[NQD * NSD];
@@ -320,10 +373,10 @@ DEV int cv_fS(Cv<BWD> &m, double t, const double *y, const double (&ys)[NQD][NSD
     rc = sa_dydp(t, y, m.ps, PR_OF(m), dp);
     int bad = 0;
     SFOR_S(is, i) {
-        double acc = Jt[0 * NS + i] * ys[is][0];
-        SFOR(j, 1, NS) acc = FMA(Jt[j * NS + i], ys[is][j], acc); SEND
+        double acc = Jt[0 * NS + i] * m.sv[v_in][is][0];
+        SFOR(j, 1, NS) acc = FMA(Jt[j * NS + i], m.sv[v_in][is][j], acc); SEND
         acc = acc + dp[is * NS + i];
-        out[is][i] = acc;
+        m.sv[v_out][is][i] = acc;
         bad |= !(acc * 0.0 == 0.0);
     } SEND_S
     return (rc != 0 || bad) ? 1 : 0;
@@ -392,31 +445,6 @@ DEV int ewtQ_set(const Cv<BWD> &m, const double *qcur, double *w)
     return bad ? -1 : 0;
 }
 
-#ifdef SA_SENS
-/* cvSensEwtSetEE / cvSensUpdateNorm (see the oracle) */
-template <bool BWD>
-DEV int sens_ewt_set(const Cv<BWD> &m, const double (&ys)[NQD][NSD], double (&w)[NQD][NSD])
-{
-    int bad = 0;
-    SFOR_S(is, i) {
-        const double v = FMA(m.rtol, fabs(m.pbar[is] * ys[is][i]), m.atol[i]);
-        bad |= (v <= 0.0);
-        w[is][i] = m.pbar[is] * (1.0 / v);
-    } SEND_S
-    return bad ? -1 : 0;
-}
-
-template <bool BWD>
-DEV double sens_update_norm(const Cv<BWD> &m, double old_nrm, const double (&x)[NQD][NSD], const double (&w)[NQD][NSD])
-{
-    double nrm = old_nrm;
-    SFOR(is, 0, NQ) {
-        const double snrm = wrms<NS>(x[is], w[is]);
-        nrm = snrm > nrm ? snrm : nrm;
-    } SEND
-    return nrm;
-}
-#endif
 
 /* ---- dense LU with partial pivoting, column-major, fully unrolled (denseGETRF/GETRS) ---- */
 DEV int dense_getrf(double *a, int *p, double *inv_piv)
@@ -479,357 +507,6 @@ DEV void dense_getrs(const double *a, const int *p, const double *inv_piv, doubl
     if (NS > 0) b[0] *= inv_piv[0];
 }
 
-/* ---- CVodeInit / CVodeReInit ---- */
-template <bool BWD>
-DEV void cv_reinit(Cv<BWD> &m, double t0, const double *y0, const double *q0)
-{
-    m.tn = t0;
-    m.q = 1; m.L = 2; m.qwait = 2; m.etamax = ETAMX1;
-    m.qu = 0; m.hu = 0.0;
-    SFOR(j, 0, (QMAX) + 1) {
-        SFOR(i, 0, NS) m.zn[j][i] = 0.0; SEND
-        SFOR(i, 0, NQ) m.znQ[j][i] = 0.0; SEND
-    } SEND
-    SFOR(i, 0, NS) m.zn[0][i] = y0[i]; SEND
-    if (BWD) { SFOR(i, 0, NQ) m.znQ[0][i] = q0[i]; SEND }
-    m.nst = m.nfe = m.ncfn = m.netf = m.nni = m.nsetups = 0;
-    m.nje = 0; m.nstlp = 0; m.nstlj = 0; m.nfQe = m.netfQ = 0;
-    m.h = 0.0; m.hprime = 0.0; m.hscale = 0.0; m.eta = 1.0;
-    m.qprime = 1;
-    m.gamma = m.gammap = 0.0; m.gamrat = 1.0; m.crate = 1.0; m.delp = 0.0;
-    m.acnrm = 0.0; m.saved_tq5 = 0.0;
-    m.jcur = 0; m.nls_jcur = 0;
-    SFOR(i, 0, 7) { m.tau[i] = 0.0; m.l[i] = 0.0; } SEND
-    SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
-    SFOR(i, 0, NS) { m.acor[i] = 0.0; m.tempv[i] = 0.0; m.ftemp[i] = 0.0; m.y[i] = 0.0; m.zsave[i] = 0.0; } SEND
-    SFOR(i, 0, NQ) { m.acorQ[i] = 0.0; m.tempvQ[i] = 0.0; m.zsaveQ[i] = 0.0; } SEND
-#ifdef SA_SENS
-    m.crateS = 1.0; m.delpS = 0.0; m.acnrmS = 0.0;
-    m.nfSe = m.nniS = m.ncfnS = m.netfS = m.nsetupsS = 0;
-#endif
-}
-
-/* ---- cvHin ---- */
-template <bool BWD>
-DEV double cv_upper_bound_h0(Cv<BWD> &m, double tdist)
-{
-    double hub_inv = 0.0;
-    {
-        double temp1[NSD];
-        ewt_set(m, m.zn[0], temp1);
-        SFOR(i, 0, NS) {
-            double t2 = fabs(m.zn[0][i]);
-            double t1 = 1.0 / temp1[i];
-            t1 = FMA(HUB_FACTOR, t2, t1);
-            double v = fabs(m.zn[1][i]) / t1;
-            if (v > hub_inv) hub_inv = v;
-        } SEND
-    }
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        sens_ewt_set(m, m.znS[0], m.tempvS);
-        SFOR_S(is, i) {
-            const double t2 = fabs(m.znS[0][is][i]);
-            double t1 = 1.0 / m.tempvS[is][i];
-            t1 = FMA(HUB_FACTOR, t2, t1);
-            const double v = fabs(m.znS[1][is][i]) / t1;
-            if (v > hub_inv) hub_inv = v;
-        } SEND_S
-    }
-#endif
-    if (BWD) {
-        double tempQ[NQD];
-        ewtQ_set(m, m.znQ[0], tempQ);
-        double hubQ_inv = 0.0;
-        SFOR(i, 0, NQ) {
-            double t2 = fabs(m.znQ[0][i]);
-            double t1 = 1.0 / tempQ[i];
-            t1 = FMA(HUB_FACTOR, t2, t1);
-            double v = fabs(m.znQ[1][i]) / t1;
-            if (v > hubQ_inv) hubQ_inv = v;
-        } SEND
-        if (hubQ_inv > hub_inv) hub_inv = hubQ_inv;
-    }
-    double hub = HUB_FACTOR * tdist;
-    if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
-    return hub;
-}
-
-template <bool BWD>
-DEV int cv_ydd_norm(Cv<BWD> &m, double hg, double *yddnrm)
-{
-    SFOR(i, 0, NS) m.y[i] = FMA(hg, m.zn[1][i], m.zn[0][i]); SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) { SFOR_S(is, i) m.yS[is][i] = FMA(hg, m.znS[1][is][i], m.znS[0][is][i]); SEND_S }
-#endif
-    if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-    int retval = cv_f(m, m.tn + hg, m.y, m.tempv);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return RHSFUNC_RECVR;
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        retval = cv_fS(m, m.tn + hg, m.y, m.yS, m.tempvS);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return SRHSFUNC_RECVR;
-    }
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn + hg, m.y, m.tempvQ);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return QRHSFUNC_RECVR;
-    }
-    SFOR(i, 0, NS) {
-        m.tempv[i] = m.tempv[i] - m.zn[1][i];
-        m.tempv[i] = (1.0 / hg) * m.tempv[i];
-    } SEND
-    *yddnrm = wrms<NS>(m.tempv, m.ewt);
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        SFOR_S(is, i) {
-            const double v = m.tempvS[is][i] - m.znS[1][is][i];
-            m.tempvS[is][i] = (1.0 / hg) * v;
-        } SEND_S
-        *yddnrm = sens_update_norm(m, *yddnrm, m.tempvS, m.ewtS);
-    }
-#endif
-    if (BWD) {
-        SFOR(i, 0, NQ) {
-            m.tempvQ[i] = m.tempvQ[i] - m.znQ[1][i];
-            m.tempvQ[i] = (1.0 / hg) * m.tempvQ[i];
-        } SEND
-        *yddnrm = quad_update_norm(m, *yddnrm, m.tempvQ);
-    }
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_hin(Cv<BWD> &m, double tout)
-{
-    double tdiff = tout - m.tn;
-    if (tdiff == 0.0) return CV_TOO_CLOSE;
-    double sign = (tdiff > 0.0) ? 1.0 : -1.0;
-    double tdist = fabs(tdiff);
-    double tround = UROUND * fmax(fabs(m.tn), fabs(tout));
-    if (tdist < 2.0 * tround) return CV_TOO_CLOSE;
-    double hlb = HLB_FACTOR * tround;
-    double hub = cv_upper_bound_h0(m, tdist);
-    double hg = sqrt(hlb * hub);
-    if (hub < hlb) {
-        m.h = (sign < 0.0) ? -hg : hg;
-        return CV_SUCCESS;
-    }
-    double hs = hg, hnew = hg, yddnrm = 0.0;
-    int result = 1;               /* 1 = still iterating */
-    for (int count1 = 1; count1 <= HIN_MAX_ITERS && result == 1; count1++) {
-        int hgOK = 0;
-        for (int count2 = 1; count2 <= HIN_MAX_ITERS; count2++) {
-            double hgs = hg * sign;
-            int retval = cv_ydd_norm(m, hgs, &yddnrm);
-            if (retval < 0) { result = CV_RHSFUNC_FAIL; break; }
-            if (retval == CV_SUCCESS) { hgOK = 1; break; }
-            hg *= 0.2;
-        }
-        if (result != 1) break;
-        if (!hgOK) {
-            if (count1 <= 2) { result = CV_REPTD_RHSFUNC_ERR; break; }
-            hnew = hs;
-            result = 0;
-            break;
-        }
-        hs = hg;
-        hnew = (yddnrm * hub * hub > 2.0) ? sqrt(2.0 / yddnrm) : sqrt(hg * hub);
-        if (count1 == HIN_MAX_ITERS) { result = 0; break; }
-        double hrat = hnew / hg;
-        if ((hrat > 0.5) && (hrat < 2.0)) { result = 0; break; }
-        if ((count1 > 1) && (hrat > 2.0)) { hnew = hg; result = 0; break; }
-        hg = hnew;
-    }
-    if (result < 0) return result;
-    double h0 = H_BIAS * hnew;
-    if (h0 < hlb) h0 = hlb;
-    if (h0 > hub) h0 = hub;
-    if (sign < 0.0) h0 = -h0;
-    m.h = h0;
-    return CV_SUCCESS;
-}
-
-/* ---- Nordsieck array manipulation ---- */
-template <bool BWD>
-DEV void cv_rescale(Cv<BWD> &m)
-{
-    double factor = m.eta;
-    SFOR(j, 1, (QMAX) + 1) {
-        SFOR(i, 0, NS) m.zn[j][i] *= factor; SEND
-        if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] *= factor; SEND }
-#ifdef SA_SENS
-        if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j][is][i] *= factor; SEND_S }
-#endif
-        factor *= m.eta;
-    } SEND
-    m.h = m.hscale * m.eta;
-    m.hscale = m.h;
-}
-
-template <bool BWD>
-DEV void cv_increase_bdf(Cv<BWD> &m)
-{
-    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
-    double alpha1 = 1.0, prod = 1.0, xiold = 1.0, alpha0 = -1.0, hsum = m.hscale;
-    m.l[2] = 1.0;
-    SFOR(j, 1, QMAX - 1) {
-        if (j < m.q) {
-            hsum += m.tau[j + 1];
-            double xi = hsum / m.hscale;
-            prod *= xi;
-            alpha0 -= 1.0 / (j + 1);
-            alpha1 += 1.0 / xi;
-            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xiold, m.l[i - 1]); SEND
-            xiold = xi;
-        }
-    } SEND
-    double A1 = (-alpha0 - alpha1) / prod;
-    const int L = m.L;
-    double znL[NSD], znQL[NQD];
-    SFOR(i, 0, NS) znL[i] = A1 * m.zsave[i]; SEND
-    SFOR(i, 0, NQ) znQL[i] = BWD ? A1 * m.zsaveQ[i] : 0.0; SEND
-    SFOR(j, 2, (QMAX) + 1) {
-        if (j == L) {
-            SFOR(i, 0, NS) m.zn[j][i] = znL[i]; SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = znQL[i]; SEND }
-        }
-    } SEND
-    SFOR(j, 2, QMAX) {
-        if (j <= m.q) {
-            SFOR(i, 0, NS) m.zn[j][i] = FMA(m.l[j], znL[i], m.zn[j][i]); SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(m.l[j], znQL[i], m.znQ[j][i]); SEND }
-        }
-    } SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        double znLS[NQD][NSD];
-        SFOR_S(is, i) znLS[is][i] = A1 * m.zsaveS[is][i]; SEND_S
-        SFOR(j, 2, (QMAX) + 1) { if (j == L) { SFOR_S(is, i) m.znS[j][is][i] = znLS[is][i]; SEND_S } } SEND
-        SFOR(j, 2, QMAX) {
-            if (j <= m.q) { SFOR_S(is, i) m.znS[j][is][i] = FMA(m.l[j], znLS[is][i], m.znS[j][is][i]); SEND_S }
-        } SEND
-    }
-#endif
-}
-
-template <bool BWD>
-DEV void cv_decrease_bdf(Cv<BWD> &m)
-{
-    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
-    m.l[2] = 1.0;
-    double hsum = 0.0;
-    SFOR(j, 1, (QMAX - 2) + 1) {
-        if (j <= m.q - 2) {
-            hsum += m.tau[j];
-            double xi = hsum / m.hscale;
-            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xi, m.l[i - 1]); SEND
-        }
-    } SEND
-    double znq[NSD], znQq[NQD];
-    SFOR(i, 0, NS) {
-        double r = m.zn[2][i];
-        SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.zn[k][i] : r; SEND
-        znq[i] = r;
-    } SEND
-    SFOR(i, 0, NQ) {
-        double r = m.znQ[2][i];
-        SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.znQ[k][i] : r; SEND
-        znQq[i] = r;
-    } SEND
-    SFOR(j, 2, QMAX) {
-        if (j < m.q) {
-            SFOR(i, 0, NS) m.zn[j][i] = FMA(-m.l[j], znq[i], m.zn[j][i]); SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(-m.l[j], znQq[i], m.znQ[j][i]); SEND }
-        }
-    } SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        double znSq[NQD][NSD];
-        SFOR_S(is, i) {
-            double r = m.znS[2][is][i];
-            SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.znS[k][is][i] : r; SEND
-            znSq[is][i] = r;
-        } SEND_S
-        SFOR(j, 2, QMAX) {
-            if (j < m.q) { SFOR_S(is, i) m.znS[j][is][i] = FMA(-m.l[j], znSq[is][i], m.znS[j][is][i]); SEND_S }
-        } SEND
-    }
-#endif
-}
-
-/* restore the zero-column invariant after the order dropped from q_old to q_old - 1 */
-template <bool BWD>
-DEV void cv_clear_column(Cv<BWD> &m, int q_old)
-{
-    SFOR(j, 2, (QMAX) + 1) {
-        if (j == q_old) {
-            SFOR(i, 0, NS) m.zn[j][i] = 0.0; SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = 0.0; SEND }
-#ifdef SA_SENS
-            if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j][is][i] = 0.0; SEND_S }
-#endif
-        }
-    } SEND
-}
-
-template <bool BWD>
-DEV void cv_adjust_order(Cv<BWD> &m, int deltaq)
-{
-    if ((m.q == 2) && (deltaq != 1)) return;
-    if (deltaq == 1) cv_increase_bdf(m);
-    else if (deltaq == -1) cv_decrease_bdf(m);
-}
-
-template <bool BWD>
-DEV void cv_adjust_params(Cv<BWD> &m)
-{
-    if (m.qprime != m.q) {
-        cv_adjust_order(m, m.qprime - m.q);
-        if (m.qprime < m.q) cv_clear_column(m, m.q);
-        m.q = m.qprime;
-        m.L = m.q + 1;
-        m.qwait = m.L;
-    }
-    cv_rescale(m);
-}
-
-template <bool BWD>
-DEV void cv_predict(Cv<BWD> &m)
-{
-    m.tn += m.h;
-    if (BWD) {
-        if ((m.tn - m.tstop) * m.h > 0.0) m.tn = m.tstop;
-    }
-    SFOR(k, 1, (QMAX) + 1) {
-        SFOR_DOWN(j, QMAX, k) {
-            SFOR(i, 0, NS) m.zn[j - 1][i] = m.zn[j - 1][i] + m.zn[j][i]; SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] + m.znQ[j][i]; SEND }
-#ifdef SA_SENS
-            if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j - 1][is][i] = m.znS[j - 1][is][i] + m.znS[j][is][i]; SEND_S }
-#endif
-        } SEND
-    } SEND
-}
-
-template <bool BWD>
-DEV void cv_restore(Cv<BWD> &m, double saved_t)
-{
-    m.tn = saved_t;
-    SFOR(k, 1, (QMAX) + 1) {
-        SFOR_DOWN(j, QMAX, k) {
-            SFOR(i, 0, NS) m.zn[j - 1][i] = m.zn[j - 1][i] - m.zn[j][i]; SEND
-            if (BWD) { SFOR(i, 0, NQ) m.znQ[j - 1][i] = m.znQ[j - 1][i] - m.znQ[j][i]; SEND }
-#ifdef SA_SENS
-            if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j - 1][is][i] = m.znS[j - 1][is][i] - m.znS[j][is][i]; SEND_S }
-#endif
-        } SEND
-    } SEND
-}
-
 /* ---- linear solver interface (cvLsSetup / cvLsSolve on SUNLinSol_Dense) ---- */
 template <bool BWD>
 DEV int cv_lsetup(Cv<BWD> &m, int convfail)
@@ -862,752 +539,30 @@ DEV int cv_lsetup(Cv<BWD> &m, int convfail)
     return ier > 0 ? 1 : 0;
 }
 
+
+/* ---- the mapping bdf_core.h needs: one lane = one instance, a vector = NS doubles in this lane's registers ---- */
+#define SA_STATE Cv
+#define RS NSD
+#define RQ NQD
+#define IDX(m, r) (r)
+#define wave_max(lane, x) (x)
+#define COLD_STORE(m)
+#define COLD_LOAD(m)
+#define PH_T0
+#define PH_ADD(m, k) PHASE(m, k);
+#define SA_RESCALE_ALWAYS 1          /* cv_attempt: the rescale runs for every lane (eta = 1: exact no-op), see there */
 template <bool BWD>
-DEV int cv_nls_lsetup(Cv<BWD> &m, int jbad, int &convfail)
-{
-    if (jbad) convfail = CV_FAIL_BAD_J;
-    int retval = cv_lsetup(m, convfail);
-    m.nsetups++;
-    m.nls_jcur = m.jcur;
-    m.gamrat = 1.0;
-    m.gammap = m.gamma;
-    m.crate = 1.0;
-#ifdef SA_SENS
-    m.crateS = 1.0;
-#endif
-    m.nstlp = m.nst;
-    if (retval < 0) return CV_LSETUP_FAIL;
-    if (retval > 0) return NLS_CONV_RECVR;
-    return CV_SUCCESS;
-}
-
+DEV double wrms_n(const Cv<BWD> &, const double (&x)[RS], const double (&w)[RS]) { return wrms<NS>(x, w); }
 template <bool BWD>
-DEV int cv_nls_residual(Cv<BWD> &m, double *res)
-{
-    SFOR(i, 0, NS) m.y[i] = m.zn[0][i] + m.acor[i]; SEND
-    int retval = cv_f(m, m.tn, m.y, m.ftemp);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return RHSFUNC_RECVR;
-    SFOR(i, 0, NS) {
-        res[i] = FMA(m.rl1, m.zn[1][i], m.acor[i]);
-        res[i] = FMA(-m.gamma, m.ftemp[i], res[i]);
-    } SEND
-    return CV_SUCCESS;
-}
-
-#ifdef SA_SENS
-/* cvNlsResidualSensSim / cvNlsResidualSensStg: residuals of the sensitivity systems -> m.deltaS (m.y holds the state) */
+DEV double wrms_q(const Cv<BWD> &, const double (&x)[RQ], const double (&w)[RQ]) { return wrms<NQ>(x, w); }
 template <bool BWD>
-DEV int cv_nls_residual_sens(Cv<BWD> &m)
-{
-    SFOR_S(is, i) m.yS[is][i] = m.znS[0][is][i] + m.acorS[is][i]; SEND_S
-    int retval = cv_fS(m, m.tn, m.y, m.yS, m.ftempS);
-    if (retval < 0) return CV_SRHSFUNC_FAIL;
-    if (retval > 0) return SRHSFUNC_RECVR;
-    SFOR_S(is, i) {
-        const double r = FMA(m.rl1, m.znS[1][is][i], m.acorS[is][i]);
-        m.deltaS[is][i] = FMA(-m.gamma, m.ftempS[is][i], r);
-    } SEND_S
-    return CV_SUCCESS;
-}
-
-/* one Newton update of every sensitivity system with the current factorisation */
-template <bool BWD>
-DEV void cv_sens_newton_update(Cv<BWD> &m)
-{
-    SFOR(is, 0, NQ) {
-        SFOR(i, 0, NS) m.deltaS[is][i] = -1.0 * m.deltaS[is][i]; SEND
-        dense_getrs(m.A, m.piv, m.inv_piv, m.deltaS[is]);
-        if (m.gamrat != 1.0) {
-            double s = 2.0 / (1.0 + m.gamrat);
-            SFOR(i, 0, NS) m.deltaS[is][i] *= s; SEND
-        }
-        SFOR(i, 0, NS) m.acorS[is][i] = m.acorS[is][i] + m.deltaS[is][i]; SEND
-    } SEND
-}
-#endif
-
-/* One pass of SUNNonlinSolSolve_Newton's outer loop (residual, optional setup, <=3 corrector
-   iterations).  Returns 0 on convergence, >0 recoverable, <0 fatal. */
-template <bool BWD>
-DEV int cv_newton_pass(Cv<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
-{
-    double delta[NSD];
+DEV void dense_getrs(const Cv<BWD> &m, double (&b)[RS]) { dense_getrs(m.A, m.piv, m.inv_piv, b); }
 #ifdef SA_SENS
-    const bool sim = SENS_ON(m) && m.ism == 0;
+#define SV(m, v, is, r) (m).sv[v][is][r]
+#define SLOOP_BEGIN(is) SFOR(is, 0, NQ)
+#define SLOOP_END SEND
 #endif
-    in_loop = 0;
-    SFOR(i, 0, NS) m.acor[i] = 0.0; SEND
-#ifdef SA_SENS
-    if (sim) { SFOR_S(is, i) m.acorS[is][i] = 0.0; SEND_S }
-#endif
-    int retval = cv_nls_residual(m, delta);
-    if (retval != CV_SUCCESS) return retval;
-#ifdef SA_SENS
-    if (sim) {
-        retval = cv_nls_residual_sens(m);
-        if (retval != CV_SUCCESS) return retval;
-    }
-#endif
-    if (callSetup) {
-        retval = cv_nls_lsetup(m, jbad, convfail);
-        if (retval != CV_SUCCESS) return retval;
-    }
-    int curiter = 0;
-    in_loop = 1;
-    for (;;) {
-        m.nni++;
-        SFOR(i, 0, NS) delta[i] = -1.0 * delta[i]; SEND
-        dense_getrs(m.A, m.piv, m.inv_piv, delta);
-        if (m.gamrat != 1.0) {
-            double s = 2.0 / (1.0 + m.gamrat);
-            SFOR(i, 0, NS) delta[i] *= s; SEND
-        }
-        SFOR(i, 0, NS) m.acor[i] = m.acor[i] + delta[i]; SEND
-        /* cvNlsConvTest */
-        double del = wrms<NS>(delta, m.ewt);
-#ifdef SA_SENS
-        if (sim) {
-            cv_sens_newton_update(m);
-            del = sens_update_norm(m, del, m.deltaS, m.ewtS);
-        }
-#endif
-        if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
-        double dcon = del * fmin(1.0, m.crate) * m.tq[4];
-        if (dcon <= 1.0) {
-            if (curiter == 0) m.acnrm = del;
-            else {
-                m.acnrm = wrms<NS>(m.acor, m.ewt);
-#ifdef SA_SENS
-                if (sim) m.acnrm = sens_update_norm(m, m.acnrm, m.acorS, m.ewtS);
-#endif
-            }
-            m.nls_jcur = 0;
-            return CV_SUCCESS;
-        }
-        if ((curiter >= 1) && (del > RDIV * m.delp)) return NLS_CONV_RECVR;
-        m.delp = del;
-        curiter++;
-        if (curiter >= NLS_MAXCOR) return NLS_CONV_RECVR;
-        retval = cv_nls_residual(m, delta);
-        if (retval != CV_SUCCESS) return retval;
-#ifdef SA_SENS
-        if (sim) {
-            retval = cv_nls_residual_sens(m);
-            if (retval != CV_SUCCESS) return retval;
-        }
-#endif
-    }
-}
-
-#ifdef SA_SENS
-/* cvStgrNls (ism = CV_STAGGERED): Newton on the sensitivity systems with the state fixed */
-template <bool BWD>
-DEV int cv_stgr_nls(Cv<BWD> &m)
-{
-    int callSetup = 0, jbad = 0, convfail = CV_FAIL_OTHER, retval;
-    SFOR_S(is, i) m.acorS[is][i] = 0.0; SEND_S
-    for (;;) {
-        retval = cv_nls_residual_sens(m);
-        if (retval != CV_SUCCESS) break;
-        if (callSetup) {
-            retval = cv_nls_lsetup(m, jbad, convfail);
-            m.nsetupsS++;
-            if (retval != CV_SUCCESS) break;
-        }
-        int curiter = 0;
-        for (;;) {
-            m.nniS++;
-            cv_sens_newton_update(m);
-            double del = sens_update_norm(m, 0.0, m.deltaS, m.ewtS);
-            if (curiter > 0) m.crateS = fmax(CRDOWN * m.crateS, del / m.delpS);
-            double dcon = del * fmin(1.0, m.crateS) * m.tq[4];
-            if (dcon <= 1.0) {
-                m.acnrmS = (curiter == 0) ? del : sens_update_norm(m, 0.0, m.acorS, m.ewtS);
-                retval = CV_SUCCESS;
-                m.nls_jcur = 0;
-                break;
-            }
-            if ((curiter >= 1) && (del > RDIV * m.delpS)) { retval = NLS_CONV_RECVR; break; }
-            m.delpS = del;
-            curiter++;
-            if (curiter >= NLS_MAXCOR) { retval = NLS_CONV_RECVR; break; }
-            retval = cv_nls_residual_sens(m);
-            if (retval != CV_SUCCESS) break;
-        }
-        if (retval == CV_SUCCESS) break;
-        if ((retval > 0) && !m.nls_jcur) {
-            callSetup = 1;
-            jbad = 1;
-            SFOR_S(is, i) m.acorS[is][i] = 0.0; SEND_S
-            continue;
-        }
-        break;
-    }
-    if (retval != CV_SUCCESS) return retval;
-    SFOR_S(is, i) m.yS[is][i] = m.znS[0][is][i] + m.acorS[is][i]; SEND_S
-    return CV_SUCCESS;
-}
-#endif
-
-/* tail of cvDoErrorTest after a failed test; returns 0 = try again, <0 = give up */
-template <bool BWD>
-DEV int cv_error_test_failed(Cv<BWD> &m, double saved_t, double dsm, int &nef, int &netf_counter)
-{
-    nef++;
-    netf_counter++;
-    cv_restore(m, saved_t);
-    if (nef == MXNEF) return CV_ERR_FAILURE;
-    m.etamax = 1.0;
-    if (nef <= MXNEF1) {
-        m.eta = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
-        m.eta = fmax(ETAMIN, m.eta);
-        if (nef >= SMALL_NEF) m.eta = fmin(m.eta, ETAMXF);
-        cv_rescale(m);
-        return 0;
-    }
-    if (m.q > 1) {
-        m.eta = ETAMIN;
-        cv_adjust_order(m, -1);
-        cv_clear_column(m, m.q);
-        m.L = m.q;
-        m.q--;
-        m.qwait = m.L;
-        cv_rescale(m);
-        return 0;
-    }
-    m.eta = ETAMIN;
-    m.h *= m.eta;
-    m.hscale = m.h;
-    m.qwait = LONG_WAIT;
-    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-    int retval = cv_f(m, m.tn, m.zn[0], m.tempv);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
-    SFOR(i, 0, NS) m.zn[1][i] = m.h * m.tempv[i]; SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        retval = cv_fS(m, m.tn, m.zn[0], m.znS[0], m.tempvS);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return CV_UNREC_SRHSFUNC_ERR;
-        SFOR_S(is, i) m.znS[1][is][i] = m.h * m.tempvS[is][i]; SEND_S
-    }
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn, m.zn[0], m.tempvQ);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return CV_UNREC_QRHSFUNC_ERR;
-        SFOR(i, 0, NQ) m.znQ[1][i] = m.h * m.tempvQ[i]; SEND
-    }
-    return 0;
-}
-
-template <bool BWD>
-DEV void cv_complete_step(Cv<BWD> &m)
-{
-    m.nst++;
-    m.hu = m.h;
-    m.qu = m.q;
-    SFOR_DOWN(i, QMAX, 2) m.tau[i] = (i <= m.q) ? m.tau[i - 1] : m.tau[i]; SEND
-    m.tau[2] = ((m.q == 1) && (m.nst > 1)) ? m.tau[1] : m.tau[2];
-    m.tau[1] = m.h;
-    SFOR(j, 0, (QMAX) + 1) {                 /* l[j] == 0 for j > q */
-        SFOR(i, 0, NS) m.zn[j][i] = FMA(m.l[j], m.acor[i], m.zn[j][i]); SEND
-        if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] = FMA(m.l[j], m.acorQ[i], m.znQ[j][i]); SEND }
-#ifdef SA_SENS
-        if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j][is][i] = FMA(m.l[j], m.acorS[is][i], m.znS[j][is][i]); SEND_S }
-#endif
-    } SEND
-    m.qwait--;
-    {
-        const bool sv = (m.qwait == 1) && (m.q != QMAX);
-#ifdef SA_SENS
-        if (SENS_ON(m)) { SFOR_S(is, i) m.zsaveS[is][i] = sv ? m.acorS[is][i] : m.zsaveS[is][i]; SEND_S }
-#endif
-        SFOR(i, 0, NS) m.zsave[i] = sv ? m.acor[i] : m.zsave[i]; SEND
-        if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = sv ? m.acorQ[i] : m.zsaveQ[i]; SEND }
-        m.saved_tq5 = sv ? m.tq[5] : m.saved_tq5;
-    }
-}
-
-template <bool BWD>
-DEV void cv_set_eta(Cv<BWD> &m)
-{
-    if (m.eta < THRESH) {
-        m.eta = 1.0;
-        m.hprime = m.h;
-    } else {
-        m.eta = fmin(m.eta, m.etamax);
-        m.hprime = m.h * m.eta;
-    }
-}
-
-#ifdef SA_SENS
-/* the branching form of cvPrepareNextStep's order decision (sensitivity builds: the sensitivity norms take part) */
-template <bool BWD>
-DEV void cv_prepare_next_step_branchy(Cv<BWD> &m, double dsm)
-{
-    m.etaq = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
-    if (m.qwait != 0) {
-        m.eta = m.etaq;
-        m.qprime = m.q;
-        cv_set_eta(m);
-        return;
-    }
-    m.qwait = 2;
-    /* cvComputeEtaqm1 */
-    m.etaqm1 = 0.0;
-    if (m.q > 1) {
-        double znq[NSD], znQq[NQD];
-        SFOR(i, 0, NS) {
-            double r = m.zn[2][i];
-            SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.zn[k][i] : r; SEND
-            znq[i] = r;
-        } SEND
-        double ddn = wrms<NS>(znq, m.ewt);
-        if (BWD) {
-            SFOR(i, 0, NQ) {
-                double r = m.znQ[2][i];
-                SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.znQ[k][i] : r; SEND
-                znQq[i] = r;
-            } SEND
-            ddn = quad_update_norm(m, ddn, znQq);
-        }
-#ifdef SA_SENS
-        if (SENS_ON(m)) {
-            SFOR_S(is, i) {
-                double r = m.znS[2][is][i];
-                SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.znS[k][is][i] : r; SEND
-                m.tempvS[is][i] = r;
-            } SEND_S
-            ddn = sens_update_norm(m, ddn, m.tempvS, m.ewtS);
-        }
-#endif
-        ddn = ddn * m.tq[1];
-        m.etaqm1 = 1.0 / (rpower_r(BIAS1 * ddn, inv_int(m.q)) + ADDON);
-    }
-    /* cvComputeEtaqp1 */
-    m.etaqp1 = 0.0;
-    if (m.q != QMAX) {
-        if (m.saved_tq5 != 0.0) {
-            double base = m.h / m.tau[2];
-            double pw = 1.0;
-            SFOR(i, 1, (QMAX + 1) + 1) { if (i <= m.L) pw *= base; } SEND
-            double cquot = (m.tq[5] / m.saved_tq5) * pw;
-            SFOR(i, 0, NS) m.tempv[i] = FMA(-cquot, m.zsave[i], m.acor[i]); SEND
-            double dup = wrms<NS>(m.tempv, m.ewt);
-            if (BWD) {
-                SFOR(i, 0, NQ) m.tempvQ[i] = FMA(-cquot, m.zsaveQ[i], m.acorQ[i]); SEND
-                dup = quad_update_norm(m, dup, m.tempvQ);
-            }
-#ifdef SA_SENS
-            if (SENS_ON(m)) {
-                SFOR_S(is, i) m.tempvS[is][i] = FMA(-cquot, m.zsaveS[is][i], m.acorS[is][i]); SEND_S
-                dup = sens_update_norm(m, dup, m.tempvS, m.ewtS);
-            }
-#endif
-            dup = dup * m.tq[3];
-            m.etaqp1 = 1.0 / (rpower_r(BIAS3 * dup, inv_int(m.L + 1)) + ADDON);
-        }
-    }
-    /* cvChooseEta */
-    double etam = fmax(m.etaqm1, fmax(m.etaq, m.etaqp1));
-    if (etam < THRESH) {
-        m.eta = 1.0;
-        m.qprime = m.q;
-    } else if (etam == m.etaq) {
-        m.eta = m.etaq;
-        m.qprime = m.q;
-    } else if (etam == m.etaqm1) {
-        m.eta = m.etaqm1;
-        m.qprime = m.q - 1;
-    } else {
-        m.eta = m.etaqp1;
-        m.qprime = m.q + 1;
-        SFOR(i, 0, NS) m.zsave[i] = m.acor[i]; SEND
-        if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = m.acorQ[i]; SEND }
-#ifdef SA_SENS
-        if (SENS_ON(m)) { SFOR_S(is, i) m.zsaveS[is][i] = m.acorS[is][i]; SEND_S }
-#endif
-    }
-    cv_set_eta(m);
-}
-#endif
-
-template <bool BWD>
-DEV void cv_prepare_next_step(Cv<BWD> &m, double dsm)
-{
-    if (m.etamax == 1.0) {
-        m.qwait = m.qwait > 2 ? m.qwait : 2;
-        m.qprime = m.q;
-        m.hprime = m.h;
-        m.eta = 1.0;
-        return;
-    }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { cv_prepare_next_step_branchy(m, dsm); return; }
-#endif
-    /* cvComputeEtaqm1 / cvComputeEtaqp1 / cvChooseEta as ONE straight-line block (values identical to the
-       branching form below, which the sensitivity builds keep): in a wavefront some lane is at qwait == 0 in nearly
-       every iteration, so the full path runs anyway -- but as three serial power evaluations (~60 dependent
-       instructions each) behind data-dependent branches.  Here the two norms and the three powers are independent
-       chains of one basic block (the scheduler interleaves them), lanes that are not at an order decision
-       (qwait != 0) or whose candidate is not defined (q == 1, q == qmax, no saved correction) discard the values
-       through selects; no field is written that the branching form would not write. */
-    const bool full = (m.qwait == 0);
-    double znq[NSD], znQq[NQD], tv[NSD], tvQ[NQD];
-    SFOR(i, 0, NS) {
-        double r = m.zn[2][i];
-        SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.zn[k][i] : r; SEND
-        znq[i] = r;
-    } SEND
-    double ddn = wrms<NS>(znq, m.ewt);
-    if (BWD) {
-        SFOR(i, 0, NQ) {
-            double r = m.znQ[2][i];
-            SFOR(k, 3, (QMAX) + 1) r = (m.q == k) ? m.znQ[k][i] : r; SEND
-            znQq[i] = r;
-        } SEND
-        ddn = quad_update_norm(m, ddn, znQq);
-    }
-    ddn = ddn * m.tq[1];
-    const double base = m.h / m.tau[2];
-    double pw = 1.0;
-    SFOR(i, 1, (QMAX + 1) + 1) { pw = (i <= m.L) ? pw * base : pw; } SEND
-    const double cquot = (m.tq[5] / m.saved_tq5) * pw;
-    SFOR(i, 0, NS) tv[i] = FMA(-cquot, m.zsave[i], m.acor[i]); SEND
-    double dup = wrms<NS>(tv, m.ewt);
-    if (BWD) {
-        SFOR(i, 0, NQ) tvQ[i] = FMA(-cquot, m.zsaveQ[i], m.acorQ[i]); SEND
-        dup = quad_update_norm(m, dup, tvQ);
-    }
-    dup = dup * m.tq[3];
-    const double p0 = rpower_nb(BIAS2 * dsm, inv_int(m.L));
-    const double p1 = rpower_nb(BIAS1 * ddn, inv_int(m.q));
-    const double p2 = rpower_nb(BIAS3 * dup, inv_int(m.L + 1));
-    const double etaq = 1.0 / (p0 + ADDON), e1 = 1.0 / (p1 + ADDON), e2 = 1.0 / (p2 + ADDON);
-    const double etaqm1 = (m.q > 1) ? e1 : 0.0;
-    const double etaqp1 = ((m.q != QMAX) && (m.saved_tq5 != 0.0)) ? e2 : 0.0;
-    m.etaq = etaq;
-    m.etaqm1 = full ? etaqm1 : m.etaqm1;
-    m.etaqp1 = full ? etaqp1 : m.etaqp1;
-    m.qwait = full ? 2 : m.qwait;
-    /* cvChooseEta (full) or eta = etaq (not at an order decision) */
-    const double etam = fmax(etaqm1, fmax(etaq, etaqp1));
-    const bool c0 = etam < THRESH, c1 = (etam == etaq), c2 = (etam == etaqm1);
-    const double eta_f = c0 ? 1.0 : (c1 ? etaq : (c2 ? etaqm1 : etaqp1));
-    const int qp_f = c0 ? m.q : (c1 ? m.q : (c2 ? m.q - 1 : m.q + 1));
-    const bool up = full && !c0 && !c1 && !c2;
-    m.eta = full ? eta_f : etaq;
-    m.qprime = full ? qp_f : m.q;
-    SFOR(i, 0, NS) m.zsave[i] = up ? m.acor[i] : m.zsave[i]; SEND
-    if (BWD) { SFOR(i, 0, NQ) m.zsaveQ[i] = up ? m.acorQ[i] : m.zsaveQ[i]; SEND }
-    {   /* cvSetEta */
-        const bool small = m.eta < THRESH;
-        const double capped = fmin(m.eta, m.etamax);
-        m.hprime = small ? m.h : m.h * capped;
-        m.eta = small ? 1.0 : capped;
-    }
-}
-
-/* CVodeGetDky, k = 0 (and CVodeGetQuadDky) */
-template <bool BWD>
-DEV int cv_get_dky0(const Cv<BWD> &m, double t, double *dky, double *dkyQ)
-{
-    double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.hu));
-    if (m.hu < 0.0) tfuzz = -tfuzz;
-    double tp = m.tn - m.hu - tfuzz;
-    double tn1 = m.tn + tfuzz;
-    if ((t - tp) * (t - tn1) > 0.0) return CV_BAD_T;
-    double s = (t - m.tn) / m.h;
-    double pw[QMAX + 1];
-    pw[0] = 1.0;
-    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
-    SFOR(i, 0, NS) {
-        double acc = pw[QMAX] * m.zn[QMAX][i];
-        SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.zn[j][i], acc); SEND
-        dky[i] = acc;
-    } SEND
-    if (BWD) {
-        SFOR(i, 0, NQ) {
-            double acc = pw[QMAX] * m.znQ[QMAX][i];
-            SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.znQ[j][i], acc); SEND
-            dkyQ[i] = acc;
-        } SEND
-    }
-    return CV_SUCCESS;
-}
-
-#ifdef SA_SENS
-/* CVodeGetSensDky, k = 0, all parameters; the caller has validated t with cv_get_dky0 */
-template <bool BWD>
-DEV void cv_get_sens_dky0(const Cv<BWD> &m, double t, double (&dkyS)[NQD][NSD])
-{
-    double s = (t - m.tn) / m.h;
-    double pw[QMAX + 1];
-    pw[0] = 1.0;
-    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
-    SFOR_S(is, i) {
-        double acc = pw[QMAX] * m.znS[QMAX][is][i];
-        SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.znS[j][is][i], acc); SEND
-        dkyS[is][i] = acc;
-    } SEND_S
-}
-#endif
-
-/* first-call block of CVode(): f(t0,y0), h0 from cvHin, scale zn[1] */
-template <bool BWD>
-DEV int cv_first_call(Cv<BWD> &m, double tout)
-{
-#ifdef SA_CONSTRAINTS
-    if (!BWD && m.constr) {             /* cvInitialSetup: y0 must satisfy the constraints */
-        bool bad = false;
-        SFOR(i, 0, NS) bad = bad || constr_violated(m.cons[i], m.zn[0][i]); SEND
-        if (bad) return CV_ILL_INPUT;
-    }
-#endif
-    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
-    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { if (sens_ewt_set(m, m.znS[0], m.ewtS) != 0) return CV_ILL_INPUT; }
-#endif
-    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-    int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
-#ifdef SA_HERMITE
-    if (!BWD) { SFOR(i, 0, NS) m.f0[i] = m.zn[1][i]; SEND }
-#endif
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        retval = cv_fS(m, m.tn, m.zn[0], m.znS[0], m.znS[1]);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return CV_FIRST_SRHSFUNC_ERR;
-    }
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn, m.zn[0], m.znQ[1]);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return CV_FIRST_QRHSFUNC_ERR;
-    }
-    double tout_hin = tout;
-    if (BWD) {
-        if ((m.tstop - m.tn) * (tout - m.tn) <= 0.0) return CV_ILL_INPUT;
-        if ((tout - m.tn) * (tout - m.tstop) > 0.0) tout_hin = m.tstop;
-    }
-    int hflag = cv_hin(m, tout_hin);
-    if (hflag != CV_SUCCESS) return hflag;
-    if (BWD) {
-        if ((m.tn + m.h - m.tstop) * m.h > 0.0) m.h = (m.tstop - m.tn) * (1.0 - 4.0 * UROUND);
-    }
-    m.hscale = m.h;
-    m.hprime = m.h;
-    SFOR(i, 0, NS) m.zn[1][i] = m.h * m.zn[1][i]; SEND
-    if (BWD) { SFOR(i, 0, NQ) m.znQ[1][i] = m.h * m.znQ[1][i]; SEND }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { SFOR_S(is, i) m.znS[1][is][i] = m.h * m.znS[1][is][i]; SEND_S }
-#endif
-    return CV_SUCCESS;
-}
-
-/* pre-step block of CVode()'s internal loop */
-template <bool BWD>
-DEV int cv_pre_step(Cv<BWD> &m)
-{
-    /* CVODES refreshes the weights only for nst > 0; at nst == 0 they were just computed from the
-       same zn[0], so doing it always gives identical values without a per-lane branch */
-    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
-    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { if (sens_ewt_set(m, m.znS[0], m.ewtS) != 0) return CV_ILL_INPUT; }
-#endif
-    double nrm = wrms<NS>(m.zn[0], m.ewt);
-    if (BWD) nrm = quad_update_norm(m, nrm, m.znQ[0]);
-#ifdef SA_SENS
-    if (SENS_ON(m)) nrm = sens_update_norm(m, nrm, m.znS[0], m.ewtS);
-#endif
-    if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
-    return CV_SUCCESS;
-}
-
-/* Per-lane control state of the attempt loop. */
-struct StepCtl {
-    int in_step, redo, nflag, ncf, nef, nefQ, convfail, ncfS, nefS;
-    double saved_t;
-};
-
-/* cvHandleNFlag for a failed nonlinear (or quadrature) solve; 0 = predict again, <0 = give up */
-template <bool BWD>
-DEV int cv_handle_nflag_failed(Cv<BWD> &m, StepCtl &c, int nflag, int &ncf, int &ncfn)
-{
-    ncfn++;
-    cv_restore(m, c.saved_t);
-    if (nflag < 0) return nflag;
-    ncf++;
-    m.etamax = 1.0;
-    if (ncf == MXNCF) {
-        if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
-        if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
-        if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
-        if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
-        return CV_REPTD_QRHSFUNC_ERR;
-    }
-    if (nflag != CONSTR_RECVR) m.eta = ETACF;         /* CONSTR_RECVR: eta was set by the constraint check */
-    c.nflag = PREV_CONV_FAIL;
-    cv_rescale(m);
-    return 0;
-}
-
-/*
- * One step ATTEMPT of cvStep (predict, cvSet, Newton, error tests).  Returns
- *   1  step completed (cvCompleteStep / cvPrepareNextStep done)
- *   0  attempt rejected, or Newton to be redone with a fresh Jacobian -> call again
- *  <0  unrecoverable failure (CVODES code)
- */
-template <bool BWD>
-DEV int cv_attempt(Cv<BWD> &m, StepCtl &c)
-{
-    if (!c.in_step) {
-        c.saved_t = m.tn;
-        c.ncf = c.nef = c.nefQ = 0;
-        c.ncfS = c.nefS = 0;
-        c.nflag = FIRST_CALL;
-        c.redo = 0;
-        /* cvAdjustParams: the (rare) order change stays a branch, the rescale runs always with
-           eta = 1 (exact no-op) for lanes whose step size does not change */
-        const bool adj = (m.nst > 0) && (m.hprime != m.h);
-        if (adj && (m.qprime != m.q)) {
-            cv_adjust_order(m, m.qprime - m.q);
-            if (m.qprime < m.q) cv_clear_column(m, m.q);
-            m.q = m.qprime;
-            m.L = m.q + 1;
-            m.qwait = m.L;
-        }
-        {
-            const double eta = adj ? m.eta : 1.0;
-            double factor = eta;
-            SFOR(j, 1, (QMAX) + 1) {
-                SFOR(i, 0, NS) m.zn[j][i] *= factor; SEND
-                if (BWD) { SFOR(i, 0, NQ) m.znQ[j][i] *= factor; SEND }
-#ifdef SA_SENS
-                if (SENS_ON(m)) { SFOR_S(is, i) m.znS[j][is][i] *= factor; SEND_S }
-#endif
-                factor *= eta;
-            } SEND
-            const double hnew = m.hscale * m.eta;
-            m.h = adj ? hnew : m.h;
-            m.hscale = adj ? hnew : m.hscale;
-        }
-        c.in_step = 1;
-    }
-    int callSetup, jbad;
-    if (!c.redo) {
-        PHASE(m, 1);
-        cv_predict(m);
-        cv_set(m);
-        PHASE(m, 2);
-        if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-        c.convfail = ((c.nflag == FIRST_CALL) || (c.nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
-        callSetup = (c.nflag == PREV_CONV_FAIL) || (c.nflag == PREV_ERR_FAIL) || (m.nst == 0) ||
-                    (m.nst >= m.nstlp + MSBP) || (fabs(m.gamrat - 1.0) > DGMAX);
-        jbad = 0;
-    } else {
-        callSetup = 1;
-        jbad = 1;
-    }
-    int in_loop;
-    PHASE(m, 3);
-    int nls = cv_newton_pass(m, callSetup, jbad, c.convfail, in_loop);
-    PHASE(m, 4);
-    if ((nls > 0) && in_loop && !m.nls_jcur) {
-        /* SUNNonlinSol_Newton: recoverable failure with stale Jacobian data -> redo with jbad */
-        c.redo = 1;
-        return 0;
-    }
-    c.redo = 0;
-    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls, c.ncf, m.ncfn);
-
-    SFOR(i, 0, NS) m.y[i] = m.zn[0][i] + m.acor[i]; SEND
-#ifdef SA_CONSTRAINTS
-    if (!BWD && m.constr) {             /* cvCheckConstraints (see the oracle) */
-        double mm[NSD], v[NSD];
-        bool any = false;
-        SFOR(i, 0, NS) { const bool bad = constr_violated(m.cons[i], m.y[i]); mm[i] = bad ? 1.0 : 0.0; any = any || bad; } SEND
-        if (any) {
-            SFOR(i, 0, NS) {
-                const double aa = (fabs(m.cons[i]) >= 1.5) ? 1.0 : 0.0;
-                double tmp = (aa * m.cons[i]) / m.ewt[i];
-                tmp = FMA(-0.1, tmp, m.y[i]);
-                v[i] = tmp * mm[i];
-            } SEND
-            const double vnorm = wrms<NS>(v, m.ewt);
-            if (vnorm * m.tq[4] <= 1.0) {
-                SFOR(i, 0, NS) m.acor[i] = m.acor[i] - v[i]; SEND
-            } else {
-                double minq = 1e308;
-                SFOR(i, 0, NS) {
-                    const double d = mm[i] * (m.zn[0][i] - m.y[i]);
-                    const double qv = m.zn[0][i] / d;
-                    minq = (d != 0.0 && qv < minq) ? qv : minq;
-                } SEND
-                m.eta = fmax(0.9 * minq, 0.1);
-                return cv_handle_nflag_failed(m, c, CONSTR_RECVR, c.ncf, m.ncfn);
-            }
-        }
-    }
-#endif
-    double dsm = m.acnrm * m.tq[2];
-    if (dsm > 1.0) {
-        c.nflag = PREV_ERR_FAIL;
-        return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
-    }
-#ifdef SA_SENS
-    if (SENS_ON(m) && m.ism == 0) { SFOR_S(is, i) m.yS[is][i] = m.znS[0][is][i] + m.acorS[is][i]; SEND_S }
-    if (SENS_ON(m) && m.ism == 1) {      /* CV_STAGGERED: sensitivities after the state passed (oracle cv_step) */
-        c.ncf = c.nef = 0;
-        int retval = cv_f(m, m.tn, m.y, m.ftemp);
-        if (retval < 0) return CV_RHSFUNC_FAIL;
-        if (retval > 0) { c.nflag = PREV_CONV_FAIL; return 0; }
-        const int nflagS = cv_stgr_nls(m);
-        if (nflagS != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nflagS, c.ncfS, m.ncfnS);
-        m.acnrmS = sens_update_norm(m, 0.0, m.acorS, m.ewtS);
-        const double dsmS = m.acnrmS * m.tq[2];
-        if (dsmS > 1.0) {
-            c.nflag = PREV_ERR_FAIL;
-            return cv_error_test_failed(m, c.saved_t, dsmS, c.nefS, m.netfS);
-        }
-        if (dsmS > dsm) dsm = dsmS;
-    }
-#endif
-    if (BWD) {
-        c.ncf = c.nef = 0;
-        int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
-        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR, c.ncf, m.ncfn);
-        SFOR(i, 0, NQ) {
-            m.acorQ[i] = FMA(m.h, m.acorQ[i], -m.znQ[1][i]);
-            m.acorQ[i] = m.rl1 * m.acorQ[i];
-        } SEND
-        double acnrmQ = wrms<NQ>(m.acorQ, m.ewtQ);
-        double dsmQ = acnrmQ * m.tq[2];
-        if (dsmQ > 1.0) {
-            c.nflag = PREV_ERR_FAIL;
-            return cv_error_test_failed(m, c.saved_t, dsmQ, c.nefQ, m.netfQ);
-        }
-        if (dsmQ > dsm) dsm = dsmQ;
-    }
-    PHASE(m, 5);
-    cv_complete_step(m);
-    cv_prepare_next_step(m, dsm);
-    PHASE(m, 6);
-    m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
-    SFOR(i, 0, NS) m.acor[i] = m.tq[2] * m.acor[i]; SEND
-    if (BWD) { SFOR(i, 0, NQ) m.acorQ[i] = m.tq[2] * m.acorQ[i]; SEND }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { SFOR_S(is, i) m.acorS[is][i] = m.tq[2] * m.acorS[is][i]; SEND_S }
-#endif
-    c.in_step = 0;
-    return 1;
-}
+#include "bdf_core.h"
 
 template <bool BWD>
 DEV void load_params(Cv<BWD> &m, const double *ps, const double *pr, int rem_stride, int inst)
@@ -1620,14 +575,6 @@ DEV void load_params(Cv<BWD> &m, const double *ps, const double *pr, int rem_str
         m.prl[0] = 0.0;
         m.prg = pr + (int64_t)inst * rem_stride;
     }
-}
-
-template <bool BWD>
-DEV void accumulate_stats(const Cv<BWD> &m, int64_t *acc)
-{
-    acc[ST_NST] += m.nst; acc[ST_NFE] += m.nfe; acc[ST_NSETUPS] += m.nsetups; acc[ST_NJE] += m.nje;
-    acc[ST_NNI] += m.nni; acc[ST_NCFN] += m.ncfn; acc[ST_NETF] += m.netf; acc[ST_QLAST] = m.qu;
-    acc[ST_NFQE] += m.nfQe; acc[ST_NETFQ] += m.netfQ;
 }
 
 #define SA_NAN __builtin_bit_cast(double, (uint64_t)0x7ff8000000000000ULL)
@@ -1649,21 +596,21 @@ DEV void store_table(double *r, int order, double dt, const double (&hT)[QMAX + 
 {
     double Y[QMAX + 1][NSD];
     SFOR(j, 0, (QMAX) + 1) { SFOR(i, 0, NS) Y[j][i] = hY[j][i]; SEND } SEND
-    SFOR(i, 1, (QMAX) + 1) {
-        SFOR_DOWN(j, QMAX, 1) {
-            if constexpr (j >= i) {
-                if (j <= order) {
-                    double factor = dt / (hT[j] - hT[j - i]);
-                    SFOR(k, 0, NS) Y[j][k] = factor * (Y[j][k] - Y[j - 1][k]); SEND
-                }
-            }
-        } SEND
-    } SEND
+    build_table(order, dt, hT, Y);
     r[0] = (double)order;
     r[1] = dt;
     SFOR(j, 0, (QMAX) + 1) r[2 + j] = hT[j]; SEND
     SFOR(j, 0, (QMAX) + 1) { SFOR(i, 0, NS) r[8 + j * NS + i] = Y[j][i]; SEND } SEND
 }
+
+#if SA_COMPACT
+DEV void store_point(double *r, int order, double t, const double (&y)[NSD])
+{
+    r[0] = (double)order;
+    r[TREC_T] = t;
+    SFOR(i, 0, NS) r[TREC_Y + i] = y[i]; SEND
+}
+#endif
 
 /* ------------------------------------------------------------------------------------ */
 /* forward kernel: Solver.solve (mode PLAIN) / AdjointSolver.solve_forward (mode ADJ_FWD)   */
@@ -1691,7 +638,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
 
     double y0[NSD];
     SFOR(i, 0, NS) y0[i] = a.y0[(int64_t)inst * NS + i]; SEND
-    cv_reinit(m, a.t0, y0, (const double *)nullptr);
+    { double q0_[NQD]; SFOR(i, 0, NQD) q0_[i] = 0.0; SEND cv_reinit(m, a.t0, y0, q0_); }
 
     /* store: CVodeF semantics (every step is a data point, no mxstep budget); wr: the points are written to the
        arena (SA_MODE_ADJ_COUNT runs the identical pass and only counts them, see sunode_amd.cpp) */
@@ -1718,6 +665,8 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
 #ifdef SA_HERMITE
             if (wr) store_hermite(trec, m.tn, m.zn[0], m.f0, 1.0);
+#elif SA_COMPACT
+            if (wr) store_point(trec, 0, m.tn, m.zn[0]);
 #else
             if (wr) store_table(trec, 0, 1.0, hT, hY);
 #endif
@@ -1752,6 +701,8 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                         SFOR(i, 0, NS) hY[0][i] = m.zn[0][i]; SEND
 #ifdef SA_HERMITE
                         if (wr && np < a.traj_cap) store_hermite(trec + (int64_t)np * trow, m.tn, m.zn[0], m.zn[1], 1.0 / m.h);
+#elif SA_COMPACT
+                        if (wr && np < a.traj_cap) store_point(trec + (int64_t)np * trow, m.qu, m.tn, m.zn[0]);
 #else
                         if (wr && np < a.traj_cap) store_table(trec + (int64_t)np * trow, m.qu, fabs(hT[0] - hT[1]), hT, hY);
 #endif
@@ -1764,8 +715,8 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                         SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = y0[i]; SEND
                         k++;
                     } else if ((m.tn - tout) * m.h >= 0.0) {
-                        double dky[NSD];
-                        cv_get_dky0(m, tout, dky, (double *)nullptr);
+                        double dky[NSD], dq[NQD];
+                        cv_get_dky0(m, tout, dky, dq);
                         SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = dky[i]; SEND
                         k++;
                         nstloc = 0; retries = 0;
@@ -1819,12 +770,8 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
     double y0[NSD], s0[NQD][NSD];
     SFOR(i, 0, NS) y0[i] = a.y0[(int64_t)inst * NS + i]; SEND
     SFOR_S(is, i) s0[is][i] = a.sens0[((int64_t)inst * NQ + is) * NS + i]; SEND_S
-    cv_reinit(m, a.t0, y0, (const double *)nullptr);
-    SFOR(j, 0, (QMAX) + 1) { SFOR_S(is, i) m.znS[j][is][i] = (j == 0) ? s0[is][i] : 0.0; SEND_S } SEND
-    SFOR_S(is, i) {
-        m.zsaveS[is][i] = 0.0; m.ewtS[is][i] = 0.0; m.acorS[is][i] = 0.0; m.tempvS[is][i] = 0.0;
-        m.ftempS[is][i] = 0.0; m.yS[is][i] = 0.0; m.deltaS[is][i] = 0.0;
-    } SEND_S
+    { double q0_[NQD]; SFOR(i, 0, NQD) q0_[i] = 0.0; SEND cv_reinit(m, a.t0, y0, q0_); }
+    SFOR(v, 0, SV_COUNT) { SFOR_S(is, i) m.sv[v][is][i] = (v == SV_ZN0) ? s0[is][i] : 0.0; SEND_S } SEND
 
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
     double *so = a.sens_out + (int64_t)inst * a.n_t * NQ * NS;
@@ -1866,9 +813,19 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
                         SFOR_S(is, i) so[((int64_t)k * NQ + is) * NS + i] = s0[is][i]; SEND_S
                         k++;
                     } else if ((m.tn - tout) * m.h >= 0.0) {
-                        double dky[NSD], dkyS[NQD][NSD];
-                        cv_get_dky0(m, tout, dky, (double *)nullptr);
-                        cv_get_sens_dky0(m, tout, dkyS);
+                        double dky[NSD], dq[NQD], dkyS[NQD][NSD];
+                        cv_get_dky0(m, tout, dky, dq);
+                        {   /* CVodeGetSensDky, k = 0, all parameters (t validated by cv_get_dky0) */
+                            const double sx = (tout - m.tn) / m.h;
+                            double pw[QMAX + 1];
+                            pw[0] = 1.0;
+                            SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * sx; SEND
+                            SFOR_S(is, i) {
+                                double acc = pw[QMAX] * m.sv[SV_ZN0 + QMAX][is][i];
+                                SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.sv[SV_ZN0 + j][is][i], acc); SEND
+                                dkyS[is][i] = acc;
+                            } SEND_S
+                        }
                         SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = dky[i]; SEND
                         SFOR_S(is, i) so[((int64_t)k * NQ + is) * NS + i] = dkyS[is][i]; SEND_S
                         k++;
@@ -1899,7 +856,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
 /* ------------------------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
 {
-    __shared__ double ltab[TREC * 64];        /* per-lane copy of the current divided-difference table */
+    __shared__ double ltab[TTAB * 64];        /* per-lane copy of the current divided-difference table */
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
     int64_t st[SA_N_STATS];
@@ -1917,7 +874,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     m.traj = a.traj + (int64_t)inst * a.traj_istride * TREC;
     m.trow = a.traj_stride * TREC;
     m.np = np;
-    m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + 2] : a.tinitial;
+    m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + TREC_T] : a.tinitial;
     m.cur_idx = 0; m.tlo2 = 0.0;
     m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
 #ifdef SA_ABLATE_PROFILE
@@ -1925,7 +882,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     m.prof_last = __builtin_readcyclecounter(); m.prof_cur = 7;
 #endif
     m.ltab = ltab + threadIdx.x;
-    SFOR(f, 0, TREC) m.ltab[f * 64] = 0.0; SEND
+    SFOR(f, 0, TTAB) m.ltab[f * 64] = 0.0; SEND
     m.ltab[64] = 1.0;
     m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
     m.tlo = 0.0; m.thi = 0.0;
@@ -2081,5 +1038,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
     }
 }
 
+/* doubles per arena record when it is not the default 8 + 6n table record (read by sa_solver_create() if present) */
+#if SA_COMPACT
+extern "C" __device__ __attribute__((used)) const int32_t sa_traj_rec = TREC;
+#endif
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance} read back by sa_solver_create() */
 extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, SA_DEVICE_ABI_VERSION, 1, 0};

@@ -418,7 +418,6 @@ constexpr int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 #define WS_DP (WS_SMALL0 + NS * NS)
 #define WS_SMALL (WS_SMALL0 + NS * NS + NQD_ * NS)
 #define NQD_ (NQ > 0 ? NQ : 1)
-enum { SV_ZN0 = 0, SV_ZSAVE = 6, SV_EWT = 7, SV_ACOR = 8, SV_TEMPV = 9, SV_FTEMP = 10, SV_Y = 11, SV_DELTA = 12, SV_COUNT = 13 };
 #define WS_DOUBLES (WS_SMALL + SV_COUNT * NQD_ * RS * G)
 #else
 #define WS_SMALL WS_SMALL0
@@ -1814,7 +1813,8 @@ DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
 static_assert(SA_LEAN, "the sensitivity corrector of bdf_wave.hip exists in the lean lane-group builds (n <= 21); larger: bdf_mem.hip");
 #define SENS_ON(m) (!BWD && (m).sensi)
 #define SV(m, v, is, r) (m).sws[(int64_t)(((v) * NQ + (is)) * RS + (r)) * 64]
-#define SLOOP(is) for (int is = 0; is < NQ; is++)
+#define SLOOP_BEGIN(is) for (int is = 0; is < NQ; is++) {
+#define SLOOP_END }
 
 /* out[is] = J ys[is] + dp[is] for the rows of this lane; J, dp: workspace copies the callbacks just wrote */
 static __device__ __attribute__((noinline)) int sens_rhs_rows(double *sws, const gdouble *js, const gdouble *dp, int li,
@@ -1841,8 +1841,8 @@ static __device__ __attribute__((noinline)) int sens_rhs_rows(double *sws, const
     return bad ? 1 : 0;
 }
 
-template <bool BWD>
-DEV int cv_fS(Cw<BWD> &m, double t, const double (&y)[RS], int v_in, int v_out)
+template <int v_in, int v_out, bool BWD>
+DEV int cv_fS(Cw<BWD> &m, double t, const double (&y)[RS])
 {
     m.nfSe++;
     stage_inputs(m, y);
@@ -1858,418 +1858,7 @@ DEV int cv_fS(Cw<BWD> &m, double t, const double (&y)[RS], int v_in, int v_out)
     return (rc != 0 || ((any >> m.gbase) & GMASK) != 0) ? 1 : 0;
 }
 
-/* cvSensEwtSetEE: w[is] = pbar / (rtol |pbar s| + atol) */
-template <bool BWD>
-DEV int sens_ewt_set(Cw<BWD> &m, int v_in, int v_out)
-{
-    double bad = 0.0;
-    SLOOP(is) {
-        const double pb = m.pbar[is];
-        SFOR(r, 0, RS) {
-            const double v = FMA(m.rtol, fabs(pb * SV(m, v_in, is, r)), m.atol[r]);
-            bad = (IDX(m, r) < NS && v <= 0.0) ? 1.0 : bad;
-            SV(m, v_out, is, r) = pb * (1.0 / v);
-        } SEND
-    }
-    return wave_max(m.lane, bad) > 0.0 ? -1 : 0;
-}
-
-/* cvSensUpdateNorm: max(old, max_is wrms(x[is], w[is])) */
-template <bool BWD>
-DEV double sens_update_norm(const Cw<BWD> &m, double old_nrm, int v_x, int v_w)
-{
-    double nrm = old_nrm;
-    SLOOP(is) {
-        double x[RS], w[RS];
-        SFOR(r, 0, RS) { x[r] = SV(m, v_x, is, r); w[r] = SV(m, v_w, is, r); } SEND
-        const double snrm = wrms_n(m, x, w);
-        nrm = snrm > nrm ? snrm : nrm;
-    }
-    return nrm;
-}
-
-/* cvNlsResidualSensSim / ...Stg: residuals of the sensitivity systems -> DELTA (m.y holds the state) */
-template <bool BWD>
-DEV int cv_nls_residual_sens(Cw<BWD> &m)
-{
-    SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND }
-    int retval = cv_fS(m, m.tn, m.y, SV_Y, SV_FTEMP);
-    if (retval < 0) return CV_SRHSFUNC_FAIL;
-    if (retval > 0) return SRHSFUNC_RECVR;
-    SLOOP(is) {
-        SFOR(r, 0, RS) {
-            const double rr = FMA(m.rl1, SV(m, SV_ZN0 + 1, is, r), SV(m, SV_ACOR, is, r));
-            SV(m, SV_DELTA, is, r) = FMA(-m.gamma, SV(m, SV_FTEMP, is, r), rr);
-        } SEND
-    }
-    return CV_SUCCESS;
-}
-
-/* one Newton update of every sensitivity system with the current factorisation */
-template <bool BWD>
-DEV void cv_sens_newton_update(Cw<BWD> &m)
-{
-    SLOOP(is) {
-        double d[RS];
-        SFOR(r, 0, RS) d[r] = -1.0 * SV(m, SV_DELTA, is, r); SEND
-        dense_getrs(m, d);
-        if (m.gamrat != 1.0) {
-            double sc = 2.0 / (1.0 + m.gamrat);
-            SFOR(r, 0, RS) d[r] *= sc; SEND
-        }
-        SFOR(r, 0, RS) { SV(m, SV_DELTA, is, r) = d[r]; SV(m, SV_ACOR, is, r) = SV(m, SV_ACOR, is, r) + d[r]; } SEND
-    }
-}
 #endif
-
-/* ---- CVodeInit / CVodeReInit ---- */
-template <bool BWD>
-DEV void cv_reinit(Cw<BWD> &m, double t0, const double (&y0)[RS], const double (&q0)[RQ])
-{
-    m.tn = t0;
-    m.q = 1; m.L = 2; m.qwait = 2; m.etamax = ETAMX1;
-    m.qu = 0; m.hu = 0.0;
-    SFOR(j, 0, (QMAX) + 1) {
-        SFOR(r, 0, RS) m.zn[j][r] = 0.0; SEND
-        SFOR(r, 0, RQ) m.znQ[j][r] = 0.0; SEND
-    } SEND
-    SFOR(r, 0, RS) m.zn[0][r] = y0[r]; SEND
-    if (BWD) { SFOR(r, 0, RQ) m.znQ[0][r] = q0[r]; SEND }
-    m.nst = m.nfe = m.ncfn = m.netf = m.nni = m.nsetups = 0;
-    m.nje = 0; m.nstlp = 0; m.nstlj = 0; m.nfQe = m.netfQ = 0;
-    m.h = 0.0; m.hprime = 0.0; m.hscale = 0.0; m.eta = 1.0;
-    m.qprime = 1;
-    m.gamma = m.gammap = 0.0; m.gamrat = 1.0; m.crate = 1.0; m.delp = 0.0;
-    m.acnrm = 0.0; m.saved_tq5 = 0.0;
-    m.jcur = 0; m.nls_jcur = 0;
-    SFOR(i, 0, 7) { m.tau[i] = 0.0; m.l[i] = 0.0; } SEND
-    SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
-    SFOR(r, 0, RS) { m.acor[r] = m.tempv[r] = m.ftemp[r] = m.y[r] = m.zsave[r] = 0.0; } SEND
-    SFOR(r, 0, RQ) { m.acorQ[r] = m.tempvQ[r] = m.zsaveQ[r] = 0.0; } SEND
-#ifdef SA_SENS
-    m.crateS = 1.0; m.delpS = 0.0; m.acnrmS = 0.0;
-    m.nfSe = m.nniS = m.ncfnS = m.netfS = m.nsetupsS = 0;
-#endif
-}
-
-/* ---- cvHin ---- */
-template <bool BWD>
-DEV double cv_upper_bound_h0(Cw<BWD> &m, double tdist)
-{
-    double w[RS];
-    ewt_set(m, m.zn[0], w);
-    double loc = 0.0;
-    SFOR(r, 0, RS) {
-        const double t1 = FMA(HUB_FACTOR, fabs(m.zn[0][r]), 1.0 / w[r]);
-        const double v = (IDX(m, r) < NS) ? fabs(m.zn[1][r]) / t1 : 0.0;
-        loc = v > loc ? v : loc;
-    } SEND
-    double hub_inv = wave_max(m.lane, loc);
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        sens_ewt_set(m, SV_ZN0, SV_TEMPV);
-        double locS = 0.0;
-        SLOOP(is) {
-            SFOR(r, 0, RS) {
-                const double t2 = fabs(SV(m, SV_ZN0, is, r));
-                double t1 = 1.0 / SV(m, SV_TEMPV, is, r);
-                t1 = FMA(HUB_FACTOR, t2, t1);
-                const double v = (IDX(m, r) < NS) ? fabs(SV(m, SV_ZN0 + 1, is, r)) / t1 : 0.0;
-                locS = v > locS ? v : locS;
-            } SEND
-        }
-        const double hubS = wave_max(m.lane, locS);
-        if (hubS > hub_inv) hub_inv = hubS;
-    }
-#endif
-    if (BWD) {
-        double wq[RQ];
-        ewtQ_set(m, m.znQ[0], wq);
-        double locq = 0.0;
-        SFOR(r, 0, RQ) {
-            const double t1q = FMA(HUB_FACTOR, fabs(m.znQ[0][r]), 1.0 / wq[r]);
-            const double v = (IDX(m, r) < NQ) ? fabs(m.znQ[1][r]) / t1q : 0.0;
-            locq = v > locq ? v : locq;
-        } SEND
-        const double hubQ_inv = wave_max(m.lane, locq);
-        if (hubQ_inv > hub_inv) hub_inv = hubQ_inv;
-    }
-    double hub = HUB_FACTOR * tdist;
-    if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
-    return hub;
-}
-
-template <bool BWD>
-DEV int cv_ydd_norm(Cw<BWD> &m, double hg, double *yddnrm)
-{
-    SFOR(r, 0, RS) m.y[r] = FMA(hg, m.zn[1][r], m.zn[0][r]); SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_Y, is, r) = FMA(hg, SV(m, SV_ZN0 + 1, is, r), SV(m, SV_ZN0, is, r)); SEND } }
-#endif
-    if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-    int retval = cv_f(m, m.tn + hg, m.y, m.tempv);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return RHSFUNC_RECVR;
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        retval = cv_fS(m, m.tn + hg, m.y, SV_Y, SV_TEMPV);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return SRHSFUNC_RECVR;
-    }
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn + hg, m.y, m.tempvQ);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return QRHSFUNC_RECVR;
-    }
-    SFOR(r, 0, RS) {
-        m.tempv[r] = m.tempv[r] - m.zn[1][r];
-        m.tempv[r] = (1.0 / hg) * m.tempv[r];
-    } SEND
-    *yddnrm = wrms_n(m, m.tempv, m.ewt);
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        SLOOP(is) {
-            SFOR(r, 0, RS) {
-                const double v = SV(m, SV_TEMPV, is, r) - SV(m, SV_ZN0 + 1, is, r);
-                SV(m, SV_TEMPV, is, r) = (1.0 / hg) * v;
-            } SEND
-        }
-        *yddnrm = sens_update_norm(m, *yddnrm, SV_TEMPV, SV_EWT);
-    }
-#endif
-    if (BWD) {
-        SFOR(r, 0, RQ) {
-            m.tempvQ[r] = m.tempvQ[r] - m.znQ[1][r];
-            m.tempvQ[r] = (1.0 / hg) * m.tempvQ[r];
-        } SEND
-        *yddnrm = quad_update_norm(m, *yddnrm, m.tempvQ);
-    }
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_hin(Cw<BWD> &m, double tout)
-{
-    double tdiff = tout - m.tn;
-    if (tdiff == 0.0) return CV_TOO_CLOSE;
-    double sign = (tdiff > 0.0) ? 1.0 : -1.0;
-    double tdist = fabs(tdiff);
-    double tround = UROUND * fmax(fabs(m.tn), fabs(tout));
-    if (tdist < 2.0 * tround) return CV_TOO_CLOSE;
-    double hlb = HLB_FACTOR * tround;
-    double hub = cv_upper_bound_h0(m, tdist);
-    double hg = sqrt(hlb * hub);
-    if (hub < hlb) {
-        m.h = (sign < 0.0) ? -hg : hg;
-        return CV_SUCCESS;
-    }
-    double hs = hg, hnew = hg, yddnrm = 0.0;
-    int result = 1;
-    for (int count1 = 1; count1 <= HIN_MAX_ITERS && result == 1; count1++) {
-        int hgOK = 0;
-        for (int count2 = 1; count2 <= HIN_MAX_ITERS; count2++) {
-            double hgs = hg * sign;
-            int retval = cv_ydd_norm(m, hgs, &yddnrm);
-            if (retval < 0) { result = CV_RHSFUNC_FAIL; break; }
-            if (retval == CV_SUCCESS) { hgOK = 1; break; }
-            hg *= 0.2;
-        }
-        if (result != 1) break;
-        if (!hgOK) {
-            if (count1 <= 2) { result = CV_REPTD_RHSFUNC_ERR; break; }
-            hnew = hs;
-            result = 0;
-            break;
-        }
-        hs = hg;
-        hnew = (yddnrm * hub * hub > 2.0) ? sqrt(2.0 / yddnrm) : sqrt(hg * hub);
-        if (count1 == HIN_MAX_ITERS) { result = 0; break; }
-        double hrat = hnew / hg;
-        if ((hrat > 0.5) && (hrat < 2.0)) { result = 0; break; }
-        if ((count1 > 1) && (hrat > 2.0)) { hnew = hg; result = 0; break; }
-        hg = hnew;
-    }
-    if (result < 0) return result;
-    double h0 = H_BIAS * hnew;
-    if (h0 < hlb) h0 = hlb;
-    if (h0 > hub) h0 = hub;
-    if (sign < 0.0) h0 = -h0;
-    m.h = h0;
-    return CV_SUCCESS;
-}
-
-/* ---- Nordsieck array manipulation (columns j > q are kept at zero, see bdf_kernels.hip) ---- */
-template <bool BWD>
-DEV void cv_rescale(Cw<BWD> &m)
-{
-    double factor = m.eta;
-    SFOR(j, 1, (QMAX) + 1) {
-        SFOR(r, 0, RS) m.zn[j][r] *= factor; SEND
-        if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] *= factor; SEND }
-#ifdef SA_SENS
-        if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) *= factor; SEND } }
-#endif
-        factor *= m.eta;
-    } SEND
-    m.h = m.hscale * m.eta;
-    m.hscale = m.h;
-}
-
-template <bool BWD>
-DEV void cv_increase_bdf(Cw<BWD> &m)
-{
-    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
-    double alpha1 = 1.0, prod = 1.0, xiold = 1.0, alpha0 = -1.0, hsum = m.hscale;
-    m.l[2] = 1.0;
-    SFOR(j, 1, QMAX - 1) {
-        if (j < m.q) {
-            hsum += m.tau[j + 1];
-            double xi = hsum / m.hscale;
-            prod *= xi;
-            alpha0 -= 1.0 / (j + 1);
-            alpha1 += 1.0 / xi;
-            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xiold, m.l[i - 1]); SEND
-            xiold = xi;
-        }
-    } SEND
-    const double A1 = (-alpha0 - alpha1) / prod;
-    const int L = m.L;
-    double znL[RS], znQL[RQ];
-    SFOR(r, 0, RS) znL[r] = A1 * m.zsave[r]; SEND
-    SFOR(r, 0, RQ) znQL[r] = BWD ? A1 * m.zsaveQ[r] : 0.0; SEND
-    SFOR(j, 2, (QMAX) + 1) {
-        if (j == L) {
-            SFOR(r, 0, RS) m.zn[j][r] = znL[r]; SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = znQL[r]; SEND }
-        }
-    } SEND
-    SFOR(j, 2, QMAX) {
-        if (j <= m.q) {
-            SFOR(r, 0, RS) m.zn[j][r] = FMA(m.l[j], znL[r], m.zn[j][r]); SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(m.l[j], znQL[r], m.znQ[j][r]); SEND }
-        }
-    } SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        SLOOP(is) {
-            double zl[RS];
-            SFOR(r, 0, RS) zl[r] = A1 * SV(m, SV_ZSAVE, is, r); SEND
-            SFOR(j, 2, (QMAX) + 1) { if (j == L) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = zl[r]; SEND } } SEND
-            SFOR(j, 2, QMAX) {
-                if (j <= m.q) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], zl[r], SV(m, SV_ZN0 + j, is, r)); SEND }
-            } SEND
-        }
-    }
-#endif
-}
-
-template <bool BWD>
-DEV void cv_decrease_bdf(Cw<BWD> &m)
-{
-    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
-    m.l[2] = 1.0;
-    double hsum = 0.0;
-    SFOR(j, 1, (QMAX - 2) + 1) {
-        if (j <= m.q - 2) {
-            hsum += m.tau[j];
-            double xi = hsum / m.hscale;
-            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xi, m.l[i - 1]); SEND
-        }
-    } SEND
-    double znq[RS], znQq[RQ];
-    SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
-    SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
-    SFOR(j, 2, QMAX) {
-        if (j < m.q) {
-            SFOR(r, 0, RS) m.zn[j][r] = FMA(-m.l[j], znq[r], m.zn[j][r]); SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(-m.l[j], znQq[r], m.znQ[j][r]); SEND }
-        }
-    } SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        SLOOP(is) {
-            double zq[RS];
-            SFOR(r, 0, RS) {
-                zq[r] = SV(m, SV_ZN0 + 2, is, r);
-                SFOR(k, 3, (QMAX) + 1) { if (m.q == k) zq[r] = SV(m, SV_ZN0 + k, is, r); } SEND
-            } SEND
-            SFOR(j, 2, QMAX) {
-                if (j < m.q) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(-m.l[j], zq[r], SV(m, SV_ZN0 + j, is, r)); SEND }
-            } SEND
-        }
-    }
-#endif
-}
-
-template <bool BWD>
-DEV void cv_clear_column(Cw<BWD> &m, int q_old)
-{
-    SFOR(j, 2, (QMAX) + 1) {
-        if (j == q_old) {
-            SFOR(r, 0, RS) m.zn[j][r] = 0.0; SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = 0.0; SEND }
-#ifdef SA_SENS
-            if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = 0.0; SEND } }
-#endif
-        }
-    } SEND
-}
-
-template <bool BWD>
-DEV void cv_adjust_order(Cw<BWD> &m, int deltaq)
-{
-    if ((m.q == 2) && (deltaq != 1)) return;
-    if (deltaq == 1) cv_increase_bdf(m);
-    else if (deltaq == -1) cv_decrease_bdf(m);
-}
-
-template <bool BWD>
-DEV void cv_predict(Cw<BWD> &m)
-{
-    m.tn += m.h;
-    if (BWD) {
-        if ((m.tn - m.tstop) * m.h > 0.0) m.tn = m.tstop;
-    }
-    SFOR(k, 1, (QMAX) + 1) {
-        SFOR_DOWN(j, QMAX, k) {
-            SFOR(r, 0, RS) m.zn[j - 1][r] = m.zn[j - 1][r] + m.zn[j][r]; SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j - 1][r] = m.znQ[j - 1][r] + m.znQ[j][r]; SEND }
-        } SEND
-    } SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {           /* the same Pascal-triangle pass, one load and one store per entry */
-        SLOOP(is) {
-            double z[QMAX + 1][RS];
-            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) z[j][r] = SV(m, SV_ZN0 + j, is, r); SEND } SEND
-            SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { SFOR(r, 0, RS) z[j - 1][r] = z[j - 1][r] + z[j][r]; SEND } SEND } SEND
-            SFOR(j, 0, QMAX) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = z[j][r]; SEND } SEND
-        }
-    }
-#endif
-}
-
-template <bool BWD>
-DEV void cv_restore(Cw<BWD> &m, double saved_t)
-{
-    m.tn = saved_t;
-    SFOR(k, 1, (QMAX) + 1) {
-        SFOR_DOWN(j, QMAX, k) {
-            SFOR(r, 0, RS) m.zn[j - 1][r] = m.zn[j - 1][r] - m.zn[j][r]; SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j - 1][r] = m.znQ[j - 1][r] - m.znQ[j][r]; SEND }
-        } SEND
-    } SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        SLOOP(is) {
-            double z[QMAX + 1][RS];
-            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) z[j][r] = SV(m, SV_ZN0 + j, is, r); SEND } SEND
-            SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { SFOR(r, 0, RS) z[j - 1][r] = z[j - 1][r] - z[j][r]; SEND } SEND } SEND
-            SFOR(j, 0, QMAX) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = z[j][r]; SEND } SEND
-        }
-    }
-#endif
-}
 
 /* ---- linear solver interface ---- */
 #define COPY_BATCH 8
@@ -2357,434 +1946,6 @@ DEV int cv_lsetup(Cw<BWD> &m, int convfail)
     return ier > 0 ? 1 : 0;
 }
 
-template <bool BWD>
-DEV int cv_nls_lsetup(Cw<BWD> &m, int jbad, int &convfail)
-{
-    if (jbad) convfail = CV_FAIL_BAD_J;
-    int retval = cv_lsetup(m, convfail);
-    m.nsetups++;
-    m.nls_jcur = m.jcur;
-    m.gamrat = 1.0;
-    m.gammap = m.gamma;
-    m.crate = 1.0;
-#ifdef SA_SENS
-    m.crateS = 1.0;
-#endif
-    m.nstlp = m.nst;
-    if (retval < 0) return CV_LSETUP_FAIL;
-    if (retval > 0) return NLS_CONV_RECVR;
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_nls_residual(Cw<BWD> &m, double (&res)[RS])
-{
-    SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
-    int retval = cv_f(m, m.tn, m.y, m.ftemp);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return RHSFUNC_RECVR;
-    SFOR(r, 0, RS) {
-        res[r] = FMA(m.rl1, m.zn[1][r], m.acor[r]);
-        res[r] = FMA(-m.gamma, m.ftemp[r], res[r]);
-    } SEND
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_newton_pass(Cw<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
-{
-    double delta[RS];
-#ifdef SA_SENS
-    const bool sim = SENS_ON(m) && m.ism == 0;
-#endif
-    in_loop = 0;
-    SFOR(r, 0, RS) m.acor[r] = 0.0; SEND
-#ifdef SA_SENS
-    if (sim) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND } }
-#endif
-    int retval = cv_nls_residual(m, delta);
-    if (retval != CV_SUCCESS) return retval;
-#ifdef SA_SENS
-    if (sim) {
-        retval = cv_nls_residual_sens(m);
-        if (retval != CV_SUCCESS) return retval;
-    }
-#endif
-    if (callSetup) {
-        retval = cv_nls_lsetup(m, jbad, convfail);
-        if (retval != CV_SUCCESS) return retval;
-    }
-    int curiter = 0;
-    in_loop = 1;
-    for (;;) {
-        m.nni++;
-        SFOR(r, 0, RS) delta[r] = -1.0 * delta[r]; SEND
-        dense_getrs(m, delta);
-        if (m.gamrat != 1.0) {
-            double s = 2.0 / (1.0 + m.gamrat);
-            SFOR(r, 0, RS) delta[r] *= s; SEND
-        }
-        SFOR(r, 0, RS) m.acor[r] = m.acor[r] + delta[r]; SEND
-        double del = wrms_n(m, delta, m.ewt);
-#ifdef SA_SENS
-        if (sim) {
-            cv_sens_newton_update(m);
-            del = sens_update_norm(m, del, SV_DELTA, SV_EWT);
-        }
-#endif
-        if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
-        double dcon = del * fmin(1.0, m.crate) * m.tq[4];
-        if (dcon <= 1.0) {
-            m.acnrm = (curiter == 0) ? del : wrms_n(m, m.acor, m.ewt);
-#ifdef SA_SENS
-            if (sim && curiter != 0) m.acnrm = sens_update_norm(m, m.acnrm, SV_ACOR, SV_EWT);
-#endif
-            m.nls_jcur = 0;
-            return CV_SUCCESS;
-        }
-        if ((curiter >= 1) && (del > RDIV * m.delp)) return NLS_CONV_RECVR;
-        m.delp = del;
-        curiter++;
-        if (curiter >= NLS_MAXCOR) return NLS_CONV_RECVR;
-        retval = cv_nls_residual(m, delta);
-        if (retval != CV_SUCCESS) return retval;
-#ifdef SA_SENS
-        if (sim) {
-            retval = cv_nls_residual_sens(m);
-            if (retval != CV_SUCCESS) return retval;
-        }
-#endif
-    }
-}
-
-#ifdef SA_SENS
-/* cvStgrNls (ism = CV_STAGGERED): Newton on the sensitivity systems with the state fixed */
-template <bool BWD>
-DEV int cv_stgr_nls(Cw<BWD> &m)
-{
-    int callSetup = 0, jbad = 0, convfail = CV_FAIL_OTHER, retval;
-    SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND }
-    for (;;) {
-        retval = cv_nls_residual_sens(m);
-        if (retval != CV_SUCCESS) break;
-        if (callSetup) {
-            retval = cv_nls_lsetup(m, jbad, convfail);
-            m.nsetupsS++;
-            if (retval != CV_SUCCESS) break;
-        }
-        int curiter = 0;
-        for (;;) {
-            m.nniS++;
-            cv_sens_newton_update(m);
-            double del = sens_update_norm(m, 0.0, SV_DELTA, SV_EWT);
-            if (curiter > 0) m.crateS = fmax(CRDOWN * m.crateS, del / m.delpS);
-            double dcon = del * fmin(1.0, m.crateS) * m.tq[4];
-            if (dcon <= 1.0) {
-                m.acnrmS = (curiter == 0) ? del : sens_update_norm(m, 0.0, SV_ACOR, SV_EWT);
-                retval = CV_SUCCESS;
-                m.nls_jcur = 0;
-                break;
-            }
-            if ((curiter >= 1) && (del > RDIV * m.delpS)) { retval = NLS_CONV_RECVR; break; }
-            m.delpS = del;
-            curiter++;
-            if (curiter >= NLS_MAXCOR) { retval = NLS_CONV_RECVR; break; }
-            retval = cv_nls_residual_sens(m);
-            if (retval != CV_SUCCESS) break;
-        }
-        if (retval == CV_SUCCESS) break;
-        if ((retval > 0) && !m.nls_jcur) {
-            callSetup = 1;
-            jbad = 1;
-            SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND }
-            continue;
-        }
-        break;
-    }
-    if (retval != CV_SUCCESS) return retval;
-    SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND }
-    return CV_SUCCESS;
-}
-#endif
-
-template <bool BWD>
-DEV int cv_error_test_failed(Cw<BWD> &m, double saved_t, double dsm, int &nef, int &netf_counter)
-{
-    nef++;
-    netf_counter++;
-    cv_restore(m, saved_t);
-    if (nef == MXNEF) return CV_ERR_FAILURE;
-    m.etamax = 1.0;
-    if (nef <= MXNEF1) {
-        m.eta = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
-        m.eta = fmax(ETAMIN, m.eta);
-        if (nef >= SMALL_NEF) m.eta = fmin(m.eta, ETAMXF);
-        cv_rescale(m);
-        return 0;
-    }
-    if (m.q > 1) {
-        m.eta = ETAMIN;
-        cv_adjust_order(m, -1);
-        cv_clear_column(m, m.q);
-        m.L = m.q;
-        m.q--;
-        m.qwait = m.L;
-        cv_rescale(m);
-        return 0;
-    }
-    m.eta = ETAMIN;
-    m.h *= m.eta;
-    m.hscale = m.h;
-    m.qwait = LONG_WAIT;
-    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-    int retval = cv_f(m, m.tn, m.zn[0], m.tempv);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
-    SFOR(r, 0, RS) m.zn[1][r] = m.h * m.tempv[r]; SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        retval = cv_fS(m, m.tn, m.zn[0], SV_ZN0, SV_TEMPV);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return CV_UNREC_SRHSFUNC_ERR;
-        SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZN0 + 1, is, r) = m.h * SV(m, SV_TEMPV, is, r); SEND }
-    }
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn, m.zn[0], m.tempvQ);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return CV_UNREC_QRHSFUNC_ERR;
-        SFOR(r, 0, RQ) m.znQ[1][r] = m.h * m.tempvQ[r]; SEND
-    }
-    return 0;
-}
-
-template <bool BWD>
-DEV void cv_complete_step(Cw<BWD> &m)
-{
-    m.nst++;
-    m.hu = m.h;
-    m.qu = m.q;
-    SFOR_DOWN(i, QMAX, 2) m.tau[i] = (i <= m.q) ? m.tau[i - 1] : m.tau[i]; SEND
-    m.tau[2] = ((m.q == 1) && (m.nst > 1)) ? m.tau[1] : m.tau[2];
-    m.tau[1] = m.h;
-    SFOR(j, 0, (QMAX) + 1) {
-        SFOR(r, 0, RS) m.zn[j][r] = FMA(m.l[j], m.acor[r], m.zn[j][r]); SEND
-        if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(m.l[j], m.acorQ[r], m.znQ[j][r]); SEND }
-    } SEND
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        SLOOP(is) {
-            double ac[RS];
-            SFOR(r, 0, RS) ac[r] = SV(m, SV_ACOR, is, r); SEND
-            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], ac[r], SV(m, SV_ZN0 + j, is, r)); SEND } SEND
-            if ((m.qwait - 1 == 1) && (m.q != QMAX)) { SFOR(r, 0, RS) SV(m, SV_ZSAVE, is, r) = ac[r]; SEND }
-        }
-    }
-#endif
-    m.qwait--;
-    {
-        const bool sv = (m.qwait == 1) && (m.q != QMAX);
-        SFOR(r, 0, RS) m.zsave[r] = sv ? m.acor[r] : m.zsave[r]; SEND
-        if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = sv ? m.acorQ[r] : m.zsaveQ[r]; SEND }
-        m.saved_tq5 = sv ? m.tq[5] : m.saved_tq5;
-    }
-}
-
-template <bool BWD>
-DEV void cv_set_eta(Cw<BWD> &m)
-{
-    if (m.eta < THRESH) {
-        m.eta = 1.0;
-        m.hprime = m.h;
-    } else {
-        m.eta = fmin(m.eta, m.etamax);
-        m.hprime = m.h * m.eta;
-    }
-}
-
-template <bool BWD>
-DEV void cv_prepare_next_step(Cw<BWD> &m, double dsm)
-{
-    if (m.etamax == 1.0) {
-        m.qwait = m.qwait > 2 ? m.qwait : 2;
-        m.qprime = m.q;
-        m.hprime = m.h;
-        m.eta = 1.0;
-        return;
-    }
-    /* cvComputeEtaqm1 / cvComputeEtaqp1 / cvChooseEta as ONE straight-line block (see bdf_kernels.hip): with 64/G
-       instances per wavefront some group is at an order decision in nearly every iteration, so the full path runs
-       anyway; here its two norms and three powers are independent chains of one basic block, groups that are not at
-       a decision (qwait != 0) or whose candidate is not defined discard the values through selects.  Values and
-       written fields identical to the branching form. */
-    const bool full = (m.qwait == 0);
-    double znq[RS], znQq[RQ], tv[RS], tvQ[RQ];
-    SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
-    SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
-    double ddn = wrms_n(m, znq, m.ewt);
-    if (BWD) ddn = quad_update_norm(m, ddn, znQq);
-#ifdef SA_SENS
-    if (SENS_ON(m) && full && m.q > 1) {            /* cvComputeEtaqm1: the sensitivities' column q takes part */
-        SLOOP(is) {
-            SFOR(r, 0, RS) {
-                double v = SV(m, SV_ZN0 + 2, is, r);
-                SFOR(k, 3, (QMAX) + 1) { if (m.q == k) v = SV(m, SV_ZN0 + k, is, r); } SEND
-                SV(m, SV_TEMPV, is, r) = v;
-            } SEND
-        }
-        ddn = sens_update_norm(m, ddn, SV_TEMPV, SV_EWT);
-    }
-#endif
-    ddn = ddn * m.tq[1];
-    const double base = m.h / m.tau[2];
-    double pw = 1.0;
-    SFOR(i, 1, (QMAX + 1) + 1) { pw = (i <= m.L) ? pw * base : pw; } SEND
-    const double cquot = (m.tq[5] / m.saved_tq5) * pw;
-    SFOR(r, 0, RS) tv[r] = FMA(-cquot, m.zsave[r], m.acor[r]); SEND
-    double dup = wrms_n(m, tv, m.ewt);
-    if (BWD) {
-        SFOR(r, 0, RQ) tvQ[r] = FMA(-cquot, m.zsaveQ[r], m.acorQ[r]); SEND
-        dup = quad_update_norm(m, dup, tvQ);
-    }
-#ifdef SA_SENS
-    if (SENS_ON(m) && full && (m.q != QMAX) && (m.saved_tq5 != 0.0)) {     /* cvComputeEtaqp1 */
-        SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_TEMPV, is, r) = FMA(-cquot, SV(m, SV_ZSAVE, is, r), SV(m, SV_ACOR, is, r)); SEND }
-        dup = sens_update_norm(m, dup, SV_TEMPV, SV_EWT);
-    }
-#endif
-    dup = dup * m.tq[3];
-    const double p0 = rpower_nb(BIAS2 * dsm, inv_int(m.L));
-    const double p1 = rpower_nb(BIAS1 * ddn, inv_int(m.q));
-    const double p2 = rpower_nb(BIAS3 * dup, inv_int(m.L + 1));
-    const double etaq = 1.0 / (p0 + ADDON), e1 = 1.0 / (p1 + ADDON), e2 = 1.0 / (p2 + ADDON);
-    const double etaqm1 = (m.q > 1) ? e1 : 0.0;
-    const double etaqp1 = ((m.q != QMAX) && (m.saved_tq5 != 0.0)) ? e2 : 0.0;
-    m.etaq = etaq;
-    m.etaqm1 = full ? etaqm1 : m.etaqm1;
-    m.etaqp1 = full ? etaqp1 : m.etaqp1;
-    m.qwait = full ? 2 : m.qwait;
-    const double etam = fmax(etaqm1, fmax(etaq, etaqp1));
-    const bool c0 = etam < THRESH, c1 = (etam == etaq), c2 = (etam == etaqm1);
-    const double eta_f = c0 ? 1.0 : (c1 ? etaq : (c2 ? etaqm1 : etaqp1));
-    const int qp_f = c0 ? m.q : (c1 ? m.q : (c2 ? m.q - 1 : m.q + 1));
-    const bool up = full && !c0 && !c1 && !c2;
-    m.eta = full ? eta_f : etaq;
-    m.qprime = full ? qp_f : m.q;
-    SFOR(r, 0, RS) m.zsave[r] = up ? m.acor[r] : m.zsave[r]; SEND
-    if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = up ? m.acorQ[r] : m.zsaveQ[r]; SEND }
-#ifdef SA_SENS
-    if (SENS_ON(m) && up) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZSAVE, is, r) = SV(m, SV_ACOR, is, r); SEND } }
-#endif
-    {   /* cvSetEta */
-        const bool small = m.eta < THRESH;
-        const double capped = fmin(m.eta, m.etamax);
-        m.hprime = small ? m.h : m.h * capped;
-        m.eta = small ? 1.0 : capped;
-    }
-}
-
-template <bool BWD>
-DEV int cv_get_dky0(const Cw<BWD> &m, double t, double (&dky)[RS], double (&dkyQ)[RQ])
-{
-    double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.hu));
-    if (m.hu < 0.0) tfuzz = -tfuzz;
-    double tp = m.tn - m.hu - tfuzz;
-    double tn1 = m.tn + tfuzz;
-    if ((t - tp) * (t - tn1) > 0.0) return CV_BAD_T;
-    double s = (t - m.tn) / m.h;
-    double pw[QMAX + 1];
-    pw[0] = 1.0;
-    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
-    SFOR(r, 0, RS) {
-        double acc = pw[QMAX] * m.zn[QMAX][r];
-        SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.zn[j][r], acc); SEND
-        dky[r] = acc;
-    } SEND
-    if (BWD) {
-        SFOR(r, 0, RQ) {
-            double acc = pw[QMAX] * m.znQ[QMAX][r];
-            SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.znQ[j][r], acc); SEND
-            dkyQ[r] = acc;
-        } SEND
-    }
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_first_call(Cw<BWD> &m, double tout)
-{
-#ifdef SA_CONSTRAINTS
-    if (!BWD && m.constr) {
-        double bad = 0.0;
-        SFOR(r, 0, RS) bad = ((IDX(m, r) < NS) && constr_violated(m.cons[r], m.zn[0][r])) ? 1.0 : bad; SEND
-        if (wave_max(m.lane, bad) > 0.0) return CV_ILL_INPUT;
-    }
-#endif
-    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
-    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { if (sens_ewt_set(m, SV_ZN0, SV_EWT) != 0) return CV_ILL_INPUT; }
-#endif
-    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-    int retval = cv_f(m, m.tn, m.zn[0], m.zn[1]);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
-#ifdef SA_HERMITE
-    SFOR(r, 0, RS) m.f0[r] = m.zn[1][r]; SEND
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn, m.zn[0], m.znQ[1]);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return CV_FIRST_QRHSFUNC_ERR;
-    }
-#ifdef SA_SENS
-    if (SENS_ON(m)) {
-        retval = cv_fS(m, m.tn, m.zn[0], SV_ZN0, SV_ZN0 + 1);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return CV_FIRST_SRHSFUNC_ERR;
-    }
-#endif
-    double tout_hin = tout;
-    if (BWD) {
-        if ((m.tstop - m.tn) * (tout - m.tn) <= 0.0) return CV_ILL_INPUT;
-        if ((tout - m.tn) * (tout - m.tstop) > 0.0) tout_hin = m.tstop;
-    }
-    int hflag = cv_hin(m, tout_hin);
-    if (hflag != CV_SUCCESS) return hflag;
-    if (BWD) {
-        if ((m.tn + m.h - m.tstop) * m.h > 0.0) m.h = (m.tstop - m.tn) * (1.0 - 4.0 * UROUND);
-    }
-    m.hscale = m.h;
-    m.hprime = m.h;
-    SFOR(r, 0, RS) m.zn[1][r] = m.h * m.zn[1][r]; SEND
-    if (BWD) { SFOR(r, 0, RQ) m.znQ[1][r] = m.h * m.znQ[1][r]; SEND }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ZN0 + 1, is, r) = m.h * SV(m, SV_ZN0 + 1, is, r); SEND } }
-#endif
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_pre_step(Cw<BWD> &m)
-{
-    if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
-    if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { if (sens_ewt_set(m, SV_ZN0, SV_EWT) != 0) return CV_ILL_INPUT; }
-#endif
-    double nrm = wrms_n(m, m.zn[0], m.ewt);
-    if (BWD) nrm = quad_update_norm(m, nrm, m.znQ[0]);
-#ifdef SA_SENS
-    if (SENS_ON(m)) nrm = sens_update_norm(m, nrm, SV_ZN0, SV_EWT);
-#endif
-    if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
-    return CV_SUCCESS;
-}
-
-struct StepCtl {
-    int in_step, redo, nflag, ncf, nef, nefQ, convfail, ncfS, nefS;
-    double saved_t;
-};
 
 #if SA_LEAN
 template <bool BWD>
@@ -2816,178 +1977,8 @@ DEV void cold_load(Cw<BWD> &m)
 #define COLD_LOAD(m)
 #endif
 
-template <bool BWD>
-DEV int cv_handle_nflag_failed(Cw<BWD> &m, StepCtl &c, int nflag, int &ncf, int &ncfn)
-{
-    ncfn++;
-    cv_restore(m, c.saved_t);
-    if (nflag < 0) return nflag;
-    ncf++;
-    m.etamax = 1.0;
-    if (ncf == MXNCF) {
-        if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
-        if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
-        if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
-        if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
-        return CV_REPTD_QRHSFUNC_ERR;
-    }
-    if (nflag != CONSTR_RECVR) m.eta = ETACF;         /* CONSTR_RECVR: eta was set by the constraint check */
-    c.nflag = PREV_CONV_FAIL;
-    cv_rescale(m);
-    return 0;
-}
-
-/* one step ATTEMPT; 1 = step completed, 0 = call again, <0 = unrecoverable (see bdf_kernels.hip) */
-template <bool BWD>
-DEV int cv_attempt(Cw<BWD> &m, StepCtl &c)
-{
-    if (!c.in_step) {
-        c.saved_t = m.tn;
-        c.ncf = c.nef = c.nefQ = 0;
-        c.ncfS = c.nefS = 0;
-        c.nflag = FIRST_CALL;
-        c.redo = 0;
-        if ((m.nst > 0) && (m.hprime != m.h)) {
-            if (m.qprime != m.q) {
-                cv_adjust_order(m, m.qprime - m.q);
-                if (m.qprime < m.q) cv_clear_column(m, m.q);
-                m.q = m.qprime;
-                m.L = m.q + 1;
-                m.qwait = m.L;
-            }
-            cv_rescale(m);
-        }
-        c.in_step = 1;
-    }
-    int callSetup, jbad;
-    PH_T0
-    if (!c.redo) {
-        cv_predict(m);
-        cv_set(m);
-        PH_ADD(m, 1)
-        COLD_STORE(m);          /* until the Newton pass (and the quadrature callback) are over */
-        if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-        PH_ADD(m, 2)
-        c.convfail = ((c.nflag == FIRST_CALL) || (c.nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
-        callSetup = (c.nflag == PREV_CONV_FAIL) || (c.nflag == PREV_ERR_FAIL) || (m.nst == 0) ||
-                    (m.nst >= m.nstlp + MSBP) || (fabs(m.gamrat - 1.0) > DGMAX);
-        jbad = 0;
-    } else {
-        callSetup = 1;
-        jbad = 1;
-        COLD_STORE(m);
-    }
-    int in_loop;
-    int nls = cv_newton_pass(m, callSetup, jbad, c.convfail, in_loop);
-    PH_ADD(m, 3)
-    if ((nls > 0) && in_loop && !m.nls_jcur) {
-        COLD_LOAD(m);
-        c.redo = 1;
-        return 0;
-    }
-    c.redo = 0;
-    if (nls != CV_SUCCESS) { COLD_LOAD(m); return cv_handle_nflag_failed(m, c, nls, c.ncf, m.ncfn); }
-
-    SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
-#ifdef SA_CONSTRAINTS
-    if (!BWD && m.constr) {             /* cvCheckConstraints (see the oracle) */
-        double mm[RS], v[RS];
-        double anyv = 0.0;
-        SFOR(r, 0, RS) {
-            const bool bad = (IDX(m, r) < NS) && constr_violated(m.cons[r], m.y[r]);
-            mm[r] = bad ? 1.0 : 0.0;
-            anyv = bad ? 1.0 : anyv;
-        } SEND
-        if (wave_max(m.lane, anyv) > 0.0) {
-            SFOR(r, 0, RS) {
-                const double aa = (fabs(m.cons[r]) >= 1.5) ? 1.0 : 0.0;
-                double tmp = (aa * m.cons[r]) / m.ewt[r];
-                tmp = FMA(-0.1, tmp, m.y[r]);
-                v[r] = (IDX(m, r) < NS) ? tmp * mm[r] : 0.0;
-            } SEND
-            const double vnorm = wrms_n(m, v, m.ewt);
-            if (vnorm * m.tq[4] <= 1.0) {
-                SFOR(r, 0, RS) m.acor[r] = m.acor[r] - v[r]; SEND
-            } else {
-                double q = 1e308;
-                SFOR(r, 0, RS) {
-                    const double d = mm[r] * (m.zn[0][r] - m.y[r]);
-                    const double qv = (IDX(m, r) < NS && d != 0.0) ? m.zn[0][r] / d : 1e308;
-                    q = qv < q ? qv : q;
-                } SEND
-                const double minq = -wave_max(m.lane, -q);
-                m.eta = fmax(0.9 * minq, 0.1);
-                COLD_LOAD(m);
-                return cv_handle_nflag_failed(m, c, CONSTR_RECVR, c.ncf, m.ncfn);
-            }
-        }
-    }
-#endif
-    double dsm = m.acnrm * m.tq[2];
-    if (dsm > 1.0) {
-        c.nflag = PREV_ERR_FAIL;
-        COLD_LOAD(m);
-        return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
-    }
-#ifdef SA_SENS
-    if (SENS_ON(m) && m.ism == 0) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND } }
-    if (SENS_ON(m) && m.ism == 1) {      /* CV_STAGGERED: sensitivities after the state passed (oracle cv_step) */
-        c.ncf = c.nef = 0;
-        int retval = cv_f(m, m.tn, m.y, m.ftemp);
-        if (retval < 0) return CV_RHSFUNC_FAIL;
-        if (retval > 0) { COLD_LOAD(m); c.nflag = PREV_CONV_FAIL; return 0; }
-        const int nflagS = cv_stgr_nls(m);
-        if (nflagS != CV_SUCCESS) { COLD_LOAD(m); return cv_handle_nflag_failed(m, c, nflagS, c.ncfS, m.ncfnS); }
-        m.acnrmS = sens_update_norm(m, 0.0, SV_ACOR, SV_EWT);
-        const double dsmS = m.acnrmS * m.tq[2];
-        if (dsmS > 1.0) {
-            c.nflag = PREV_ERR_FAIL;
-            COLD_LOAD(m);
-            return cv_error_test_failed(m, c.saved_t, dsmS, c.nefS, m.netfS);
-        }
-        if (dsmS > dsm) dsm = dsmS;
-    }
-#endif
-    if (BWD) {
-        c.ncf = c.nef = 0;
-        int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
-        COLD_LOAD(m);
-        if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR, c.ncf, m.ncfn);
-        SFOR(r, 0, RQ) {
-            m.acorQ[r] = FMA(m.h, m.acorQ[r], -m.znQ[1][r]);
-            m.acorQ[r] = m.rl1 * m.acorQ[r];
-        } SEND
-        double acnrmQ = wrms_q(m, m.acorQ, m.ewtQ);
-        double dsmQ = acnrmQ * m.tq[2];
-        if (dsmQ > 1.0) {
-            c.nflag = PREV_ERR_FAIL;
-            return cv_error_test_failed(m, c.saved_t, dsmQ, c.nefQ, m.netfQ);
-        }
-        if (dsmQ > dsm) dsm = dsmQ;
-    } else {
-        COLD_LOAD(m);
-    }
-    PH_ADD(m, 4)
-    cv_complete_step(m);
-    cv_prepare_next_step(m, dsm);
-    m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
-    SFOR(r, 0, RS) m.acor[r] = m.tq[2] * m.acor[r]; SEND
-    if (BWD) { SFOR(r, 0, RQ) m.acorQ[r] = m.tq[2] * m.acorQ[r]; SEND }
-#ifdef SA_SENS
-    if (SENS_ON(m)) { SLOOP(is) { SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = m.tq[2] * SV(m, SV_ACOR, is, r); SEND } }
-#endif
-    c.in_step = 0;
-    PH_ADD(m, 5)
-    return 1;
-}
-
-template <bool BWD>
-DEV void accumulate_stats(const Cw<BWD> &m, int64_t *acc)
-{
-    acc[ST_NST] += m.nst; acc[ST_NFE] += m.nfe; acc[ST_NSETUPS] += m.nsetups; acc[ST_NJE] += m.nje;
-    acc[ST_NNI] += m.nni; acc[ST_NCFN] += m.ncfn; acc[ST_NETF] += m.netf; acc[ST_QLAST] = m.qu;
-    acc[ST_NFQE] += m.nfQe; acc[ST_NETFQ] += m.netfQ;
-}
+#define SA_STATE Cw
+#include "bdf_core.h"
 
 template <bool BWD>
 DEV void setup_common(Cw<BWD> &m, const double *ps, const double *pr, int rem_stride, int inst, double *ws)
@@ -3232,14 +2223,14 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
     cv_reinit(m, a.t0, y0, q0);
     const double *s0 = a.sens0 + (int64_t)inst * NQ * NS;
     for (int v = 0; v < SV_COUNT; v++)
-        SLOOP(is) { SFOR(r, 0, RS) SV(m, v, is, r) = (v == SV_ZN0 && IDX(m, r) < NS) ? s0[is * NS + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND }
+        SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, v, is, r) = (v == SV_ZN0 && IDX(m, r) < NS) ? s0[is * NS + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND SLOOP_END
 
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
     double *so = a.sens_out + (int64_t)inst * a.n_t * NQ * NS;
     int status = CV_SUCCESS, k = 0, nstloc = 0, retries = 0, total_retries = 0, attempts = 0;
     while (k < a.n_t && a.tvals[k] == a.t0) {
         SFOR(r, 0, RS) { if (IDX(m, r) < NS) yo[(int64_t)k * NS + IDX(m, r)] = y0[r]; } SEND
-        SLOOP(is) { SFOR(r, 0, RS) { if (IDX(m, r) < NS) so[((int64_t)k * NQ + is) * NS + IDX(m, r)] = s0[is * NS + IDX(m, r)]; } SEND }
+        SLOOP_BEGIN(is) SFOR(r, 0, RS) { if (IDX(m, r) < NS) so[((int64_t)k * NQ + is) * NS + IDX(m, r)] = s0[is * NS + IDX(m, r)]; } SEND SLOOP_END
         k++;
     }
     bool done = (k >= a.n_t);
@@ -3271,7 +2262,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
                     double tout = a.tvals[k];
                     if (tout == a.t0) {
                         SFOR(s, 0, RS) { if (IDX(m, s) < NS) yo[(int64_t)k * NS + IDX(m, s)] = y0[s]; } SEND
-                        SLOOP(is) { SFOR(s, 0, RS) { if (IDX(m, s) < NS) so[((int64_t)k * NQ + is) * NS + IDX(m, s)] = s0[is * NS + IDX(m, s)]; } SEND }
+                        SLOOP_BEGIN(is) SFOR(s, 0, RS) { if (IDX(m, s) < NS) so[((int64_t)k * NQ + is) * NS + IDX(m, s)] = s0[is * NS + IDX(m, s)]; } SEND SLOOP_END
                         k++;
                     } else if ((m.tn - tout) * m.h >= 0.0) {
                         double dky[RS], dq[RQ];
@@ -3282,13 +2273,13 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
                             double pw[QMAX + 1];
                             pw[0] = 1.0;
                             SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * sx; SEND
-                            SLOOP(is) {
+                            SLOOP_BEGIN(is)
                                 SFOR(s, 0, RS) {
                                     double acc = pw[QMAX] * SV(m, SV_ZN0 + QMAX, is, s);
                                     SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], SV(m, SV_ZN0 + j, is, s), acc); SEND
                                     if (IDX(m, s) < NS) so[((int64_t)k * NQ + is) * NS + IDX(m, s)] = acc;
                                 } SEND
-                            }
+                            SLOOP_END
                         }
                         k++;
                         nstloc = 0; retries = 0;

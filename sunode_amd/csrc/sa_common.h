@@ -114,6 +114,10 @@ DEV void sfor_down(F &&f)          /* B, B-1, ..., E (inclusive) */
 #define CV_FAIL_BAD_J 1
 #define CV_FAIL_OTHER 2
 
+/* forward-sensitivity vectors of an instance (one NQ x n block each): the six Nordsieck columns, the saved correction
+   and the work vectors of the corrector; SV(m, vector, parameter, slot) in the kernels (bdf_core.h) */
+enum { SV_ZN0 = 0, SV_ZSAVE = 6, SV_EWT = 7, SV_ACOR = 8, SV_TEMPV = 9, SV_FTEMP = 10, SV_Y = 11, SV_DELTA = 12, SV_COUNT = 13 };
+
 enum { ST_NST, ST_NFE, ST_NSETUPS, ST_NJE, ST_NNI, ST_NCFN, ST_NETF, ST_QLAST,
        ST_NPTS, ST_NFQE, ST_NETFQ, ST_NINTERP, ST_NREBUILD, ST_RETRIES, ST_ATTEMPTS, ST_RESERVED1 };
 

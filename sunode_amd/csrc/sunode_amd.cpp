@@ -68,6 +68,7 @@ struct sa_solver {
     int n = 0, p = 0, r = 0;
     int group = 1;                 /* lanes per instance: 1 = thread-per-instance, 2^k = lane group / workgroup build */
     int64_t ws_doubles = 0;        /* per-instance workspace of the memory-resident build (0: register builds) */
+    int32_t rec_doubles = 0;       /* doubles per arena record: 8 + 6n (table records) unless the code object says otherwise */
     DevBuf ws;
     hipModule_t module = nullptr;
     hipFunction_t k_forward = nullptr, k_backward = nullptr, k_eval = nullptr, k_math = nullptr;
@@ -181,6 +182,15 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
         return fail(SA_ERR_MODULE, "%s: sa_meta missing or ABI mismatch", path);
     }
     s->n = meta[0]; s->p = meta[1]; s->r = meta[2]; s->group = meta[4]; s->ws_doubles = meta[5];
+    s->rec_doubles = 8 + 6 * s->n;
+    {   /* compact-trajectory builds store {order, t, y[n]} per step and say so */
+        hipDeviceptr_t rp = nullptr;
+        size_t rsz = 0;
+        int32_t rec = 0;
+        if (hipModuleGetGlobal(&rp, &rsz, s->module, "sa_traj_rec") == hipSuccess && rsz == sizeof(rec) &&
+            hipMemcpyDtoH(&rec, rp, sizeof(rec)) == hipSuccess && rec >= 2) s->rec_doubles = rec;
+        else (void)hipGetLastError();
+    }
     const char *names[4] = {"sa_k_forward", "sa_k_backward", "sa_k_eval", "sa_k_math"};
     hipFunction_t *slots[4] = {&s->k_forward, &s->k_backward, &s->k_eval, &s->k_math};
     for (int i = 0; i < 4; i++) {
@@ -359,7 +369,7 @@ static size_t arena_budget(const sa_solver *s)
     return dflt;
 }
 
-static size_t record_bytes(const sa_solver *s) { return sizeof(double) * (size_t)(8 + 6 * s->n); }
+static size_t record_bytes(const sa_solver *s) { return sizeof(double) * (size_t)s->rec_doubles; }
 
 struct FwdLaunch {
     int mode; int32_t B, n_t, rem_stride, rows; int64_t stride; double t0;

@@ -333,13 +333,17 @@ class AdjointSolver(_EngineMixin):
     budget of the stored trajectories (default 96 GiB, at most 60 % of the free memory): batches
     that fit stay resident between ``solve_forward`` and ``solve_backward``, larger ones are
     re-integrated tile by tile inside ``solve_backward`` -- CVODES' check-point scheme, same
-    results (csrc/sunode_amd.cpp, "trajectory arena").
+    results (csrc/sunode_amd.cpp, "trajectory arena").  ``compact_trajectory=True`` stores what CVODES itself
+    keeps per step, {order, t, y[n]}, instead of the ready-made interpolation table (8 + 6n doubles) and lets the
+    backward kernel rebuild the table when its index moves: 5-6x less arena and forward write traffic for a slower
+    backward pass (one-lane-per-instance kernel, polynomial interpolation; ignored elsewhere); results identical.
     """
 
     def __init__(self, problem, *, abstol=1e-10, reltol=1e-10, checkpoint_n=500_000, interpolation="polynomial",
                  constraints=None, solver="BDF", adjoint_solver="BDF", backward_abstol=1e-10,
                  backward_reltol=1e-10, quad_abstol=1e-10, quad_reltol=1e-10, mxsteps: int = 500,
-                 max_steps: Optional[int] = None, arena_gib: Optional[float] = None, device: int = 0):
+                 max_steps: Optional[int] = None, arena_gib: Optional[float] = None, device: int = 0,
+                 compact_trajectory: bool = False):
         if solver not in ("BDF", "ADAMS"):
             raise ValueError(f"Unknown solver {solver}.")
         if adjoint_solver not in ("BDF", "ADAMS"):
@@ -364,7 +368,11 @@ class AdjointSolver(_EngineMixin):
         self._arena_bytes = int(arena_gib * 2**30) if arena_gib else 0
         self._device = device
         self._source = problem.native_source()
-        _native.build_code_object(self._source, constraints=self._constraints is not None, hermite=self._hermite)
+        # (only bdf_kernels.hip carries the compact-record option)
+        self._compact = bool(compact_trajectory) and not self._hermite and \
+            _native.kernel_variant(self._source, hermite=self._hermite)[0] == "bdf_kernels.hip"
+        _native.build_code_object(self._source, constraints=self._constraints is not None, hermite=self._hermite,
+                                  compact=self._compact)
         self._native = None
         self._last_forward = None
 
@@ -372,7 +380,7 @@ class AdjointSolver(_EngineMixin):
         if self._native is None:
             self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
                                                 constraints=self._constraints, hermite=self._hermite,
-                                                **self._native_kwargs())
+                                                compact=self._compact, **self._native_kwargs())
         return self._native
 
     def _set_tolerances(self, atol=None, rtol=None):
