@@ -139,7 +139,8 @@ class GpuEngine:
             source += "".join("\n#define SA_ABLATE_%s 1\n" % k for k in os.environ["SA_ABLATE"].split(","))
         rt, at = tol
         self.eng = _native.NativeSolver(source, device=local_rank, rtol=rt, atol=at, rtolB=rt, atolB=at,
-                                        rtolQB=rt, atolQB=at, n_states=n, arena_bytes=arena_bytes)
+                                        rtolQB=rt, atolQB=at, n_states=n, arena_bytes=arena_bytes,
+                                        compact=_native.default_compact_trajectory(source))   # = AdjointSolver's default
         # stream ordering (include/sunode_amd.h): the solver launches on the torch stream that owns the tensors
         self.stream = torch.cuda.Stream(device=self.dev)
         self.eng.set_stream(self.stream.cuda_stream)
@@ -287,12 +288,13 @@ def algorithmic_flops(prob, sf, sb):
     return float(fwd), float(bwd)
 
 
-def pmc_profile(kernel):
-    """Committed rocprofv3 --pmc results of this command (profiles/pmc_traffic.json; collected in separate
-    passes as MI355X_MICROARCH.md prescribes -- counters cannot be read from inside the timed run)."""
+def pmc_profile(workload, kernel):
+    """Committed rocprofv3 --pmc results of this command for `workload` (profiles/pmc_traffic.json, written by
+    tools/make_pmc_traffic.py from the PMC summaries of tools/gpu_profiles.sh; collected in separate passes as
+    MI355X_MICROARCH.md prescribes -- counters cannot be read from inside the timed run)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            return json.load(fh)[kernel]
+            return json.load(fh)[workload][kernel]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -307,9 +309,15 @@ def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, faile
     bwd_s, fwd_s = float(np.mean(bwd_ms)) * 1e-3, float(np.mean(fwd_ms)) * 1e-3
     achieved = B * bwd_alg / bwd_s / 1e9
     f_fwd, f_bwd = algorithmic_flops(prob, sf, sb)
-    pmc = pmc_profile("sa_k_backward") if name == "lv" else None
+    pmc = pmc_profile(name, "sa_k_backward")
+    pmc_f = pmc_profile(name, "sa_k_forward")
+    have = bool(pmc and "fetch" in pmc and "write" in pmc)
+    traffic_b = (pmc["fetch"] + pmc["write"]) if have else None
+    traffic_f = (pmc_f["fetch"] + pmc_f["write"]) if (pmc_f and "fetch" in pmc_f and "write" in pmc_f) else None
     arena_bytes, tiles, tiled = res.get("arena", (0, 0, False))
-    rec = 8 * (8 + 6 * n)
+    from sunode_amd import _native
+    compact = _native.default_compact_trajectory(prob.native_source())
+    rec = 8 * (n + 2) if compact else 8 * (8 + 6 * n)
     out = {
         "metric": "fp64 forward+adjoint ODE solves/sec at rtol=1e-8 (%s, batch %d/GPU)"
                   % ({"lv": "Lotka-Volterra"}.get(name, name), B),
@@ -323,17 +331,28 @@ def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, faile
             # `valu` below is the roofline that binds.
             "bound": "hbm", "kernel": "sa_k_backward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": (pmc["fetch"] + pmc["write"]) if pmc else None,
-            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if pmc else None,
+            "traffic": traffic_b,
+            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if have else None,
+            # what the counters say the kernels really move, against the same peak (bytes of the committed PMC pass /
+            # this run's kernel time): the figure to watch for wasted re-reads
+            "hbm_frac_traffic": (traffic_b / bwd_s / 1e9 / HBM_PEAK_GBS) if have else None,
+            "forward_traffic": traffic_f,
+            "forward_hbm_frac_traffic": (traffic_f / fwd_s / 1e9 / HBM_PEAK_GBS) if traffic_f else None,
+            "traffic_over_algorithmic": ((traffic_b + (traffic_f or 0.0)) / (B * (bwd_alg + (fwd_alg if traffic_f else 0.0)))) if have else None,
+            "arena_record": "compact {order, t, y[n]}: %d B per stored step" % rec if compact else
+                            "table {order, dt, T[6], Y[6][n]}: %d B per stored step" % rec,
             "algorithmic_bytes_per_launch": B * bwd_alg, "kernel_ms": 1e3 * bwd_s,
             "forward_kernel_ms": 1e3 * fwd_s, "forward_bytes_per_launch": B * fwd_alg,
             "algorithmic_bytes_per_solve_8d": fwd_alg + bwd_alg,
             # what the implementation moves by design: one {order, dt, T[6], Y[6][n]} record per stored point
             "traffic_model": B * (8 * (p + prob.n_remainder) + npts * rec + 8 * (p + n) + 140),
-            "binding": "fp64 VALU dependent-issue latency (see valu), not HBM",
+            "limiter": "neither contract roofline binds: the path is thousands of tiny sequential solves (SURVEY 8d); "
+                       "what limits it is fp64 VALU dependent-issue latency at one wavefront per SIMD -- see valu",
             "valu": {"kernel": "sa_k_backward", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
                      "algorithmic": B * f_bwd / bwd_s / 1e12, "frac_algorithmic": B * f_bwd / bwd_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      "issued": (pmc["valu_fp64_flops"] / bwd_s / 1e12) if pmc and "valu_fp64_flops" in pmc else None,
+                     "valu_busy": pmc.get("valu_busy") if pmc else None,
+                     "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
                      "note": "algorithmic = SURVEY 8(d) F_alg from the kernel's own counters; issued = fp64 "
                              "FMA/MUL/ADD lane-ops of the committed PMC pass (all 64 lanes counted) / this run's "
                              "kernel time"}},
@@ -449,7 +468,12 @@ def extra_configs(args):
                    "ms_per_step": r["ms_per_step"], "forward_kernel_ms": r["roofline"]["forward_kernel_ms"],
                    "backward_kernel_ms": r["roofline"]["kernel_ms"],
                    "failed_instances": r["config"]["failed_instances"],
-                   "hbm_frac": r["roofline"]["frac"], "valu_frac_algorithmic": r["roofline"]["valu"]["frac_algorithmic"],
+                   "hbm_frac": r["roofline"]["frac"], "hbm_frac_traffic": r["roofline"]["hbm_frac_traffic"],
+                   "forward_hbm_frac_traffic": r["roofline"]["forward_hbm_frac_traffic"],
+                   "traffic_over_algorithmic": r["roofline"]["traffic_over_algorithmic"],
+                   "arena_record": r["roofline"]["arena_record"],
+                   "valu_frac_algorithmic": r["roofline"]["valu"]["frac_algorithmic"],
+                   "valu_busy": r["roofline"]["valu"]["valu_busy"], "lane_utilisation": r["roofline"]["valu"]["lane_utilisation"],
                    "work": r["work"]}
             if not args.no_cpu_baseline:
                 row["cpu_baseline"] = cpu_baseline(name, prob, w, target_seconds=6.0)

@@ -180,6 +180,15 @@ def lane_group_size(n: int, p: int) -> int:
     return g
 
 
+def default_compact_trajectory(native_source: str, hermite: bool = False) -> bool:
+    """Arena record format AdjointSolver picks by default: compact {order, t, y[n]} records (table rebuilt by the
+    backward kernel) for the one-lane-per-instance kernel from three states on -- measured, profiles/
+    r03_compact_trajectory.txt: Robertson 73 -> 14 GB and +18 %, Lotka-Volterra (n = 2) -4 % -- table records otherwise."""
+    import re
+    n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
+    return (not hermite) and n >= 3 and kernel_variant(native_source, hermite=hermite)[0] == "bdf_kernels.hip"
+
+
 def _size_defines(native_source: str):
     """-D flags of the device build: problem sizes + SA_KERNEL_DEFINES (tuning / profiling builds,
     e.g. SA_KERNEL_DEFINES="-DSA_WAVE_PROFILE"; part of the cache key)."""

@@ -101,6 +101,10 @@ __shared__ double s_tab[KPW * W_TRECP];
 #define W_RQ_PRE (W_NQ > 0 ? (W_NQ + G - 1) / G : 1)
 #define W_NCOLD (5 * W_RS_PRE + 7 * W_RQ_PRE)
 __shared__ double s_cold[W_NCOLD * 64];
+/* ... and the group-uniform coefficient vectors the Newton pass does not read: l[0..5], tau[1..5], tq[1], tq[3], tq[5]
+   (lane 0 of the group writes, every lane reads them back) */
+#define W_NCTL 14
+__shared__ double s_ctl[KPW * W_NCTL];
 #endif
 /* Workgroup barrier as ONE inline instruction sequence.  In this build pipeline (clang -O0 -> always-inline -> -O3)
    HIP's __syncthreads() stays a real function call: every call site spilled the caller's live VGPRs to scratch and
@@ -125,7 +129,7 @@ static __device__ __forceinline__ int sa_grp()
 static_assert(G == 64 || SA_WAVES == 1, "worker wavefronts need 64 lanes per instance");
 __shared__ int s_cmd, s_nwaves, s_flag;
 __shared__ double s_targ;
-__shared__ int s_rc[SA_WAVES];
+__shared__ int s_rc[SA_WAVES];      /* (only s_nwaves is referenced by the single-wavefront builds: the rest costs them no LDS) */
 enum { CMD_EXIT = 0, CMD_RHS = 1, CMD_QUAD = 2, CMD_JAC = 3, CMD_GETRF = 4 };
 static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 #define SA_CHUNK_CALL(c, call) do { if (((c) % s_nwaves) == sa_wave_index()) bad |= call; } while (0)
@@ -1958,6 +1962,12 @@ DEV void cold_store(const Cw<BWD> &m)
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) c[(5 * RS + j * RQ + r) * 64] = m.znQ[j][r]; SEND } SEND
         SFOR(r, 0, RQ) c[(5 * RS + 6 * RQ + r) * 64] = m.zsaveQ[r]; SEND
     }
+    if (m.li == 0) {
+        double *u = s_ctl + (m.lane / G) * W_NCTL;
+        SFOR(i, 0, 6) u[i] = m.l[i]; SEND
+        SFOR(i, 1, 6) u[5 + i] = m.tau[i]; SEND
+        u[11] = m.tq[1]; u[12] = m.tq[3]; u[13] = m.tq[5];
+    }
 }
 template <bool BWD>
 DEV void cold_load(Cw<BWD> &m)
@@ -1968,6 +1978,12 @@ DEV void cold_load(Cw<BWD> &m)
     if (BWD) {
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) m.znQ[j][r] = c[(5 * RS + j * RQ + r) * 64]; SEND } SEND
         SFOR(r, 0, RQ) m.zsaveQ[r] = c[(5 * RS + 6 * RQ + r) * 64]; SEND
+    }
+    {
+        const double *u = s_ctl + (m.lane / G) * W_NCTL;
+        SFOR(i, 0, 6) m.l[i] = u[i]; SEND
+        SFOR(i, 1, 6) m.tau[i] = u[5 + i]; SEND
+        m.tq[1] = u[11]; m.tq[3] = u[12]; m.tq[5] = u[13];
     }
 }
 #define COLD_STORE(m) cold_store(m)
@@ -2318,8 +2334,10 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
         worker_loop<true>(a.pr + (int64_t)inst * a.rem_stride, ws_inst(a.ws, inst) + WS_OUT);
         return;
     }
-    int64_t st[SA_N_STATS];
-    SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
+    /* Little stays live across the step loops of an interval: the counters of finished intervals accumulate in the
+       instance's row of the stats array, the adjoint state / quadrature between two intervals wait in the output rows
+       (lamda_out / grad_out are ours until the kernel ends) -- ~50 registers the Newton pass does not have to spill. */
+    int64_t *strow = a.stats + (int64_t)inst * SA_N_STATS;
     int status = CV_SUCCESS;
     const int np = a.traj_np[inst];
     if (a.fwd_status[inst] != CV_SUCCESS || np < 2) status = CV_NO_FWD;
@@ -2338,20 +2356,29 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
     m.n_interp = 0; m.n_rebuild = 0;
 
-    double lam[RS], quad[RQ], quad_out[RQ];
-    SFOR(r, 0, RS) lam[r] = 0.0; SEND
-    SFOR(r, 0, RQ) { quad[r] = 0.0; quad_out[r] = 0.0; } SEND
+    double *lam_g = a.lamda_out + (int64_t)inst * NS, *quad_g = a.grad_out + (int64_t)inst * NQ;
+    {
+        double lam0[RS], quad0[RQ];
+        SFOR(r, 0, RS) { lam0[r] = 0.0; if (IDX(m, r) < NS) lam_g[IDX(m, r)] = 0.0; } SEND
+        SFOR(r, 0, RQ) { quad0[r] = 0.0; if (IDX(m, r) < NQ) quad_g[IDX(m, r)] = 0.0; } SEND
+        if (m.li == 0) { SFOR(i, 0, SA_N_STATS) strow[i] = 0; SEND }
+        cv_reinit(m, a.t0, lam0, quad0);
+    }
     const double *g = a.grads + (int64_t)inst * a.grads_stride;
     bool first_call = true;
     int total_retries = 0, attempts = 0;
-    cv_reinit(m, a.t0, lam, quad);
 
     for (int iv = 0; iv <= a.n_t; iv++) {
         const double t_upper = (iv == 0) ? a.t0 : a.tvals[a.n_t - iv];
         const double t_lower = (iv == a.n_t) ? a.tend : a.tvals[a.n_t - 1 - iv];
         if (t_lower < t_upper) {
             if (status == CV_SUCCESS) {
-                cv_reinit(m, t_upper, lam, quad);
+                {
+                    double lam[RS], quad[RQ];
+                    SFOR(r, 0, RS) lam[r] = (IDX(m, r) < NS) ? lam_g[IDX(m, r) < NS ? IDX(m, r) : 0] : 0.0; SEND
+                    SFOR(r, 0, RQ) quad[r] = (IDX(m, r) < NQ) ? quad_g[IDX(m, r) < NQ ? IDX(m, r) : 0] : 0.0; SEND
+                    cv_reinit(m, t_upper, lam, quad);
+                }
                 if (first_call) {
                     if ((t_upper - a.tinitial) < 0.0 || (m.tfinal - t_upper) < 0.0) status = CV_BAD_TB0;
                     first_call = false;
@@ -2394,7 +2421,10 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
                         double troundoff = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.h));
                         if (fabs(m.tn - m.tstop) <= troundoff) m.tn = m.tstop;
                         if ((m.tn - t_lower) * m.h >= 0.0) {
+                            double lam[RS], quad_out[RQ];
                             cv_get_dky0(m, t_lower, lam, quad_out);
+                            SFOR(r, 0, RS) { if (IDX(m, r) < NS) lam_g[IDX(m, r)] = lam[r]; } SEND
+                            SFOR(r, 0, RQ) { if (IDX(m, r) < NQ) quad_g[IDX(m, r)] = quad_out[r]; } SEND
                             idone = true;
                         } else {
                             troundoff = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.h));
@@ -2407,15 +2437,24 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
                     }
                 }
             }
-            if (status == CV_SUCCESS || m.nst > 0) accumulate_stats(m, st);
-            if (status == CV_SUCCESS) { SFOR(r, 0, RQ) quad[r] = quad_out[r]; SEND }
+            if ((status == CV_SUCCESS || m.nst > 0) && m.li == 0) {
+                int64_t st[SA_N_STATS];
+                SFOR(i, 0, SA_N_STATS) st[i] = strow[i]; SEND
+                accumulate_stats(m, st);
+                SFOR(i, 0, SA_N_STATS) strow[i] = st[i]; SEND
+            }
         }
         if (iv < a.n_t && status == CV_SUCCESS) {
             const double *gi = g + (int64_t)(a.n_t - 1 - iv) * NS;
-            SFOR(r, 0, RS) { if (IDX(m, r) < NS) lam[r] -= gi[IDX(m, r)]; } SEND
             const int64_t row = (int64_t)inst * a.n_t + (iv == 0 ? 0 : a.n_t - iv);
-            if (a.lamda_all) { SFOR(r, 0, RS) { if (IDX(m, r) < NS) a.lamda_all[row * NS + IDX(m, r)] = lam[r]; } SEND }
-            if (a.quad_all) { SFOR(r, 0, RQ) { if (IDX(m, r) < NQ) a.quad_all[row * NQ + IDX(m, r)] = quad[r]; } SEND }
+            SFOR(r, 0, RS) {
+                if (IDX(m, r) < NS) {
+                    const double v = lam_g[IDX(m, r)] - gi[IDX(m, r)];
+                    lam_g[IDX(m, r)] = v;
+                    if (a.lamda_all) a.lamda_all[row * NS + IDX(m, r)] = v;
+                }
+            } SEND
+            if (a.quad_all) { SFOR(r, 0, RQ) { if (IDX(m, r) < NQ) a.quad_all[row * NQ + IDX(m, r)] = quad_g[IDX(m, r)]; } SEND }
         }
     }
     release_workers(m);
@@ -2423,14 +2462,14 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
         if (a.lamda_all) for (int j = m.li; j < a.n_t * NS; j += G) a.lamda_all[(int64_t)inst * a.n_t * NS + j] = SA_NAN;
         if (a.quad_all) for (int j = m.li; j < a.n_t * NQ; j += G) a.quad_all[(int64_t)inst * a.n_t * NQ + j] = SA_NAN;
     }
-    SFOR(r, 0, RQ) {
-        if (IDX(m, r) < NQ) a.grad_out[(int64_t)inst * NQ + IDX(m, r)] = (status == CV_SUCCESS) ? quad_out[r] : SA_NAN;
-    } SEND
-    SFOR(r, 0, RS) {
-        if (IDX(m, r) < NS) a.lamda_out[(int64_t)inst * NS + IDX(m, r)] = (status == CV_SUCCESS) ? lam[r] : SA_NAN;
-    } SEND
+    if (status != CV_SUCCESS) {
+        SFOR(r, 0, RQ) { if (IDX(m, r) < NQ) quad_g[IDX(m, r)] = SA_NAN; } SEND
+        SFOR(r, 0, RS) { if (IDX(m, r) < NS) lam_g[IDX(m, r)] = SA_NAN; } SEND
+    }
     if (m.li == 0) {
         a.status[inst] = status;
+        int64_t st[SA_N_STATS];
+        SFOR(i, 0, SA_N_STATS) st[i] = strow[i]; SEND
         st[ST_NPTS] = np; st[ST_NINTERP] = m.n_interp; st[ST_NREBUILD] = m.n_rebuild;
         st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
 #ifdef SA_WAVE_PROFILE

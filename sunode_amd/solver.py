@@ -335,15 +335,16 @@ class AdjointSolver(_EngineMixin):
     re-integrated tile by tile inside ``solve_backward`` -- CVODES' check-point scheme, same
     results (csrc/sunode_amd.cpp, "trajectory arena").  ``compact_trajectory=True`` stores what CVODES itself
     keeps per step, {order, t, y[n]}, instead of the ready-made interpolation table (8 + 6n doubles) and lets the
-    backward kernel rebuild the table when its index moves: 5-6x less arena and forward write traffic for a slower
-    backward pass (one-lane-per-instance kernel, polynomial interpolation; ignored elsewhere); results identical.
+    backward kernel rebuild the table when its index moves: 5x less arena and HBM traffic (one-lane-per-instance
+    kernel, polynomial interpolation; ignored elsewhere); results identical.  Default (None): on from three states
+    (Robertson B = 262 144: 73 -> 14 GB, 2.37 -> 2.79 M solves/s; Lotka-Volterra, n = 2, is 4 % faster without).
     """
 
     def __init__(self, problem, *, abstol=1e-10, reltol=1e-10, checkpoint_n=500_000, interpolation="polynomial",
                  constraints=None, solver="BDF", adjoint_solver="BDF", backward_abstol=1e-10,
                  backward_reltol=1e-10, quad_abstol=1e-10, quad_reltol=1e-10, mxsteps: int = 500,
                  max_steps: Optional[int] = None, arena_gib: Optional[float] = None, device: int = 0,
-                 compact_trajectory: bool = False):
+                 compact_trajectory: Optional[bool] = None):
         if solver not in ("BDF", "ADAMS"):
             raise ValueError(f"Unknown solver {solver}.")
         if adjoint_solver not in ("BDF", "ADAMS"):
@@ -369,6 +370,8 @@ class AdjointSolver(_EngineMixin):
         self._device = device
         self._source = problem.native_source()
         # (only bdf_kernels.hip carries the compact-record option)
+        if compact_trajectory is None:        # measured (profiles/r03_compact_trajectory.txt): pays from three states on
+            compact_trajectory = _native.default_compact_trajectory(self._source, self._hermite)
         self._compact = bool(compact_trajectory) and not self._hermite and \
             _native.kernel_variant(self._source, hermite=self._hermite)[0] == "bdf_kernels.hip"
         _native.build_code_object(self._source, constraints=self._constraints is not None, hermite=self._hermite,

@@ -80,7 +80,8 @@ def test_solver_sens_argument_checks():
         Solver(prob, sens_mode="simultaneous", scaling_factors=np.ones(3))
     sol = Solver(prob, sens_mode="staggered")                        # compiles the sensitivity build
     assert _native.kernel_variant(prob.native_source(), sens=True)[0] == "bdf_kernels.hip"     # n p = 4: registers
-    assert _native.kernel_variant(make_problem("seir").native_source(), sens=True)[0] == "bdf_mem.hip"
+    assert _native.kernel_variant(make_problem("seir").native_source(), sens=True) == ("bdf_wave.hip", 4)    # lean lane groups
+    assert _native.kernel_variant(make_problem("network24").native_source(), sens=True)[0] == "bdf_mem.hip"   # beyond them
     assert os.path.exists(_native.code_object_path(prob.native_source(), sens=True))
     with pytest.raises(ValueError):
         sol.solve(0.0, np.linspace(0, 1, 3), np.ones(2), np.zeros((3, 2)))      # sens0 / sens_out missing

@@ -35,8 +35,10 @@ def main():
         g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
     f, b = sol._engine().last_kernel_ms()
     print("%s B=%d fwd %.2f ms bwd %.2f ms -> %.3g solves/s" % (name, B, f, b, B / ((f + b) * 1e-3)))
-    names = ["step tail + output checks + rejected attempts", "pre_step + adjust", "predict + cvSet", "interpolation",
-             "newton", "error test + quadrature", "complete + prepare", "interval restart"]
+    # marks: kernel loop top (0), bdf_core.h cv_attempt PH_ADD 1..5, end of an observation interval (7)
+    names = ["step tail + output checks + rejected attempts", "pre_step + adjust + predict + cvSet", "interpolation",
+             "newton", "error test + quadrature", "complete + prepare", "(unused)",
+             "waiting for the slowest lane of the wavefront at the end of an observation interval + restart"]
     p = statsb[:, 8:16].astype(float)
     tot = p.sum(axis=1).mean()
     print("bwd: steps %.0f, nfe %.0f, nsetups %.0f, nni %.0f, netf %.0f"
