@@ -105,6 +105,14 @@ __shared__ double s_cold[W_NCOLD * 64];
    (lane 0 of the group writes, every lane reads them back) */
 #define W_NCTL 14
 __shared__ double s_ctl[KPW * W_NCTL];
+#ifdef SA_SENS
+/* The forward-sensitivity builds keep these in registers: with them parked the 4-lane SEIR build (2 600 spill slots)
+   stops being bit-equal to the oracle -- and to its own 8-lane build -- although every path between store and load was
+   checked not to touch them; the same kernel gives different answers again when a read of m.l is added after the Newton
+   pass.  Unresolved (a code-generation problem at that register pressure is the suspicion); the validated
+   configuration is the one shipped and tests/test_forward_sens.py pins it in three mappings. */
+#define SA_NO_CTL_PARK 1
+#endif
 #endif
 /* Workgroup barrier as ONE inline instruction sequence.  In this build pipeline (clang -O0 -> always-inline -> -O3)
    HIP's __syncthreads() stays a real function call: every call site spilled the caller's live VGPRs to scratch and
@@ -1962,12 +1970,16 @@ DEV void cold_store(const Cw<BWD> &m)
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) c[(5 * RS + j * RQ + r) * 64] = m.znQ[j][r]; SEND } SEND
         SFOR(r, 0, RQ) c[(5 * RS + 6 * RQ + r) * 64] = m.zsaveQ[r]; SEND
     }
+#ifndef SA_NO_CTL_PARK
     if (m.li == 0) {
         double *u = s_ctl + (m.lane / G) * W_NCTL;
         SFOR(i, 0, 6) u[i] = m.l[i]; SEND
         SFOR(i, 1, 6) u[5 + i] = m.tau[i]; SEND
         u[11] = m.tq[1]; u[12] = m.tq[3]; u[13] = m.tq[5];
     }
+    lds_sync();         /* lane 0 wrote what the other lanes of the group read back: without the fence the compiler is free
+                           to move their loads above the (for them absent) store -- it did, at four lanes per instance */
+#endif
 }
 template <bool BWD>
 DEV void cold_load(Cw<BWD> &m)
@@ -1979,12 +1991,15 @@ DEV void cold_load(Cw<BWD> &m)
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) m.znQ[j][r] = c[(5 * RS + j * RQ + r) * 64]; SEND } SEND
         SFOR(r, 0, RQ) m.zsaveQ[r] = c[(5 * RS + 6 * RQ + r) * 64]; SEND
     }
+#ifndef SA_NO_CTL_PARK
     {
+        lds_sync();
         const double *u = s_ctl + (m.lane / G) * W_NCTL;
         SFOR(i, 0, 6) m.l[i] = u[i]; SEND
         SFOR(i, 1, 6) m.tau[i] = u[5 + i]; SEND
         m.tq[1] = u[11]; m.tq[3] = u[12]; m.tq[5] = u[13];
     }
+#endif
 }
 #define COLD_STORE(m) cold_store(m)
 #define COLD_LOAD(m) cold_load(m)
