@@ -615,7 +615,16 @@ DEV void store_point(double *r, int order, double t, const double (&y)[NSD])
 /* ------------------------------------------------------------------------------------ */
 /* forward kernel: Solver.solve (mode PLAIN) / AdjointSolver.solve_forward (mode ADJ_FWD)   */
 /* ------------------------------------------------------------------------------------ */
-extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
+/* Compact-record builds (three states and more: long trajectories, batches of several wavefronts per SIMD) cap the
+   FORWARD kernel at 256 registers = two wavefronts per SIMD: without the table build and the point history it is at
+   ~300, the cap costs 46 spill slots and buys latency hiding (Robertson B = 262 144: 25.3 -> 22.9 ms).  The backward
+   kernel needs its 450+ registers; -DSA_FWD_OCC1 switches the cap off. */
+#if SA_COMPACT && NS <= 3 && !defined(SA_FWD_OCC1)      /* (n = 5: 265 spill slots under the cap -- not worth it) */
+#define SA_FWD_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define SA_FWD_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(64) SA_FWD_ATTR sa_k_forward(sa_fwd_args a)
 {
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;

@@ -106,12 +106,20 @@ __shared__ double s_cold[W_NCOLD * 64];
 #define W_NCTL 14
 __shared__ double s_ctl[KPW * W_NCTL];
 #ifdef SA_SENS
-/* The forward-sensitivity builds keep these in registers: with them parked the 4-lane SEIR build (2 600 spill slots)
-   stops being bit-equal to the oracle -- and to its own 8-lane build -- although every path between store and load was
-   checked not to touch them; the same kernel gives different answers again when a read of m.l is added after the Newton
-   pass.  Unresolved (a code-generation problem at that register pressure is the suspicion); the validated
+/* The forward-sensitivity builds keep these in registers.  With l[] parked, the 4-lane SEIR build (2 600 spill slots,
+   4 KB of scratch per lane) stops being bit-equal to the oracle and to its own 8-lane build (which stays equal with
+   the parking on).  Measured: deterministic and independent of the batch; parking tau / tq alone is fine; a
+   lane-PRIVATE copy of l[] fails the same way, so it is not the cross-lane hand-over; merely READING m.l after the
+   Newton pass (comparing it with the parked copy: always equal) changes the result too; inlining sens_rhs_rows does
+   not help.  No path between store and load writes l[] (bdf_core.h: only cvSet and the order changes do, all before
+   the store).  Unresolved -- a code-generation problem at that register pressure is the suspicion; the validated
    configuration is the one shipped and tests/test_forward_sens.py pins it in three mappings. */
+#ifndef SA_SENS_CTL_PARK            /* (experiments) */
 #define SA_NO_CTL_PARK 1
+#endif
+#endif
+#ifdef SA_CTL_PRIVATE               /* experiment: every lane parks its own copy */
+__shared__ double s_ctlp[W_NCTL * 64];
 #endif
 #endif
 /* Workgroup barrier as ONE inline instruction sequence.  In this build pipeline (clang -O0 -> always-inline -> -O3)
@@ -1829,7 +1837,12 @@ static_assert(SA_LEAN, "the sensitivity corrector of bdf_wave.hip exists in the 
 #define SLOOP_END }
 
 /* out[is] = J ys[is] + dp[is] for the rows of this lane; J, dp: workspace copies the callbacks just wrote */
-static __device__ __attribute__((noinline)) int sens_rhs_rows(double *sws, const gdouble *js, const gdouble *dp, int li,
+#ifdef SA_SENS_RHS_INLINE
+#define SENS_RHS_ATTR __forceinline__
+#else
+#define SENS_RHS_ATTR __attribute__((noinline))
+#endif
+static __device__ SENS_RHS_ATTR int sens_rhs_rows(double *sws, const gdouble *js, const gdouble *dp, int li,
                                                               int v_in, int v_out)
 {
     double ys[NQ][RS], acc[NQ][RS];
@@ -1970,15 +1983,22 @@ DEV void cold_store(const Cw<BWD> &m)
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) c[(5 * RS + j * RQ + r) * 64] = m.znQ[j][r]; SEND } SEND
         SFOR(r, 0, RQ) c[(5 * RS + 6 * RQ + r) * 64] = m.zsaveQ[r]; SEND
     }
-#ifndef SA_NO_CTL_PARK
+#if defined(SA_CTL_PRIVATE) && !defined(SA_NO_CTL_PARK)
+    {
+        double *u = s_ctlp + m.lane;
+        SFOR(i, 0, 6) u[i * 64] = m.l[i]; SEND
+        SFOR(i, 1, 6) u[(5 + i) * 64] = m.tau[i]; SEND
+        u[11 * 64] = m.tq[1]; u[12 * 64] = m.tq[3]; u[13 * 64] = m.tq[5];
+    }
+#elif !defined(SA_NO_CTL_PARK)
     if (m.li == 0) {
         double *u = s_ctl + (m.lane / G) * W_NCTL;
         SFOR(i, 0, 6) u[i] = m.l[i]; SEND
         SFOR(i, 1, 6) u[5 + i] = m.tau[i]; SEND
         u[11] = m.tq[1]; u[12] = m.tq[3]; u[13] = m.tq[5];
     }
-    lds_sync();         /* lane 0 wrote what the other lanes of the group read back: without the fence the compiler is free
-                           to move their loads above the (for them absent) store -- it did, at four lanes per instance */
+    lds_sync();         /* lane 0 wrote what the other lanes of the group read back: the fence keeps the compiler from
+                           moving their loads above the (for them absent) store */
 #endif
 }
 template <bool BWD>
@@ -1991,7 +2011,14 @@ DEV void cold_load(Cw<BWD> &m)
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) m.znQ[j][r] = c[(5 * RS + j * RQ + r) * 64]; SEND } SEND
         SFOR(r, 0, RQ) m.zsaveQ[r] = c[(5 * RS + 6 * RQ + r) * 64]; SEND
     }
-#ifndef SA_NO_CTL_PARK
+#if defined(SA_CTL_PRIVATE) && !defined(SA_NO_CTL_PARK)
+    {
+        const double *u = s_ctlp + m.lane;
+        SFOR(i, 0, 6) m.l[i] = u[i * 64]; SEND
+        SFOR(i, 1, 6) m.tau[i] = u[(5 + i) * 64]; SEND
+        m.tq[1] = u[11 * 64]; m.tq[3] = u[12 * 64]; m.tq[5] = u[13 * 64];
+    }
+#elif !defined(SA_NO_CTL_PARK)
     {
         lds_sync();
         const double *u = s_ctl + (m.lane / G) * W_NCTL;
