@@ -182,11 +182,12 @@ def lane_group_size(n: int, p: int) -> int:
 
 def default_compact_trajectory(native_source: str, hermite: bool = False) -> bool:
     """Arena record format AdjointSolver picks by default: compact {order, t, y[n]} records (table rebuilt by the
-    backward kernel) for the one-lane-per-instance kernel from three states on -- measured, profiles/
-    r03_compact_trajectory.txt: Robertson 73 -> 14 GB and +18 %, Lotka-Volterra (n = 2) -4 % -- table records otherwise."""
+    backward kernel) from three states on, in the register-resident kernels -- measured, profiles/
+    r03_compact_trajectory.txt: Robertson 73 -> 14 GB and +18 %; SEIR / network24 / network100 the same throughput
+    (+-0.5 %) in a sixth of the arena; Lotka-Volterra (n = 2) -4 % -- table records there and in bdf_mem.hip."""
     import re
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
-    return (not hermite) and n >= 3 and kernel_variant(native_source, hermite=hermite)[0] == "bdf_kernels.hip"
+    return (not hermite) and n >= 3 and kernel_variant(native_source, hermite=hermite)[0] in ("bdf_kernels.hip", "bdf_wave.hip")
 
 
 def _size_defines(native_source: str):

@@ -424,7 +424,20 @@ static_assert(NS <= 8 * G && NQ <= 8 * G && NS >= 1 && NS <= 128, "at most eight
 constexpr int ilog2_c(int v) { int r = 0; while ((1 << r) < v) r++; return r; }
 #define LOG2G ilog2_c(G)
 #define GMASK (G == 64 ? ~0ull : ((1ull << G) - 1ull))
+/* arena records: the divided-difference table of the point {order, dt, T[6], Y[6][n]}, or with -DSA_COMPACT_TRAJ what
+   CVODES itself stores per step, {order, t, y[n]} (the table is then rebuilt in the backward pass when the index
+   moves: bdf_kernels.hip has the same switch) */
+#if defined(SA_COMPACT_TRAJ) && !defined(SA_HERMITE)
+#define SA_COMPACT 1
+#define TREC (NS + 2)
+#define TREC_T 1
+#define TREC_Y 2
+#else
+#define SA_COMPACT 0
 #define TREC (8 + 6 * NS)
+#define TREC_T 2
+#define TREC_Y 8
+#endif
 #define SA_NAN __builtin_bit_cast(double, (uint64_t)0x7ff8000000000000ULL)
 constexpr int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 /* workspace (doubles per instance): saved Jacobian + callback output vector */
@@ -657,7 +670,41 @@ DEV int ewtQ_set(const Cw<BWD> &m, const double (&qcur)[RQ], double (&w)[RQ])
 
 /* ---- stored trajectory: records as in bdf_kernels.hip ({order, dt, T[6], Y[6][n]} per point) ---- */
 template <bool BWD>
-DEV double point_time(const Cw<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + 2]; }
+DEV double point_time(const Cw<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + TREC_T]; }
+
+#if SA_COMPACT
+/* the table CVApolynomialGetY builds at index indx from the stored points indx, indx-1, .. indx-order (newest first):
+   hdr = {order, dt, T[0..5]}, Y[j] = divided differences scaled by dt^j -- the operation order of the oracle
+   (factor = dt / (T[j] - T[j-i]); Y[j] = factor * (Y[j] - Y[j-1])), all loads in flight together, unused columns zero */
+template <bool BWD>
+DEV void load_points(const Cw<BWD> &m, int indx, double (&hdr)[8], double (&Y)[QMAX + 1][RS])
+{
+    const gdouble *r = (const gdouble *)(m.traj + (int64_t)indx * m.trow);
+    const int order = (int)r[0];
+    double hT[QMAX + 1];
+    SFOR(j, 0, (QMAX) + 1) {
+        const gdouble *rj = (const gdouble *)(m.traj + (int64_t)(indx - j > 0 ? indx - j : 0) * m.trow);
+        hT[j] = rj[TREC_T];
+        SFOR(s, 0, RS) {
+            const double v = rj[TREC_Y + (IDX(m, s) < NS ? IDX(m, s) : 0)];
+            Y[j][s] = (j <= order) ? v : 0.0;
+        } SEND
+    } SEND
+    const double dt = fabs(hT[0] - hT[1]);
+    SFOR(i, 1, (QMAX) + 1) {
+        SFOR_DOWN(j, QMAX, 1) {
+            if constexpr (j >= i) {
+                if (j <= order) {
+                    const double factor = dt / (hT[j] - hT[j - i]);
+                    SFOR(s, 0, RS) Y[j][s] = factor * (Y[j][s] - Y[j - 1][s]); SEND
+                }
+            }
+        } SEND
+    } SEND
+    hdr[0] = (double)order; hdr[1] = dt;
+    SFOR(j, 0, (QMAX) + 1) hdr[2 + j] = hT[j]; SEND
+}
+#endif
 
 template <bool BWD>
 DEV int interp_y(Cw<BWD> &m, double t)
@@ -710,7 +757,7 @@ DEV int interp_y(Cw<BWD> &m, double t)
     m.have_last = 1;
     m.last_t = t;
     if (indx == 0) {
-        SFOR(r, 0, RS) m.ytmp[r] = (IDX(m, r) < NS) ? m.traj[8 + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND
+        SFOR(r, 0, RS) m.ytmp[r] = (IDX(m, r) < NS) ? m.traj[TREC_Y + (IDX(m, r) < NS ? IDX(m, r) : 0)] : 0.0; SEND
         return CV_SUCCESS;
     }
 #ifdef SA_HERMITE
@@ -755,12 +802,23 @@ DEV int interp_y(Cw<BWD> &m, double t)
            (Measured and not kept, SEIR: touching the lines of the next-left record ahead of time -- at the move itself
            every function call then waits for the touch, interp 7.8 -> 10.5 ms; after the attempt's last callback,
            8 k call-free cycles ahead of the next move: 9.0 ms, the whole backward kernel 63.1 -> 65.3 ms.) */
+#if SA_COMPACT
+        {   /* rebuild from the order + 1 points ending at indx: every lane its own components, the times group-uniform */
+            double hdr[8], Y[QMAX + 1][RS];
+            load_points(m, indx, hdr, Y);
+            lds_sync();
+            if (m.li == 0) { SFOR(f, 0, 8) tab[f] = hdr[f]; SEND }
+            SFOR(j, 0, (QMAX) + 1) { SFOR(s2, 0, RS) { if (IDX(m, s2) < NS) tab[8 + j * NS + IDX(m, s2)] = Y[j][s2]; } SEND } SEND
+            lds_sync();
+        }
+#else
         constexpr int NCP = (W_TREC + G - 1) / G;
         double cp[NCP];
         SFOR(u, 0, NCP) { const int f = u * G + m.li; cp[u] = r[f < W_TREC ? f : 0]; } SEND
         lds_sync();
         SFOR(u, 0, NCP) { const int f = u * G + m.li; if (f < W_TREC) tab[f] = cp[u]; } SEND
         lds_sync();
+#endif
         if (tab[0] > (double)indx) return CV_GETY_BADT;
         if (indx == m.ilast) m.tlo2 = tab[4];
     }
@@ -784,6 +842,9 @@ DEV int interp_y(Cw<BWD> &m, double t)
     if (newpoint) {
         m.n_rebuild++;
         m.cur_idx = indx;
+#if SA_COMPACT
+        load_points(m, indx, m.tab_hdr, m.tabY);
+#else
         const double *r = m.traj + (int64_t)indx * m.trow;
         SFOR(f, 0, 8) m.tab_hdr[f] = r[f]; SEND
         SFOR(j, 0, (QMAX) + 1) {
@@ -792,6 +853,7 @@ DEV int interp_y(Cw<BWD> &m, double t)
                 m.tabY[j][s] = r[8 + j * NS + c];
             } SEND
         } SEND
+#endif
         if (m.tab_hdr[0] > (double)indx) return CV_GETY_BADT;
         if (indx == m.ilast) m.tlo2 = m.tab_hdr[4];
     }
@@ -2088,6 +2150,13 @@ DEV void store_hermite(double *rec, int li, double t, const double (&y)[RS], con
 }
 #endif
 
+#if SA_COMPACT
+DEV void store_point(double *rec, int lane, int order, double t, const double (&y)[RS])
+{
+    if (lane == 0) { rec[0] = (double)order; rec[TREC_T] = t; }
+    SFOR(r, 0, RS) { const int i = r * G + lane; if (i < NS) rec[TREC_Y + i] = y[r]; } SEND
+}
+#endif
 /* forward: trajectory record of the newest point (see bdf_kernels.hip::store_table) */
 DEV void store_table(double *rec, int lane, int order, double dt, const double (&hT)[QMAX + 1],
                      const double (&hY)[QMAX + 1][RS])
@@ -2168,6 +2237,8 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
             SFOR(r, 0, RS) hY[0][r] = m.zn[0][r]; SEND
 #ifdef SA_HERMITE
             if (wr) store_hermite(trec, m.li, m.tn, m.zn[0], m.f0);
+#elif SA_COMPACT
+            if (wr) store_point(trec, m.li, 0, m.tn, m.zn[0]);
 #else
             if (wr) store_table(trec, m.li, 0, 1.0, hT, hY);
 #endif
@@ -2205,6 +2276,8 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
                             SFOR(s, 0, RS) ydp[s] = (1.0 / m.h) * m.zn[1][s]; SEND
                             if (wr && np < a.traj_cap) store_hermite(trec + (int64_t)np * trow, m.li, m.tn, m.zn[0], ydp);
                         }
+#elif SA_COMPACT
+                        if (wr && np < a.traj_cap) store_point(trec + (int64_t)np * trow, m.li, m.qu, m.tn, m.zn[0]);
 #else
                         if (wr && np < a.traj_cap) store_table(trec + (int64_t)np * trow, m.li, m.qu, fabs(hT[0] - hT[1]), hT, hY);
 #endif
@@ -2393,7 +2466,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     m.traj = a.traj + (int64_t)inst * a.traj_istride * TREC;
     m.trow = a.traj_stride * TREC;
     m.np = np;
-    m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + 2] : a.tinitial;
+    m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + TREC_T] : a.tinitial;
     m.cur_idx = 0; m.tlo2 = 0.0; m.tlo = m.thi = 0.0;
     m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
     m.n_interp = 0; m.n_rebuild = 0;
@@ -2580,4 +2653,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 }
 
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance, workspace doubles per instance} */
+#if SA_COMPACT
+extern "C" __device__ __attribute__((used)) const int32_t sa_traj_rec = TREC;
+#endif
 extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, SA_DEVICE_ABI_VERSION, G * SA_WAVES, WS_DOUBLES};

@@ -369,11 +369,11 @@ class AdjointSolver(_EngineMixin):
         self._arena_bytes = int(arena_gib * 2**30) if arena_gib else 0
         self._device = device
         self._source = problem.native_source()
-        # (only bdf_kernels.hip carries the compact-record option)
+        # (bdf_kernels.hip and bdf_wave.hip carry the compact-record option)
         if compact_trajectory is None:        # measured (profiles/r03_compact_trajectory.txt): pays from three states on
             compact_trajectory = _native.default_compact_trajectory(self._source, self._hermite)
         self._compact = bool(compact_trajectory) and not self._hermite and \
-            _native.kernel_variant(self._source, hermite=self._hermite)[0] == "bdf_kernels.hip"
+            _native.kernel_variant(self._source, hermite=self._hermite)[0] in ("bdf_kernels.hip", "bdf_wave.hip")
         _native.build_code_object(self._source, constraints=self._constraints is not None, hermite=self._hermite,
                                   compact=self._compact)
         self._native = None

@@ -937,16 +937,23 @@ def test_device_structured_callbacks_match_reference(name, variant, golden_dir, 
         assert got["codes"][i].tolist() == pt["codes"]
 
 
-@pytest.mark.parametrize("name", ["lv", "robertson"])
+@pytest.mark.parametrize("name", ["lv", "robertson", "seir", "network24"])
 def test_compact_trajectory_equals_table_records(name):
     """AdjointSolver(compact_trajectory=True): {order, t, y[n]} per stored step, divided-difference table rebuilt in the
     backward kernel on every index move -- everything (states, gradients, all counters incl. the number of rebuilds)
-    bit-identical to the default table records, in a fifth of the arena."""
+    bit-identical to the default table records, in a fifth of the arena.  lv / robertson: one lane per instance;
+    seir: lean lane groups (table in LDS); network24: lane groups with the table in registers."""
     from sunode_amd.solver import AdjointSolver
     prob = make_problem(name)
     B = 300
     if name == "lv":
         d = lv_batch(B); ps, pr = d["params"][:, :2], d["params"][:, 2:]; rt, at = 1e-8, 1e-8
+    elif name == "seir":
+        B = 70
+        d = seir_batch(B); ps, pr = d["ps"], d["pr"]; rt, at = 1e-8, 1e-8
+    elif name == "network24":
+        B = 20
+        d = network_batch(B, 24); ps, pr = d["ps"], d["pr"]; rt, at = d["rtol"], d["atol"]
     else:
         d = robertson_batch(B); ps, pr = d["params"], np.zeros(0); rt, at = 1e-8, 1e-10
     tv = d["tvals"]
