@@ -18,6 +18,7 @@
  *   interp_y          forward state at t from the stored trajectory (backward problem)
  *   SV / SLOOP_BEGIN / SLOOP_END      sensitivity vectors (registers, or streamed from the workspace)
  *   COLD_STORE / COLD_LOAD, PH_T0 / PH_ADD           optional hooks (LDS parking of cold state, phase timers)
+ *   SA_POLY_CM(BWD)   whether the pow polynomials read their coefficients from constant memory (sa_common.h)
  * A controller change is an edit of THIS file; bit-equality with the oracle (tests -m gpu) covers both mappings.
  * (bdf_mem.hip, the memory-resident fall-back for n > 128, keeps its own loop-based restatement.)
  *
@@ -600,7 +601,7 @@ DEV int cv_error_test_failed(SA_STATE<BWD> &m, double saved_t, double dsm, int &
     if (nef == MXNEF) return CV_ERR_FAILURE;
     m.etamax = 1.0;
     if (nef <= MXNEF1) {
-        m.eta = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
+        m.eta = 1.0 / (rpower_r<SA_POLY_CM(BWD)>(BIAS2 * dsm, inv_int(m.L)) + ADDON);
         m.eta = fmax(ETAMIN, m.eta);
         if (nef >= SMALL_NEF) m.eta = fmin(m.eta, ETAMXF);
         cv_rescale(m);
@@ -737,9 +738,9 @@ DEV void cv_prepare_next_step(SA_STATE<BWD> &m, double dsm)
     }
 #endif
     dup = dup * m.tq[3];
-    const double p0 = rpower_nb(BIAS2 * dsm, inv_int(m.L));
-    const double p1 = rpower_nb(BIAS1 * ddn, inv_int(m.q));
-    const double p2 = rpower_nb(BIAS3 * dup, inv_int(m.L + 1));
+    const double p0 = rpower_nb<SA_POLY_CM(BWD)>(BIAS2 * dsm, inv_int(m.L));
+    const double p1 = rpower_nb<SA_POLY_CM(BWD)>(BIAS1 * ddn, inv_int(m.q));
+    const double p2 = rpower_nb<SA_POLY_CM(BWD)>(BIAS3 * dup, inv_int(m.L + 1));
     const double etaq = 1.0 / (p0 + ADDON), e1 = 1.0 / (p1 + ADDON), e2 = 1.0 / (p2 + ADDON);
     const double etaqm1 = (m.q > 1) ? e1 : 0.0;
     const double etaqp1 = ((m.q != QMAX) && (m.saved_tq5 != 0.0)) ? e2 : 0.0;

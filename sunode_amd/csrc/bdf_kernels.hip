@@ -51,6 +51,18 @@
 /* ------------------------------------------------------------------------------------ */
 /* per-lane integrator state                                                              */
 /* ------------------------------------------------------------------------------------ */
+/* The saved Jacobian (cvLsSetup reuses it while jbad is false) is read and written only at matrix set-ups: from three
+   states on it waits in LDS, [entry][lane] (conflict-free), instead of in n*n register pairs. */
+#ifndef SA_SJ_LDS
+#define SA_SJ_LDS (NS >= 3)
+#endif
+#if SA_SJ_LDS
+__shared__ double s_savedJ[NS * NS * 64];
+#define SAVEDJ(m, i) s_savedJ[(i) * 64 + threadIdx.x]
+#else
+#define SAVEDJ(m, i) (m).savedJ[i]
+#endif
+
 template <bool BWD>
 struct Cv {
     /* Invariant: columns j > q of zn / znQ are exactly zero (CVODES leaves stale data there and
@@ -76,7 +88,10 @@ struct Cv {
     double etaq, etaqm1, etaqp1;
     double tstop;                     /* backward: forward t0 (CVodeSetStopTime in CVodeB) */
     int nst, nfe, nje, nsetups, nni, ncfn, netf, nfQe, netfQ, nstlp, nstlj;
-    double A[NSD * NSD], savedJ[NSD * NSD];
+    double A[NSD * NSD];
+#if !SA_SJ_LDS
+    double savedJ[NSD * NSD];
+#endif
     int piv[NSD];
     double inv_piv[NSD];
     int jcur, nls_jcur;
@@ -518,13 +533,13 @@ DEV int cv_lsetup(Cv<BWD> &m, int convfail)
     int jret = 0;
     if (!jbad) {
         m.jcur = 0;
-        SFOR(i, 0, NS * NS) m.A[i] = m.savedJ[i]; SEND
+        SFOR(i, 0, NS * NS) m.A[i] = SAVEDJ(m, i); SEND
     } else {
         m.nje++;
         m.nstlj = m.nst;
         m.jcur = 1;
         jret = cv_jac(m, m.tn, m.y, m.A);
-        if (jret == 0) { SFOR(i, 0, NS * NS) m.savedJ[i] = m.A[i]; SEND }
+        if (jret == 0) { SFOR(i, 0, NS * NS) SAVEDJ(m, i) = m.A[i]; SEND }
     }
     if (jret < 0) return -1;
     if (jret > 0) return 1;
@@ -541,11 +556,24 @@ DEV int cv_lsetup(Cv<BWD> &m, int convfail)
 
 
 /* ---- the mapping bdf_core.h needs: one lane = one instance, a vector = NS doubles in this lane's registers ---- */
+#if SA_COMPACT && NS <= 3 && !defined(SA_FWD_OCC1)      /* (n = 5: 265 spill slots under the cap -- not worth it) */
+#define SA_FWD_CAP 1                 /* the forward kernel runs at two wavefronts per SIMD (see sa_k_forward) */
+#else
+#define SA_FWD_CAP 0
+#endif
+#ifdef SA_POLY_CM_FORCE              /* (A/B switch: -DSA_POLY_CM_FORCE=0|1) */
+#define SA_POLY_CM(BWD) (SA_POLY_CM_FORCE)
+#else
+#define SA_POLY_CM(BWD) (!(BWD) && SA_FWD_CAP)       /* pow coefficients from constant memory (sa_common.h) */
+#endif
 #define SA_STATE Cv
 #define RS NSD
 #define RQ NQD
 #define IDX(m, r) (r)
 #define wave_max(lane, x) (x)
+/* (LDS parking of the cold Nordsieck columns / coefficient vectors around the Newton pass, as in the lean lane groups,
+   was measured here for the capped forward kernel: not needed once the pow coefficients left the registers --
+   Robertson forward 20.9 ms with it, 20.1 ms without) */
 #define COLD_STORE(m)
 #define COLD_LOAD(m)
 #define PH_T0
@@ -603,24 +631,35 @@ DEV void store_table(double *r, int order, double dt, const double (&hT)[QMAX + 
     SFOR(j, 0, (QMAX) + 1) { SFOR(i, 0, NS) r[8 + j * NS + i] = Y[j][i]; SEND } SEND
 }
 
+/* (measured, Robertson B = 262 144: streaming / non-temporal stores for the arena records make the forward kernel
+   50 % SLOWER, 20.4 -> 31.1 ms -- plain stores; -DSA_ARENA_NT switches them on) */
+#ifdef SA_ARENA_NT
+#define ARENA_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define ARENA_ST(p, v) (*(p) = (v))
+#endif
 #if SA_COMPACT
 DEV void store_point(double *r, int order, double t, const double (&y)[NSD])
 {
-    r[0] = (double)order;
-    r[TREC_T] = t;
-    SFOR(i, 0, NS) r[TREC_Y + i] = y[i]; SEND
+    ARENA_ST(&r[0], (double)order);
+    ARENA_ST(&r[TREC_T], t);
+    SFOR(i, 0, NS) ARENA_ST(&r[TREC_Y + i], y[i]); SEND
 }
 #endif
 
 /* ------------------------------------------------------------------------------------ */
 /* forward kernel: Solver.solve (mode PLAIN) / AdjointSolver.solve_forward (mode ADJ_FWD)   */
 /* ------------------------------------------------------------------------------------ */
-/* Compact-record builds (three states and more: long trajectories, batches of several wavefronts per SIMD) cap the
-   FORWARD kernel at 256 registers = two wavefronts per SIMD: without the table build and the point history it is at
-   ~300, the cap costs 46 spill slots and buys latency hiding (Robertson B = 262 144: 25.3 -> 22.9 ms).  The backward
-   kernel needs its 450+ registers; -DSA_FWD_OCC1 switches the cap off. */
-#if SA_COMPACT && NS <= 3 && !defined(SA_FWD_OCC1)      /* (n = 5: 265 spill slots under the cap -- not worth it) */
-#define SA_FWD_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+/* Compact-record builds of three-state systems (long trajectories, batches of several wavefronts per SIMD) cap the
+   FORWARD kernel at 256 registers = two wavefronts per SIMD (SA_FWD_CAP, defined with the mapping above): without the
+   table build and the point history, with the saved Jacobian in LDS and the pow coefficients in constant memory it
+   needs 254 and no scratch; the second wavefront buys latency hiding (Robertson
+   B = 262 144: 25.3 -> 20.4 ms).  The backward kernel needs its 410+ registers; -DSA_FWD_OCC1 switches the cap off. */
+#if SA_FWD_CAP
+#ifndef SA_FWD_WAVES
+#define SA_FWD_WAVES 2
+#endif
+#define SA_FWD_ATTR __attribute__((amdgpu_waves_per_eu(SA_FWD_WAVES, SA_FWD_WAVES)))
 #else
 #define SA_FWD_ATTR
 #endif
@@ -720,8 +759,8 @@ extern "C" __global__ void __launch_bounds__(64) SA_FWD_ATTR sa_k_forward(sa_fwd
                 }
                 while (!done && k < a.n_t) {
                     double tout = a.tvals[k];
-                    if (tout == a.t0) {
-                        SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = y0[i]; SEND
+                    if (tout == a.t0) {       /* (re-read: y0 is not worth NS register pairs across the whole loop) */
+                        SFOR(i, 0, NS) yo[(int64_t)k * NS + i] = a.y0[(int64_t)inst * NS + i]; SEND
                         k++;
                     } else if ((m.tn - tout) * m.h >= 0.0) {
                         double dky[NSD], dq[NQD];

@@ -2097,6 +2097,11 @@ DEV void cold_load(Cw<BWD> &m)
 #define COLD_LOAD(m)
 #endif
 
+#ifdef SA_POLY_CM_FORCE              /* (A/B switch: -DSA_POLY_CM_FORCE=0|1) */
+#define SA_POLY_CM(BWD) (SA_POLY_CM_FORCE)
+#else
+#define SA_POLY_CM(BWD) SA_LEAN             /* pow coefficients from constant memory (sa_common.h): measured on SEIR */
+#endif
 #define SA_STATE Cw
 #include "bdf_core.h"
 

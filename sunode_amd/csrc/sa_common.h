@@ -141,6 +141,23 @@ DEV double fdiv(double a, double b)
 /* ------------------------------------------------------------------------------------ */
 /* deterministic pow (pure +,-,*,/): same operation sequence as the CPU restatement       */
 /* ------------------------------------------------------------------------------------ */
+/* Horner coefficients of det_log / det_exp.  As literals the compiler hoists all 26 out of the step loop into vector
+   register pairs (~50 registers for the whole kernel); CM = true reads them from constant memory instead (uniform
+   scalar loads feed the FMAs from scalar registers).  Measured (profiles/r03_compact_trajectory.txt, "coefficients"):
+   pays where registers are the limit -- the forward kernel capped at 256 registers (Robertson: 46 spill slots and
+   24 GB of scratch traffic per launch -> none, 22.7 -> 20.4 ms) and the lean lane groups (SEIR backward 360 -> 290
+   spill slots, 58.5 -> 54.2 ms) -- and costs 1-2 % in the one-wavefront-per-SIMD backward kernels of the register
+   mapping, which keep the literals.  Same values either way (the quotients are folded at compile time). */
+#define SA_POLY_LOG {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, \
+                     1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0, 1.0}
+#define SA_POLY_EXP {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, \
+                     1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0}
+__constant__ double sa_poly_log[12] = SA_POLY_LOG;
+__constant__ double sa_poly_exp[14] = SA_POLY_EXP;
+template <bool CM, int I> DEV double poly_log_c() { constexpr double c[12] = SA_POLY_LOG; if constexpr (CM) return sa_poly_log[I]; else return c[I]; }
+template <bool CM, int I> DEV double poly_exp_c() { constexpr double c[14] = SA_POLY_EXP; if constexpr (CM) return sa_poly_exp[I]; else return c[I]; }
+
+template <bool CM = false>
 DEV double det_log(double x)
 {
     uint64_t u = __builtin_bit_cast(uint64_t, x);
@@ -156,57 +173,38 @@ DEV double det_log(double x)
     double f = m - 1.0;
     double s = fdiv(f, 2.0 + f);         /* |f| < 0.42: far from every exponent limit */
     double z = s * s;
-    double p = 1.0 / 23.0;
-    p = FMA(p, z, 1.0 / 21.0);
-    p = FMA(p, z, 1.0 / 19.0);
-    p = FMA(p, z, 1.0 / 17.0);
-    p = FMA(p, z, 1.0 / 15.0);
-    p = FMA(p, z, 1.0 / 13.0);
-    p = FMA(p, z, 1.0 / 11.0);
-    p = FMA(p, z, 1.0 / 9.0);
-    p = FMA(p, z, 1.0 / 7.0);
-    p = FMA(p, z, 1.0 / 5.0);
-    p = FMA(p, z, 1.0 / 3.0);
-    p = FMA(p, z, 1.0);
+    double p = poly_log_c<CM, 0>();
+    SFOR(i, 1, 12) p = FMA(p, z, (poly_log_c<CM, i>())); SEND
     return FMA((double)e, 0.6931471805599453, 2.0 * s * p);
 }
 
+template <bool CM = false>
 DEV double det_exp(double w)
 {
     if (w > 700.0) w = 700.0;
     if (w < -700.0) w = -700.0;
     double kf = floor(FMA(w, 1.4426950408889634, 0.5));
     double r = FMA(-kf, 1.90821492927058770002e-10, FMA(-kf, 0.693147180369123816490, w));
-    double p = 1.0 / 6227020800.0;
-    p = FMA(p, r, 1.0 / 479001600.0);
-    p = FMA(p, r, 1.0 / 39916800.0);
-    p = FMA(p, r, 1.0 / 3628800.0);
-    p = FMA(p, r, 1.0 / 362880.0);
-    p = FMA(p, r, 1.0 / 40320.0);
-    p = FMA(p, r, 1.0 / 5040.0);
-    p = FMA(p, r, 1.0 / 720.0);
-    p = FMA(p, r, 1.0 / 120.0);
-    p = FMA(p, r, 1.0 / 24.0);
-    p = FMA(p, r, 1.0 / 6.0);
-    p = FMA(p, r, 0.5);
-    p = FMA(p, r, 1.0);
-    p = FMA(p, r, 1.0);
+    double p = poly_exp_c<CM, 0>();
+    SFOR(i, 1, 14) p = FMA(p, r, (poly_exp_c<CM, i>())); SEND
     uint64_t bits = (uint64_t)((int64_t)kf + 1023) << 52;
     return p * __builtin_bit_cast(double, bits);
 }
 
+template <bool CM = false>
 DEV double rpower_r(double base, double expo)
 {
     if (base <= 0.0) return 0.0;
-    return det_exp(expo * det_log(base));
+    return det_exp<CM>(expo * det_log<CM>(base));
 }
 
 /* the same value without the early return (select instead of branch): independent powers written one after the
    other stay in one basic block and the scheduler interleaves their dependent chains */
+template <bool CM = false>
 DEV double rpower_nb(double base, double expo)
 {
     const bool nonpos = (base <= 0.0);
-    const double r = det_exp(expo * det_log(nonpos ? 1.0 : base));
+    const double r = det_exp<CM>(expo * det_log<CM>(nonpos ? 1.0 : base));
     return nonpos ? 0.0 : r;
 }
 

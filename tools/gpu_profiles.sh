@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 out="/tmp/prof_${tag}"
 mkdir -p "$out" "$root/gpurun_out"
 summ() { db=$(ls -t "$1"/*/*_results.db 2>/dev/null | head -1); [ -z "$db" ] && db=$(ls -t "$1"/*results.db | head -1); python tools/rocpd_summary.py "$db" "${@:2}"; }
-for w in lv robertson seir network100; do
+for w in ${WORKLOADS:-lv robertson seir network100}; do
     steps=5; [ "$w" != lv ] && steps=3
     cmd="python bench.py --workload $w --steps $steps --warmup 2 --no-cpu-baseline --no-extra-configs"
     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$out/kt_$w" -o $w -- bash -c "cd $root && $cmd" > "$out/kt_$w.log" 2>&1)

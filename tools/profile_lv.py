@@ -28,8 +28,10 @@ def main():
         d = robertson_batch(B); ps, pr = d["params"], np.zeros(0); at = 1e-10
     tv = d["tvals"]
     grads = np.ones((len(tv), prob.n_states))
-    sol = AdjointSolver(prob, abstol=at, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8,
-                        quad_abstol=1e-8, quad_reltol=1e-8)
+    if name != "lv":       # (Robertson conserves y1 + y2 + y3: a cotangent of ones has a zero adjoint)
+        grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(prob.n_states)[None, :])
+    sol = AdjointSolver(prob, abstol=at, reltol=1e-8, backward_abstol=at, backward_reltol=1e-8,
+                        quad_abstol=at, quad_reltol=1e-8)
     for rep in range(2):
         y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
         g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
