@@ -89,8 +89,10 @@ def build_host_library(force: bool = False) -> str:
 
 
 #: measured on MI355X (LV, B=65536): the iterative ILP scheduler is ~5 % faster than the default
-#: for this latency-bound single-wave-per-SIMD kernel (profiles/ notes)
-DEFAULT_CODEGEN_FLAGS = "-mllvm -amdgpu-sched-strategy=iterative-ilp"
+#: for this latency-bound single-wave-per-SIMD kernel (profiles/ notes).  Machine LICM off: the hoisted literal
+#: constants otherwise occupy vector registers for the whole kernel (LV backward 370 -> 318 registers, no AGPR
+#: shuffling; LV -0.7 %, Robertson backward -1.2 % kernel time, profiles/r03_compact_trajectory.txt block 4)
+DEFAULT_CODEGEN_FLAGS = "-mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -disable-machine-licm"
 
 
 def _extra_codegen_flags():

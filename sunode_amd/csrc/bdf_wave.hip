@@ -2100,7 +2100,7 @@ DEV void cold_load(Cw<BWD> &m)
 #ifdef SA_POLY_CM_FORCE              /* (A/B switch: -DSA_POLY_CM_FORCE=0|1) */
 #define SA_POLY_CM(BWD) (SA_POLY_CM_FORCE)
 #else
-#define SA_POLY_CM(BWD) SA_LEAN             /* pow coefficients from constant memory (sa_common.h): measured on SEIR */
+#define SA_POLY_CM(BWD) 1                   /* pow coefficients from constant memory (sa_common.h): SEIR +7 %, network100 +1 %, network24 +-0 */
 #endif
 #define SA_STATE Cw
 #include "bdf_core.h"
