@@ -92,7 +92,14 @@ def build_host_library(force: bool = False) -> str:
 #: for this latency-bound single-wave-per-SIMD kernel (profiles/ notes).  Machine LICM off: the hoisted literal
 #: constants otherwise occupy vector registers for the whole kernel (LV backward 370 -> 318 registers, no AGPR
 #: shuffling; LV -0.7 %, Robertson backward -1.2 % kernel time, profiles/r03_compact_trajectory.txt block 4)
-DEFAULT_CODEGEN_FLAGS = "-mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -disable-machine-licm"
+#: -split-spill-mode=size (the register allocator splits live ranges for fewer spill instructions): LV backward -0.9 %,
+#: SEIR backward -3.4 % (290 -> 221 spill slots), Robertson / network24 / network100 unchanged, SEIR forward
+#: sensitivities +2 % -- on for the adjoint builds (profiles/r03_compact_trajectory.txt block 5)
+DEFAULT_CODEGEN_FLAGS = "-mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -disable-machine-licm -mllvm -split-spill-mode=size"
+#: the lane-group kernels: plain -O3 scheduling (the ILP strategies are slower there and take several times longer to
+#: build at n = 100), the spill-splitting mode as above except in the forward-sensitivity builds; machine LICM and
+#: the splitting of critical edges for sinking off (SEIR backward 52.4 -> 51.7 ms, 221 -> 208 spill slots)
+WAVE_CODEGEN_FLAGS = "-mllvm -split-spill-mode=size -mllvm -disable-machine-licm -mllvm -machine-sink-split=0"
 
 
 def _extra_codegen_flags():
@@ -207,7 +214,8 @@ def code_object_path(native_source: str, sens: bool = False, constraints: bool =
     kern = os.path.join(_CSRC, fname)
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h", "bdf_core.h")]
     deps = [d for d in deps if os.path.exists(d)]
-    extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode() + b"G%d" % group + fname.encode()
+    extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode() + WAVE_CODEGEN_FLAGS.encode()
+             + b"G%d" % group + fname.encode()
              + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode()
              + (b"SENS" if sens else b"") + (b"CONSTR" if constraints else b"") + (b"HERMITE" if hermite else b"")
              + (b"COMPACT" if compact else b""))
@@ -261,7 +269,7 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
         # n = 100): default scheduler there, the ILP strategies take several times longer
         extra = _extra_codegen_flags()
         if fname in ("bdf_mem.hip", "bdf_wave.hip") and "SA_CLANG_FLAGS" not in os.environ:
-            extra = []
+            extra = WAVE_CODEGEN_FLAGS.split() if (fname == "bdf_wave.hip" and not sens) else []
         try:
             _run(base + extra + ["-c", "-o", obj])
         except NativeBuildError:
