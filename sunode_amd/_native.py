@@ -88,18 +88,20 @@ def build_host_library(force: bool = False) -> str:
     return lib
 
 
-#: measured on MI355X (LV, B=65536): the iterative ILP scheduler is ~5 % faster than the default
-#: for this latency-bound single-wave-per-SIMD kernel (profiles/ notes).  Machine LICM off: the hoisted literal
+#: Flags of the final clang -O3 stage, all measured on MI355X (same-call A/B blocks in
+#: profiles/r03_compact_trajectory.txt).  One lane per instance (bdf_kernels.hip): the iterative ILP scheduler is ~5 %
+#: faster than the default for this latency-bound single-wave-per-SIMD kernel; machine LICM off -- the hoisted literal
 #: constants otherwise occupy vector registers for the whole kernel (LV backward 370 -> 318 registers, no AGPR
-#: shuffling; LV -0.7 %, Robertson backward -1.2 % kernel time, profiles/r03_compact_trajectory.txt block 4)
-#: -split-spill-mode=size (the register allocator splits live ranges for fewer spill instructions): LV backward -0.9 %,
-#: SEIR backward -3.4 % (290 -> 221 spill slots), Robertson / network24 / network100 unchanged, SEIR forward
-#: sensitivities +2 % -- on for the adjoint builds (profiles/r03_compact_trajectory.txt block 5)
-DEFAULT_CODEGEN_FLAGS = "-mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -disable-machine-licm -mllvm -split-spill-mode=size"
-#: the lane-group kernels: plain -O3 scheduling (the ILP strategies are slower there and take several times longer to
-#: build at n = 100), the spill-splitting mode as above except in the forward-sensitivity builds; machine LICM and
-#: the splitting of critical edges for sinking off (SEIR backward 52.4 -> 51.7 ms, 221 -> 208 spill slots)
-WAVE_CODEGEN_FLAGS = "-mllvm -split-spill-mode=size -mllvm -disable-machine-licm -mllvm -machine-sink-split=0"
+#: shuffling; LV -0.7 %, Robertson backward -1.2 %, Robertson sensitivities -2.5 %).
+DEFAULT_CODEGEN_FLAGS = "-mllvm -amdgpu-sched-strategy=iterative-ilp -mllvm -disable-machine-licm"
+#: Adjoint builds only: the register allocator splits live ranges for fewer spill instructions (LV backward -0.9 %,
+#: SEIR backward -3.4 %, 290 -> 221 spill slots; Robertson / network24 / network100 unchanged); the forward-sensitivity
+#: builds lose with it (LV +4 %, Robertson +7 %, SEIR +2 %) and do not get it.
+ADJOINT_CODEGEN_FLAGS = "-mllvm -split-spill-mode=size"
+#: The lane-group kernels (bdf_wave.hip): plain -O3 scheduling (the ILP strategies are slower there and take several
+#: times longer to build at n = 100); adjoint builds: machine LICM and the splitting of critical edges for sinking
+#: off (SEIR backward 52.4 -> 51.7 ms, 221 -> 208 spill slots) + the adjoint flag above.
+WAVE_CODEGEN_FLAGS = "-mllvm -disable-machine-licm -mllvm -machine-sink-split=0"
 
 
 def _extra_codegen_flags():
@@ -214,7 +216,8 @@ def code_object_path(native_source: str, sens: bool = False, constraints: bool =
     kern = os.path.join(_CSRC, fname)
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h", "bdf_core.h")]
     deps = [d for d in deps if os.path.exists(d)]
-    extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode() + WAVE_CODEGEN_FLAGS.encode()
+    extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode()
+             + (WAVE_CODEGEN_FLAGS + ADJOINT_CODEGEN_FLAGS).encode()
              + b"G%d" % group + fname.encode()
              + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode()
              + (b"SENS" if sens else b"") + (b"CONSTR" if constraints else b"") + (b"HERMITE" if hermite else b"")
@@ -268,8 +271,13 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
         # the memory-resident build is dominated by the generated callbacks (10^4 statements at
         # n = 100): default scheduler there, the ILP strategies take several times longer
         extra = _extra_codegen_flags()
-        if fname in ("bdf_mem.hip", "bdf_wave.hip") and "SA_CLANG_FLAGS" not in os.environ:
-            extra = WAVE_CODEGEN_FLAGS.split() if (fname == "bdf_wave.hip" and not sens) else []
+        if "SA_CLANG_FLAGS" not in os.environ:
+            if fname == "bdf_kernels.hip":
+                extra = extra + ([] if sens else ADJOINT_CODEGEN_FLAGS.split())
+            elif fname == "bdf_wave.hip":
+                extra = [] if sens else (WAVE_CODEGEN_FLAGS + " " + ADJOINT_CODEGEN_FLAGS).split()
+            else:
+                extra = []
         try:
             _run(base + extra + ["-c", "-o", obj])
         except NativeBuildError:

@@ -1786,7 +1786,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a.n) return;
-    a.pow_out[i] = rpower_r(a.x[i], a.y[i]);
+    {   /* both coefficient sources of the deterministic pow (literals / constant memory, sa_common.h) must agree bit for bit */
+        const double plit = rpower_r<false>(a.x[i], a.y[i]), pcm = rpower_r<true>(a.x[i], a.y[i]);
+        a.pow_out[i] = (__builtin_bit_cast(uint64_t, plit) == __builtin_bit_cast(uint64_t, pcm)) ? plit : SA_NAN;
+    }
     a.sqrt_out[i] = sqrt(a.x[i]);
     {   /* odd entries with operands far from the exponent limits go through fdiv (cvSet's division): the host test
            compares every entry with the IEEE quotient */

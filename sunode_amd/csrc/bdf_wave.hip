@@ -1724,7 +1724,11 @@ DEV int getrf_lean(Cw<BWD> &m, bool &beaten)
     return ier;
 }
 
-/* M = I + c*J (c = -gamma) from the saved Jacobian in the workspace, straight into the factor registers */
+/* M = I + c*J (c = -gamma) from the saved Jacobian in the workspace, straight into the factor registers.
+   (Measured and not kept: a second, lane-ordered copy of the saved Jacobian -- [column][slot][lane], one coalesced
+   512-byte load per entry instead of 16 scattered 32-byte pieces -- bit-exact and 63 % SLOWER, SEIR backward 51.9 ->
+   84.8 ms: the copy adds 4 MB of hot data per XCD next to the 4 MB of natural-layout Jacobians and 3.7 MB of scratch
+   that already compete for the 4 MB L2, and the allocator answered the change with 352 instead of 208 spill slots.) */
 template <bool BWD>
 DEV void lean_load_matrix(Cw<BWD> &m, double c)
 {
@@ -2647,7 +2651,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a.n) return;
-    a.pow_out[i] = rpower_r(a.x[i], a.y[i]);
+    {   /* both coefficient sources of the deterministic pow (literals / constant memory, sa_common.h) must agree bit for bit */
+        const double plit = rpower_r<false>(a.x[i], a.y[i]), pcm = rpower_r<true>(a.x[i], a.y[i]);
+        a.pow_out[i] = (__builtin_bit_cast(uint64_t, plit) == __builtin_bit_cast(uint64_t, pcm)) ? plit : SA_NAN;
+    }
     a.sqrt_out[i] = sqrt(a.x[i]);
     {   /* odd entries with operands far from the exponent limits go through fdiv (cvSet's division): the host test
            compares every entry with the IEEE quotient */

@@ -30,7 +30,9 @@ def _lv_inputs(B):
 
 
 def test_device_arithmetic_matches_host_bitwise():
-    """IEEE divide / sqrt and the deterministic pow must agree bit-for-bit with the host."""
+    """IEEE divide / sqrt and the deterministic pow must agree bit-for-bit with the host.  (The math kernel evaluates
+    the pow with both coefficient sources -- literals and constant memory, csrc/sa_common.h -- and returns NaN where
+    they differ, so this pins both.)"""
     from sunode_amd.solver import Solver
     prob = make_problem("lv")
     eng = Solver(prob)._engine()
