@@ -78,13 +78,17 @@ def build_host_library(force: bool = False) -> str:
             return lib
     if want is None:
         raise NativeBuildError("host library sources missing and no prebuilt %s" % lib)
+    # several ranks of one job may get here at once (bench.py --gpus N on a box without the prebuilt files): every
+    # process writes its own temporary and publishes it with an atomic rename
+    tmp = "%s.tmp%d" % (lib, os.getpid())
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
-           "-I" + os.path.join(ROCM, "include"), src, "-o", lib + ".tmp",
+           "-I" + os.path.join(ROCM, "include"), src, "-o", tmp,
            "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     _run(cmd)
-    os.replace(lib + ".tmp", lib)
-    with open(stamp, "w") as fh:
+    os.replace(tmp, lib)
+    with open(tmp + ".stamp", "w") as fh:
         fh.write(want)
+    os.replace(tmp + ".stamp", stamp)
     return lib
 
 
@@ -239,8 +243,9 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
     fname, group = kernel_variant(native_source, sens, constraints, hermite)
     kern = os.path.join(_CSRC, fname)
     hdr = out[:-6] + ".h"
-    with open(hdr, "w") as fh:
+    with open("%s.tmp%d" % (hdr, os.getpid()), "w") as fh:      # (concurrent ranks: private temporaries, atomic renames)
         fh.write(native_source)
+    os.replace("%s.tmp%d" % (hdr, os.getpid()), hdr)
     tmp = tempfile.mkdtemp(prefix="sa_build_", dir=_CACHE)
     try:
         bc0, bc1, obj = (os.path.join(tmp, n) for n in ("k0.bc", "k1.bc", "k.o"))
@@ -285,8 +290,8 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
                 raise
             # the non-default scheduler strategies crash clang on very large kernels: plain -O3 then
             _run(base + ["-c", "-o", obj])
-        _run([os.path.join(LLVM_BIN, "ld.lld"), "-shared", obj, "-o", out + ".tmp"])
-        os.replace(out + ".tmp", out)
+        _run([os.path.join(LLVM_BIN, "ld.lld"), "-shared", obj, "-o", "%s.tmp%d" % (out, os.getpid())])
+        os.replace("%s.tmp%d" % (out, os.getpid()), out)
     finally:
         if not keep_temps:
             shutil.rmtree(tmp, ignore_errors=True)

@@ -50,3 +50,19 @@ assert np.array_equal(g0, g1)
 run(np.argsort(sf[:, 0] * 4096 + sb[:, 0] % 4096, kind="stable"), "sorted by fwd steps, bwd steps")
 run(np.argsort(sb[:, 0], kind="stable"), "sorted by backward steps")
 run(np.random.default_rng(0).permutation(B), "random permutation")
+
+
+def wave_order(key, descending=True):
+    """permutation that keeps every wavefront (64 consecutive instances) together and orders the wavefronts by key"""
+    W = B // 64
+    k = key[:W * 64].reshape(W, 64).max(axis=1)
+    order = np.argsort(-k if descending else k, kind="stable")
+    perm = (order[:, None] * 64 + np.arange(64)[None, :]).ravel()
+    return np.concatenate([perm, np.arange(W * 64, B)])
+
+
+# launch order of the wavefronts (longest first = LPT list scheduling over the SIMDs), instances stay in their wavefront
+run(wave_order(sb[:, 14]), "waves: most bwd attempts first")
+run(wave_order(sf[:, 8]), "waves: most fwd points first")
+run(wave_order(sb[:, 14], False), "waves: fewest bwd attempts first")
+run(ident, "as generated (again)")
