@@ -199,3 +199,26 @@ def test_hermite_kernel_selection_with_many_parameters():
     small = "#define SA_N_STATES 3\n#define SA_N_SUB 3\n#define SA_N_REM 0\n"
     assert _native.kernel_variant(small, hermite=True) == ("bdf_kernels.hip", 1)     # register kernel carries Hermite
     assert _native.kernel_variant(small) == ("bdf_kernels.hip", 1)
+
+
+def test_default_arena_record_format_and_build_flags(monkeypatch):
+    """AdjointSolver's default record format (compact {order, t, y[n]} from three states on in the register-resident
+    kernels, table records for n = 2, Hermite data and the memory-resident kernel) and the per-build code-generation
+    flags (the spill-splitting allocator mode only in adjoint builds; the lane-group kernels without the ILP scheduler)."""
+    from sunode_amd import _native
+    hdr = "#define SA_N_STATES %d\n#define SA_N_SUB %d\n#define SA_N_REM 0\n"
+    monkeypatch.delenv("SA_FORCE_GROUP", raising=False)
+    assert _native.default_compact_trajectory(hdr % (2, 2)) is False                 # Lotka-Volterra: table records
+    assert _native.default_compact_trajectory(hdr % (3, 3)) is True                  # Robertson
+    assert _native.default_compact_trajectory(hdr % (16, 8)) is True                 # SEIR: lean lane groups
+    assert _native.default_compact_trajectory(hdr % (100, 4)) is True                # network100: workgroup per instance
+    assert _native.default_compact_trajectory(hdr % (3, 3), hermite=True) is False
+    assert _native.default_compact_trajectory(hdr % (200, 4)) is False               # memory-resident kernel
+    assert "split-spill-mode" in _native.ADJOINT_CODEGEN_FLAGS
+    assert "split-spill-mode" not in _native.DEFAULT_CODEGEN_FLAGS and "iterative-ilp" in _native.DEFAULT_CODEGEN_FLAGS
+    assert "sched-strategy" not in _native.WAVE_CODEGEN_FLAGS
+    # the cache key separates the record formats and the sensitivity builds of one problem
+    src = hdr % (3, 3)
+    keys = {_native.code_object_path(src), _native.code_object_path(src, compact=True),
+            _native.code_object_path(src, sens=True), _native.code_object_path(src, hermite=True)}
+    assert len(keys) == 4
