@@ -295,7 +295,10 @@ DEV int interp_y(Cv<BWD> &m, double t)
            destination registers reserved until now, i.e. the loads were never waited for early) */
         asm volatile("" :: "v"(m.pf[0]), "v"(m.pf[1]), "v"(m.pf[2]), "v"(m.pf[3]));
 #if SA_COMPACT
-        {   /* rebuild: the order + 1 points ending at indx (all loads in flight together; unused columns zero) */
+        {   /* rebuild: the order + 1 points ending at indx (all loads in flight together; unused columns zero).
+               (Measured and not kept: reading the six points as ONE contiguous block of 6 (n + 2) doubles at
+               constant offsets from a single base -- an instance's records are contiguous -- with a per-point
+               fall-back for indx < 5: Robertson backward 68.4 -> 70.8 ms.) */
             const int order = (int)r[0];
             double hT[QMAX + 1], Y[QMAX + 1][NSD];
             SFOR(j, 0, (QMAX) + 1) {
@@ -945,7 +948,15 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     int total_retries = 0, attempts = 0, wave_iters = 0;
     cv_reinit(m, a.t0, lam, quad);
 
-    /* ts = [t0] + reversed(tvals) + [tend]; interval iv = (ts[iv+1], ts[iv]) */
+    /* ts = [t0] + reversed(tvals) + [tend]; interval iv = (ts[iv+1], ts[iv]).  The wavefront walks the intervals
+       together: every lane waits for the slowest at each observation, then all restart at once.
+       (Measured and not kept -- profiles/r03_restart_batching.txt: the restart as a per-lane state of ONE attempt
+       loop, executed when `batch` lanes wait for it or nobody is left stepping.  Bit-identical for every batch size,
+       and slower for all of them: the flattened loop alone costs 10 % (batch = 64 = this schedule: Robertson backward
+       68.1 -> 75.4 ms, LV 9.2 -> 10.1 ms); letting early lanes run ahead makes it worse (batch 32 / 16 / 8 / 4:
+       100 / 99 / 96 / 93 ms) although 23 % of the Robertson kernel is lanes waiting at its six interval ends --
+       what follows a restart (order-one steps, a matrix set-up with a fresh Jacobian in nearly every attempt while
+       the step size grows) is cheap only while all 64 lanes go through it in the same iterations.) */
     for (int iv = 0; iv <= a.n_t; iv++) {
         const double t_upper = (iv == 0) ? a.t0 : a.tvals[a.n_t - iv];
         const double t_lower = (iv == a.n_t) ? a.tend : a.tvals[a.n_t - 1 - iv];
