@@ -973,3 +973,51 @@ def test_compact_trajectory_equals_table_records(name):
     for a, b in zip(res[0][:5], res[1][:5]):
         np.testing.assert_array_equal(a, b)
     assert res[1][5] * 4 < res[0][5]            # arena bytes: (n + 2) against (8 + 6 n) doubles per point
+
+
+@pytest.mark.parametrize("name", ["lv", "robertson", "seir"])
+def test_randomized_sweep_matches_oracle(name):
+    """Draws far outside the BASELINE batches: parameters spread over an order of magnitude (including draws whose
+    solves fail or hit the step budget), three tolerance settings with DIFFERENT forward / backward / quadrature
+    tolerances, irregular output grids with repeated and t0-valued entries, per-instance cotangents -- states,
+    gradients, adjoint states, every status code and every counter must equal the oracle's, instance by instance."""
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem(name)
+    rng = np.random.RandomState({"lv": 11, "robertson": 12, "seir": 13}[name])
+    B = {"lv": 2048, "robertson": 1024, "seir": 192}[name]
+    if name == "lv":
+        d = lv_batch(B); p0 = d["params"]; y0 = d["y0"] * np.exp(0.5 * rng.randn(B, 2)); T = 10.0
+        par = p0 * np.exp(0.8 * rng.randn(B, 4)); ps, pr = par[:, :2], par[:, 2:]
+    elif name == "robertson":
+        d = robertson_batch(B); y0 = d["y0"]; T = 400.0
+        ps, pr = d["params"] * np.exp(0.7 * rng.randn(B, 3)), np.zeros(0)
+    else:
+        d = seir_batch(B); y0 = d["y0"]; T = 60.0
+        ps, pr = d["ps"] * np.exp(0.6 * rng.randn(B, 8)), d["pr"]
+    n = prob.n_states
+    orc = make_oracle(name)
+    for k, (rt, at, rtb, atb, rtq, atq) in enumerate([(1e-6, 1e-8, 1e-5, 1e-7, 1e-4, 1e-6),
+                                                     (1e-9, 1e-11, 1e-8, 1e-9, 1e-8, 1e-8),
+                                                     (1e-4, 1e-6, 1e-6, 1e-9, 1e-7, 1e-9)]):
+        inner = np.sort(rng.uniform(0.0, T, 9))
+        tv = np.concatenate([[0.0], inner[:4], inner[3:4], inner[4:], [T]])       # starts at t0, one repeated time
+        grads = rng.randn(B, len(tv), n)
+        sol = AdjointSolver(prob, abstol=at, reltol=rt, backward_abstol=atb, backward_reltol=rtb, quad_abstol=atq,
+                            quad_reltol=rtq, mxsteps=400)
+        y, st, sf = sol.solve_forward_batch(0.0, tv, y0, ps, pr)
+        g, lam, stb, sb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+        cfg = orc.config(rtol=rt, atol=at, rtolB=rtb, atolB=atb, rtolQB=rtq, atolQB=atq, mxstep=400)
+        yo, so, sfo = orc.solve_forward(cfg, y0, ps, pr, 0.0, tv, nthreads=os.cpu_count() or 8)
+        go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=os.cpu_count() or 8)
+        np.testing.assert_array_equal(st, so, err_msg="forward status, setting %d" % k)
+        np.testing.assert_array_equal(stb, sbo, err_msg="backward status, setting %d" % k)
+        ok = (so == 0)
+        np.testing.assert_array_equal(sf[ok][:, CMP], sfo[ok][:, CMP])
+        np.testing.assert_array_equal(y[ok], yo[ok])
+        okb = ok & (sbo == 0)
+        assert okb.sum() > B // 2, "too few successful draws for a meaningful comparison: %d" % okb.sum()
+        np.testing.assert_array_equal(sb[okb][:, CMP_B], stbo[okb][:, CMP_B])
+        np.testing.assert_array_equal(g[okb], go[okb])
+        np.testing.assert_array_equal(lam[okb], lo[okb])
+        assert np.isnan(y[~ok]).all() and np.isnan(g[~okb]).all()
+        sol._engine().close()
