@@ -203,3 +203,45 @@ def test_device_sensitivities_seir_lane_groups_vs_oracle(mode, mapping, monkeypa
     np.testing.assert_array_equal(y, yo)
     np.testing.assert_array_equal(S, So)
     assert np.abs(S[:, -1]).max() > 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lv", "robertson", "seir"])
+@pytest.mark.parametrize("mode", ["simultaneous", "staggered"])
+def test_device_sensitivities_randomized_sweep_vs_oracle(name, mode):
+    """Forward sensitivities far outside the BASELINE draws: parameters spread over an order of magnitude, two tolerance
+    settings, an irregular output grid, random initial sensitivities, a step budget that forces retries -- states,
+    sensitivities, statuses and counters equal the oracle's, instance by instance (register kernel for LV / Robertson,
+    lean lane groups for SEIR)."""
+    import os
+    from sunode_amd.solver import Solver
+    from tools.problems import lv_batch, robertson_batch, seir_batch
+    prob = make_problem(name)
+    rng = np.random.RandomState({"lv": 21, "robertson": 22, "seir": 23}[name])
+    B = {"lv": 1024, "robertson": 512, "seir": 48}[name]
+    if name == "lv":
+        d = lv_batch(B); y0 = d["y0"] * np.exp(0.5 * rng.randn(B, 2)); T = 10.0
+        par = d["params"] * np.exp(0.8 * rng.randn(B, 4)); ps, pr = par[:, :2], par[:, 2:]
+    elif name == "robertson":
+        d = robertson_batch(B); y0 = d["y0"]; T = 400.0
+        ps, pr = d["params"] * np.exp(0.7 * rng.randn(B, 3)), np.zeros(0)
+    else:
+        d = seir_batch(B); y0 = d["y0"]; T = 40.0
+        ps, pr = d["ps"] * np.exp(0.5 * rng.randn(B, 8)), d["pr"]
+    orc = make_oracle(name)
+    cmp = [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13]
+    for k, (rt, at) in enumerate([(1e-6, 1e-8), (1e-9, 1e-10)]):
+        tv = np.concatenate([[0.0], np.sort(rng.uniform(0.0, T, 6)), [T]])
+        sens0 = 0.1 * rng.randn(prob.n_params, prob.n_states)
+        sol = Solver(prob, abstol=at, reltol=rt, sens_mode=mode, mxsteps=300)
+        y, S, st, stats = sol.solve_sens_batch(0.0, tv, y0, ps, pr, sens0)
+        cfg = orc.config(rtol=rt, atol=at, mxstep=300)
+        yo, So, so, sto = orc.solve_sens(cfg, y0, ps, pr, sens0, 0.0, tv, mode=mode, nthreads=os.cpu_count() or 8)
+        np.testing.assert_array_equal(st, so, err_msg="status, setting %d" % k)
+        ok = (so == 0)
+        assert ok.sum() > B // 2
+        np.testing.assert_array_equal(stats[ok][:, cmp], sto[ok][:, cmp])
+        np.testing.assert_array_equal(y[ok], yo[ok])
+        np.testing.assert_array_equal(S[ok], So[ok])
+        assert np.isnan(y[~ok]).all() and np.isnan(S[~ok]).all()
+        sol._engine().close()
