@@ -106,6 +106,10 @@ ADJOINT_CODEGEN_FLAGS = "-mllvm -split-spill-mode=size"
 #: times longer to build at n = 100); adjoint builds: machine LICM and the splitting of critical edges for sinking
 #: off (SEIR backward 52.4 -> 51.7 ms, 221 -> 208 spill slots) + the adjoint flag above.
 WAVE_CODEGEN_FLAGS = "-mllvm -disable-machine-licm -mllvm -machine-sink-split=0"
+#: ... and up to 8 lanes per instance (the lean groups and their neighbours) without memory-operation clustering in the
+#: scheduler: SEIR backward 52.0 -> 48.9 ms (291 -> 305 k solves/s), network24 unchanged; the workgroup-per-instance
+#: build (network100) loses 0.5 % with it and the sensitivity builds 1 %: not applied there (block 8 of the A/B file)
+SMALL_GROUP_CODEGEN_FLAGS = "-mllvm -misched-cluster=0"
 
 
 def _extra_codegen_flags():
@@ -221,7 +225,7 @@ def code_object_path(native_source: str, sens: bool = False, constraints: bool =
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h", "bdf_core.h")]
     deps = [d for d in deps if os.path.exists(d)]
     extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode()
-             + (WAVE_CODEGEN_FLAGS + ADJOINT_CODEGEN_FLAGS).encode()
+             + (WAVE_CODEGEN_FLAGS + ADJOINT_CODEGEN_FLAGS + SMALL_GROUP_CODEGEN_FLAGS).encode()
              + b"G%d" % group + fname.encode()
              + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode()
              + (b"SENS" if sens else b"") + (b"CONSTR" if constraints else b"") + (b"HERMITE" if hermite else b"")
@@ -280,7 +284,8 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
             if fname == "bdf_kernels.hip":
                 extra = extra + ([] if sens else ADJOINT_CODEGEN_FLAGS.split())
             elif fname == "bdf_wave.hip":
-                extra = [] if sens else (WAVE_CODEGEN_FLAGS + " " + ADJOINT_CODEGEN_FLAGS).split()
+                extra = [] if sens else (WAVE_CODEGEN_FLAGS + " " + ADJOINT_CODEGEN_FLAGS
+                                         + (" " + SMALL_GROUP_CODEGEN_FLAGS if group <= 8 else "")).split()
             else:
                 extra = []
         try:

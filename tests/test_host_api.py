@@ -217,6 +217,7 @@ def test_default_arena_record_format_and_build_flags(monkeypatch):
     assert "split-spill-mode" in _native.ADJOINT_CODEGEN_FLAGS
     assert "split-spill-mode" not in _native.DEFAULT_CODEGEN_FLAGS and "iterative-ilp" in _native.DEFAULT_CODEGEN_FLAGS
     assert "sched-strategy" not in _native.WAVE_CODEGEN_FLAGS
+    assert "misched-cluster" in _native.SMALL_GROUP_CODEGEN_FLAGS and "misched-cluster" not in _native.WAVE_CODEGEN_FLAGS
     # the cache key separates the record formats and the sensitivity builds of one problem
     src = hdr % (3, 3)
     keys = {_native.code_object_path(src), _native.code_object_path(src, compact=True),
