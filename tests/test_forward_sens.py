@@ -21,10 +21,12 @@ def _load(golden_dir, name):
 
 def _rel_err(S, truth):
     scale = np.abs(truth).max(axis=(1, 3), keepdims=True)          # per instance and parameter
+    scale = np.maximum(scale, 1e-300)           # (SEIR's unused rates mu, nu: identically zero rows, on both sides)
     return float(np.max(np.abs(S - truth) / scale))
 
 
-@pytest.mark.parametrize("name,tol,bar", [("lv", 1e-8, 2e-5), ("lv", 1e-10, 1e-6), ("robertson", 1e-8, 2e-4)])
+@pytest.mark.parametrize("name,tol,bar", [("lv", 1e-8, 2e-5), ("lv", 1e-10, 1e-6), ("robertson", 1e-8, 2e-4),
+                                          ("seir", 1e-8, 2e-5), ("seir", 1e-10, 1e-6)])
 @pytest.mark.parametrize("mode", ["simultaneous", "staggered"])
 def test_oracle_sensitivities_match_truth(name, tol, bar, mode, golden_dir):
     t = _load(golden_dir, name)
@@ -203,6 +205,27 @@ def test_device_sensitivities_seir_lane_groups_vs_oracle(mode, mapping, monkeypa
     np.testing.assert_array_equal(y, yo)
     np.testing.assert_array_equal(S, So)
     assert np.abs(S[:, -1]).max() > 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["simultaneous", "staggered"])
+@pytest.mark.parametrize("mapping", [None, "wave8", "mem"])
+def test_device_sensitivities_seir_match_truth(mode, mapping, golden_dir, monkeypatch):
+    """SEIR's 16 x 8 sensitivity matrix from the DEVICE against a code that is not ours (DOP853 on the
+    sensitivity equations, numpy restatement of the model: tests/golden/truth_sens_seir.npz), all three mappings:
+    2e-5 of the largest |dy/dp_i| at rtol = atol = 1e-8; the rows of the unused rates mu, nu are exactly zero."""
+    from sunode_amd.solver import Solver
+    if mapping:
+        monkeypatch.setenv("SA_FORCE_GROUP", mapping)
+    t = _load(golden_dir, "seir")
+    prob = make_problem("seir")
+    sol = Solver(prob, abstol=1e-8, reltol=1e-8, sens_mode=mode)
+    sens0 = np.zeros((prob.n_params, prob.n_states))
+    y, S, status, stats = sol.solve_sens_batch(0.0, t["tvals"], t["y0"], t["ps"], t["pr"], sens0)
+    assert (status == 0).all()
+    assert _rel_err(S, t["sens"]) < 2e-5
+    assert (S[:, :, 6:] == 0).all()
+    assert np.max(np.abs(y - t["y_out"]) / np.abs(t["y_out"]).max(axis=(0, 1))) < 1e-5
 
 
 @pytest.mark.gpu

@@ -1021,3 +1021,56 @@ def test_randomized_sweep_matches_oracle(name):
         np.testing.assert_array_equal(lam[okb], lo[okb])
         assert np.isnan(y[~ok]).all() and np.isnan(g[~okb]).all()
         sol._engine().close()
+
+
+@pytest.mark.parametrize("n,group", [(100, None), (100, "mem"), (24, None), (24, "wave"), (24, "mem")])
+def test_network_device_counters_equal_dvode(n, group, golden_dir, monkeypatch):
+    """a counter oracle that is not ours at config 5's size.  The 100-state network forward through
+    the workgroup-per-instance kernel (panel LU in registers, matrix-vector callbacks) and the memory-resident one,
+    the 24-state network through 16-lane groups, a forced workgroup and the memory-resident kernel: every step counter
+    equals Fortran DVODE's (tests/golden/dvode_network.json: numpy restatement of the model), states to round-off."""
+    import json
+    from sunode_amd.solver import AdjointSolver
+    with open(os.path.join(golden_dir, "dvode_network.json")) as fh:
+        dv = json.load(fh)
+    if group:
+        monkeypatch.setenv("SA_FORCE_GROUP", group)
+    prob = make_problem("network%d" % n)
+    cases = [dv["network%d_batch_%d" % (n, b)] for b in range(4)]
+    d = network_batch(4, n=n)
+    assert d["ps"].tolist() == [c["ps"] for c in cases]
+    tv = np.array(cases[0]["tvals"])
+    sol = AdjointSolver(prob, abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8,
+                        quad_abstol=1e-8, quad_reltol=1e-8, max_steps=1024)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], d["pr"])
+    assert (st == 0).all()
+    for b, c in enumerate(cases):
+        got = [int(v) for v in stats[b][:8]]
+        assert got == [c["nst"], c["nfe"], c["nlu"], c["nje"], c["nni"], c["ncfn"], c["netf"], c["qlast"]]
+        assert stats[b][8] == c["nst"] + 1                      # stored data points
+        ref = np.array(c["y"])
+        np.testing.assert_allclose(y[b], ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n,group", [(100, None), (24, None), (24, "wave"), (24, "mem")])
+def test_network_device_gradients_match_truth(n, group, golden_dir, monkeypatch):
+    """dL/dp and dL/dy0 of the networks from the DEVICE against DOP853 on the sensitivity equations
+    (tests/golden/truth_network*.npz, non-trivial cotangent): 2e-6 of the largest component at rtol = atol = 1e-8."""
+    from sunode_amd.solver import AdjointSolver
+    if group:
+        monkeypatch.setenv("SA_FORCE_GROUP", group)
+    d = np.load(os.path.join(golden_dir, "truth_network%d.npz" % n))
+    B = len(d["ps"])
+    pr = network_batch(B, n=n)["pr"]
+    prob = make_problem("network%d" % n)
+    tol = 1e-8
+    sol = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol,
+                        quad_abstol=tol, quad_reltol=tol, max_steps=1024)
+    tv = d["tvals"]
+    y, st, _ = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], pr)
+    g, lam, st2, _ = sol.solve_backward_batch(tv[-1], 0.0, tv, d["grads"])
+    assert (st == 0).all() and (st2 == 0).all()
+    assert np.max(np.abs(y - d["y_out"]) / np.abs(d["y_out"]).max(axis=(0, 1))) < 1e-6
+    gt = d["grad_params"]
+    assert np.max(np.abs(g - gt) / np.abs(gt).max(axis=1, keepdims=True)) < 2e-6
+    assert np.max(np.abs(-lam - d["grad_y0"]) / np.abs(d["grad_y0"]).max(axis=1, keepdims=True)) < 2e-6

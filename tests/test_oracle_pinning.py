@@ -345,3 +345,58 @@ def test_backward_step_trace_equals_dvode(golden_dir):
         for row in c["intervals"]:
             if BACKWARD_EXACT(tag, row["t_mid"]) or row is long_row:
                 assert int((tt > row["t_mid"]).sum()) + 1 == row["nst"], (tag, row["t_mid"])
+
+
+# ---- n = 100 / n = 24: DVODE counters and sensitivity-equation truth (tools/make_golden_network.py: numpy
+# restatements of the model, no generated code) -- the dense LU path at config 5's size pinned by codes that are not ours
+@pytest.fixture(scope="module")
+def dvode_network(golden_dir):
+    with open(os.path.join(golden_dir, "dvode_network.json")) as fh:
+        return json.load(fh)
+
+
+def network_case_inputs(case, b):
+    from tools.problems import network_batch
+    d = network_batch(4, n=case["n"])
+    assert d["ps"][b].tolist() == case["ps"]            # the fixture's draw is the generator's draw
+    return d["y0"][b:b + 1], d["ps"][b:b + 1], d["pr"]
+
+
+@pytest.mark.parametrize("n", [24, 100])
+@pytest.mark.parametrize("b", range(4))
+def test_network_forward_statistics_equal_dvode(dvode_network, n, b):
+    """Every counter of the restated controller equals Fortran DVODE's on four draws of the 24-state network and four
+    of the 100-state one (BASELINE config 5: nst 126 / 127 / 126 / 129), states to round-off: the dense
+    factorisation / back-substitution at n = 100 and the matrix-vector form of the callbacks, through the controller."""
+    case = dvode_network["network%d_batch_%d" % (n, b)]
+    orc = make_oracle("network%d" % n)
+    y0, ps, pr = network_case_inputs(case, b)
+    cfg = orc.config(rtol=case["rtol"], atol=case["atol"])
+    for fn in (orc.solve, orc.solve_forward):
+        y, status, stats = fn(cfg, y0, ps, pr, 0.0, np.array(case["tvals"]))
+        assert status[0] == 0
+        got = {k: int(stats[0][i]) for k, i in STAT.items()}
+        assert got == dict(nst=case["nst"], nfe=case["nfe"], nsetups=case["nlu"], nje=case["nje"], nni=case["nni"],
+                           ncfn=case["ncfn"], netf=case["netf"], qlast=case["qlast"])
+        ref = np.array(case["y"])
+        np.testing.assert_allclose(y[0], ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n,rtol,tol_y,tol_g", [(24, 1e-8, 1e-6, 2e-6), (24, 1e-10, 2e-8, 5e-8),
+                                                (100, 1e-8, 1e-6, 2e-6), (100, 1e-10, 2e-8, 5e-8)])
+def test_network_forward_and_adjoint_match_truth(golden_dir, n, rtol, tol_y, tol_g):
+    """States, dL/dp and dL/dy0 (non-trivial cotangent) of the networks vs DOP853 on the sensitivity equations."""
+    from tools.problems import network_batch
+    d = np.load(os.path.join(golden_dir, "truth_network%d.npz" % n))
+    B = len(d["ps"])
+    pr = network_batch(B, n=n)["pr"]
+    orc = make_oracle("network%d" % n)
+    cfg = orc.config(rtol=rtol, atol=rtol, rtolB=rtol, atolB=rtol, rtolQB=rtol, atolQB=rtol)
+    tvals = d["tvals"]
+    y, st, _ = orc.solve_forward(cfg, d["y0"], d["ps"], pr, 0.0, tvals, nthreads=B)
+    g, lam, st2, _ = orc.solve_backward(cfg, tvals[-1], 0.0, tvals, d["grads"], nthreads=B)
+    assert (st == 0).all() and (st2 == 0).all()
+    assert np.max(np.abs(y - d["y_out"]) / np.abs(d["y_out"]).max(axis=(0, 1))) < tol_y
+    gt = d["grad_params"]
+    assert np.max(np.abs(g - gt) / np.abs(gt).max(axis=1, keepdims=True)) < tol_g
+    assert np.max(np.abs(-lam - d["grad_y0"]) / np.abs(d["grad_y0"]).max(axis=1, keepdims=True)) < tol_g
