@@ -172,6 +172,92 @@ class GpuEngine:
         self.eng.close()
 
 
+class MultiDeviceEngine:
+    """--single-process: ONE Python process drives several GPUs -- one GpuEngine (handle, stream, arena, device
+    tensors) per entry of `devices`, every step issued from one host thread per engine (the native calls release
+    the GIL).  The second launcher next to one-process-per-GPU; what AdjointSolver(devices=[...]) does for host
+    arrays, with device-resident shards."""
+
+    def __init__(self, name, prob, batch, tol, devices, factory=None):
+        from concurrent.futures import ThreadPoolExecutor
+        factory = factory or GpuEngine
+        B = batch["y0"].shape[0]
+        per = B // len(devices)
+        assert per * len(devices) == B
+        self.engines = []
+        for k, d in enumerate(devices):
+            rows = slice(k * per, (k + 1) * per)
+            shard = dict(batch, y0=batch["y0"][rows], ps=batch["ps"][rows],
+                         pr=batch["pr"][rows] if batch["rem_stride"] else batch["pr"])
+            self.engines.append(factory(name, prob, shard, tol, d, arena_bytes=self._arena_share(devices, d)))
+        self.dev = getattr(self.engines[0], "dev", "cpu")
+        self.pool = ThreadPoolExecutor(max_workers=len(devices), thread_name_prefix="bench")
+
+    @staticmethod
+    def _arena_share(devices, d):
+        k = devices.count(d)
+        if k == 1:
+            return 0                      # the library default (96 GiB, at most 60 % of the free HBM)
+        from sunode_amd import _native
+        free_b, _ = _native.device_memory(d)
+        return min(96 << 30, int(0.6 * free_b)) // k
+
+    def step(self):
+        for f in [self.pool.submit(e.step) for e in self.engines]:
+            f.result()
+
+    def kernel_ms(self):
+        ms = [e.kernel_ms() for e in self.engines]
+        return max(m[0] for m in ms), max(m[1] for m in ms)
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
+
+    def results(self):
+        rs = [e.results() for e in self.engines]
+        return dict(failed=sum(r["failed"] for r in rs),
+                    stats_f=np.mean([r["stats_f"] for r in rs], axis=0), stats_b=np.mean([r["stats_b"] for r in rs], axis=0),
+                    arena=(max(r["arena"][0] for r in rs), sum(r["arena"][1] for r in rs), any(r["arena"][2] for r in rs)))
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.pool.shutdown()
+
+
+def run_single_process(args, *, make_engine=None):
+    """`--gpus N --single-process [--devices 0,1,...]`: no process group; N engines in this process."""
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(max(1, args.gpus)))
+    if len(devices) != max(1, args.gpus):
+        raise SystemExit("bench.py: --devices names %d device(s) but --gpus is %d" % (len(devices), args.gpus))
+    name = args.workload
+    prob = make_problem(name)
+    w = WORKLOADS[name]
+    B = args.batch or w["batch"]
+    world = len(devices)
+    batch = make_batch(name, prob, B * world)
+    eng = MultiDeviceEngine(name, prob, batch, (w["rtol"], w["atol"]), devices, factory=make_engine)
+    for _ in range(args.warmup):
+        eng.step()
+    eng.sync()
+    fwd_ms, bwd_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+        f, b = eng.kernel_ms()
+        fwd_ms.append(f)
+        bwd_ms.append(b)
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    res = eng.results()
+    out = summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, res["failed"])
+    out["config"]["parallelism"] = "instance-sharded x%d, one process, one host thread per device (devices %s)" \
+        % (world, ",".join(map(str, devices)))
+    eng.close()
+    return out
+
+
 def run_rank(args, *, backend="nccl", make_engine=None):
     """One rank of the benchmark (rank / world from the torch.distributed.run environment).  Returns the result
     dict on rank 0, None elsewhere.  `backend` and `make_engine` are injectable so that the world-size-2 CPU
@@ -492,6 +578,11 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="lv", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive the --gpus N devices from THIS process (one engine + host thread per device) instead "
+                         "of one process per GPU")
+    ap.add_argument("--devices", default="", help="--single-process: comma-separated device ordinals "
+                                                   "(default 0..N-1; an ordinal may repeat: two engines on one GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="form the process group (nccl = RCCL), barrier and device all-reduce even with one rank")
     return ap.parse_args(argv)
@@ -515,9 +606,12 @@ def launch_ranks(args, argv):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        launch_ranks(args, argv)                      # does not return
-    out = run_rank(args)
+    if args.single_process:
+        out = run_single_process(args)
+    else:
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            launch_ranks(args, argv)                  # does not return
+        out = run_rank(args)
     if out is not None:
         if args.gpus == 1:
             if not args.no_cpu_baseline:

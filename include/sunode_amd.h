@@ -103,6 +103,14 @@ typedef struct sa_options {
 int sa_abi_version(void);
 const char *sa_last_error(void);
 
+/* HIP devices visible to the library and their memory.  For callers that shard a batch over several handles from
+   one process (sunode_amd.solver: AdjointSolver(problem, devices=[0..7]) -- the reference's call pattern is one
+   solver object inside one PyMC process, wrappers/as_pytensor.py:279-344): one sa_solver per entry, each call
+   issued from its own host thread (every entry point selects its handle's device for the calling thread; error
+   strings are per thread), arena budgets of handles that share a device divided by the caller. */
+int sa_device_count(int32_t *count);
+int sa_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes);
+
 /* Load the per-problem code object (generated callbacks + integrator kernels, built by
    sunode_amd._native from bdf_kernels.hip) on opt->device.
    Replaces CVodeCreate/CVodeInit/CVodeSetUserData/SUNLinSol_Dense/CVodeSetLinearSolver/

@@ -303,6 +303,66 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
     return out
 
 
+#: fields of a kernel's code-object notes that the budget (profiles/code_object_budget.json) bounds
+NOTE_FIELDS = ("vgpr_count", "agpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
+               "group_segment_fixed_size")
+
+
+def code_object_notes(path: str) -> dict:
+    """{kernel name: {field: value}} from the AMDGPU metadata notes of a code object (llvm-readelf --notes):
+    registers, spill slots, scratch bytes per lane and static LDS of every kernel in it."""
+    import re
+    text = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", path], capture_output=True, text=True,
+                          check=True).stdout
+    out = {}
+    for block in re.split(r"\n\s+- \.agpr_count:", "\n" + text)[1:]:
+        block = "    .agpr_count:" + block
+        name = re.search(r"\.name:\s+(\S+)", block)
+        if not name:
+            continue
+        row = {}
+        for f in NOTE_FIELDS:
+            m = re.search(r"\.%s:\s+(\d+)" % f, block)
+            if m:
+                row[f] = int(m.group(1))
+        out[name.group(1)] = row
+    return out
+
+
+def toolchain_id() -> dict:
+    """What compiled the code objects: the version banners of hipcc / clang and a short hash of them (bench.py prints
+    it next to the counter-traffic source so that a profile taken with another toolchain is detectable)."""
+    banners = []
+    for exe in (os.path.join(ROCM, "bin", "hipcc"), os.path.join(LLVM_BIN, "clang")):
+        try:
+            banners.append(subprocess.run([exe, "--version"], capture_output=True, text=True).stdout.strip())
+        except OSError:
+            banners.append("%s: not found" % exe)
+    text = "\n".join(banners)
+    first = [ln for ln in text.splitlines() if "version" in ln.lower()]
+    return {"hash": hashlib.sha256(text.encode()).hexdigest()[:12], "banner": "; ".join(first[:2])}
+
+
+def file_hash(path: str) -> str:
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:12]
+
+
+def check_code_object_budget(label: str, path: str, budget: dict) -> list:
+    """Violations (strings) of ``budget`` = {kernel: {field: ceiling}} by the code object at ``path``."""
+    notes = code_object_notes(path)
+    bad = []
+    for kernel, limits in budget.items():
+        if kernel not in notes:
+            bad.append("%s: kernel %s missing from %s" % (label, kernel, os.path.basename(path)))
+            continue
+        for field, ceiling in limits.items():
+            got = notes[kernel].get(field)
+            if got is None or got > ceiling:
+                bad.append("%s: %s.%s = %s exceeds the budget %s" % (label, kernel, field, got, ceiling))
+    return bad
+
+
 class _Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("device", ctypes.c_int32), ("rtol", ctypes.c_double),
                 ("atol", ctypes.POINTER(ctypes.c_double)), ("rtolB", ctypes.c_double), ("atolB", ctypes.c_double),
@@ -344,12 +404,14 @@ def load_library() -> ctypes.CDLL:
     L.sa_math_probe.argtypes = [vp, i32] + [_dp] * 5
     L.sa_arena_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32)]
     L.sa_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.sa_device_count.argtypes = [ctypes.POINTER(i32)]
+    L.sa_device_memory.argtypes = [i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.sa_set_stream.argtypes = [vp, vp]
     L.sa_synchronize.argtypes = [vp]
     for name in ("sa_solver_create", "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
                  "sa_solve_forward_batch", "sa_solve_backward_batch", "sa_solve_backward_batch_all",
                  "sa_eval_callbacks", "sa_math_probe", "sa_last_kernel_ms", "sa_set_stream", "sa_synchronize",
-                 "sa_arena_info"):
+                 "sa_arena_info", "sa_device_count", "sa_device_memory"):
         getattr(L, name).restype = ctypes.c_int
     _LIB = L
     return L
@@ -360,11 +422,29 @@ EXPORTED_SYMBOLS = ["sa_abi_version", "sa_last_error", "sa_solver_create", "sa_s
                     "sa_solve_forward_batch",
                     "sa_solve_backward_batch", "sa_solve_backward_batch_all", "sa_eval_callbacks", "sa_math_probe",
                     "sa_last_kernel_ms", "sa_arena_info",
-                    "sa_set_stream", "sa_synchronize"]
+                    "sa_set_stream", "sa_synchronize", "sa_device_count", "sa_device_memory"]
 
 
 class NativeError(RuntimeError):
     pass
+
+
+def device_count() -> int:
+    """HIP devices visible to the library (include/sunode_amd.h: sa_device_count)."""
+    L = load_library()
+    n = ctypes.c_int32()
+    if L.sa_device_count(ctypes.byref(n)) != 0:
+        raise NativeError("sa_device_count: %s" % L.sa_last_error().decode())
+    return n.value
+
+
+def device_memory(device: int):
+    """(free, total) bytes of HBM on ``device`` (sa_device_memory)."""
+    L = load_library()
+    f, t = ctypes.c_int64(), ctypes.c_int64()
+    if L.sa_device_memory(int(device), ctypes.byref(f), ctypes.byref(t)) != 0:
+        raise NativeError("sa_device_memory: %s" % L.sa_last_error().decode())
+    return f.value, t.value
 
 
 def _addr(x) -> int:

@@ -1246,13 +1246,318 @@ DEV int getrf_group_regs(const Grp &g, double (&inv_piv)[RS], int &nswaps)
  * J comes from the saved copy in the workspace (from_saved) or from LDS where the Jacobian callback just wrote it
  * (and is saved on the way); the factors end up in LDS (s_A) for the triangular solves of wavefront 0, the
  * reciprocal pivots in s_invp. */
-#if SA_WAVES > 1
+#if SA_WAVES > 1 && !defined(SA_LU_CYCLIC)
+/* PANEL version (round 4) -- the blocked right-looking LU (swap rows, triangular panel solve, rank-4 update) with the
+ * element-wise operation order of denseGETRF.  Columns are owned in panels of LU_NB = 4 consecutive columns, dealt
+ * round robin to the wavefronts: wavefront w holds the panels p = pr * SA_WAVES + w (pr < LU_NPR) in the register
+ * columns pr * LU_NB .. pr * LU_NB + 3; lane l the rows l, l + 64.
+ *   - A panel is factorised INSIDE its owner: four elimination steps (pivot check, reciprocal, scaling, update of
+ *     the panel's later columns) in straight-line code, no LDS and no barrier in between.  The diagonal is the pivot
+ *     in all but a few factorisations of I - gamma*J: the check is one ballot; only if some row beats the diagonal
+ *     does the arg-max butterfly run and are the two rows EXCHANGED (readlane + select, in the panel's columns).
+ *   - The owner publishes the four multiplier columns as they stand after the whole panel (i.e. with the panel's
+ *     later exchanges applied, zero on and above the diagonal) and the four pivot rows: ONE workgroup barrier per
+ *     panel (25 at n = 100 instead of 100).
+ *   - Every wavefront applies the panel's row exchanges to its other columns (rare), then the four steps to its
+ *     trailing columns, k-outer / column-inner (independent FMAs back to back; column-outer was a serial
+ *     select-readlane-FMA chain of ~60 cycles per link): pivot-row entry = v_readlane of its own register column (row
+ *     k already carries the steps before k), one FMA per owned entry.  Exchanging rows l > k, k' > k before instead
+ *     of after the update of step k changes no value (each row's arithmetic is the same, the multipliers are
+ *     published in the exchanged frame), so every entry receives a(i,j) = fma(-a(k,j), l(i,k), a(i,j)) for k = 0, 1,
+ *     2 ... in this order with l(i,k) = a(i,k) * (1 / pivot): denseGETRF's operations on the same values in the same
+ *     order, hence the same factors bit for bit (test_row_exchanges_in_the_dense_lu[wave], every network test).
+ * (Round 3: one column per barrier, 1 970 cycles per step, half of them the owner's serial chain with the other three
+ * wavefronts waiting: profiles/r03_network100_sections.txt.) */
+#define LU_NB 4
+#define LU_NPANEL ((NS + LU_NB - 1) / LU_NB)
+#define LU_NPR ((LU_NPANEL + SA_WAVES - 1) / SA_WAVES)
+#define LU_NC (LU_NPR * LU_NB)
+static_assert(RS <= 2 && 64 % (LU_NB * SA_WAVES) == 0, "the rows of a panel round share one register slot");
+__shared__ __attribute__((aligned(16))) double s_col[2][RS * 64 * LU_NB];
+__shared__ double s_invp[W_NS];
+__shared__ __attribute__((aligned(16))) int s_luinfo[2 * LU_NB];
+__shared__ int s_luier, s_lunswaps;
+#ifdef SA_WAVE_PROFILE
+__shared__ int64_t s_luprof[10];           /* wavefront 0: cycles before the barrier, in the barrier, in the update, prologue, epilogue */
+#define LUP_T(x) const int64_t x = (int64_t)__builtin_readcyclecounter();
+#define LUP_ADD(k, a, b) if (wave == 0 && lane == 0) L.prof[k] += (b) - (a);
+#else
+#define LUP_T(x)
+#define LUP_ADD(k, a, b)
+#endif
+#define LU_SING 0x100000
+
+static __device__ __forceinline__ LuLds lu_lds()
+{
+    LuLds L;
+    L.A = lds_opaque((lds_f64 *)s_A); L.col = lds_opaque((lds_f64 *)&s_col[0][0]); L.invp = lds_opaque((lds_f64 *)s_invp);
+    L.piv = lds_opaque((lds_u8 *)s_piv);
+    L.ier = lds_opaque((lds_i32 *)&s_luier); L.nswaps = lds_opaque((lds_i32 *)&s_lunswaps);
+    L.info = lds_opaque((lds_i32 *)&s_luinfo[0]);
+#ifdef SA_WAVE_PROFILE
+    L.prof = lds_opaque((lds_i64 *)s_luprof);
+#else
+    L.prof = nullptr;
+#endif
+    return L;
+}
+
+static __device__ __forceinline__ void lu_pin(double &x) { asm volatile("" : "+v"(x)); }
+/* value of register slot `slot` (wave-uniform) of a column */
+#define LU_SEL(col, slot) (RS == 1 ? (col)[0] : ((slot) == 0 ? (col)[0] : (col)[RS - 1]))
+/* exchange rows (slot s1, lane l1) and (slot s2, lane l2) of a register column (rare path) */
+#define LU_SWAP_ROWS(col, s1, l1, s2, l2) do {                                                              \
+        const double v1_ = readlane_d(LU_SEL(col, s1), l1), v2_ = readlane_d(LU_SEL(col, s2), l2);        \
+        SFOR(r_, 0, RS) {                                                                                   \
+            (col)[r_] = (r_ == (s1) && lane == (l1)) ? v2_ : ((r_ == (s2) && lane == (l2)) ? v1_ : (col)[r_]); \
+        } SEND } while (0)
+
+/* noinline on purpose: the 2*LU_NC matrix registers of a lane must not compete with the integrator state of
+   wavefront 0 (inlined, the pair spilled ~1.6 KB per lane to scratch); results come back through LDS */
+static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L)
+{
+    double a[LU_NC][RS];
+    LUP_T(t_in)
+#ifdef SA_WAVE_PROFILE
+    const int64_t w_in = (int64_t)wall_clock64();
+#endif
+    wave = __builtin_amdgcn_readfirstlane(wave);            /* wave-uniform by construction: let the compiler know */
+    /* register column cc <-> matrix column ((cc / LU_NB) * SA_WAVES + wave) * LU_NB + cc % LU_NB.  All loads of the
+       matrix are issued back to back (clamped index instead of a branch per entry) */
+#define LU_COL(cc) ((((cc) / LU_NB) * SA_WAVES + wave) * LU_NB + (cc) % LU_NB)
+    typedef __attribute__((address_space(1))) double glb_f64;
+    glb_f64 *sjg = (glb_f64 *)sj;
+    if (from_saved) {
+        SFOR(cc, 0, LU_NC) {
+            const int j = LU_COL(cc);
+            SFOR(r, 0, RS) {
+                const int i = r * 64 + lane;
+                const bool ok = (j < NS && i < NS);
+                a[cc][r] = sjg[ok ? j * NS + i : 0];
+            } SEND
+        } SEND
+    } else {
+        SFOR(cc, 0, LU_NC) {
+            const int j = LU_COL(cc);
+            SFOR(r, 0, RS) {
+                const int i = r * 64 + lane;
+                const bool ok = (j < NS && i < NS);
+                a[cc][r] = L.A[ok ? j * NS + i : 0];
+            } SEND
+        } SEND
+        SFOR(cc, 0, LU_NC) {
+            const int j = LU_COL(cc);
+            SFOR(r, 0, RS) {
+                const int i = r * 64 + lane;
+                if (j < NS && i < NS) sjg[j * NS + i] = a[cc][r];
+            } SEND
+        } SEND
+    }
+    SFOR(cc, 0, LU_NC) {
+        const int j = LU_COL(cc);
+        SFOR(r, 0, RS) {
+            const int i = r * 64 + lane;
+            const double v = a[cc][r];
+            const double w = (i == j) ? FMA(c, v, 1.0) : v * c;
+            a[cc][r] = (j < NS && i < NS) ? w : 0.0;
+        } SEND
+    } SEND
+    if (wave == 0 && lane == 0) (*L.ier) = 0;
+    int nswaps = 0, ier = 0;
+#ifdef SA_WAVE_PROFILE
+    asm volatile("" :: "v"(a[0][0]), "v"(a[LU_NC - 1][RS - 1]));
+#endif
+    LUP_T(t_ld)
+    sa_barrier();
+    LUP_T(t_loop)
+    LUP_ADD(5, t_in, t_ld) LUP_ADD(6, t_ld, t_loop)
+    /* the panel round pr (which register columns the owner works on) is unrolled, the SA_WAVES panels of a round are a
+       run-time loop; no exit edges (an exit edge makes the register allocator copy the whole register matrix on
+       every iteration): panels past the end or after a zero pivot run as no-ops (zero multipliers).
+       A lone wavefront issues ONE instruction of any kind per four cycles, so what counts below is the number of
+       instructions, scalar ones included -- not only the dependent chain.  The rows of a whole round live in one
+       register slot S (compile-time): slots below S hold finished rows (no work at all), slot S is masked by the
+       lane, slots above S take part with every row. */
+    SFOR(pr, 0, LU_NPR) {
+        constexpr int S = (RS == 1) ? 0 : ((pr * SA_WAVES * LU_NB) >> 6);       /* register slot of the round's rows */
+        static_assert(S < RS || (pr * SA_WAVES * LU_NB) >= NS, "panel rows beyond the register slots");
+        constexpr int SC = S < RS ? S : RS - 1;
+#pragma nounroll
+        for (int o = 0; o < SA_WAVES; o++) {
+            const int k0 = (pr * SA_WAVES + o) * LU_NB, buf = (pr * SA_WAVES + o) & 1;
+            const int pl0 = k0 & 63;                            /* lane of the panel's first row (slot S) */
+            LUP_T(t_a)
+            if (wave == o) {
+                int word[LU_NB];
+                bool done[LU_NB];
+                double mults[LU_NB];
+                SFOR(kk, 0, LU_NB) {
+                    const int k = k0 + kk;
+                    constexpr int kc = pr * LU_NB + kk;
+                    /* a step past the end (k >= n) or after a zero pivot runs with a unit pivot and no rows below it:
+                       nothing changes, and no branch joins here (a join copies the panel's register columns) */
+                    const bool valid = (k < NS) && (ier == 0);
+                    double akk = readlane_d(a[kc][SC], pl0 + kk);
+                    /* the diagonal stays the pivot unless a row below it is strictly larger */
+                    const bool below = valid && (lane > pl0 + kk);          /* (slot S; the slots above: every row) */
+                    bool beaten = below && (fabs(a[kc][SC]) > fabs(akk));
+                    SFOR(r, SC + 1, RS) beaten = beaten || (valid && fabs(a[kc][r]) > fabs(akk)); SEND
+                    int l = k;
+                    if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
+                        /* pivot: first (lowest index) row i >= k with the largest |a(i,k)| */
+                        double best = -1.0;
+                        int bi = 1 << 20;
+                        SFOR(r, SC, RS) {
+                            const int i = r * 64 + lane;
+                            const double v = fabs(a[kc][r]);
+                            if (i >= k && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+                        } SEND
+#pragma nounroll
+                        for (int b = 0; b < 6; b++) {
+                            const double ov = shfl_d(best, lane ^ (1 << b));
+                            const int oi = shfl_i(bi, lane ^ (1 << b));
+                            const bool take = (ov > best) || (ov == best && oi < bi);
+                            best = take ? ov : best;
+                            bi = take ? oi : bi;
+                        }
+                        l = __builtin_amdgcn_readfirstlane(bi);
+                        if (l != k) {
+                            nswaps++;
+                            const int ls = (RS == 1) ? 0 : (l >> 6), ll = l & 63;
+                            SFOR(jj, 0, LU_NB) LU_SWAP_ROWS(a[pr * LU_NB + jj], SC, pl0 + kk, ls, ll); SEND
+                            akk = readlane_d(a[kc][SC], pl0 + kk);
+                        }
+                    }
+                    /* (akk is the same in every lane: tell the compiler, or everything that depends on ier turns into
+                       divergent control flow with lane-mask merges) */
+                    const bool sing = valid && __builtin_amdgcn_readfirstlane(akk == 0.0 ? 1 : 0);
+                    if (sing) {                         /* (rare; nothing below changes anything after it) */
+                        ier = k + 1;
+                        if (lane == 0) (*L.ier) = k + 1;
+                    }
+                    const bool ok = valid && !sing;
+                    const double mult = 1.0 / (ok ? akk : 1.0);
+                    done[kk] = ok;
+                    word[kk] = sing ? (LU_SING | (k & 0xff)) : (l & 0xff);
+                    mults[kk] = mult;
+                    double lc[RS];
+                    {
+                        const bool on = ok && (lane > pl0 + kk);
+                        const double v = a[kc][SC] * mult;
+                        lc[SC] = on ? v : 0.0;
+                        a[kc][SC] = on ? v : a[kc][SC];
+                    }
+                    SFOR(r, SC + 1, RS) { a[kc][r] = a[kc][r] * mult; lc[r] = ok ? a[kc][r] : 0.0; } SEND
+                    SFOR(jj, kk + 1, LU_NB) {           /* the panel's later columns */
+                        const double akj = readlane_d(a[pr * LU_NB + jj][SC], pl0 + kk);
+                        SFOR(r, SC, RS) a[pr * LU_NB + jj][r] = FMA(-akj, lc[r], a[pr * LU_NB + jj][r]); SEND
+                    } SEND
+                } SEND
+                /* the multiplier columns as they stand now (the panel's later exchanges applied), slots S and above */
+                SFOR(r, SC, RS) {
+                    SFOR(kk, 0, LU_NB) {
+                        L.col[((buf * RS + r) * 64 + lane) * LU_NB + kk] =
+                            (done[kk] && (r > SC || lane > pl0 + kk)) ? a[pr * LU_NB + kk][r] : 0.0;
+                    } SEND
+                } SEND
+                if (lane == 0) {
+                    SFOR(kk, 0, LU_NB) {
+                        L.info[buf * LU_NB + kk] = word[kk];
+                        if (done[kk]) { L.piv[k0 + kk] = (uint8_t)(word[kk] & 0xff); L.invp[k0 + kk] = mults[kk]; }
+                    } SEND
+                }
+            }
+            LUP_T(t_b)
+            sa_barrier();
+            LUP_T(t_c)
+            double lc[LU_NB][RS];
+            int word[LU_NB];
+            SFOR(kk, 0, LU_NB) word[kk] = L.info[buf * LU_NB + kk]; SEND
+            SFOR(r, SC, RS) {
+                SFOR(kk, 0, LU_NB) lc[kk][r] = L.col[((buf * RS + r) * 64 + lane) * LU_NB + kk]; SEND
+            } SEND
+            bool anyswap = false;
+            SFOR(kk, 0, LU_NB) {
+                word[kk] = __builtin_amdgcn_readfirstlane(word[kk]);
+                if (wave != o && (word[kk] & LU_SING)) ier = (ier == 0) ? k0 + kk + 1 : ier;
+                anyswap = anyswap || ((word[kk] & 0xff) != ((k0 + kk) & 0xff));
+            } SEND
+            if (anyswap) {          /* the panel's row exchanges, in order, in every other column (rare: a run-time loop,
+                                       one copy of the exchange code per panel round) */
+#pragma nounroll
+                for (int kk = 0; kk < LU_NB; kk++) {
+                    int w = word[0];
+                    SFOR(u, 1, LU_NB) w = (kk == u) ? word[u] : w; SEND
+                    const int l = w & 0xff;
+                    if (l != ((k0 + kk) & 0xff)) {
+                        const int ls = (RS == 1) ? 0 : (l >> 6), ll = l & 63;
+                        if (wave != o) {
+                            nswaps++;
+                            SFOR(cc, pr * LU_NB, pr * LU_NB + LU_NB) LU_SWAP_ROWS(a[cc], SC, pl0 + kk, ls, ll); SEND
+                        }
+                        SFOR(cc, 0, pr * LU_NB) LU_SWAP_ROWS(a[cc], SC, pl0 + kk, ls, ll); SEND
+                        SFOR(cc, (pr + 1) * LU_NB, LU_NC) LU_SWAP_ROWS(a[cc], SC, pl0 + kk, ls, ll); SEND
+                    }
+                }
+            }
+            /* trailing update of this wavefront's later panels (of this round only behind the owner): step-outer,
+               column-inner in groups of LU_GC columns -- the broadcasts of a group, then its FMAs, a scheduling barrier
+               (left alone the scheduler hoists every broadcast of a step to the front, runs out of scalar registers and
+               spills them through v_writelane / v_readlane: three lane operations per value instead of one).
+               Branch-free: the multiplier of a row that takes no part in a step is zero; slots below S hold finished
+               rows only and are skipped.  (denseGETRF skips a column whose pivot-row entry is zero; a - 0*l equals
+               a -- only the sign of a zero entry can differ -- so the factors compare equal and no result changes.) */
+#define LU_GC 4
+#define LU_UPD_GROUP(C0, C1, KK) {                                                                               \
+                double akj_[LU_GC];                                                                                \
+                SFOR(cc, C0, C1) akj_[cc - (C0)] = readlane_d(a[cc][SC], pl0 + (KK)); SEND                         \
+                SFOR(cc, C0, C1) { SFOR(r, SC, RS) a[cc][r] = FMA(-akj_[cc - (C0)], lc[KK][r], a[cc][r]); SEND } SEND \
+                /* pin the results here: the rows of the slots above S are not read again before the end of the        \
+                   factorisation, and the compiler otherwise sinks their whole FMA chains below everything else --     \
+                   keeping every broadcast value alive (spilled lane by lane) until then */                             \
+                SFOR(cc, C0, C1) { SFOR(r, SC, RS) lu_pin(a[cc][r]); SEND } SEND                                        \
+                __builtin_amdgcn_sched_barrier(0); }
+            /* (one straight-line block for the later rounds' columns, then ONE branch for the panel of this round:
+               a branch per step lets the compiler sink the FMAs of a step below the next step's branch -- and
+               spill the scalar registers that wait there) */
+            SFOR(kk, 0, LU_NB) {
+                SFOR(g, 0, (LU_NC - (pr + 1) * LU_NB + LU_GC - 1) / LU_GC) {
+                    constexpr int c0 = (pr + 1) * LU_NB + g * LU_GC, c1 = (c0 + LU_GC < LU_NC) ? c0 + LU_GC : LU_NC;
+                    LU_UPD_GROUP(c0, c1, kk)
+                } SEND
+            } SEND
+            if (wave > o) {
+                SFOR(kk, 0, LU_NB) LU_UPD_GROUP(pr * LU_NB, pr * LU_NB + LU_NB, kk) SEND
+            }
+#undef LU_UPD_GROUP
+            LUP_T(t_d)
+            LUP_ADD(0, t_a, t_b) LUP_ADD(1, t_b, t_c) LUP_ADD(2, t_c, t_d)
+        }
+    } SEND
+    LUP_T(t_out)
+    if (ier == 0) {
+        SFOR(cc, 0, LU_NC) {
+            const int j = LU_COL(cc);
+            SFOR(r, 0, RS) { if (j < NS && r * 64 + lane < NS) L.A[j * NS + r * 64 + lane] = a[cc][r]; } SEND
+        } SEND
+    }
+    if (wave == 0 && lane == 0) (*L.nswaps) = nswaps;
+    LUP_T(t_wr)
+    sa_barrier();
+    LUP_T(t_end)
+    LUP_ADD(4, t_in, t_end) LUP_ADD(7, t_out, t_wr) LUP_ADD(8, t_wr, t_end)
+#ifdef SA_WAVE_PROFILE
+    if (wave == 0 && lane == 0) L.prof[3] += (int64_t)wall_clock64() - w_in;        /* 10 ns ticks over the same span */
+#endif
+#undef LU_COL
+}
+#elif SA_WAVES > 1
 #define LU_NC ((NS + SA_WAVES - 1) / SA_WAVES)
 __shared__ double s_col[2][RS * 64];
 __shared__ double s_invp[W_NS];
 __shared__ int s_luier, s_lunswaps, s_luinfo[2];
 #ifdef SA_WAVE_PROFILE
-__shared__ int64_t s_luprof[5];           /* wavefront 0: cycles before the barrier, in the barrier, in the update, prologue, epilogue */
+__shared__ int64_t s_luprof[10];           /* wavefront 0: cycles before the barrier, in the barrier, in the update, prologue, epilogue */
 #define LUP_T(x) const int64_t x = (int64_t)__builtin_readcyclecounter();
 #define LUP_ADD(k, a, b) if (wave == 0 && lane == 0) L.prof[k] += (b) - (a);
 #else
@@ -1328,8 +1633,13 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
     SFOR(r, 0, RS) logpos[r] = (r * 64 + lane < NS) ? r * 64 + lane : -1; SEND
     if (wave == 0 && lane == 0) (*L.ier) = 0;
     int nswaps = 0, ier = 0;
+#ifdef SA_WAVE_PROFILE
+    asm volatile("" :: "v"(a[0][0]), "v"(a[LU_NC - 1][RS - 1]));
+#endif
+    LUP_T(t_ld)
     sa_barrier();
     LUP_T(t_loop)
+    LUP_ADD(5, t_in, t_ld) LUP_ADD(6, t_ld, t_loop)
     /* kcr (the owner's register column) is a compile-time index: the ownership round is unrolled (LU_NC copies of
        the step), the SA_WAVES steps inside a round are a run-time loop.  (Measured alternatives that were slower:
        one run-time loop over k with compare-chain column selects; branch-free FMA blocks with scalar zero
@@ -1452,9 +1762,10 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
         } SEND
     }
     if (wave == 0 && lane == 0) (*L.nswaps) = nswaps;
+    LUP_T(t_wr)
     sa_barrier();
     LUP_T(t_end)
-    LUP_ADD(4, t_in, t_end)
+    LUP_ADD(4, t_in, t_end) LUP_ADD(7, t_out, t_wr) LUP_ADD(8, t_wr, t_end)
 #ifdef SA_WAVE_PROFILE
     if (wave == 0 && lane == 0) L.prof[3] += (int64_t)wall_clock64() - w_in;        /* 10 ns ticks over the same span */
 #endif
@@ -2454,7 +2765,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     if (inst >= a.B) return;
     if (threadIdx.x == 0) s_nwaves = SA_WAVES;
 #if defined(SA_WAVE_PROFILE) && SA_WAVES > 1
-    if (threadIdx.x == 0) { s_luprof[0] = 0; s_luprof[1] = 0; s_luprof[2] = 0; s_luprof[3] = 0; s_luprof[4] = 0; }
+    if (threadIdx.x == 0) { for (int i = 0; i < 10; i++) s_luprof[i] = 0; }
 #endif
     if (sa_wave_index() != 0) {
         worker_loop<true>(a.pr + (int64_t)inst * a.rem_stride, ws_inst(a.ws, inst) + WS_OUT);
@@ -2607,6 +2918,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
 #if SA_WAVES > 1
         st[5] = s_luprof[0]; st[6] = s_luprof[1]; st[7] = s_luprof[2];      /* LU: cycles pre-barrier / barrier / update */
         st[8] = s_luprof[3] + (s_luprof[4] << 32);                          /* ... prologue | epilogue << 32 */
+#ifdef SA_LU_PROFILE_SEGMENTS       /* load + form | first barrier | write-back | last barrier, cycles (replace the section slots) */
+        st[9] = s_luprof[5]; st[10] = s_luprof[6]; st[11] = s_luprof[7]; st[12] = s_luprof[8];
+#endif
 #endif
 #endif
         SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND

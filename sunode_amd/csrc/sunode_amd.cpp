@@ -154,6 +154,28 @@ static int apply_options(sa_solver *s, const sa_options *opt)
 extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
 extern "C" const char *sa_last_error(void) { return g_err.c_str(); }
 
+extern "C" int sa_device_count(int32_t *count)
+{
+    if (!count) return fail(SA_ERR_ARG, "null argument");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    *count = ndev;
+    return SA_OK;
+}
+
+extern "C" int sa_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes)
+{
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(SA_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (free_bytes) *free_bytes = (int64_t)free_b;
+    if (total_bytes) *total_bytes = (int64_t)total_b;
+    return SA_OK;
+}
+
 extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solver **out)
 {
     if (!path || !opt || !out) return fail(SA_ERR_ARG, "null argument");

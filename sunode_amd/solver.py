@@ -77,6 +77,12 @@ def _flat_state(problem, y0) -> np.ndarray:
     return y0
 
 
+def _rows(a: np.ndarray, lo: int, hi: int, per_instance) -> np.ndarray:
+    """Rows [lo, hi) of a per-instance array; arrays shared by the batch (``per_instance`` false: no differentiated
+    parameters / a shared remainder vector) are passed whole."""
+    return a[lo:hi] if per_instance else a
+
+
 def _is_device_tensor(x) -> bool:
     return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
 
@@ -90,11 +96,98 @@ class _EngineMixin:
     def _native_kwargs(self) -> Dict[str, Any]:
         raise NotImplementedError
 
+    def _engine_kwargs(self) -> Dict[str, Any]:
+        """Keyword arguments of one NativeSolver handle (without device / arena share)."""
+        return self._native_kwargs()
+
+    # -- devices (SURVEY.md section 8e: the batch shards by instance, no exchange step) ------------
+    # ``devices=[0, 1, ..., 7]``: ONE Python process drives several GPUs -- the reference's call pattern is one solver
+    # object inside one PyMC process (/root/reference/sunode/wrappers/as_pytensor.py:279-344).  One ``sa_solver``
+    # handle (own stream, own trajectory arena) per entry; every batch call splits the instances into contiguous
+    # balanced shards (parallel.shard_bounds), issues the shards from one thread per handle (ctypes releases the
+    # GIL for the duration of the native call) and the handles write into disjoint row ranges of the caller's
+    # arrays.  An ordinal may appear more than once (two handles on one device: the arena budget of the device is
+    # split between them).  Results are those of the one-handle call bit for bit (instances are independent).
+    def _init_devices(self, device, devices):
+        if devices is None:
+            devices = [int(device)]
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("devices must name at least one HIP device ordinal")
+        if any(d < 0 for d in devices):
+            raise ValueError("negative device ordinal")
+        self._devices = devices
+        self._device = devices[0]
+        self._natives = None
+        self._pool = None
+
+    def _arena_share(self, device: int) -> int:
+        """arena_bytes of ONE handle on ``device``: the device's budget divided by the handles that share it.
+        With one handle per device the library's own default applies (0)."""
+        sharing = self._devices.count(device)
+        budget = getattr(self, "_arena_bytes", 0)
+        if sharing == 1:
+            return budget
+        if not budget:          # the library default, evaluated once for the device instead of once per handle
+            free_b, _total = _native.device_memory(device)
+            budget = min(96 << 30, int(0.6 * free_b))
+        return max(budget // sharing, 1)
+
+    def _engines(self):
+        if self._natives is None:
+            kw = self._engine_kwargs()
+            natives = []
+            for d in self._devices:
+                k = dict(kw, device=d)
+                if "arena_bytes" in k:
+                    k["arena_bytes"] = self._arena_share(d)
+                natives.append(_native.NativeSolver(self._source, n_states=self._problem.n_states, **k))
+            self._natives = natives
+            self._native = natives[0]
+        return self._natives
+
     def _engine(self) -> _native.NativeSolver:
-        if self._native is None:
-            self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
-                                                **self._native_kwargs())
-        return self._native
+        return self._engines()[0]
+
+    def _shards(self, B: int):
+        """[(handle, lo, hi)] -- contiguous balanced instance ranges, empty ones dropped."""
+        from sunode_amd.parallel import shard_bounds
+        engines = self._engines()
+        out = []
+        for r, eng in enumerate(engines):
+            lo, hi = shard_bounds(B, r, len(engines))
+            if hi > lo:
+                out.append((eng, lo, hi))
+        return out
+
+    def _run_shards(self, shards, call):
+        """call(handle, lo, hi) for every shard: inline for one, one thread per handle otherwise; the first
+        exception (in shard order) propagates after all shards have finished."""
+        if len(shards) == 1:
+            call(*shards[0])
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self._devices), thread_name_prefix="sunode_amd")
+        futures = [self._pool.submit(call, *sh) for sh in shards]
+        errors = []
+        for f in futures:
+            try:
+                f.result()
+            except Exception as exc:        # noqa: BLE001 -- re-raised below
+                errors.append(exc)
+        if errors:
+            raise errors[0]
+
+    def last_kernel_ms(self):
+        """(forward, backward) kernel time of the last batch call: the slowest handle's (they run concurrently)."""
+        ms = [e.last_kernel_ms() for e in self._engines()]
+        return max(m[0] for m in ms), max(m[1] for m in ms)
+
+    def _set_retries(self, **kw):
+        for eng in self._engines():
+            if any(eng._opt_kw[k] != v for k, v in kw.items()):
+                eng.set_options(**kw)
 
     # -- reference parameter API (solver.py:435-465 / 650-680) ----------------------------
     @property
@@ -170,7 +263,7 @@ class Solver(_EngineMixin):
     def __init__(self, problem, *, abstol: float = 1e-10, reltol: float = 1e-10, sens_mode: Optional[str] = None,
                  scaling_factors: Optional[np.ndarray] = None, constraints: Optional[np.ndarray] = None,
                  solver="BDF", linear_solver="dense", linear_solver_kwargs=None, mxsteps: int = 500,
-                 device: int = 0):
+                 device: int = 0, devices=None):
         if sens_mode in (None, False):
             sens_mode = None
         elif sens_mode == "staggered1":
@@ -212,11 +305,11 @@ class Solver(_EngineMixin):
         self._compute_sens = sens_mode is not None
         self._scaling_factors = scaling_factors
         self._mxsteps = mxsteps
-        self._device = device
+        self._init_devices(device, devices)
         self._set_tolerances(abstol, reltol)
         self._state_names = ["_problem", "_user_data", "_constraints", "_abstol", "_reltol",
                              "_linear_solver_kind", "_linear_solver_kwargs", "_sens_mode", "_scaling_factors",
-                             "_mxsteps", "_device", "_state_names"]
+                             "_mxsteps", "_device", "_devices", "_state_names"]
         self._init_native()
 
     def _init_native(self):
@@ -224,13 +317,11 @@ class Solver(_EngineMixin):
         # compile at construction like the reference JITs; sensitivity solves use their own build
         _native.build_code_object(self._source, sens=self._compute_sens, constraints=self._constraints is not None)
         self._native = None
+        self._natives = None
+        self._pool = None
 
-    def _engine(self) -> _native.NativeSolver:
-        if self._native is None:
-            self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
-                                                sens=self._compute_sens, constraints=self._constraints,
-                                                **self._native_kwargs())
-        return self._native
+    def _engine_kwargs(self):
+        return dict(self._native_kwargs(), sens=self._compute_sens, constraints=self._constraints)
 
     def __getstate__(self):
         return {name: self.__dict__[name] for name in self._state_names}
@@ -253,8 +344,7 @@ class Solver(_EngineMixin):
         self._atol, self._rtol = atol, rtol
 
     def _native_kwargs(self):
-        return dict(device=self._device, rtol=float(self._rtol), atol=self._atol, mxstep=self._mxsteps,
-                    traj_capacity=2)
+        return dict(rtol=float(self._rtol), atol=self._atol, mxstep=self._mxsteps, traj_capacity=2)
 
     def make_output_buffers(self, tvals):
         """y_out, or (y_out, sens_out) when sensitivities are computed (reference solver.py:419-426)."""
@@ -291,9 +381,7 @@ class Solver(_EngineMixin):
         (y_out [B,n_t,n], sens_out [B,n_t,p,n], status [B], stats [B,16]); ``sens0`` is [B,p,n] or [p,n]."""
         if not self._compute_sens:
             raise ValueError("construct the Solver with sens_mode='simultaneous' or 'staggered'")
-        eng = self._engine()
-        if max_retries != eng._opt_kw["max_retries_fwd"]:
-            eng.set_options(max_retries_fwd=max_retries)
+        self._set_retries(max_retries_fwd=max_retries)
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         n, p = self._problem.n_states, self._problem.n_params
         sens0 = np.ascontiguousarray(np.broadcast_to(np.asarray(sens0, dtype=np.float64), (B, p, n)))
@@ -302,23 +390,31 @@ class Solver(_EngineMixin):
         sens_out = np.zeros((B, len(tvals), p, n))
         status = np.zeros(B, np.int32)
         stats = np.zeros((B, _native.N_STATS), np.int64)
-        eng.solve_sens(_native.SA_MEM_HOST, 0 if self._sens_mode == "simultaneous" else 1, self._scaling_factors,
-                       B, y0, ps, pr, stride, sens0 if sens0.size else np.zeros(1), t0, tvals, len(tvals), y_out,
-                       sens_out if sens_out.size else np.zeros(1), status, stats)
+        ism = 0 if self._sens_mode == "simultaneous" else 1
+
+        def call(eng, lo, hi):
+            eng.solve_sens(_native.SA_MEM_HOST, ism, self._scaling_factors, hi - lo, y0[lo:hi],
+                           _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride), stride,
+                           sens0[lo:hi] if sens0.size else np.zeros(1), t0, tvals, len(tvals), y_out[lo:hi],
+                           sens_out[lo:hi] if sens_out.size else np.zeros(1), status[lo:hi], stats[lo:hi])
+        self._run_shards(self._shards(B), call)
         return y_out, sens_out, status, stats
 
     def solve_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5
                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """``solve`` for B parameter draws at once: returns (y_out [B,n_t,n], status [B], stats [B,16])."""
-        eng = self._engine()
-        if max_retries != eng._opt_kw["max_retries_fwd"]:
-            eng.set_options(max_retries_fwd=max_retries)
+        self._set_retries(max_retries_fwd=max_retries)
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
+        p = self._problem.n_params
         y_out = np.zeros((B, len(tvals), self._problem.n_states))
         status = np.zeros(B, np.int32)
         stats = np.zeros((B, _native.N_STATS), np.int64)
-        eng.solve(_native.SA_MEM_HOST, B, y0, ps, pr, stride, t0, tvals, len(tvals), y_out, status, stats)
+
+        def call(eng, lo, hi):
+            eng.solve(_native.SA_MEM_HOST, hi - lo, y0[lo:hi], _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride),
+                      stride, t0, tvals, len(tvals), y_out[lo:hi], status[lo:hi], stats[lo:hi])
+        self._run_shards(self._shards(B), call)
         return y_out, status, stats
 
 
@@ -344,7 +440,7 @@ class AdjointSolver(_EngineMixin):
                  constraints=None, solver="BDF", adjoint_solver="BDF", backward_abstol=1e-10,
                  backward_reltol=1e-10, quad_abstol=1e-10, quad_reltol=1e-10, mxsteps: int = 500,
                  max_steps: Optional[int] = None, arena_gib: Optional[float] = None, device: int = 0,
-                 compact_trajectory: Optional[bool] = None):
+                 compact_trajectory: Optional[bool] = None, devices=None):
         if solver not in ("BDF", "ADAMS"):
             raise ValueError(f"Unknown solver {solver}.")
         if adjoint_solver not in ("BDF", "ADAMS"):
@@ -366,8 +462,8 @@ class AdjointSolver(_EngineMixin):
         self._mxsteps = mxsteps
         self._max_steps = int(min(max_steps if max_steps is not None else checkpoint_n + 1, checkpoint_n + 1,
                                   2**31 - 1))
-        self._arena_bytes = int(arena_gib * 2**30) if arena_gib else 0
-        self._device = device
+        self._arena_bytes = int(arena_gib * 2**30) if arena_gib else 0      # per DEVICE (handles sharing one split it)
+        self._init_devices(device, devices)
         self._source = problem.native_source()
         # (bdf_kernels.hip and bdf_wave.hip carry the compact-record option)
         if compact_trajectory is None:        # measured (profiles/r03_compact_trajectory.txt): pays from three states on
@@ -379,12 +475,9 @@ class AdjointSolver(_EngineMixin):
         self._native = None
         self._last_forward = None
 
-    def _engine(self) -> _native.NativeSolver:
-        if self._native is None:
-            self._native = _native.NativeSolver(self._source, n_states=self._problem.n_states,
-                                                constraints=self._constraints, hermite=self._hermite,
-                                                compact=self._compact, **self._native_kwargs())
-        return self._native
+    def _engine_kwargs(self):
+        return dict(self._native_kwargs(), constraints=self._constraints, hermite=self._hermite,
+                    compact=self._compact)
 
     def _set_tolerances(self, atol=None, rtol=None):
         atol, rtol = np.array(atol, dtype=float), np.array(rtol, dtype=float)
@@ -396,7 +489,7 @@ class AdjointSolver(_EngineMixin):
 
     def _native_kwargs(self):
         rB, aB, rQ, aQ = self._tolB
-        return dict(device=self._device, rtol=float(self._rtol), atol=self._atol, rtolB=rB, atolB=aB,
+        return dict(rtol=float(self._rtol), atol=self._atol, rtolB=rB, atolB=aB,
                     rtolQB=rQ, atolQB=aQ, mxstep=self._mxsteps, traj_capacity=self._max_steps,
                     arena_bytes=self._arena_bytes)
 
@@ -434,6 +527,10 @@ class AdjointSolver(_EngineMixin):
             code = int(status[0])
             if code == -1:
                 raise SolverError("Too many solver retries.")
+            if code == -9001:
+                raise SolverError(f"Solving ode failed: the stored forward trajectory does not fit the arena budget "
+                                  f"or exceeds max_steps={self._max_steps} points (SA_STATUS_ARENA_FULL); raise "
+                                  "arena_gib / max_steps")
             raise SolverError(f"Solving ode failed: {ERRORS.get(code, 'unknown')} ({code})")
         grad_out[...] = g[0]
         lamda_out[...] = lam[0]
@@ -445,17 +542,20 @@ class AdjointSolver(_EngineMixin):
     # -- batch API -------------------------------------------------------------------------
     def solve_forward_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5):
         """B forward solves with stored trajectories: (y_out [B,n_t,n], status [B], stats [B,16])."""
-        eng = self._engine()
-        if max_retries != eng._opt_kw["max_retries_fwd"]:
-            eng.set_options(max_retries_fwd=max_retries)
+        self._set_retries(max_retries_fwd=max_retries)
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
+        p = self._problem.n_params
         y_out = np.zeros((B, len(tvals), self._problem.n_states))
         status = np.zeros(B, np.int32)
         stats = np.zeros((B, _native.N_STATS), np.int64)
-        eng.solve(_native.SA_MEM_HOST, B, y0, ps, pr, stride, t0, tvals, len(tvals), y_out, status, stats,
-                  adjoint=True)
-        self._last_forward = (B, ps, pr, stride)
+        shards = self._shards(B)
+
+        def call(eng, lo, hi):
+            eng.solve(_native.SA_MEM_HOST, hi - lo, y0[lo:hi], _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride),
+                      stride, t0, tvals, len(tvals), y_out[lo:hi], status[lo:hi], stats[lo:hi], adjoint=True)
+        self._run_shards(shards, call)
+        self._last_forward = (B, ps, pr, stride, shards)     # every handle keeps ITS shard's trajectories
         return y_out, status, stats
 
     def solve_backward_batch(self, t0, tend, tvals, grads, *, max_retries=50, return_all=False):
@@ -467,10 +567,8 @@ class AdjointSolver(_EngineMixin):
         after every jump, rows ordered as the reference's ``lamda_all_out[-i]`` (solver.py:778-781)."""
         if self._last_forward is None:
             raise SolverError("solve_backward called before solve_forward")
-        eng = self._engine()
-        if max_retries != eng._opt_kw["max_retries_bwd"]:
-            eng.set_options(max_retries_bwd=max_retries)
-        B, ps, pr, stride = self._last_forward
+        self._set_retries(max_retries_bwd=max_retries)
+        B, ps, pr, stride, shards = self._last_forward
         n, p = self._problem.n_states, self._problem.n_params
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         n_t = len(tvals)
@@ -487,8 +585,19 @@ class AdjointSolver(_EngineMixin):
         stats = np.zeros((B, _native.N_STATS), np.int64)
         lam_all = np.zeros((B, n_t, max(n, 1))) if return_all else None
         quad_all = np.zeros((B, n_t, max(p, 1))) if return_all else None
-        eng.solve_backward(_native.SA_MEM_HOST, B, ps, pr, stride, t0, tend, tvals, n_t, grads, gstride,
-                           grad_out, lamda_out, status, stats, lam_all, quad_all)
+
+        def call(eng, lo, hi):
+            eng.solve_backward(_native.SA_MEM_HOST, hi - lo, _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride), stride,
+                               t0, tend, tvals, n_t, _rows(grads, lo, hi, gstride), gstride, grad_out[lo:hi],
+                               lamda_out[lo:hi], status[lo:hi], stats[lo:hi],
+                               lam_all[lo:hi] if return_all else None, quad_all[lo:hi] if return_all else None)
+        self._run_shards(shards, call)
+        if (status == -9001).any():
+            import warnings
+            warnings.warn("solve_backward: %d instance(s) returned SA_STATUS_ARENA_FULL (a 64-instance group of stored "
+                          "trajectories exceeds the arena budget, or an instance more than max_steps=%d points); their "
+                          "gradients are NaN -- raise AdjointSolver(arena_gib=..., max_steps=...)"
+                          % (int((status == -9001).sum()), self._max_steps), RuntimeWarning, stacklevel=2)
         if return_all:
             return grad_out[:, :p], lamda_out[:, :n], status, stats, lam_all[:, :, :n], quad_all[:, :, :p]
         return grad_out[:, :p], lamda_out[:, :n], status, stats

@@ -1,0 +1,211 @@
+"""One Python process driving several GPUs: ``AdjointSolver(problem, devices=[...])`` / ``Solver(..., devices=[...])``
+(the reference's call pattern is one solver object inside one PyMC process,
+/root/reference/sunode/wrappers/as_pytensor.py:279-344).
+
+CPU: the sharding / threading / arena-split logic against a recording fake of the native handle.
+GPU (-m gpu, one device on the box): ``devices=[0, 0]`` -- two handles, two streams, two arenas on one device -- must
+equal the one-handle result bit for bit, through the batch API and under the batched pytensor Op's solver calls.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_problem
+
+
+class FakeNative:
+    """Records what a NativeSolver would be asked to do and fills the outputs with values that identify the instance
+    (so a row written by the wrong shard, or to the wrong place, shows)."""
+    created = []
+    N_STATS = 16
+    rendezvous = None           # threading.Barrier: every handle's forward call must be in flight at the same time
+
+    def __init__(self, source, *, device=0, arena_bytes=0, **kw):
+        self.device, self.arena_bytes, self.kw = device, arena_bytes, kw
+        self._opt_kw = dict(max_retries_fwd=5, max_retries_bwd=50)
+        self.calls = []
+        FakeNative.created.append(self)
+
+    def set_options(self, **kw):
+        self._opt_kw.update(kw)
+
+    def solve(self, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats, adjoint=False):
+        self.calls.append(("forward" if adjoint else "solve", B, threading.get_ident()))
+        if FakeNative.rendezvous is not None:
+            FakeNative.rendezvous.wait(timeout=30)
+        assert y0.shape[0] == B and y_out.shape[0] == B and status.shape == (B,) and y_out.flags["C_CONTIGUOUS"]
+        self.last_ps = np.array(ps[:B]) if np.ndim(ps) == 2 else None
+        y_out[...] = y0[:, None, :] * (1.0 + np.asarray(tvals)[None, :, None]) + (ps[:, :1, None] if np.ndim(ps) == 2 else 0.0)
+        status[...] = 0
+        stats[:, 0] = 100 + self.device
+
+    def solve_backward(self, mem, B, ps, pr, rem_stride, t0, tend, tvals, n_t, grads, gstride, grad_out, lamda_out,
+                       status, stats, lamda_all=None, quad_all=None):
+        self.calls.append(("backward", B, threading.get_ident()))
+        assert grad_out.shape[0] == B and lamda_out.shape[0] == B
+        np.testing.assert_array_equal(ps[:B], self.last_ps)          # the shard this handle integrated forward
+        g = grads if gstride == 0 else grads.sum(axis=(1, 2))[:, None]
+        grad_out[...] = ps[:B, :grad_out.shape[1]] * 2.0 + (0.0 if gstride == 0 else g)
+        lamda_out[...] = -1.0 - ps[:B, :1]
+        status[...] = 0
+        if lamda_all is not None:
+            lamda_all[...] = 7.0
+            quad_all[...] = 8.0
+
+    def solve_sens(self, mem, ism, scaling, B, y0, ps, pr, rem_stride, sens0, t0, tvals, n_t, y_out, sens_out,
+                   status, stats):
+        self.calls.append(("sens", B, threading.get_ident()))
+        y_out[...] = y0[:, None, :]
+        sens_out[...] = ps[:, None, :, None]
+        status[...] = 0
+
+    def last_kernel_ms(self):
+        return 1.0 + self.device, 2.0 + self.device
+
+
+@pytest.fixture
+def fake_native(monkeypatch):
+    from sunode_amd import _native
+    FakeNative.created = []
+    monkeypatch.setattr(_native, "NativeSolver", FakeNative)
+    monkeypatch.setattr(_native, "device_memory", lambda d: (200 << 30, 288 << 30))
+    return FakeNative
+
+
+def _lv_inputs(B):
+    from tools.problems import lv_batch
+    d = lv_batch(B)
+    return d, d["params"][:, :2], d["params"][:, 2:]
+
+
+def test_shards_are_contiguous_balanced_and_land_in_the_callers_rows(fake_native):
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("lv")
+    B = 37
+    d, ps, pr = _lv_inputs(B)
+    sol = AdjointSolver(prob, devices=[0, 1, 2, 3], arena_gib=8)
+    fake_native.rendezvous = threading.Barrier(4)       # passes only if the four calls overlap in time
+    try:
+        y, st, stats = sol.solve_forward_batch(0.0, d["tvals"], d["y0"], ps, pr)
+    finally:
+        fake_native.rendezvous = None
+    handles = fake_native.created
+    assert [h.device for h in handles] == [0, 1, 2, 3]
+    assert [h.arena_bytes for h in handles] == [8 << 30] * 4            # one handle per device: the whole budget each
+    assert [h.calls[0][1] for h in handles] == [10, 9, 9, 9]            # balanced contiguous shards
+    assert len({h.calls[0][2] for h in handles}) == 4                    # one host thread per handle
+    want = d["y0"][:, None, :] * (1.0 + d["tvals"][None, :, None]) + ps[:, :1, None]
+    np.testing.assert_array_equal(y, want)
+    np.testing.assert_array_equal(stats[:, 0], np.repeat([100, 101, 102, 103], [10, 9, 9, 9]))
+    grads = np.cos(np.arange(B * len(d["tvals"]) * 2.0)).reshape(B, len(d["tvals"]), 2)
+    g, lam, stb, _ = sol.solve_backward_batch(d["tvals"][-1], 0.0, d["tvals"], grads)     # per-instance cotangents
+    np.testing.assert_array_equal(g, ps * 2.0 + grads.sum(axis=(1, 2))[:, None])
+    np.testing.assert_array_equal(lam, np.tile(-1.0 - ps[:, :1], (1, 2)))
+    g2, lam2, _, _, la, qa = sol.solve_backward_batch(d["tvals"][-1], 0.0, d["tvals"], grads[0], return_all=True)
+    np.testing.assert_array_equal(g2, ps * 2.0)                          # shared cotangent: passed whole to every handle
+    assert (la == 7.0).all() and (qa == 8.0).all()
+    assert sol.last_kernel_ms() == (4.0, 5.0)                            # the slowest handle's
+
+
+def test_handles_sharing_a_device_split_its_arena_budget(fake_native):
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("lv")
+    d, ps, pr = _lv_inputs(5)
+    sol = AdjointSolver(prob, devices=[0, 0, 1], arena_gib=10)
+    sol.solve_forward_batch(0.0, d["tvals"], d["y0"], ps, pr)
+    assert [h.arena_bytes for h in fake_native.created] == [5 << 30, 5 << 30, 10 << 30]
+    fake_native.created.clear()
+    sol = AdjointSolver(prob, devices=[0, 0])                           # no explicit budget: the library default
+    sol.solve_forward_batch(0.0, d["tvals"], d["y0"], ps, pr)           # (96 GiB, at most 60 % of the free HBM) ONCE
+    assert [h.arena_bytes for h in fake_native.created] == [48 << 30, 48 << 30]
+    fake_native.created.clear()
+    sol = AdjointSolver(prob)                                            # default: one handle, the library decides
+    sol.solve_forward_batch(0.0, d["tvals"], d["y0"], ps, pr)
+    assert [(h.device, h.arena_bytes) for h in fake_native.created] == [(0, 0)]
+    assert len({c[2] for c in fake_native.created[0].calls}) == 1 and \
+        fake_native.created[0].calls[0][2] == threading.get_ident()     # ... and no thread
+
+
+def test_more_handles_than_instances_and_forward_solver(fake_native):
+    from sunode_amd.solver import Solver
+    prob = make_problem("lv")
+    d, ps, pr = _lv_inputs(3)
+    sol = Solver(prob, devices=[0, 1, 2, 3, 4, 5, 6, 7])
+    y, st, _ = sol.solve_batch(0.0, d["tvals"], d["y0"], ps, pr)
+    assert [len(h.calls) for h in fake_native.created] == [1, 1, 1, 0, 0, 0, 0, 0]      # empty shards are not launched
+    np.testing.assert_array_equal(y, d["y0"][:, None, :] * (1.0 + d["tvals"][None, :, None]) + ps[:, :1, None])
+    sol = Solver(prob, devices=[0, 1], sens_mode="simultaneous")
+    y, S, st, _ = sol.solve_sens_batch(0.0, d["tvals"], d["y0"], ps, pr, np.zeros((2, 2)))
+    np.testing.assert_array_equal(S, np.broadcast_to(ps[:, None, :, None], S.shape))
+    with pytest.raises(ValueError):
+        Solver(prob, devices=[])
+
+
+def test_a_failing_shard_raises_after_the_others_finished(fake_native, monkeypatch):
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("lv")
+    d, ps, pr = _lv_inputs(8)
+    done = []
+
+    def solve(self, mem, B, *a, **k):
+        if self.device == 1:
+            raise RuntimeError("device 1 lost")
+        done.append(self.device)
+    monkeypatch.setattr(FakeNative, "solve", solve)
+    sol = AdjointSolver(prob, devices=[0, 1, 2])
+    with pytest.raises(RuntimeError, match="device 1 lost"):
+        sol.solve_forward_batch(0.0, d["tvals"], d["y0"], ps, pr)
+    assert sorted(done) == [0, 2]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lv", "seir"])
+def test_two_handles_on_one_device_equal_one_handle(name):
+    """devices=[0, 0]: two handles (two streams, two arenas, the device's budget split) driven from two host threads
+    give the one-handle results bit for bit -- forward states, counters, gradients with per-instance cotangents."""
+    from sunode_amd.solver import AdjointSolver
+    from tools.problems import lv_batch, seir_batch
+    prob = make_problem(name)
+    B = 1000 if name == "lv" else 200
+    if name == "lv":
+        d = lv_batch(B); ps, pr = d["params"][:, :2], d["params"][:, 2:]
+    else:
+        d = seir_batch(B); ps, pr = d["ps"], d["pr"]
+    tv = d["tvals"]
+    n = prob.n_states
+    rng = np.random.RandomState(3)
+    grads = rng.randn(B, len(tv), n)
+    res = {}
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        sol = AdjointSolver(prob, abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8,
+                            quad_abstol=1e-8, quad_reltol=1e-8, devices=devs, arena_gib=6)
+        y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+        g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+        assert (st == 0).all() and (stb == 0).all()
+        assert len(sol._engines()) == len(devs)
+        assert [e._opt_kw["arena_bytes"] for e in sol._engines()] == [(6 << 30) // len(devs)] * len(devs)
+        res[len(devs)] = (y, stats[:, :9], g, lam, statsb[:, :8])
+    for k in (2, 3):
+        for a, b in zip(res[1], res[k]):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_forward_solver_and_sensitivities_on_two_handles():
+    from sunode_amd.solver import Solver
+    from tools.problems import lv_batch
+    prob = make_problem("lv")
+    d = lv_batch(300)
+    ps, pr = d["params"][:, :2], d["params"][:, 2:]
+    res = {}
+    for devs in ([0], [0, 0]):
+        sol = Solver(prob, abstol=1e-8, reltol=1e-8, sens_mode="staggered", devices=devs)
+        res[len(devs)] = sol.solve_sens_batch(0.0, d["tvals"], d["y0"], ps, pr, np.zeros((2, 2)))
+    for a, b in zip(res[1], res[2]):
+        np.testing.assert_array_equal(a, b)
+    from sunode_amd import _native
+    assert _native.device_count() >= 1
+    free_b, total_b = _native.device_memory(0)
+    assert 0 < free_b <= total_b and total_b > (100 << 30)             # MI355X: 288 GB

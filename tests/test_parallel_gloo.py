@@ -146,6 +146,35 @@ def test_bench_rank_function_two_ranks_gloo(tmp_path):
     assert line["work"]["fwd_steps_mean"] == float(sf[:, 0].mean())
 
 
+def test_bench_single_process_launcher_two_devices(monkeypatch):
+    """`bench.py --gpus 2 --single-process`: one process, one engine + host thread per device, no process group;
+    the engines get the two contiguous halves of the global 2 x B batch (the per-device solve played by the CPU
+    oracle), the line has the contract fields of the one-process-per-GPU launcher."""
+    import bench
+    from sunode_amd import _native
+    monkeypatch.setattr(_native, "device_memory", lambda d: (200 << 30, 288 << 30))
+    made = []
+
+    def factory(name, prob, batch, tol, device, arena_bytes=0):
+        e = _OracleEngine(name, prob, batch, tol, device)
+        made.append((device, arena_bytes, batch["y0"].shape[0], batch["ps"][0].copy()))
+        return e
+    args = bench.parse_args(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "12", "--single-process",
+                             "--devices", "0,0"])
+    line = bench.run_single_process(args, make_engine=factory)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 24
+    assert line["config"]["failed_instances"] == 0 and "one process" in line["config"]["parallelism"]
+    assert abs(line["value"] - 24 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    from tests.helpers import make_problem
+    full = bench.make_batch("lv", make_problem("lv"), 24)
+    assert [m[2] for m in made] == [12, 12]
+    np.testing.assert_array_equal(made[0][3], full["ps"][0])
+    np.testing.assert_array_equal(made[1][3], full["ps"][12])
+    assert [m[1] for m in made] == [48 << 30, 48 << 30]              # two engines on one device share its arena budget
+    with pytest.raises(SystemExit):
+        bench.run_single_process(bench.parse_args(["--gpus", "3", "--single-process", "--devices", "0,1"]))
+
+
 def test_bench_gpus_flag_must_match_world(monkeypatch):
     import bench
     monkeypatch.setenv("WORLD_SIZE", "1")

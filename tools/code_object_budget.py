@@ -1,0 +1,93 @@
+"""Register / spill / scratch / LDS budget of the shipped code objects (performance hangs on compiler
+switches -- sunode_amd/_native.py DEFAULT/WAVE/ADJOINT/SMALL_GROUP_CODEGEN_FLAGS -- so a toolchain update that turns
+179 spill slots into 600 must not pass silently).
+
+    python tools/code_object_budget.py            compare the current builds with profiles/code_object_budget.json
+    python tools/code_object_budget.py --write    record the current builds as the budget (after a deliberate change)
+
+The budget bounds, per kernel, vgpr_spill_count / sgpr_spill_count / private_segment_fixed_size (scratch bytes per
+lane) / group_segment_fixed_size (static LDS) and the register counts; `build()` (__graft_entry__.py) and
+tests/test_code_object_budget.py fail above it.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+BUDGET = os.path.join(ROOT, "profiles", "code_object_budget.json")
+
+#: label -> (problem, build_code_object keyword arguments); the builds the solvers select by default for the
+#: BASELINE problems (compact records from three states on) and the forward-sensitivity builds
+BUILDS = {
+    "lv": ("lv", {}),
+    "robertson": ("robertson", {"compact": True}),
+    "seir": ("seir", {"compact": True}),
+    "network24": ("network24", {"compact": True}),
+    "network100": ("network100", {"compact": True}),
+    "lv/sens": ("lv", {"sens": True}),
+    "robertson/sens": ("robertson", {"sens": True}),
+    "seir/sens": ("seir", {"sens": True}),
+}
+KERNELS = ("sa_k_forward", "sa_k_backward", "sa_k_sens")
+FIELDS = ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size",
+          "vgpr_count", "agpr_count")
+
+
+def source_of(problem):
+    from tests.helpers import make_problem
+    return make_problem(problem).native_source()
+
+
+def current(labels=None):
+    from sunode_amd import _native
+    rows = {}
+    for label in (labels or BUILDS):
+        problem, kw = BUILDS[label]
+        path = _native.build_code_object(source_of(problem), **kw)
+        notes = _native.code_object_notes(path)
+        want = ("sa_k_forward", "sa_k_sens") if kw.get("sens") else ("sa_k_forward", "sa_k_backward")
+        rows[label] = {k: {f: notes[k][f] for f in FIELDS if f in notes[k]} for k in want}
+    return rows
+
+
+def load():
+    with open(BUDGET) as fh:
+        return json.load(fh)
+
+
+def violations(labels=None):
+    """[(label, message)] of every budget violation of the current builds."""
+    from sunode_amd import _native
+    doc = load()
+    bad = []
+    for label in (labels or doc["budgets"]):
+        problem, kw = BUILDS[label]
+        path = _native.build_code_object(source_of(problem), **kw)
+        bad += _native.check_code_object_budget(label, path, doc["budgets"][label])
+    return bad
+
+
+def main():
+    from sunode_amd import _native
+    if "--write" in sys.argv:
+        doc = {"toolchain": _native.toolchain_id(),
+               "note": "ceilings = the values of the builds that were measured (profiles/r04_*); regenerate with "
+                       "`python tools/code_object_budget.py --write` after a deliberate kernel / flag change",
+               "budgets": current()}
+        with open(BUDGET, "w") as fh:
+            json.dump(doc, fh, indent=1, sort_keys=True)
+        print("wrote", BUDGET)
+        return 0
+    bad = violations()
+    for msg in bad:
+        print("OVER BUDGET:", msg)
+    tc = _native.toolchain_id()
+    if tc["hash"] != load()["toolchain"]["hash"]:
+        print("note: toolchain %s differs from the one the budget was recorded with (%s)" % (tc["hash"], load()["toolchain"]["hash"]))
+    print("%d violation(s)" % len(bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
