@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 2          /* device ABI (sa_meta[3] of a code object) */
+#define SA_ABI_VERSION 3          /* device ABI (sa_meta[3] of a code object) */
 
 #define SA_MEM_HOST 0
 #define SA_MEM_DEVICE 1

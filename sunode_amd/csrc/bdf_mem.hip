@@ -1800,4 +1800,6 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_math(sa_math_args a)
 }
 
 /* {n_states, n_sub, n_rem, ABI version, lanes per instance, workspace doubles per instance} */
+/* arena records [point][field][instance] (a wavefront's lanes touch consecutive doubles); every other family: [instance][point] */
+extern "C" __device__ __attribute__((used)) const int32_t sa_traj_point_major = 1;
 extern "C" __device__ __attribute__((used)) const int32_t sa_meta[6] = {NS, NQ, NR, SA_DEVICE_ABI_VERSION, 1, WS_DOUBLES};

@@ -484,6 +484,14 @@ DEV double readlane_d(double v, int src)
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
 }
 
+DEV uint64_t readlane_u64(double v, int src)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, src);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), src);
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
 DEV void lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -949,7 +957,7 @@ typedef __attribute__((address_space(3))) int64_t lds_i64;
 struct LuLds {
     lds_f64 *A, *col, *invp;
     lds_u8 *piv;
-    lds_i32 *ier, *nswaps, *info;
+    lds_i32 *ier, *nswaps, *info, *pub;
     lds_i64 *prof;
 };
 static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L);
@@ -1232,53 +1240,50 @@ DEV int getrf_group_regs(const Grp &g, double (&inv_piv)[RS], int &nswaps)
 }
 
 /* ---- Newton matrix set-up + LU by the whole workgroup, matrix in REGISTERS (SA_WAVES > 1, G = 64) ----
- * M = I + c*J (c = -gamma) is built and factorised without touching LDS in the elimination: wavefront w owns the
- * columns j = SA_WAVES*cc + w (cc < LU_NC; 25 columns at n = 100), lane l the rows l, l + 64: 2*LU_NC doubles per lane.
- * Step k: the OWNER of column k checks the pivot (one ballot; the arg-max butterfly only if some row beats the
- * diagonal), scales the column and publishes the multipliers (LDS, double-buffered) -- one workgroup barrier --
- * then every wavefront updates its trailing columns from registers: the pivot-row entry a(k,j) is a v_readlane of
- * its own column register, the update one FMA per owned entry.
- * Rows are never moved: a row exchange only relabels -- every lane keeps the LOGICAL index (the row position
- * denseGETRF's explicit swaps would give) of its rows, masks and pivot ties use logical indices, and the factors
- * are written back to LDS at their logical rows.  Same operations on the same values in the same order as
- * denseGETRF / getrf_coop, hence bit-identical.  The ownership round (which register column the owner works on) is
- * unrolled, the steps inside a round are a run-time loop.
+ * M = I + c*J (c = -gamma) is built and factorised without touching LDS in the elimination.  The blocked right-looking
+ * LU (exchange rows, triangular panel solve, rank-4 update) with the element-wise operation order of denseGETRF:
+ * columns are owned in PANELS of LU_NB = 4 consecutive columns, dealt round robin to the wavefronts -- wavefront w
+ * holds the panels p = pr * SA_WAVES + w (pr < LU_NPR) in the register columns pr * LU_NB .. pr * LU_NB + 3, lane l the
+ * rows l, l + 64 (2 * LU_NC doubles per lane).
+ *   - A panel is factorised INSIDE its owner: four elimination steps (pivot check, reciprocal, scaling, update of
+ *     the panel's later columns) in straight-line code, no LDS and no synchronisation in between.  The diagonal is the
+ *     pivot in all but a few factorisations of I - gamma*J: the check is one ballot; only if some row beats the
+ *     diagonal does the arg-max butterfly run and are the two rows EXCHANGED (readlane + select) in the panel.
+ *   - The owner publishes (LDS ring) the four multiplier columns as they stand after the whole panel -- i.e. with
+ *     the panel's later exchanges applied, zero on and above the diagonal, so nobody needs a mask -- and the four
+ *     pivot rows, then bumps a counter.  There is NO barrier per panel (round 3: one per COLUMN, 100 at n = 100):
+ *     the wavefronts run as a dataflow pipeline on that counter, see the loop.
+ *   - Every wavefront applies the panel's row exchanges to its other columns (rare), then the four steps to its
+ *     trailing columns, step-outer / column-inner: pivot-row entry = v_readlane of its own register column (row k
+ *     already carries the steps before k), one FMA per owned entry.  Exchanging rows l > k, k' > k before instead of
+ *     after the update of step k changes no value (each row's arithmetic is the same, the multipliers are published
+ *     in the exchanged frame), so every entry receives a(i,j) = fma(-a(k,j), l(i,k), a(i,j)) for k = 0, 1, 2 ... in
+ *     this order with l(i,k) = a(i,k) * (1 / pivot): denseGETRF's operations on the same values in the same order,
+ *     hence the same factors bit for bit (test_row_exchanges_in_the_dense_lu[wave], every network test).
  * J comes from the saved copy in the workspace (from_saved) or from LDS where the Jacobian callback just wrote it
  * (and is saved on the way); the factors end up in LDS (s_A) for the triangular solves of wavefront 0, the
- * reciprocal pivots in s_invp. */
-#if SA_WAVES > 1 && !defined(SA_LU_CYCLIC)
-/* PANEL version (round 4) -- the blocked right-looking LU (swap rows, triangular panel solve, rank-4 update) with the
- * element-wise operation order of denseGETRF.  Columns are owned in panels of LU_NB = 4 consecutive columns, dealt
- * round robin to the wavefronts: wavefront w holds the panels p = pr * SA_WAVES + w (pr < LU_NPR) in the register
- * columns pr * LU_NB .. pr * LU_NB + 3; lane l the rows l, l + 64.
- *   - A panel is factorised INSIDE its owner: four elimination steps (pivot check, reciprocal, scaling, update of
- *     the panel's later columns) in straight-line code, no LDS and no barrier in between.  The diagonal is the pivot
- *     in all but a few factorisations of I - gamma*J: the check is one ballot; only if some row beats the diagonal
- *     does the arg-max butterfly run and are the two rows EXCHANGED (readlane + select, in the panel's columns).
- *   - The owner publishes the four multiplier columns as they stand after the whole panel (i.e. with the panel's
- *     later exchanges applied, zero on and above the diagonal) and the four pivot rows: ONE workgroup barrier per
- *     panel (25 at n = 100 instead of 100).
- *   - Every wavefront applies the panel's row exchanges to its other columns (rare), then the four steps to its
- *     trailing columns, k-outer / column-inner (independent FMAs back to back; column-outer was a serial
- *     select-readlane-FMA chain of ~60 cycles per link): pivot-row entry = v_readlane of its own register column (row
- *     k already carries the steps before k), one FMA per owned entry.  Exchanging rows l > k, k' > k before instead
- *     of after the update of step k changes no value (each row's arithmetic is the same, the multipliers are
- *     published in the exchanged frame), so every entry receives a(i,j) = fma(-a(k,j), l(i,k), a(i,j)) for k = 0, 1,
- *     2 ... in this order with l(i,k) = a(i,k) * (1 / pivot): denseGETRF's operations on the same values in the same
- *     order, hence the same factors bit for bit (test_row_exchanges_in_the_dense_lu[wave], every network test).
- * (Round 3: one column per barrier, 1 970 cycles per step, half of them the owner's serial chain with the other three
- * wavefronts waiting: profiles/r03_network100_sections.txt.) */
+ * reciprocal pivots in s_invp.
+ * History (profiles/r03_network100_sections.txt, r04_network100_lu.txt): round 3 -- one column per barrier, 1 970
+ * cycles per elimination step, half of them the owner's serial chain with the other three wavefronts waiting: 73 us
+ * per 100 x 100 factorisation.  Panels with a barrier each: 45 us.  Dataflow: see the profile. */
+#if SA_WAVES > 1
 #define LU_NB 4
 #define LU_NPANEL ((NS + LU_NB - 1) / LU_NB)
 #define LU_NPR ((LU_NPANEL + SA_WAVES - 1) / SA_WAVES)
 #define LU_NC (LU_NPR * LU_NB)
-static_assert(RS <= 2 && 64 % (LU_NB * SA_WAVES) == 0, "the rows of a panel round share one register slot");
-__shared__ __attribute__((aligned(16))) double s_col[2][RS * 64 * LU_NB];
+/* register slot (rows 64 * slot .. 64 * slot + 63) that holds the pivot rows / diagonal entries of the panels of round PR */
+#define LU_SLOT_OF_BLOCK(PR) ((RS == 1) ? 0 : ((((PR) * SA_WAVES * LU_NB) >> 6) < RS ? (((PR) * SA_WAVES * LU_NB) >> 6) : RS - 1))
+static_assert(RS <= 2 && 64 % (LU_NB * SA_WAVES) == 0 && (SA_WAVES & (SA_WAVES - 1)) == 0,
+              "the rows of a panel round share one register slot; the ring of published panels has SA_WAVES slots");
+__shared__ __attribute__((aligned(16))) double s_col[SA_WAVES][RS * 64 * LU_NB];      /* ring of published panels */
 __shared__ double s_invp[W_NS];
-__shared__ __attribute__((aligned(16))) int s_luinfo[2 * LU_NB];
-__shared__ int s_luier, s_lunswaps;
+__shared__ __attribute__((aligned(16))) int s_luinfo[SA_WAVES * 8];     /* per ring slot: 4 pivot rows, #exchanges, zero-pivot step + 1 */
+__shared__ int s_luier, s_lunswaps, s_lupub;
 #ifdef SA_WAVE_PROFILE
-__shared__ int64_t s_luprof[10];           /* wavefront 0: cycles before the barrier, in the barrier, in the update, prologue, epilogue */
+__shared__ int64_t s_luprof[10];           /* wavefront 0, cycles: panel factorisation, waiting, trailing update, whole function (ticks /
+                                              cycles), load + form, first barrier, write-back, last barrier */
+#endif
+#if defined(SA_WAVE_PROFILE) && defined(SA_LU_PROFILE_SEGMENTS)     /* (the inner timers cost ~800 cycles per panel themselves) */
 #define LUP_T(x) const int64_t x = (int64_t)__builtin_readcyclecounter();
 #define LUP_ADD(k, a, b) if (wave == 0 && lane == 0) L.prof[k] += (b) - (a);
 #else
@@ -1294,12 +1299,22 @@ static __device__ __forceinline__ LuLds lu_lds()
     L.piv = lds_opaque((lds_u8 *)s_piv);
     L.ier = lds_opaque((lds_i32 *)&s_luier); L.nswaps = lds_opaque((lds_i32 *)&s_lunswaps);
     L.info = lds_opaque((lds_i32 *)&s_luinfo[0]);
+    L.pub = lds_opaque((lds_i32 *)&s_lupub);
 #ifdef SA_WAVE_PROFILE
     L.prof = lds_opaque((lds_i64 *)s_luprof);
 #else
     L.prof = nullptr;
 #endif
     return L;
+}
+
+/* wait until `want` panels are published (the counter is written after a workgroup-scope release fence; the data
+   reads that follow are ordered behind it by the acquire fence) */
+static __device__ __forceinline__ void lu_wait(lds_i32 *pub, int want)
+{
+    /* (one wavefront per SIMD: a spinning wavefront takes nothing from anybody; with two per SIMD it yields) */
+    while (__builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)pub) < want) { if (SA_WAVES > 4) __builtin_amdgcn_s_sleep(1); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 static __device__ __forceinline__ void lu_pin(double &x) { asm volatile("" : "+v"(x)); }
@@ -1327,42 +1342,52 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
 #define LU_COL(cc) ((((cc) / LU_NB) * SA_WAVES + wave) * LU_NB + (cc) % LU_NB)
     typedef __attribute__((address_space(1))) double glb_f64;
     glb_f64 *sjg = (glb_f64 *)sj;
+    /* Instruction count matters here too (56 entries per lane): the row index is clamped once per register slot, the
+       column once per register column on the scalar unit; padding rows / columns are zeroed through the factor
+       they are multiplied with (their loads hit a valid address: finite values); the diagonal of register column cc
+       lies in the slot of its round (compile-time), only there is it looked for. */
+    int ri[RS];
+    double cr[RS];                                          /* c for the rows that exist, 0 for the padding rows */
+    SFOR(r, 0, RS) {
+        const int i = r * 64 + lane;
+        ri[r] = i < NS ? i : NS - 1;
+        cr[r] = (i < NS) ? c : 0.0;
+    } SEND
     if (from_saved) {
         SFOR(cc, 0, LU_NC) {
-            const int j = LU_COL(cc);
-            SFOR(r, 0, RS) {
-                const int i = r * 64 + lane;
-                const bool ok = (j < NS && i < NS);
-                a[cc][r] = sjg[ok ? j * NS + i : 0];
-            } SEND
+            const int j = LU_COL(cc), jc = j < NS ? j : NS - 1;
+            glb_f64 *colp = sjg + jc * NS;
+            SFOR(r, 0, RS) a[cc][r] = colp[ri[r]]; SEND
         } SEND
     } else {
         SFOR(cc, 0, LU_NC) {
-            const int j = LU_COL(cc);
-            SFOR(r, 0, RS) {
-                const int i = r * 64 + lane;
-                const bool ok = (j < NS && i < NS);
-                a[cc][r] = L.A[ok ? j * NS + i : 0];
-            } SEND
+            const int j = LU_COL(cc), jc = j < NS ? j : NS - 1;
+            lds_f64 *colp = L.A + jc * NS;
+            SFOR(r, 0, RS) a[cc][r] = colp[ri[r]]; SEND
         } SEND
         SFOR(cc, 0, LU_NC) {
             const int j = LU_COL(cc);
-            SFOR(r, 0, RS) {
-                const int i = r * 64 + lane;
-                if (j < NS && i < NS) sjg[j * NS + i] = a[cc][r];
-            } SEND
+            if (j < NS) {                                   /* (wave-uniform) */
+                glb_f64 *colp = sjg + j * NS;
+                SFOR(r, 0, RS) {
+                    if ((r + 1) * 64 <= NS) colp[r * 64 + lane] = a[cc][r];
+                    else if (r * 64 + lane < NS) colp[r * 64 + lane] = a[cc][r];
+                } SEND
+            }
         } SEND
     }
     SFOR(cc, 0, LU_NC) {
         const int j = LU_COL(cc);
+        constexpr int SD = LU_SLOT_OF_BLOCK(cc / LU_NB);    /* slot of the diagonal entry of this column */
+        double cj[RS];
+        SFOR(r, 0, RS) cj[r] = (j < NS) ? cr[r] : 0.0; SEND             /* (scalar condition) */
         SFOR(r, 0, RS) {
-            const int i = r * 64 + lane;
             const double v = a[cc][r];
-            const double w = (i == j) ? FMA(c, v, 1.0) : v * c;
-            a[cc][r] = (j < NS && i < NS) ? w : 0.0;
+            if constexpr (r == SD) a[cc][r] = (lane == (j & 63) && j < NS) ? FMA(c, v, 1.0) : v * cj[r];
+            else a[cc][r] = v * cj[r];
         } SEND
     } SEND
-    if (wave == 0 && lane == 0) (*L.ier) = 0;
+    if (wave == 0 && lane == 0) { (*L.ier) = 0; (*L.pub) = 0; }
     int nswaps = 0, ier = 0;
 #ifdef SA_WAVE_PROFILE
     asm volatile("" :: "v"(a[0][0]), "v"(a[LU_NC - 1][RS - 1]));
@@ -1371,43 +1396,172 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
     sa_barrier();
     LUP_T(t_loop)
     LUP_ADD(5, t_in, t_ld) LUP_ADD(6, t_ld, t_loop)
-    /* the panel round pr (which register columns the owner works on) is unrolled, the SA_WAVES panels of a round are a
-       run-time loop; no exit edges (an exit edge makes the register allocator copy the whole register matrix on
-       every iteration): panels past the end or after a zero pivot run as no-ops (zero multipliers).
-       A lone wavefront issues ONE instruction of any kind per four cycles, so what counts below is the number of
-       instructions, scalar ones included -- not only the dependent chain.  The rows of a whole round live in one
-       register slot S (compile-time): slots below S hold finished rows (no work at all), slot S is masked by the
-       lane, slots above S take part with every row. */
+    /* DATAFLOW over the panels p = 0, 1, ... (p = pr * SA_WAVES + o; the round pr -- which register columns the owner
+       works on -- is unrolled, the SA_WAVES panels of a round are a run-time loop), no barrier inside:
+         every wavefront, for p = 0, 1, ...:   wait until panel p-1 is published; read it; apply its row exchanges;
+             the OWNER of p:  apply p-1 to the four columns of p, factorise them, publish (ring slot p mod SA_WAVES,
+                              then the counter), ...
+             everyone:        ... apply p-1 to the other trailing columns.
+       The chain  publish(p-1) -> update of four columns -> panel factorisation -> publish(p)  is the critical path;
+       the trailing updates of all wavefronts run beside it (with a barrier per panel the three other wavefronts
+       idled through every panel factorisation and the owner through their updates).  A wavefront cannot run more
+       than SA_WAVES - 1 panels ahead of the slowest one (it needs that one's next panel), hence the ring.
+       No exit edges (an exit edge makes the register allocator copy the whole register matrix on every iteration):
+       panels past the end or after a zero pivot run as no-ops (zero multipliers).
+       A lone wavefront issues ONE instruction of any kind per four cycles (tools/ubench_issue.hip: v_fma_f64,
+       v_readlane_b32, s_nop, s_add all 4.1 cycles; a dependent FMA chain 5.1), so what counts below is the NUMBER of
+       instructions, scalar ones included.  The rows of a whole round live in one register slot S (compile-time):
+       slots below S hold finished rows (no work at all), slot S is masked by the lane, slots above S take part with
+       every row. */
+#define LU_SLOT(PR) LU_SLOT_OF_BLOCK(PR)
+#define LU_GC 4
+    /* the trailing update with panel p-1 of the register columns [C0, C1): step-outer, column-inner in groups of LU_GC
+       columns -- the broadcasts of a group, then its FMAs, a scheduling barrier (left alone the scheduler hoists every
+       broadcast of a step to the front, runs out of scalar registers and spills them through v_writelane /
+       v_readlane: three lane operations per value instead of one).  Branch-free: the multiplier of a row that takes
+       no part in a step is zero; slots below SP hold finished rows only and are skipped.  (denseGETRF skips a column
+       whose pivot-row entry is zero; a - 0*l equals a -- only the sign of a zero entry can differ -- so the factors
+       compare equal and no result changes.)  The results are pinned at the end of a group: the rows of the slots above
+       SP are not read again before the end of the factorisation, and the compiler otherwise sinks their whole FMA
+       chains below everything else, keeping every broadcast value alive (spilled lane by lane) until then. */
+#define LU_UPD_GROUP(SP, C0, C1, KK) {                                                                              \
+        double akj_[LU_GC];                                                                                           \
+        SFOR(cc, C0, C1) akj_[cc - (C0)] = readlane_d(a[cc][SP], plp + (KK)); SEND                                    \
+        SFOR(cc, C0, C1) { SFOR(r, SP, RS) a[cc][r] = FMA(-akj_[cc - (C0)], lc[KK][r], a[cc][r]); SEND } SEND         \
+        SFOR(cc, C0, C1) { SFOR(r, SP, RS) lu_pin(a[cc][r]); SEND } SEND                                              \
+        __builtin_amdgcn_sched_barrier(0); }
+#define LU_UPD_SAME(SP) SFOR(kk, 0, LU_NB) LU_UPD_GROUP(SP, pr * LU_NB, pr * LU_NB + LU_NB, kk) SEND
+#define LU_UPD_MAIN(SP) SFOR(kk, 0, LU_NB) {                                                                        \
+        SFOR(g, 0, (LU_NC - (pr + 1) * LU_NB + LU_GC - 1) / LU_GC) {                                                  \
+            constexpr int c0 = (pr + 1) * LU_NB + g * LU_GC, c1 = (c0 + LU_GC < LU_NC) ? c0 + LU_GC : LU_NC;          \
+            LU_UPD_GROUP(SP, c0, c1, kk)                                                                              \
+        } SEND } SEND
+    /* the published panel q (ring slot q mod SA_WAVES): words -> word[], multiplier columns of the slots >= SP -> lc */
+#define LU_READ(SP, Q)                                                                                              \
+        const int slot_ = (Q) & (SA_WAVES - 1);                                                                       \
+        int nex_ = L.info[slot_ * 8 + 4], ierp_ = L.info[slot_ * 8 + 5];                                              \
+        SFOR(r, SP, RS) { SFOR(kk, 0, LU_NB) lc[kk][r] = L.col[((slot_ * RS + r) * 64 + lane) * LU_NB + kk]; SEND } SEND \
+        nex_ = __builtin_amdgcn_readfirstlane(nex_); ierp_ = __builtin_amdgcn_readfirstlane(ierp_);
+    /* The row exchanges of a published panel (first row kq, pivot rows in slot SP) in the register columns [C0, C1)
+       and [C2, C3): the (at most four) exchanges are composed into ONE gather map per lane and slot -- src[r] = the
+       position (64 * slot + lane) whose value belongs here afterwards -- and every column is gathered once through
+       ds_bpermute.  Rare, straight-line (a run-time loop over the exchanges would carry the whole register matrix
+       through it, and the compiler pays for that with a copy of the matrix in front of the loop on EVERY pass).
+       Rows of the slots below SP are finished and never move. */
+#define LU_GATHER_MAP(SP, kq) int src_[RS];                                                                         \
+        SFOR(r, 0, RS) src_[r] = r * 64 + lane; SEND                                                                  \
+        SFOR(kk, 0, LU_NB) {                                                                                          \
+            const int kl_ = ((kq) + kk) & 63, l_ = word[kk] & 0xff, ls_ = (RS == 1) ? 0 : (l_ >> 6), ll_ = l_ & 63;   \
+            const int ck_ = __builtin_amdgcn_readlane(src_[SP], kl_);                                                 \
+            const int cl_ = __builtin_amdgcn_readlane(ls_ == (SP) ? src_[SP] : src_[RS - 1], ll_);                    \
+            SFOR(r, SP, RS) {                                                                                         \
+                src_[r] = (r == (SP) && lane == kl_) ? cl_ : ((r == ls_ && lane == ll_) ? ck_ : src_[r]);             \
+            } SEND                                                                                                    \
+        } SEND
+#define LU_GATHER_COL(SP, col) {                                                                                    \
+        double nv_[RS];                                                                                               \
+        SFOR(r, SP, RS) {                                                                                             \
+            nv_[r] = shfl_d((col)[SP], src_[r] & 63);                                                                 \
+            SFOR(s2, SP + 1, RS) { const double t_ = shfl_d((col)[s2], src_[r] & 63); nv_[r] = ((src_[r] >> 6) == s2) ? t_ : nv_[r]; } SEND \
+        } SEND                                                                                                        \
+        SFOR(r, SP, RS) (col)[r] = nv_[r]; SEND }
+    /* ... of panel q = p - 1 (owner oq), applied by every OTHER wavefront to all its columns before it uses the panel;
+       (the common case costs two scalar compares: the owner publishes the number of exchanges and the zero-pivot flag) */
+#define LU_SWAPS(SP, kq, oq)                                                                                        \
+        if (ierp_ != 0 && wave != (oq)) ier = (ier == 0) ? ierp_ : ier;                                               \
+        if (nex_ != 0 && wave != (oq)) {                                                                              \
+            nswaps += nex_;                                                                                           \
+            SFOR(kk, 0, LU_NB) word[kk] = __builtin_amdgcn_readfirstlane(L.info[slot_ * 8 + kk]); SEND                \
+            LU_GATHER_MAP(SP, kq)                                                                                     \
+            SFOR(cc, 0, LU_NC) LU_GATHER_COL(SP, a[cc]) SEND                                                          \
+        }
     SFOR(pr, 0, LU_NPR) {
-        constexpr int S = (RS == 1) ? 0 : ((pr * SA_WAVES * LU_NB) >> 6);       /* register slot of the round's rows */
-        static_assert(S < RS || (pr * SA_WAVES * LU_NB) >= NS, "panel rows beyond the register slots");
-        constexpr int SC = S < RS ? S : RS - 1;
+        constexpr int S = LU_SLOT(pr);                          /* register slot of this round's rows */
+        constexpr int SQ = pr > 0 ? LU_SLOT(pr - 1) : S;        /* ... of the round before (panel p-1 when o == 0) */
+        /* (panels past the last column do not exist: the last round may be shorter) */
+        constexpr int NO = (LU_NPANEL - pr * SA_WAVES) < SA_WAVES ? (LU_NPANEL - pr * SA_WAVES) : SA_WAVES;
 #pragma nounroll
-        for (int o = 0; o < SA_WAVES; o++) {
-            const int k0 = (pr * SA_WAVES + o) * LU_NB, buf = (pr * SA_WAVES + o) & 1;
-            const int pl0 = k0 & 63;                            /* lane of the panel's first row (slot S) */
+        for (int o = 0; o < NO; o++) {
+            const int p = pr * SA_WAVES + o, k0 = p * LU_NB;
+            const int pl0 = k0 & 63, plp = (k0 - LU_NB) & 63;   /* lane of the first row of panel p / of panel p-1 */
+            const int op = (o + SA_WAVES - 1) & (SA_WAVES - 1); /* owner of panel p-1 */
+            double lc[LU_NB][RS];
+            int word[LU_NB];
+            SFOR(kk, 0, LU_NB) { word[kk] = 0; SFOR(r, 0, RS) lc[kk][r] = 0.0; SEND } SEND
+            const bool first = (pr == 0) && (o == 0);           /* (no panel before the first) */
+            const bool prev_round = (S != SQ) && (o == 0);      /* panel p-1 lives in the slot of the round before */
             LUP_T(t_a)
+            if (!first) {
+                lu_wait(L.pub, p);
+                if (prev_round) { LU_READ(SQ, p - 1) LU_SWAPS(SQ, k0 - LU_NB, op) }
+                else { LU_READ(S, p - 1) LU_SWAPS(S, k0 - LU_NB, op) }
+            }
+            LUP_T(t_b)
+            int own_word[LU_NB], own_swaps = 0;
+            SFOR(kk, 0, LU_NB) own_word[kk] = 0; SEND
             if (wave == o) {
-                int word[LU_NB];
-                bool done[LU_NB];
+                if (!first) { if (prev_round) { LU_UPD_SAME(SQ) } else { LU_UPD_SAME(S) } }
+                int pword[LU_NB];
                 double mults[LU_NB];
+                constexpr bool PARTIAL = (NS % LU_NB) != 0;     /* (a last panel with columns past n exists) */
+                /* FAST PATH.  The owner's chain -- update of its four columns, these four steps, publication -- is the
+                   critical path of the whole factorisation, and it is paid in instructions (four cycles each).  So the
+                   four steps first run SPECULATIVELY as if every diagonal entry were an acceptable non-zero pivot (it
+                   is, in all but a few factorisations of I - gamma*J): no per-step branch, the rows below the diagonal
+                   under one lane mask (no selects), zero / beaten pivots only recorded.  If anything was recorded, the
+                   panel is restored from a copy and redone by the general code below -- same operations, same values in
+                   the case that counts. */
+                bool general = PARTIAL || (ier != 0);
+                if (!general) {
+                    double keep[LU_NB][RS];
+                    SFOR(kk, 0, LU_NB) { SFOR(r, S, RS) keep[kk][r] = a[pr * LU_NB + kk][r]; SEND } SEND
+                    bool beaten = false, zero = false;
+                    SFOR(kk, 0, LU_NB) {
+                        constexpr int kc = pr * LU_NB + kk;
+                        const uint64_t abits = readlane_u64(a[kc][S], pl0 + kk);
+                        const double akk = __builtin_bit_cast(double, abits);
+                        zero = zero || ((abits << 1) == 0);
+                        const double mult = 1.0 / akk;
+                        mults[kk] = mult;
+                        pword[kk] = (k0 + kk) & 0xff;
+                        double akj[LU_NB];
+                        SFOR(jj, kk + 1, LU_NB) akj[jj] = readlane_d(a[pr * LU_NB + jj][S], pl0 + kk); SEND
+                        SFOR(r, S + 1, RS) {
+                            beaten = beaten || (fabs(a[kc][r]) > fabs(akk));
+                            a[kc][r] = a[kc][r] * mult;
+                            SFOR(jj, kk + 1, LU_NB) a[pr * LU_NB + jj][r] = FMA(-akj[jj], a[kc][r], a[pr * LU_NB + jj][r]); SEND
+                        } SEND
+                        if (lane > pl0 + kk) {                  /* the rows of slot S below the diagonal */
+                            beaten = beaten || (fabs(a[kc][S]) > fabs(akk));
+                            a[kc][S] = a[kc][S] * mult;
+                            SFOR(jj, kk + 1, LU_NB) a[pr * LU_NB + jj][S] = FMA(-akj[jj], a[kc][S], a[pr * LU_NB + jj][S]); SEND
+                        }
+                    } SEND
+                    if (zero || __builtin_amdgcn_ballot_w64(beaten) != 0) {
+                        general = true;
+                        SFOR(kk, 0, LU_NB) { SFOR(r, S, RS) a[pr * LU_NB + kk][r] = keep[kk][r]; SEND } SEND
+                    }
+                }
+                if (general)
                 SFOR(kk, 0, LU_NB) {
                     const int k = k0 + kk;
                     constexpr int kc = pr * LU_NB + kk;
-                    /* a step past the end (k >= n) or after a zero pivot runs with a unit pivot and no rows below it:
-                       nothing changes, and no branch joins here (a join copies the panel's register columns) */
-                    const bool valid = (k < NS) && (ier == 0);
-                    double akk = readlane_d(a[kc][SC], pl0 + kk);
+                    /* a step past the end (k >= n) or after a zero pivot runs with a unit pivot: nothing changes, and
+                       no branch joins here (a join copies the panel's register columns).  The pivot is a scalar (the
+                       same in every lane by construction): its zero test and the bookkeeping that hangs on it stay
+                       on the scalar unit. */
+                    const bool valid = (ier == 0) && (k0 < NS) && (!PARTIAL || k < NS);
+                    uint64_t abits = readlane_u64(a[kc][S], pl0 + kk);
+                    double akk = __builtin_bit_cast(double, abits);
                     /* the diagonal stays the pivot unless a row below it is strictly larger */
-                    const bool below = valid && (lane > pl0 + kk);          /* (slot S; the slots above: every row) */
-                    bool beaten = below && (fabs(a[kc][SC]) > fabs(akk));
-                    SFOR(r, SC + 1, RS) beaten = beaten || (valid && fabs(a[kc][r]) > fabs(akk)); SEND
+                    bool beaten = (lane > pl0 + kk) && (fabs(a[kc][S]) > fabs(akk));        /* (slot S; above: every row) */
+                    SFOR(r, S + 1, RS) beaten = beaten || (fabs(a[kc][r]) > fabs(akk)); SEND
                     int l = k;
-                    if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
+                    if (valid && __builtin_amdgcn_ballot_w64(beaten) != 0) {
                         /* pivot: first (lowest index) row i >= k with the largest |a(i,k)| */
                         double best = -1.0;
                         int bi = 1 << 20;
-                        SFOR(r, SC, RS) {
+                        SFOR(r, S, RS) {
                             const int i = r * 64 + lane;
                             const double v = fabs(a[kc][r]);
                             if (i >= k && (v > best || (v == best && i < bi))) { best = v; bi = i; }
@@ -1423,122 +1577,104 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                         l = __builtin_amdgcn_readfirstlane(bi);
                         if (l != k) {
                             nswaps++;
+                            own_swaps++;
                             const int ls = (RS == 1) ? 0 : (l >> 6), ll = l & 63;
-                            SFOR(jj, 0, LU_NB) LU_SWAP_ROWS(a[pr * LU_NB + jj], SC, pl0 + kk, ls, ll); SEND
-                            akk = readlane_d(a[kc][SC], pl0 + kk);
+                            SFOR(jj, 0, LU_NB) LU_SWAP_ROWS(a[pr * LU_NB + jj], S, pl0 + kk, ls, ll); SEND
+                            abits = readlane_u64(a[kc][S], pl0 + kk);
+                            akk = __builtin_bit_cast(double, abits);
                         }
                     }
-                    /* (akk is the same in every lane: tell the compiler, or everything that depends on ier turns into
-                       divergent control flow with lane-mask merges) */
-                    const bool sing = valid && __builtin_amdgcn_readfirstlane(akk == 0.0 ? 1 : 0);
-                    if (sing) {                         /* (rare; nothing below changes anything after it) */
+                    const bool nonzero = (abits << 1) != 0;
+                    if (valid && !nonzero) {            /* (rare; nothing below changes anything after it) */
                         ier = k + 1;
                         if (lane == 0) (*L.ier) = k + 1;
                     }
-                    const bool ok = valid && !sing;
-                    const double mult = 1.0 / (ok ? akk : 1.0);
-                    done[kk] = ok;
-                    word[kk] = sing ? (LU_SING | (k & 0xff)) : (l & 0xff);
+                    const bool ok = valid && nonzero;
+                    const double mult = 1.0 / __builtin_bit_cast(double, ok ? abits : (uint64_t)0x3ff0000000000000ull);
+                    pword[kk] = l & 0xff;
+                    own_word[kk] = l & 0xff;
                     mults[kk] = mult;
-                    double lc[RS];
+                    double lcp[RS];
                     {
                         const bool on = ok && (lane > pl0 + kk);
-                        const double v = a[kc][SC] * mult;
-                        lc[SC] = on ? v : 0.0;
-                        a[kc][SC] = on ? v : a[kc][SC];
+                        const double v = a[kc][S] * mult;
+                        lcp[S] = on ? v : 0.0;
+                        a[kc][S] = on ? v : a[kc][S];
                     }
-                    SFOR(r, SC + 1, RS) { a[kc][r] = a[kc][r] * mult; lc[r] = ok ? a[kc][r] : 0.0; } SEND
+                    SFOR(r, S + 1, RS) { a[kc][r] = a[kc][r] * mult; lcp[r] = ok ? a[kc][r] : 0.0; } SEND
                     SFOR(jj, kk + 1, LU_NB) {           /* the panel's later columns */
-                        const double akj = readlane_d(a[pr * LU_NB + jj][SC], pl0 + kk);
-                        SFOR(r, SC, RS) a[pr * LU_NB + jj][r] = FMA(-akj, lc[r], a[pr * LU_NB + jj][r]); SEND
+                        const double akj = readlane_d(a[pr * LU_NB + jj][S], pl0 + kk);
+                        SFOR(r, S, RS) a[pr * LU_NB + jj][r] = FMA(-akj, lcp[r], a[pr * LU_NB + jj][r]); SEND
                     } SEND
                 } SEND
-                /* the multiplier columns as they stand now (the panel's later exchanges applied), slots S and above */
-                SFOR(r, SC, RS) {
-                    SFOR(kk, 0, LU_NB) {
-                        L.col[((buf * RS + r) * 64 + lane) * LU_NB + kk] =
-                            (done[kk] && (r > SC || lane > pl0 + kk)) ? a[pr * LU_NB + kk][r] : 0.0;
-                    } SEND
+                /* publish: the multiplier columns as they stand now (the panel's later exchanges applied): slot S
+                   masked by the lane, the slots above as they are (a step that did not run -- past the end: the
+                   column is zero; after a zero pivot: the factorisation has failed, nobody uses the result); the
+                   pivot rows, the number of exchanges, the zero-pivot flag; then -- release -- the counter */
+                const int slot = p & (SA_WAVES - 1);
+                SFOR(kk, 0, LU_NB) {
+                    L.col[((slot * RS + S) * 64 + lane) * LU_NB + kk] = (lane > pl0 + kk) ? a[pr * LU_NB + kk][S] : 0.0;
+                } SEND
+                SFOR(r, S + 1, RS) {
+                    SFOR(kk, 0, LU_NB) L.col[((slot * RS + r) * 64 + lane) * LU_NB + kk] = a[pr * LU_NB + kk][r]; SEND
                 } SEND
                 if (lane == 0) {
-                    SFOR(kk, 0, LU_NB) {
-                        L.info[buf * LU_NB + kk] = word[kk];
-                        if (done[kk]) { L.piv[k0 + kk] = (uint8_t)(word[kk] & 0xff); L.invp[k0 + kk] = mults[kk]; }
-                    } SEND
-                }
-            }
-            LUP_T(t_b)
-            sa_barrier();
-            LUP_T(t_c)
-            double lc[LU_NB][RS];
-            int word[LU_NB];
-            SFOR(kk, 0, LU_NB) word[kk] = L.info[buf * LU_NB + kk]; SEND
-            SFOR(r, SC, RS) {
-                SFOR(kk, 0, LU_NB) lc[kk][r] = L.col[((buf * RS + r) * 64 + lane) * LU_NB + kk]; SEND
-            } SEND
-            bool anyswap = false;
-            SFOR(kk, 0, LU_NB) {
-                word[kk] = __builtin_amdgcn_readfirstlane(word[kk]);
-                if (wave != o && (word[kk] & LU_SING)) ier = (ier == 0) ? k0 + kk + 1 : ier;
-                anyswap = anyswap || ((word[kk] & 0xff) != ((k0 + kk) & 0xff));
-            } SEND
-            if (anyswap) {          /* the panel's row exchanges, in order, in every other column (rare: a run-time loop,
-                                       one copy of the exchange code per panel round) */
-#pragma nounroll
-                for (int kk = 0; kk < LU_NB; kk++) {
-                    int w = word[0];
-                    SFOR(u, 1, LU_NB) w = (kk == u) ? word[u] : w; SEND
-                    const int l = w & 0xff;
-                    if (l != ((k0 + kk) & 0xff)) {
-                        const int ls = (RS == 1) ? 0 : (l >> 6), ll = l & 63;
-                        if (wave != o) {
-                            nswaps++;
-                            SFOR(cc, pr * LU_NB, pr * LU_NB + LU_NB) LU_SWAP_ROWS(a[cc], SC, pl0 + kk, ls, ll); SEND
-                        }
-                        SFOR(cc, 0, pr * LU_NB) LU_SWAP_ROWS(a[cc], SC, pl0 + kk, ls, ll); SEND
-                        SFOR(cc, (pr + 1) * LU_NB, LU_NC) LU_SWAP_ROWS(a[cc], SC, pl0 + kk, ls, ll); SEND
+                    SFOR(kk, 0, LU_NB) L.info[slot * 8 + kk] = pword[kk]; SEND
+                    L.info[slot * 8 + 4] = own_swaps;
+                    L.info[slot * 8 + 5] = ier;
+                    if (k0 < NS && ier == 0) {
+                        SFOR(kk, 0, LU_NB) {
+                            if (!PARTIAL || k0 + kk < NS) { L.piv[k0 + kk] = (uint8_t)pword[kk]; L.invp[k0 + kk] = mults[kk]; }
+                        } SEND
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) *(volatile lds_i32 *)L.pub = p + 1;
             }
-            /* trailing update of this wavefront's later panels (of this round only behind the owner): step-outer,
-               column-inner in groups of LU_GC columns -- the broadcasts of a group, then its FMAs, a scheduling barrier
-               (left alone the scheduler hoists every broadcast of a step to the front, runs out of scalar registers and
-               spills them through v_writelane / v_readlane: three lane operations per value instead of one).
-               Branch-free: the multiplier of a row that takes no part in a step is zero; slots below S hold finished
-               rows only and are skipped.  (denseGETRF skips a column whose pivot-row entry is zero; a - 0*l equals
-               a -- only the sign of a zero entry can differ -- so the factors compare equal and no result changes.) */
-#define LU_GC 4
-#define LU_UPD_GROUP(C0, C1, KK) {                                                                               \
-                double akj_[LU_GC];                                                                                \
-                SFOR(cc, C0, C1) akj_[cc - (C0)] = readlane_d(a[cc][SC], pl0 + (KK)); SEND                         \
-                SFOR(cc, C0, C1) { SFOR(r, SC, RS) a[cc][r] = FMA(-akj_[cc - (C0)], lc[KK][r], a[cc][r]); SEND } SEND \
-                /* pin the results here: the rows of the slots above S are not read again before the end of the        \
-                   factorisation, and the compiler otherwise sinks their whole FMA chains below everything else --     \
-                   keeping every broadcast value alive (spilled lane by lane) until then */                             \
-                SFOR(cc, C0, C1) { SFOR(r, SC, RS) lu_pin(a[cc][r]); SEND } SEND                                        \
-                __builtin_amdgcn_sched_barrier(0); }
-            /* (one straight-line block for the later rounds' columns, then ONE branch for the panel of this round:
-               a branch per step lets the compiler sink the FMAs of a step below the next step's branch -- and
-               spill the scalar registers that wait there) */
-            SFOR(kk, 0, LU_NB) {
-                SFOR(g, 0, (LU_NC - (pr + 1) * LU_NB + LU_GC - 1) / LU_GC) {
-                    constexpr int c0 = (pr + 1) * LU_NB + g * LU_GC, c1 = (c0 + LU_GC < LU_NC) ? c0 + LU_GC : LU_NC;
-                    LU_UPD_GROUP(c0, c1, kk)
-                } SEND
-            } SEND
-            if (wave > o) {
-                SFOR(kk, 0, LU_NB) LU_UPD_GROUP(pr * LU_NB, pr * LU_NB + LU_NB, kk) SEND
+            LUP_T(t_c)
+            if (!first) {
+                if (prev_round) { LU_UPD_MAIN(SQ) if (wave > o) { LU_UPD_SAME(SQ) } }
+                else { LU_UPD_MAIN(S) if (wave > o) { LU_UPD_SAME(S) } }
             }
-#undef LU_UPD_GROUP
+            if (wave == o && own_swaps != 0) {
+                /* the owner's OTHER columns follow its panel's row exchanges only now: they had to receive panel p-1
+                   (whose multipliers are indexed by the rows' places before these exchanges) first */
+                SFOR(kk, 0, LU_NB) word[kk] = own_word[kk]; SEND
+                LU_GATHER_MAP(S, k0)
+                SFOR(cc, 0, pr * LU_NB) LU_GATHER_COL(S, a[cc]) SEND
+                SFOR(cc, (pr + 1) * LU_NB, LU_NC) LU_GATHER_COL(S, a[cc]) SEND
+            }
             LUP_T(t_d)
-            LUP_ADD(0, t_a, t_b) LUP_ADD(1, t_b, t_c) LUP_ADD(2, t_c, t_d)
+            LUP_ADD(0, t_b, t_c) LUP_ADD(1, t_a, t_b) LUP_ADD(2, t_c, t_d)
         }
     } SEND
+    {   /* the row exchanges of the last panel */
+        constexpr int PL = LU_NPANEL - 1, SL = LU_SLOT(LU_NPR - 1);
+        double lc[LU_NB][RS];
+        int word[LU_NB];
+        lu_wait(L.pub, PL + 1);
+        LU_READ(SL, PL)
+        (void)lc;
+        LU_SWAPS(SL, PL * LU_NB, PL & (SA_WAVES - 1))
+    }
+#undef LU_SWAPS
+#undef LU_GATHER_COL
+#undef LU_GATHER_MAP
+#undef LU_READ
+#undef LU_UPD_MAIN
+#undef LU_UPD_SAME
+#undef LU_UPD_GROUP
     LUP_T(t_out)
     if (ier == 0) {
-        SFOR(cc, 0, LU_NC) {
-            const int j = LU_COL(cc);
-            SFOR(r, 0, RS) { if (j < NS && r * 64 + lane < NS) L.A[j * NS + r * 64 + lane] = a[cc][r]; } SEND
+        /* factors -> LDS for the triangular solves: full register slots unmasked, the partial one under one lane mask;
+           a padding column (wave-uniform, last round only) is skipped as a whole */
+        SFOR(r, 0, RS) {
+            if ((r + 1) * 64 <= NS || r * 64 + lane < NS) {
+                SFOR(cc, 0, LU_NC) {
+                    const int j = LU_COL(cc);
+                    if ((cc / LU_NB + 1) * SA_WAVES * LU_NB <= NS || j < NS) L.A[j * NS + r * 64 + lane] = a[cc][r];
+                } SEND
+            }
         } SEND
     }
     if (wave == 0 && lane == 0) (*L.nswaps) = nswaps;
@@ -1551,227 +1687,8 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
 #endif
 #undef LU_COL
 }
-#elif SA_WAVES > 1
-#define LU_NC ((NS + SA_WAVES - 1) / SA_WAVES)
-__shared__ double s_col[2][RS * 64];
-__shared__ double s_invp[W_NS];
-__shared__ int s_luier, s_lunswaps, s_luinfo[2];
-#ifdef SA_WAVE_PROFILE
-__shared__ int64_t s_luprof[10];           /* wavefront 0: cycles before the barrier, in the barrier, in the update, prologue, epilogue */
-#define LUP_T(x) const int64_t x = (int64_t)__builtin_readcyclecounter();
-#define LUP_ADD(k, a, b) if (wave == 0 && lane == 0) L.prof[k] += (b) - (a);
 #else
-#define LUP_T(x)
-#define LUP_ADD(k, a, b)
-#endif
-
-static __device__ __forceinline__ LuLds lu_lds()
-{
-    LuLds L;
-    L.A = lds_opaque((lds_f64 *)s_A); L.col = lds_opaque((lds_f64 *)&s_col[0][0]); L.invp = lds_opaque((lds_f64 *)s_invp);
-    L.piv = lds_opaque((lds_u8 *)s_piv);
-    L.ier = lds_opaque((lds_i32 *)&s_luier); L.nswaps = lds_opaque((lds_i32 *)&s_lunswaps);
-    L.info = lds_opaque((lds_i32 *)&s_luinfo[0]);
-#ifdef SA_WAVE_PROFILE
-    L.prof = lds_opaque((lds_i64 *)s_luprof);
-#else
-    L.prof = nullptr;
-#endif
-    return L;
-}
-
-/* noinline on purpose: the 2*LU_NC matrix registers of a lane must not compete with the integrator state of
-   wavefront 0 (inlined, the pair spilled ~1.6 KB per lane to scratch); results come back through LDS */
-static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L)
-{
-    double a[LU_NC][RS];
-    int logpos[RS];
-    LUP_T(t_in)
-#ifdef SA_WAVE_PROFILE
-    const int64_t w_in = (int64_t)wall_clock64();
-#endif
-    wave = __builtin_amdgcn_readfirstlane(wave);            /* wave-uniform by construction: let the compiler know */
-    /* all loads of the matrix are issued back to back (clamped index instead of a branch per entry: with the branch
-       every load waited for the previous one, 50 dependent round trips to the workspace = 50 us per factorisation) */
-    typedef __attribute__((address_space(1))) double glb_f64;
-    glb_f64 *sjg = (glb_f64 *)sj;
-    if (from_saved) {
-        SFOR(cc, 0, LU_NC) {
-            const int j = cc * SA_WAVES + wave;
-            SFOR(r, 0, RS) {
-                const int i = r * 64 + lane;
-                const bool ok = (j < NS && i < NS);
-                a[cc][r] = sjg[ok ? j * NS + i : 0];
-            } SEND
-        } SEND
-    } else {
-        SFOR(cc, 0, LU_NC) {
-            const int j = cc * SA_WAVES + wave;
-            SFOR(r, 0, RS) {
-                const int i = r * 64 + lane;
-                const bool ok = (j < NS && i < NS);
-                a[cc][r] = L.A[ok ? j * NS + i : 0];
-            } SEND
-        } SEND
-        SFOR(cc, 0, LU_NC) {
-            const int j = cc * SA_WAVES + wave;
-            SFOR(r, 0, RS) {
-                const int i = r * 64 + lane;
-                if (j < NS && i < NS) sjg[j * NS + i] = a[cc][r];
-            } SEND
-        } SEND
-    }
-    SFOR(cc, 0, LU_NC) {
-        const int j = cc * SA_WAVES + wave;
-        SFOR(r, 0, RS) {
-            const int i = r * 64 + lane;
-            const double v = a[cc][r];
-            const double w = (i == j) ? FMA(c, v, 1.0) : v * c;
-            a[cc][r] = (j < NS && i < NS) ? w : 0.0;
-        } SEND
-    } SEND
-    SFOR(r, 0, RS) logpos[r] = (r * 64 + lane < NS) ? r * 64 + lane : -1; SEND
-    if (wave == 0 && lane == 0) (*L.ier) = 0;
-    int nswaps = 0, ier = 0;
-#ifdef SA_WAVE_PROFILE
-    asm volatile("" :: "v"(a[0][0]), "v"(a[LU_NC - 1][RS - 1]));
-#endif
-    LUP_T(t_ld)
-    sa_barrier();
-    LUP_T(t_loop)
-    LUP_ADD(5, t_in, t_ld) LUP_ADD(6, t_ld, t_loop)
-    /* kcr (the owner's register column) is a compile-time index: the ownership round is unrolled (LU_NC copies of
-       the step), the SA_WAVES steps inside a round are a run-time loop.  (Measured alternatives that were slower:
-       one run-time loop over k with compare-chain column selects; branch-free FMA blocks with scalar zero
-       detection; ds_bpermute broadcasts of the pivot row -- each adds register-array copies at control-flow joins
-       that cost more than the v_readlane hazards they remove.) */
-    SFOR(kcr, 0, LU_NC) {
-#pragma nounroll
-        for (int o = 0; o < SA_WAVES; o++) {
-            /* no early exits from this loop: an exit edge makes the register allocator copy the whole register
-               matrix on every iteration (measured: 120 of the 420 instructions of a step).  Steps past the end
-               (k >= NS) or after a zero pivot run as no-ops: no owner work, zero multipliers. */
-            const int k = kcr * SA_WAVES + o, buf = k & 1;
-            const bool active = (k < NS) && (ier == 0);
-            LUP_T(t_a)
-            int prow_lane = 0, prow_slot = 0;           /* physical home of logical row k */
-            SFOR(r, 0, RS) {
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == k);
-                if (bal != 0) { prow_slot = r; prow_lane = __builtin_ctzll(bal); }
-            } SEND
-            if (wave == o && active) {
-                double dsel = a[kcr][0];
-                SFOR(r, 1, RS) dsel = (prow_slot == r) ? a[kcr][r] : dsel; SEND
-                const double akk = readlane_d(dsel, prow_lane);
-                /* pivot: first (lowest logical index) row i >= k with the largest |a(i,k)| */
-                double best = fabs(akk);
-                int bi = k;
-                bool beaten = false;
-                double cand[RS];
-                SFOR(r, 0, RS) {
-                    cand[r] = (logpos[r] > k) ? fabs(a[kcr][r]) : -1.0;
-                    beaten = beaten || (cand[r] > best);
-                } SEND
-                if (__builtin_amdgcn_ballot_w64(beaten) != 0) {
-                    best = -1.0;
-                    bi = 1 << 20;
-                    SFOR(r, 0, RS) {
-                        const double v = (logpos[r] == k) ? fabs(akk) : cand[r];
-                        if (logpos[r] >= k && (v > best || (v == best && logpos[r] < bi))) { best = v; bi = logpos[r]; }
-                    } SEND
-                    SFOR(b, 0, 6) {
-                        const double ov = shfl_d(best, lane ^ (1 << b));
-                        const int oi = shfl_i(bi, lane ^ (1 << b));
-                        const bool take = (ov > best) || (ov == best && oi < bi);
-                        best = take ? ov : best;
-                        bi = take ? oi : bi;
-                    } SEND
-                }
-                const int l = bi;
-                /* one word per step for the other wavefronts: pivot row, or the singular flag (read together with
-                   the multipliers after the barrier: one LDS round trip per step instead of three) */
-                if (lane == 0) L.info[buf] = (best == 0.0) ? 0x10000 : l;
-                if (best == 0.0) { if (lane == 0) (*L.ier) = k + 1; }
-                else {
-                    double apiv = akk;
-                    if (l != k) {
-                        int ls = 0, ll = 0;
-                        SFOR(r, 0, RS) {
-                            const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == l);
-                            if (bal != 0) { ls = r; ll = __builtin_ctzll(bal); }
-                        } SEND
-                        double psel = a[kcr][0];
-                        SFOR(r, 1, RS) psel = (ls == r) ? a[kcr][r] : psel; SEND
-                        apiv = readlane_d(psel, ll);
-                    }
-                    const double mult = 1.0 / apiv;
-                    if (lane == 0) { L.piv[k] = (uint8_t)l; L.invp[k] = mult; }
-                    /* multipliers of the rows still to be eliminated: every unused row except the pivot row */
-                    SFOR(r, 0, RS) {
-                        if ((logpos[r] >= k) && (logpos[r] != l)) {
-                            const double lc = a[kcr][r] * mult;
-                            a[kcr][r] = lc;
-                            L.col[buf * (RS * 64) + r * 64 + lane] = lc;
-                        }
-                    } SEND
-                }
-            }
-            LUP_T(t_b)
-            sa_barrier();
-            LUP_T(t_c)
-            double lcraw[RS];
-            SFOR(r, 0, RS) lcraw[r] = L.col[buf * (RS * 64) + r * 64 + lane]; SEND
-            const int info = active ? __builtin_amdgcn_readfirstlane(L.info[buf]) : k;
-            if (info >= 0x10000) ier = k + 1;
-            const int l = (info >= 0x10000) ? k : info;
-            if (l != k) {                       /* row exchange = relabelling */
-                nswaps++;
-                SFOR(r, 0, RS) { const int lp = logpos[r]; logpos[r] = (lp == l) ? k : ((lp == k) ? l : lp); } SEND
-                SFOR(r, 0, RS) {
-                    const uint64_t bal = __builtin_amdgcn_ballot_w64(logpos[r] == k);
-                    if (bal != 0) { prow_slot = r; prow_lane = __builtin_ctzll(bal); }
-                } SEND
-            }
-            /* trailing update of this wavefront's columns j > k (register columns cc > kcr, and cc == kcr for the
-               wavefronts behind the owner), branch-free: the multiplier of a row that is not eliminated in this step
-               and the pivot-row entry of a column that is not updated are ZERO, so the FMA leaves the entry alone.
-               denseGETRF skips a column whose pivot-row entry is zero; a - 0*l equals a (only the sign of a zero
-               entry can differ, no finite value ever does), so the factors compare equal and no result changes.
-               Per column: slot select + v_readlane of the pivot-row entry (SGPR pair), one FMA per register slot. */
-            double lcv[RS];
-            SFOR(r, 0, RS) lcv[r] = (logpos[r] > k && ier == 0) ? lcraw[r] : 0.0; SEND
-            const int pl = __builtin_amdgcn_readfirstlane(prow_lane), psl = __builtin_amdgcn_readfirstlane(prow_slot);
-            SFOR(cc, kcr, LU_NC) {
-                double src = a[cc][0];
-                SFOR(r, 1, RS) src = (psl == r) ? a[cc][r] : src; SEND
-                /* register column kcr is finished (holds factors) in the wavefronts up to the owner; the padding
-                   columns j >= NS are zero and stay zero under the update */
-                double akj = readlane_d(src, pl);
-                if constexpr (cc == kcr) akj = (wave > o) ? akj : 0.0;
-                SFOR(r, 0, RS) a[cc][r] = FMA(-akj, lcv[r], a[cc][r]); SEND
-            } SEND
-            LUP_T(t_d)
-            LUP_ADD(0, t_a, t_b) LUP_ADD(1, t_b, t_c) LUP_ADD(2, t_c, t_d)
-        }
-    } SEND
-    LUP_T(t_out)
-    if (ier == 0) {
-        SFOR(cc, 0, LU_NC) {
-            const int j = cc * SA_WAVES + wave;
-            SFOR(r, 0, RS) { if (j < NS && logpos[r] >= 0) L.A[j * NS + logpos[r]] = a[cc][r]; } SEND
-        } SEND
-    }
-    if (wave == 0 && lane == 0) (*L.nswaps) = nswaps;
-    LUP_T(t_wr)
-    sa_barrier();
-    LUP_T(t_end)
-    LUP_ADD(4, t_in, t_end) LUP_ADD(7, t_out, t_wr) LUP_ADD(8, t_wr, t_end)
-#ifdef SA_WAVE_PROFILE
-    if (wave == 0 && lane == 0) L.prof[3] += (int64_t)wall_clock64() - w_in;        /* 10 ns ticks over the same span */
-#endif
-}
-#else
-static __device__ __forceinline__ LuLds lu_lds() { return LuLds{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
+static __device__ __forceinline__ LuLds lu_lds() { return LuLds{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
 static __device__ void setup_lu_regs(int, int, double, int, double *, LuLds) {}
 #endif
 

@@ -40,8 +40,10 @@
 #define SA_N_STATS 16
 
 /* sa_meta[3] of a code object; sa_solver_create() rejects any other value (= SA_ABI_VERSION of sunode_amd.h).
-   2: arena records instance-major (traj_istride), SA_MODE_ADJ_COUNT, traj_max / overflow in sa_fwd_args */
-#define SA_DEVICE_ABI_VERSION 2
+   2: arena records instance-major (traj_istride), SA_MODE_ADJ_COUNT, traj_max / overflow in sa_fwd_args
+   3: the arena layout follows the kernel family -- [instance][point] unless the code object exports
+      sa_traj_point_major (the memory-resident kernel) -- instead of ws_doubles == 0 */
+#define SA_DEVICE_ABI_VERSION 3
 
 typedef struct {
     int32_t B, n_t, mode, mxstep, max_retries, traj_cap, rem_stride, traj_istride;

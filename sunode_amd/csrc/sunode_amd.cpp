@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -67,7 +68,8 @@ struct sa_solver {
     int device = 0;
     int n = 0, p = 0, r = 0;
     int group = 1;                 /* lanes per instance: 1 = thread-per-instance, 2^k = lane group / workgroup build */
-    int64_t ws_doubles = 0;        /* per-instance workspace of the memory-resident build (0: register builds) */
+    int64_t ws_doubles = 0;        /* per-instance workspace (0: register builds; small: lane groups; the whole state: memory-resident) */
+    bool point_major = false;      /* arena records laid out [point][..][instance] (memory-resident kernel) instead of [instance][point] */
     int32_t rec_doubles = 0;       /* doubles per arena record: 8 + 6n (table records) unless the code object says otherwise */
     DevBuf ws;
     hipModule_t module = nullptr;
@@ -212,6 +214,18 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
         if (hipModuleGetGlobal(&rp, &rsz, s->module, "sa_traj_rec") == hipSuccess && rsz == sizeof(rec) &&
             hipMemcpyDtoH(&rec, rp, sizeof(rec)) == hipSuccess && rec >= 2) s->rec_doubles = rec;
         else (void)hipGetLastError();
+    }
+    {   /* arena layout: every instance's records contiguous ([instance][point]: the backward pass walks an
+           instance's points in order) for every kernel family EXCEPT the memory-resident one, which announces its
+           [point][field][instance] layout.  (Until round 4 the choice hung on ws_doubles == 0, which the lane-group /
+           workgroup builds -- they have a small workspace for the saved Jacobian -- do not satisfy: they got the
+           point-major layout the comments said they did not have.)  SA_TRAJ_LAYOUT=point|instance: tuning override. */
+        hipDeviceptr_t rp = nullptr;
+        size_t rsz = 0;
+        s->point_major = hipModuleGetGlobal(&rp, &rsz, s->module, "sa_traj_point_major") == hipSuccess;
+        if (!s->point_major) (void)hipGetLastError();
+        const char *force = getenv("SA_TRAJ_LAYOUT");
+        if (force && !s->point_major) s->point_major = (force[0] == 'p');
     }
     const char *names[4] = {"sa_k_forward", "sa_k_backward", "sa_k_eval", "sa_k_math"};
     hipFunction_t *slots[4] = {&s->k_forward, &s->k_backward, &s->k_eval, &s->k_math};
@@ -411,7 +425,7 @@ static int launch_forward(sa_solver *s, const FwdLaunch &f)
     /* arena layout: the register / lane-group / workgroup kernels keep every instance's records contiguous
        ([instance][point]: the backward pass walks an instance's points in order, so consecutive records share cache
        lines and DRAM pages); the memory-resident kernel keeps its [point][field][instance] layout */
-    if (s->ws_doubles == 0) { a.traj_istride = f.rows; a.traj_stride = 1; }
+    if (!s->point_major) { a.traj_istride = f.rows; a.traj_stride = 1; }
     else { a.traj_istride = 1; a.traj_stride = f.stride; }
     a.traj = (double *)s->traj.p; a.traj_np = f.traj_np;
     int rc;
@@ -675,7 +689,7 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     if (!s->tiled) {
         a.B = B; a.traj_cap = s->traj_rows;
-        if (s->ws_doubles == 0) { a.traj_istride = s->traj_rows; a.traj_stride = 1; }
+        if (!s->point_major) { a.traj_istride = s->traj_rows; a.traj_stride = 1; }
         else { a.traj_istride = 1; a.traj_stride = s->traj_stride; }
         a.ps = d_ps; a.pr = d_pr; a.grads = d_g; a.grad_out = d_gout; a.lamda_out = d_lout;
         a.status = d_status; a.fwd_status = (const int32_t *)s->fwd_status.p; a.stats = d_stats;
@@ -752,7 +766,7 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
                         (double *)s->t_yout.p, (int32_t *)s->t_status.p, (int64_t *)s->t_stats.p, (int32_t *)s->t_np.p};
             if ((rc = launch_forward(s, f))) return rc;
             a.B = tB; a.traj_cap = (int32_t)rows;
-            if (s->ws_doubles == 0) { a.traj_istride = (int32_t)rows; a.traj_stride = 1; }
+            if (!s->point_major) { a.traj_istride = (int32_t)rows; a.traj_stride = 1; }
             else { a.traj_istride = 1; a.traj_stride = stride; }
             a.ps = d_ps + (size_t)lo * np_; a.pr = d_pr + (size_t)lo * (size_t)rem_stride;
             a.grads = d_g + (size_t)lo * (size_t)grads_stride;

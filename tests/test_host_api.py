@@ -24,7 +24,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     want = int(re.search(r"#define SA_ABI_VERSION (\d+)", header).group(1))
-    assert L.sa_abi_version() == want == 2         # 2: instance-major arena records, bounded store modes
+    assert L.sa_abi_version() == want == 3         # 3: arena layout by kernel family (sa_traj_point_major)
     abi = open(os.path.join(ROOT, "sunode_amd", "csrc", "sa_device_abi.h")).read()
     assert int(re.search(r"#define SA_DEVICE_ABI_VERSION (\d+)", abi).group(1)) == want
 

@@ -44,10 +44,14 @@ def main():
         parts = ", ".join("%s %.1f" % (n, stt[:, 9 + i].mean() * 1e-5) for i, n in enumerate(names))
         if tag == "bwd" and "PROFILE_PHASES" in os.environ.get("SA_KERNEL_DEFINES", "") and stt[:, 8].mean() > 1e4:
             parts += ", restarts %.1f" % (stt[:, 8].mean() * 1e-5)
+        if (stt[:, 8] & 0xffffffff).sum() > 0 and (stt[:, 8] >> 32).sum() == 0 and stt[:, 2].mean() > 0 and \
+                "PROFILE_PHASES" not in os.environ.get("SA_KERNEL_DEFINES", ""):      # workgroup LU: its own wall clock
+            print("    LU (setup_lu_regs, wavefront 0): %.1f us per factorisation"
+                  % ((stt[:, 8] & 0xffffffff).mean() / max(stt[:, 2].mean(), 1) / 1e2))
         if tag == "bwd" and (stt[:, 8] >> 32).sum() > 0 and (stt[:, 8] >> 32).max() < (1 << 30):   # workgroup-LU builds only
             nlu = max(stt[:, 2].mean(), 1)
             # the three partial counters are s_memtime reads the compiler may move across VALU work: indicative only
-            print("    LU of wavefront 0, kilo-cycles per factorisation: before barrier %.1f, in barrier %.1f, update %.1f"
+            print("    LU of wavefront 0, kilo-cycles per factorisation: panel factorisation %.1f, waiting %.1f, update %.1f"
                   % tuple(stt[:, 5 + i].mean() / nlu / 1e3 for i in range(3))
                   + "; whole function %.1f us = %.1f kilo-cycles" % ((stt[:, 8] & 0xffffffff).mean() / nlu / 1e2,
                                                                    (stt[:, 8] >> 32).mean() / nlu / 1e3))
