@@ -144,6 +144,8 @@ class GpuEngine:
         # stream ordering (include/sunode_amd.h): the solver launches on the torch stream that owns the tensors
         self.stream = torch.cuda.Stream(device=self.dev)
         self.eng.set_stream(self.stream.cuda_stream)
+        self.build = {"code_object": _native.file_hash(self.eng.code_object),
+                      "code_object_file": os.path.basename(self.eng.code_object), "toolchain": _native.toolchain_id()}
         torch.cuda.synchronize()
 
     def step(self):
@@ -166,7 +168,9 @@ class GpuEngine:
         return dict(failed=int((self.st_f != 0).sum().item() + (self.st_b != 0).sum().item()),
                     stats_f=self.stats_f.double().mean(dim=0).cpu().numpy(),
                     stats_b=self.stats_b.double().mean(dim=0).cpu().numpy(),
-                    arena=self.eng.arena_info())
+                    arena=self.eng.arena_info(), build=self.build,
+                    head_grads=self.grad_out[:16, :max(self.p, 1)].cpu().numpy(),
+                    head_lamda=self.lamda_out[:16].cpu().numpy())
 
     def close(self):
         self.eng.close()
@@ -216,9 +220,13 @@ class MultiDeviceEngine:
 
     def results(self):
         rs = [e.results() for e in self.engines]
-        return dict(failed=sum(r["failed"] for r in rs),
-                    stats_f=np.mean([r["stats_f"] for r in rs], axis=0), stats_b=np.mean([r["stats_b"] for r in rs], axis=0),
-                    arena=(max(r["arena"][0] for r in rs), sum(r["arena"][1] for r in rs), any(r["arena"][2] for r in rs)))
+        out = dict(failed=sum(r["failed"] for r in rs),
+                   stats_f=np.mean([r["stats_f"] for r in rs], axis=0), stats_b=np.mean([r["stats_b"] for r in rs], axis=0),
+                   arena=(max(r["arena"][0] for r in rs), sum(r["arena"][1] for r in rs), any(r["arena"][2] for r in rs)))
+        for key in ("build", "head_grads", "head_lamda"):      # (engine 0 integrates draws 0..B-1 of the global batch)
+            if key in rs[0]:
+                out[key] = rs[0][key]
+        return out
 
     def close(self):
         for e in self.engines:
@@ -385,6 +393,37 @@ def pmc_profile(workload, kernel):
         return None
 
 
+def pmc_context_matches(workload, B, rec, build):
+    """(ok, note): do the committed counters describe THIS run?  The profile records the batch, the arena record size,
+    the code-object hash and the toolchain it was taken with; counters of another build are not printed as
+    if measured here."""
+    ctx = pmc_profile(workload, "context")
+    if ctx is None:
+        return False, "profiles/pmc_traffic.json carries no context for this workload: counter ratios withheld"
+    diff = [k for k, v in (("batch", B), ("record_bytes", rec), ("code_object", (build or {}).get("code_object")),
+                           ("toolchain", ((build or {}).get("toolchain") or {}).get("hash"))) if ctx.get(k) != v]
+    if diff:
+        return False, "profiled with a different %s (profiles/pmc_traffic.json): counter ratios withheld" % " / ".join(diff)
+    return True, "counters of this code object, batch and record format"
+
+
+def truth_gradient_error(name, res):
+    """max relative error of dL/dp and dL/dy0 of the timed batch's first 16 draws against the committed truth fixture
+    (tests/golden/truth_lv.npz: DOP853 on the sensitivity equations, same generator, same cotangent) -- LV only."""
+    if name != "lv" or "head_grads" not in res:
+        return None
+    try:
+        t = np.load(os.path.join(ROOT, "tests", "golden", "truth_lv.npz"))
+    except OSError:
+        return None
+    g, lam = res["head_grads"], res["head_lamda"]
+    k = min(len(g), len(t["grad_params"]))
+    eg = np.max(np.abs(g[:k] - t["grad_params"][:k]) / np.abs(t["grad_params"][:k]).max(axis=1, keepdims=True))
+    el = np.max(np.abs(-lam[:k] - t["grad_y0"][:k]) / np.abs(t["grad_y0"][:k]).max(axis=1, keepdims=True))
+    return {"draws": int(k), "dL_dp_max_rel": float(eg), "dL_dy0_max_rel": float(el),
+            "fixture": "tests/golden/truth_lv.npz (rtol = atol = 1e-8 bar in the tests: 4e-6)"}
+
+
 def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, failed):
     n, p = prob.n_states, prob.n_params
     sf, sb = res["stats_f"], res["stats_b"]
@@ -397,13 +436,19 @@ def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, faile
     f_fwd, f_bwd = algorithmic_flops(prob, sf, sb)
     pmc = pmc_profile(name, "sa_k_backward")
     pmc_f = pmc_profile(name, "sa_k_forward")
-    have = bool(pmc and "fetch" in pmc and "write" in pmc)
-    traffic_b = (pmc["fetch"] + pmc["write"]) if have else None
-    traffic_f = (pmc_f["fetch"] + pmc_f["write"]) if (pmc_f and "fetch" in pmc_f and "write" in pmc_f) else None
     arena_bytes, tiles, tiled = res.get("arena", (0, 0, False))
     from sunode_amd import _native
     compact = _native.default_compact_trajectory(prob.native_source())
     rec = 8 * (n + 2) if compact else 8 * (8 + 6 * n)
+    build = res.get("build")
+    ctx_ok, ctx_note = pmc_context_matches(name, B, rec, build)
+    if not ctx_ok:
+        pmc = pmc_f = None
+    have = bool(pmc and "fetch" in pmc and "write" in pmc)
+    traffic_b = (pmc["fetch"] + pmc["write"]) if have else None
+    traffic_f = (pmc_f["fetch"] + pmc_f["write"]) if (pmc_f and "fetch" in pmc_f and "write" in pmc_f) else None
+    ctx = pmc_profile(name, "context") if ctx_ok else None
+    prof_ms = (ctx or {}).get("kernel_ms") or {}
     out = {
         "metric": "fp64 forward+adjoint ODE solves/sec at rtol=1e-8 (%s, batch %d/GPU)"
                   % ({"lv": "Lotka-Volterra"}.get(name, name), B),
@@ -413,12 +458,22 @@ def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, faile
         "config": {"workload": w["label"], "batch_per_gpu": B, "global_batch": B * world,
                    "parallelism": "instance-sharded x%d" % world, "failed_instances": failed},
         "roofline": {
-            # contract figure: HBM.  The path is NOT HBM-bound (thousands of tiny sequential solves);
-            # `valu` below is the roofline that binds.
-            "bound": "hbm", "kernel": "sa_k_backward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` names what binds: the issue rate of the fp64 vector unit at one wavefront per SIMD (one instruction of
+            # ANY kind per four cycles per wavefront: profiles/r04_ubench_issue.txt) -- see `valu`.  achieved / peak /
+            # frac / traffic are the CONTRACT figures: algorithmic HBM bytes against the 8 TB/s peak, repeated
+            # under `hbm`; the path is not HBM-bound (thousands of tiny sequential solves).
+            "bound": "valu-issue", "kernel": "sa_k_backward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic_b,
-            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command)" if have else None,
+            "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},
+            "traffic_source": ("profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command): " + ctx_note)
+                              if have else ctx_note,
+            # kernel time of the profiled run next to this run's (a gap above 5 % means the counters describe a
+            # different machine state: flagged)
+            "profiled_kernel_ms": prof_ms.get("sa_k_backward"), "profiled_forward_kernel_ms": prof_ms.get("sa_k_forward"),
+            "kernel_ms_gap": (abs(1e3 * bwd_s / prof_ms["sa_k_backward"] - 1.0) if prof_ms.get("sa_k_backward") else None),
+            "kernel_ms_gap_flag": (bool(abs(1e3 * bwd_s / prof_ms["sa_k_backward"] - 1.0) > 0.05)
+                                   if prof_ms.get("sa_k_backward") else None),
             # what the counters say the kernels really move, against the same peak (bytes of the committed PMC pass /
             # this run's kernel time): the figure to watch for wasted re-reads
             "hbm_frac_traffic": (traffic_b / bwd_s / 1e9 / HBM_PEAK_GBS) if have else None,
@@ -433,12 +488,17 @@ def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, faile
             # what the implementation moves by design: one {order, dt, T[6], Y[6][n]} record per stored point
             "traffic_model": B * (8 * (p + prob.n_remainder) + npts * rec + 8 * (p + n) + 140),
             "limiter": "neither contract roofline binds: the path is thousands of tiny sequential solves (SURVEY 8d); "
-                       "what limits it is fp64 VALU dependent-issue latency at one wavefront per SIMD -- see valu",
+                       "what limits it is the instruction issue rate of ONE wavefront per SIMD (4 cycles per instruction "
+                       "of any kind, 5 when dependent: profiles/r04_ubench_issue.txt) x lane utilisation -- see valu",
             "valu": {"kernel": "sa_k_backward", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
                      "algorithmic": B * f_bwd / bwd_s / 1e12, "frac_algorithmic": B * f_bwd / bwd_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      "issued": (pmc["valu_fp64_flops"] / bwd_s / 1e12) if pmc and "valu_fp64_flops" in pmc else None,
                      "valu_busy": pmc.get("valu_busy") if pmc else None,
                      "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
+                     # VALU wave-instructions per step attempt of a wavefront (the lever for configs 2 and 3 and for
+                     # small batches: VERDICT r3 #4): counter VALU instructions / (wavefronts x mean attempts)
+                     "valu_insts_per_attempt": (pmc["valu_insts"] / ((B + 63) // 64 * max(float(sb[14]), 1.0))
+                                                if pmc and "valu_insts" in pmc and name in ("lv", "robertson") else None),
                      "note": "algorithmic = SURVEY 8(d) F_alg from the kernel's own counters; issued = fp64 "
                              "FMA/MUL/ADD lane-ops of the committed PMC pass (all 64 lanes counted) / this run's "
                              "kernel time"}},
@@ -451,6 +511,10 @@ def summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, faile
     }
     if pmc and "valu_fp64_flops" in pmc:
         out["roofline"]["valu"]["frac_issued"] = out["roofline"]["valu"]["issued"] / FP64_VALU_PEAK_TFLOPS
+    out["build"] = dict(build or {}, batch=B, record_bytes=rec)
+    err = truth_gradient_error(name, res)
+    if err:
+        out["truth_gradient_error"] = err
     return out
 
 
@@ -557,6 +621,9 @@ def extra_configs(args):
                    "hbm_frac": r["roofline"]["frac"], "hbm_frac_traffic": r["roofline"]["hbm_frac_traffic"],
                    "forward_hbm_frac_traffic": r["roofline"]["forward_hbm_frac_traffic"],
                    "traffic_over_algorithmic": r["roofline"]["traffic_over_algorithmic"],
+                   "traffic_source": r["roofline"]["traffic_source"],
+                   "profiled_backward_kernel_ms": r["roofline"]["profiled_kernel_ms"],
+                   "kernel_ms_gap_flag": r["roofline"]["kernel_ms_gap_flag"], "build": r.get("build"),
                    "arena_record": r["roofline"]["arena_record"],
                    "valu_frac_algorithmic": r["roofline"]["valu"]["frac_algorithmic"],
                    "valu_busy": r["roofline"]["valu"]["valu_busy"], "lane_utilisation": r["roofline"]["valu"]["lane_utilisation"],

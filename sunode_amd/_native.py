@@ -112,6 +112,29 @@ WAVE_CODEGEN_FLAGS = "-mllvm -disable-machine-licm -mllvm -machine-sink-split=0"
 SMALL_GROUP_CODEGEN_FLAGS = "-mllvm -misched-cluster=0"
 
 
+#: SIOptimizeVGPRLiveRange -- the AMDGPU pass that shortens VGPR live ranges in divergent if / else regions.  Round 4
+#: traced the "parking l[] changes the results" anomaly of the 4-lane forward-sensitivity build to it: with
+#: `-disable-machine-licm` and the coefficient vectors parked in LDS the SEIR build differs from the oracle in half of its
+#: step counters; the difference survives eight other code-generation variations (no AGPR / SGPR-to-VGPR spilling, no
+#: machine CSE, no pre- / post-RA scheduler, no early if-conversion, sink splitting on / off, a hard barrier around the
+#: parked values) and disappears with exactly `-amdgpu-opt-vgpr-liverange=0`, with -O1, or when the source reads the
+#: parked values once more (which is why it looked like a heisenbug); the machine verifier is silent and the
+#: "group-uniform" values are uniform (diagnostic build -DSA_CTL_CHECK).  Reproducer: tools/repro_vgpr_liverange.sh,
+#: record: profiles/r04_sens_anomaly.txt.  That configuration is NOT shipped (the sensitivity builds carry neither the
+#: parking nor -disable-machine-licm), and every shipped build agrees with the oracle bit for bit (163 GPU tests, all
+#: BASELINE batches at full size).  Building everything without the pass costs 10 % (LV) ... 27 % (SEIR) ... 57 %
+#: (Robertson sensitivities) -- profiles/r04_vgpr_liverange_ab.txt -- so it stays ON by default and
+#: SA_VGPR_LIVERANGE_OPT=0 (or SAFE builds: `sunode_amd._native.SAFE_CODEGEN = True`) turns it off for every
+#: register-resident kernel: the conservative build for models nobody has compared with the oracle.
+SAFETY_CODEGEN_FLAGS = "-mllvm -amdgpu-opt-vgpr-liverange=0"
+SAFE_CODEGEN = False
+
+
+def _safety_flags():
+    off = os.environ.get("SA_VGPR_LIVERANGE_OPT") == "0" or (SAFE_CODEGEN and os.environ.get("SA_VGPR_LIVERANGE_OPT") != "1")
+    return SAFETY_CODEGEN_FLAGS.split() if off else []
+
+
 def _extra_codegen_flags():
     """Extra flags for the final clang -O3 stage (tuning experiments), e.g.
     SA_CLANG_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"; part of the cache key."""
@@ -226,6 +249,7 @@ def code_object_path(native_source: str, sens: bool = False, constraints: bool =
     deps = [d for d in deps if os.path.exists(d)]
     extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode()
              + (WAVE_CODEGEN_FLAGS + ADJOINT_CODEGEN_FLAGS + SMALL_GROUP_CODEGEN_FLAGS).encode()
+             + " ".join(_safety_flags()).encode()
              + b"G%d" % group + fname.encode()
              + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode()
              + (b"SENS" if sens else b"") + (b"CONSTR" if constraints else b"") + (b"HERMITE" if hermite else b"")
@@ -282,10 +306,11 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
         extra = _extra_codegen_flags()
         if "SA_CLANG_FLAGS" not in os.environ:
             if fname == "bdf_kernels.hip":
-                extra = extra + ([] if sens else ADJOINT_CODEGEN_FLAGS.split())
+                extra = extra + ([] if sens else ADJOINT_CODEGEN_FLAGS.split()) + _safety_flags()
             elif fname == "bdf_wave.hip":
-                extra = [] if sens else (WAVE_CODEGEN_FLAGS + " " + ADJOINT_CODEGEN_FLAGS
-                                         + (" " + SMALL_GROUP_CODEGEN_FLAGS if group <= 8 else "")).split()
+                extra = ([] if sens else (WAVE_CODEGEN_FLAGS + " " + ADJOINT_CODEGEN_FLAGS
+                                          + (" " + SMALL_GROUP_CODEGEN_FLAGS if group <= 8 else "")).split()) \
+                    + _safety_flags()
             else:
                 extra = []
         try:

@@ -106,14 +106,16 @@ __shared__ double s_cold[W_NCOLD * 64];
 #define W_NCTL 14
 __shared__ double s_ctl[KPW * W_NCTL];
 #ifdef SA_SENS
-/* The forward-sensitivity builds keep these in registers.  With l[] parked, the 4-lane SEIR build (2 600 spill slots,
-   4 KB of scratch per lane) stops being bit-equal to the oracle and to its own 8-lane build (which stays equal with
-   the parking on).  Measured: deterministic and independent of the batch; parking tau / tq alone is fine; a
-   lane-PRIVATE copy of l[] fails the same way, so it is not the cross-lane hand-over; merely READING m.l after the
-   Newton pass (comparing it with the parked copy: always equal) changes the result too; inlining sens_rhs_rows does
-   not help.  No path between store and load writes l[] (bdf_core.h: only cvSet and the order changes do, all before
-   the store).  Unresolved -- a code-generation problem at that register pressure is the suspicion; the validated
-   configuration is the one shipped and tests/test_forward_sens.py pins it in three mappings. */
+/* The forward-sensitivity builds keep these in registers (parking them there was never measured to pay).  Round 3
+   recorded that with l[] parked the 4-lane SEIR build stopped being bit-equal to the oracle -- and that merely reading
+   m.l after the Newton pass changed the result.  Round 4 (profiles/r04_sens_anomaly.txt, tools/repro_vgpr_liverange.sh):
+   the vectors ARE uniform across the lanes of a group (-DSA_CTL_CHECK), no LDS ordering is involved (a hard barrier
+   around the parked values changes nothing), and the wrong results follow one compiler pass: they need
+   -disable-machine-licm (which the sensitivity builds then inherited from the adjoint flag set), survive eight other
+   code-generation variations and disappear with -mllvm -amdgpu-opt-vgpr-liverange=0, i.e. without SIOptimizeVGPRLiveRange,
+   the pass that declares registers dead in the side of a divergent branch a lane does not take.  The failing
+   combination is not shipped; SA_VGPR_LIVERANGE_OPT=0 builds every register-resident kernel without the pass
+   (_native.py SAFETY_CODEGEN_FLAGS: the conservative build, 10 ... 27 % slower). */
 #ifndef SA_SENS_CTL_PARK            /* (experiments) */
 #define SA_NO_CTL_PARK 1
 #endif
@@ -561,6 +563,10 @@ struct Cw {
     double f0[RS];                    /* f(t0, y0) of the first stored point */
 #endif
     int n_interp, n_rebuild;
+#ifdef SA_CTL_CHECK
+    int ctl_diff;                     /* (diagnostic build) bit i: l[i] differed between the lanes of the group when it was parked;
+                                         bits 8..: tau, bits 16..: tq */
+#endif
 #ifdef SA_SENS
     /* forward sensitivities (Solver(sens_mode=...), reference solver.py:360-392): the NQ sensitivity Nordsieck arrays
        and work vectors live in the workspace (SV(m, vector, parameter, slot)), streamed through registers phase by phase */
@@ -1267,7 +1273,10 @@ DEV int getrf_group_regs(const Grp &g, double (&inv_piv)[RS], int &nswaps)
  * cycles per elimination step, half of them the owner's serial chain with the other three wavefronts waiting: 73 us
  * per 100 x 100 factorisation.  Panels with a barrier each: 45 us.  Dataflow: see the profile. */
 #if SA_WAVES > 1
+#ifndef LU_NB
 #define LU_NB 4
+#endif
+#define LU_INFO (LU_NB + 4)                 /* ints per ring slot: LU_NB pivot rows, #exchanges, zero-pivot step + 1, padding */
 #define LU_NPANEL ((NS + LU_NB - 1) / LU_NB)
 #define LU_NPR ((LU_NPANEL + SA_WAVES - 1) / SA_WAVES)
 #define LU_NC (LU_NPR * LU_NB)
@@ -1277,7 +1286,7 @@ static_assert(RS <= 2 && 64 % (LU_NB * SA_WAVES) == 0 && (SA_WAVES & (SA_WAVES -
               "the rows of a panel round share one register slot; the ring of published panels has SA_WAVES slots");
 __shared__ __attribute__((aligned(16))) double s_col[SA_WAVES][RS * 64 * LU_NB];      /* ring of published panels */
 __shared__ double s_invp[W_NS];
-__shared__ __attribute__((aligned(16))) int s_luinfo[SA_WAVES * 8];     /* per ring slot: 4 pivot rows, #exchanges, zero-pivot step + 1 */
+__shared__ __attribute__((aligned(16))) int s_luinfo[SA_WAVES * LU_INFO];     /* per ring slot: 4 pivot rows, #exchanges, zero-pivot step + 1 */
 __shared__ int s_luier, s_lunswaps, s_lupub;
 #ifdef SA_WAVE_PROFILE
 __shared__ int64_t s_luprof[10];           /* wavefront 0, cycles: panel factorisation, waiting, trailing update, whole function (ticks /
@@ -1415,6 +1424,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
        every row. */
 #define LU_SLOT(PR) LU_SLOT_OF_BLOCK(PR)
 #define LU_GC 4
+    static_assert(LU_NB % LU_GC == 0, "panel width in whole column groups");
     /* the trailing update with panel p-1 of the register columns [C0, C1): step-outer, column-inner in groups of LU_GC
        columns -- the broadcasts of a group, then its FMAs, a scheduling barrier (left alone the scheduler hoists every
        broadcast of a step to the front, runs out of scalar registers and spills them through v_writelane /
@@ -1430,7 +1440,8 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
         SFOR(cc, C0, C1) { SFOR(r, SP, RS) a[cc][r] = FMA(-akj_[cc - (C0)], lc[KK][r], a[cc][r]); SEND } SEND         \
         SFOR(cc, C0, C1) { SFOR(r, SP, RS) lu_pin(a[cc][r]); SEND } SEND                                              \
         __builtin_amdgcn_sched_barrier(0); }
-#define LU_UPD_SAME(SP) SFOR(kk, 0, LU_NB) LU_UPD_GROUP(SP, pr * LU_NB, pr * LU_NB + LU_NB, kk) SEND
+#define LU_UPD_SAME(SP) SFOR(kk, 0, LU_NB) {                                                                        \
+        SFOR(g, 0, LU_NB / LU_GC) LU_UPD_GROUP(SP, pr * LU_NB + g * LU_GC, pr * LU_NB + g * LU_GC + LU_GC, kk) SEND } SEND
 #define LU_UPD_MAIN(SP) SFOR(kk, 0, LU_NB) {                                                                        \
         SFOR(g, 0, (LU_NC - (pr + 1) * LU_NB + LU_GC - 1) / LU_GC) {                                                  \
             constexpr int c0 = (pr + 1) * LU_NB + g * LU_GC, c1 = (c0 + LU_GC < LU_NC) ? c0 + LU_GC : LU_NC;          \
@@ -1439,7 +1450,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
     /* the published panel q (ring slot q mod SA_WAVES): words -> word[], multiplier columns of the slots >= SP -> lc */
 #define LU_READ(SP, Q)                                                                                              \
         const int slot_ = (Q) & (SA_WAVES - 1);                                                                       \
-        int nex_ = L.info[slot_ * 8 + 4], ierp_ = L.info[slot_ * 8 + 5];                                              \
+        int nex_ = L.info[slot_ * LU_INFO + LU_NB], ierp_ = L.info[slot_ * LU_INFO + LU_NB + 1];                                              \
         SFOR(r, SP, RS) { SFOR(kk, 0, LU_NB) lc[kk][r] = L.col[((slot_ * RS + r) * 64 + lane) * LU_NB + kk]; SEND } SEND \
         nex_ = __builtin_amdgcn_readfirstlane(nex_); ierp_ = __builtin_amdgcn_readfirstlane(ierp_);
     /* The row exchanges of a published panel (first row kq, pivot rows in slot SP) in the register columns [C0, C1)
@@ -1471,7 +1482,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
         if (ierp_ != 0 && wave != (oq)) ier = (ier == 0) ? ierp_ : ier;                                               \
         if (nex_ != 0 && wave != (oq)) {                                                                              \
             nswaps += nex_;                                                                                           \
-            SFOR(kk, 0, LU_NB) word[kk] = __builtin_amdgcn_readfirstlane(L.info[slot_ * 8 + kk]); SEND                \
+            SFOR(kk, 0, LU_NB) word[kk] = __builtin_amdgcn_readfirstlane(L.info[slot_ * LU_INFO + kk]); SEND                \
             LU_GATHER_MAP(SP, kq)                                                                                     \
             SFOR(cc, 0, LU_NC) LU_GATHER_COL(SP, a[cc]) SEND                                                          \
         }
@@ -1619,9 +1630,9 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                     SFOR(kk, 0, LU_NB) L.col[((slot * RS + r) * 64 + lane) * LU_NB + kk] = a[pr * LU_NB + kk][r]; SEND
                 } SEND
                 if (lane == 0) {
-                    SFOR(kk, 0, LU_NB) L.info[slot * 8 + kk] = pword[kk]; SEND
-                    L.info[slot * 8 + 4] = own_swaps;
-                    L.info[slot * 8 + 5] = ier;
+                    SFOR(kk, 0, LU_NB) L.info[slot * LU_INFO + kk] = pword[kk]; SEND
+                    L.info[slot * LU_INFO + LU_NB] = own_swaps;
+                    L.info[slot * LU_INFO + LU_NB + 1] = ier;
                     if (k0 < NS && ier == 0) {
                         SFOR(kk, 0, LU_NB) {
                             if (!PARTIAL || k0 + kk < NS) { L.piv[k0 + kk] = (uint8_t)pword[kk]; L.invp[k0 + kk] = mults[kk]; }
@@ -1739,17 +1750,35 @@ DEV double bcast_vec(const double (&b)[RS], int k, int gbase)
 }
 
 /* Triangular solves for the whole-wavefront mapping (G = 64): the chain through b is inherently serial
-   (broadcast b_k, one FMA per owned row); everything else is taken out of it -- the loops are split by the
-   register slot that holds b_k (no slot selects), rows that need no mask get none (components beyond n carry
-   don't-care values and are zeroed at the end), and the matrix columns are fetched from LDS a block of
-   GETRS_BLOCK columns ahead (double-buffered) so that no LDS latency sits in the chain. */
+   (broadcast b_k, one FMA per owned row) and -- for a lone wavefront -- paid per INSTRUCTION (four cycles each,
+   profiles/r04_ubench_issue.txt), so everything else is taken out of it: the loops are split by the register slot that
+   holds b_k (no slot selects), the matrix columns come from LDS a block of GETRS_BLOCK columns ahead (double-buffered),
+   and there are NO ROW MASKS (round 4): the finished component of a step is filed in a second vector with one
+   v_writelane per half, after which the FMA may run over every row of the slot -- the rows it must not touch (those
+   already solved, whose matrix entries belong to the other factor) are dead values in b by then.  Per step: two
+   v_readlane, two v_writelane, one FMA per slot (before: two more v_readlane for a spilled lane mask and two
+   v_cndmask).  Same operations on the same values for every component that is ever read. */
 #define GETRS_BLOCK 4
+template <int LANE>
+DEV double writelane_d(double old, double v)                   /* old with lane LANE replaced by the (wave-uniform) v */
+{
+    static_assert(LANE >= 0 && LANE < 64, "lane of a wavefront");
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    uint64_t o = __builtin_bit_cast(uint64_t, old);
+    uint32_t lo = (uint32_t)o, hi = (uint32_t)(o >> 32);
+    /* (this clang has no __builtin_amdgcn_writelane; the lane select is an inline constant: one scalar operand only) */
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)u), "n"(LANE));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(u >> 32)), "n"(LANE));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
 template <bool BWD>
 DEV void dense_getrs64(Cw<BWD> &m, double (&b)[RS])
 {
     const int lane = m.lane;
     const double *A = s_A + m.abase;
     const double (&inv_piv)[RS] = m.inv_piv;
+    double y[RS];                                   /* the solved components, filed as they become final */
+    SFOR(r, 0, RS) y[r] = b[r]; SEND
     /* forward substitution with the unit lower factor */
     SFOR(sk, 0, RS) {
         constexpr int k_lo = sk * 64;
@@ -1771,13 +1800,20 @@ DEV void dense_getrs64(Cw<BWD> &m, double (&b)[RS])
                     constexpr int k = k0 + d;
                     if constexpr (k < k_hi) {
                         const double bk = readlane_d(b[sk], k - k_lo);
-                        if (lane > k - k_lo) b[sk] = FMA(-cur[d][sk], bk, b[sk]);
-                        SFOR(r, sk + 1, RS) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
+                        y[sk] = writelane_d<k - k_lo>(y[sk], bk);
+                        SFOR(r, sk, RS) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
                     }
                 } SEND
             } SEND
         }
+        /* the rows of this slot that no step of it finalised (the last row of the system; a slot the loop above did
+           not enter): they are final now -- rows beyond the steps only ever received their own updates */
+        {
+            constexpr int done_to = (k_lo < k_hi) ? k_hi - k_lo : 0;       /* lanes [0, done_to) are filed */
+            y[sk] = (lane >= done_to) ? b[sk] : y[sk];
+        }
     } SEND
+    SFOR(r, 0, RS) b[r] = y[r]; SEND
     /* back substitution with the upper factor (reciprocal pivots) */
     SFOR_DOWN(sk, RS - 1, 0) {
         constexpr int k_lo = sk * 64 > 1 ? sk * 64 : 1;                 /* k = NS-1 ... 1 */
@@ -1798,17 +1834,20 @@ DEV void dense_getrs64(Cw<BWD> &m, double (&b)[RS])
                     if constexpr (k >= k_lo) {
                         constexpr int kl = k - sk * 64;
                         const double scaled = b[sk] * inv_piv[sk];
-                        b[sk] = (lane == kl) ? scaled : b[sk];
                         const double bk = readlane_d(scaled, kl);
-                        if (lane < kl) b[sk] = FMA(-cur[d][sk], bk, b[sk]);
-                        SFOR(r, 0, sk) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
+                        y[sk] = writelane_d<kl>(y[sk], bk);
+                        SFOR(r, 0, sk + 1) b[r] = FMA(-cur[d][r], bk, b[r]); SEND
                     }
                 } SEND
             } SEND
         }
     } SEND
-    if (lane == 0) b[0] *= inv_piv[0];
-    SFOR(r, 0, RS) { if (r * 64 + lane >= NS) b[r] = 0.0; } SEND
+    /* component 0 (never a step of the loops above: k runs down to 1) */
+    {
+        const double scaled = b[0] * inv_piv[0];
+        y[0] = writelane_d<0>(y[0], readlane_d(scaled, 0));
+    }
+    SFOR(r, 0, RS) b[r] = (r * 64 + lane >= NS) ? 0.0 : y[r]; SEND
 }
 
 /* ---- triangular solves of an 8-lane group, unrolled (small systems: config 4) ----
@@ -2279,6 +2318,15 @@ DEV void cold_store(const Cw<BWD> &m)
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) c[(5 * RS + j * RQ + r) * 64] = m.znQ[j][r]; SEND } SEND
         SFOR(r, 0, RQ) c[(5 * RS + 6 * RQ + r) * 64] = m.zsaveQ[r]; SEND
     }
+#ifdef SA_CTL_CHECK
+    {   /* are the "group-uniform" coefficient vectors uniform?  every lane against lane 0 of its group */
+        int d = 0;
+        SFOR(i, 0, 6) { if (__builtin_bit_cast(uint64_t, m.l[i]) != __builtin_bit_cast(uint64_t, shfl_d(m.l[i], m.gbase))) d |= 1 << i; } SEND
+        SFOR(i, 1, 6) { if (__builtin_bit_cast(uint64_t, m.tau[i]) != __builtin_bit_cast(uint64_t, shfl_d(m.tau[i], m.gbase))) d |= 256 << i; } SEND
+        SFOR(i, 1, 6) { if (__builtin_bit_cast(uint64_t, m.tq[i]) != __builtin_bit_cast(uint64_t, shfl_d(m.tq[i], m.gbase))) d |= 65536 << i; } SEND
+        const_cast<Cw<BWD> &>(m).ctl_diff |= d;
+    }
+#endif
 #if defined(SA_CTL_PRIVATE) && !defined(SA_NO_CTL_PARK)
     {
         double *u = s_ctlp + m.lane;
@@ -2293,6 +2341,9 @@ DEV void cold_store(const Cw<BWD> &m)
         SFOR(i, 1, 6) u[5 + i] = m.tau[i]; SEND
         u[11] = m.tq[1]; u[12] = m.tq[3]; u[13] = m.tq[5];
     }
+#ifdef SA_COLD_HARD_SYNC             /* (experiment: a real barrier + a wait for every outstanding LDS operation) */
+    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+#endif
     lds_sync();         /* lane 0 wrote what the other lanes of the group read back: the fence keeps the compiler from
                            moving their loads above the (for them absent) store */
 #endif
@@ -2316,6 +2367,9 @@ DEV void cold_load(Cw<BWD> &m)
     }
 #elif !defined(SA_NO_CTL_PARK)
     {
+#ifdef SA_COLD_HARD_SYNC
+        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+#endif
         lds_sync();
         const double *u = s_ctl + (m.lane / G) * W_NCTL;
         SFOR(i, 0, 6) m.l[i] = u[i]; SEND
@@ -2444,6 +2498,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
     m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
+#ifdef SA_CTL_CHECK
+    m.ctl_diff = 0;
+#endif
     m.traj = nullptr; m.trow = 0;
 
     double y0[RS], q0[RQ];
@@ -2584,6 +2641,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
     m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
     m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
+#ifdef SA_CTL_CHECK
+    m.ctl_diff = 0;
+#endif
     m.traj = nullptr; m.trow = 0;
     m.sensi = 1; m.ism = a.ism; m.pbar = a.pbar;
 
@@ -2663,6 +2723,10 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
         for (int j = m.li; j < a.n_t * NS; j += G) yo[j] = SA_NAN;
         for (int j = m.li; j < a.n_t * NQ * NS; j += G) so[j] = SA_NAN;
     }
+#ifdef SA_CTL_CHECK
+    int ctl_any = m.ctl_diff;
+    SFOR(b, 0, LOG2G) ctl_any |= shfl_i(ctl_any, m.lane ^ (1 << b)); SEND
+#endif
     if (m.li == 0) {
         a.status[inst] = status;
         int64_t st[SA_N_STATS];
@@ -2671,6 +2735,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
         /* sensitivity counters ride in the quadrature / interpolation slots of the adjoint path */
         st[ST_NFQE] = m.nfSe; st[ST_NETFQ] = m.netfS; st[ST_NINTERP] = m.nniS; st[ST_NREBUILD] = m.ncfnS;
         st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+#ifdef SA_CTL_CHECK
+        st[15] = ctl_any;
+#endif
         SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
     }
 }
@@ -2709,6 +2776,9 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     m.cur_idx = 0; m.tlo2 = 0.0; m.tlo = m.thi = 0.0;
     m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
     m.n_interp = 0; m.n_rebuild = 0;
+#ifdef SA_CTL_CHECK
+    m.ctl_diff = 0;
+#endif
 
     double *lam_g = a.lamda_out + (int64_t)inst * NS, *quad_g = a.grad_out + (int64_t)inst * NQ;
     {

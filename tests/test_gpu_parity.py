@@ -1074,3 +1074,49 @@ def test_network_device_gradients_match_truth(n, group, golden_dir, monkeypatch)
     gt = d["grad_params"]
     assert np.max(np.abs(g - gt) / np.abs(gt).max(axis=1, keepdims=True)) < 2e-6
     assert np.max(np.abs(-lam - d["grad_y0"]) / np.abs(d["grad_y0"]).max(axis=1, keepdims=True)) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["lv", "seir"])
+def test_conservative_build_without_the_vgpr_liverange_pass(name, monkeypatch):
+    """SA_VGPR_LIVERANGE_OPT=0: every register-resident kernel built with -amdgpu-opt-vgpr-liverange=0 (round 4 traced a
+    miscompile of an unshipped variant of the 4-lane sensitivity build to SIOptimizeVGPRLiveRange:
+    profiles/r04_sens_anomaly.txt).  The conservative build is another code object (own cache key) with the same
+    results: forward + adjoint of LV (one lane per instance) and SEIR (4-lane groups) bit-equal to the oracle, and SEIR's
+    forward sensitivities too."""
+    from sunode_amd import _native
+    from sunode_amd.solver import AdjointSolver, Solver
+    prob = make_problem(name)
+    fast = _native.code_object_path(prob.native_source(), compact=_native.default_compact_trajectory(prob.native_source()))
+    monkeypatch.setenv("SA_VGPR_LIVERANGE_OPT", "0")
+    assert _native._safety_flags() == _native.SAFETY_CODEGEN_FLAGS.split()
+    assert _native.code_object_path(prob.native_source(), compact=_native.default_compact_trajectory(prob.native_source())) != fast
+    B = 130
+    if name == "lv":
+        d = lv_batch(B); ps, pr = d["params"][:, :2], d["params"][:, 2:]
+    else:
+        d = seir_batch(B); ps, pr = d["ps"], d["pr"]
+    tv = d["tvals"]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(prob.n_states)[None, :])
+    tol = 1e-8
+    sol = AdjointSolver(prob, abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol, quad_abstol=tol, quad_reltol=tol)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle(name)
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], ps, pr, 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (st == 0).all() and (stb == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(statsb[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+    if name == "seir":
+        sens0 = np.zeros((prob.n_params, prob.n_states))
+        s2 = Solver(prob, abstol=tol, reltol=tol, sens_mode="simultaneous")
+        ys, S, sts, _ = s2.solve_sens_batch(0.0, tv[::5], d["y0"][:21], ps[:21], pr, sens0)
+        yso, So, _, _ = orc.solve_sens(orc.config(rtol=tol, atol=tol), d["y0"][:21], ps[:21], pr, sens0, 0.0, tv[::5],
+                                       mode="simultaneous", nthreads=8)
+        np.testing.assert_array_equal(ys, yso)
+        np.testing.assert_array_equal(S, So)
+

@@ -3,7 +3,7 @@
 # bench command and separate PMC passes (MI355X_MICROARCH.md: counters in their own runs) -- HBM bytes, instruction
 # mix, wave / active / wait cycles, lane utilisation inputs -- plus the FETCH_SIZE / WRITE_SIZE calibration.
 #     usage: tools/gpu_profiles.sh <tag>          -> gpurun_out/<tag>_*.txt   (then: python tools/make_pmc_traffic.py <tag>)
-tag=${1:-r03}
+tag=${1:-r04}
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$root"
 export TMPDIR=/tmp
@@ -14,7 +14,8 @@ for w in ${WORKLOADS:-lv robertson seir network100}; do
     steps=5; [ "$w" != lv ] && steps=3
     cmd="python bench.py --workload $w --steps $steps --warmup 2 --no-cpu-baseline --no-extra-configs"
     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$out/kt_$w" -o $w -- bash -c "cd $root && $cmd" > "$out/kt_$w.log" 2>&1)
-    { echo "# rocprofv3 --kernel-trace --stats -- $cmd   (round 3, MI355X)"; summ "$out/kt_$w"; } > "$root/gpurun_out/${tag}_${w}_kernel_stats.txt"
+    { echo "# rocprofv3 --kernel-trace --stats -- $cmd   ($tag, MI355X)"; summ "$out/kt_$w"; } > "$root/gpurun_out/${tag}_${w}_kernel_stats.txt"
+    grep '^{"metric"' "$out/kt_$w.log" | tail -1 > "$root/gpurun_out/${tag}_${w}_bench.json"     # the context of the counters (make_pmc_traffic.py)
     head -4 "$root/gpurun_out/${tag}_${w}_kernel_stats.txt"
     f="$root/gpurun_out/${tag}_${w}_pmc.txt"
     echo "# rocprofv3 --kernel-trace --pmc <counters> (one pass per line) -- $cmd   (per-dispatch means; KiB for *_SIZE)" > "$f"

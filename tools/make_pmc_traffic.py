@@ -23,7 +23,7 @@ def parse(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     res = {"source": "profiles/%s_<workload>_pmc.txt (rocprofv3 --kernel-trace --pmc, one pass per counter group, of "
                      "`python bench.py --workload <w> --steps N --warmup 2 --no-cpu-baseline --no-extra-configs`)" % tag,
            "unit": "bytes per launch (fetch, write); fp64 lane-operations per launch (valu_fp64_flops); SQ counters raw",
@@ -35,6 +35,19 @@ def main():
         if not path:
             continue
         res[w] = {}
+        # what the counters belong to: the bench line of the kernel-trace run of the same command (tools/gpu_profiles.sh
+        # keeps it): batch, record size, code-object hash, toolchain, kernel times -- bench.py prints the counter ratios
+        # only when they match the run at hand
+        bpath = next((p for p in (os.path.join(ROOT, d, "%s_%s_bench.json" % (tag, w)) for d in ("profiles", "gpurun_out"))
+                      if os.path.exists(p)), None)
+        if bpath:
+            line = json.load(open(bpath))
+            b = line.get("build", {})
+            res[w]["context"] = {"batch": b.get("batch"), "record_bytes": b.get("record_bytes"),
+                                 "code_object": b.get("code_object"), "toolchain": (b.get("toolchain") or {}).get("hash"),
+                                 "kernel_ms": {"sa_k_backward": line["roofline"]["kernel_ms"],
+                                               "sa_k_forward": line["roofline"]["forward_kernel_ms"]},
+                                 "source": os.path.relpath(bpath, ROOT)}
         for k, c in parse(path).items():
             e = {}
             if "FETCH_SIZE" in c:
@@ -56,7 +69,8 @@ def main():
             res[w][k] = e
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as fh:
         json.dump(res, fh, indent=1)
-    print(json.dumps({w: {k: {a: ("%.3g" % b) for a, b in v.items()} for k, v in res[w].items()} for w in res if isinstance(res[w], dict)}, indent=1))
+    print(json.dumps({w: {k: {a: (("%.3g" % b) if isinstance(b, float) else b) for a, b in v.items()} for k, v in res[w].items()}
+                      for w in res if isinstance(res[w], dict)}, indent=1))
 
 
 if __name__ == "__main__":
