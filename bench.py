@@ -239,6 +239,13 @@ def run_single_process(args, *, make_engine=None):
     devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(max(1, args.gpus)))
     if len(devices) != max(1, args.gpus):
         raise SystemExit("bench.py: --devices names %d device(s) but --gpus is %d" % (len(devices), args.gpus))
+    if make_engine is None:
+        # torch brings its own HIP runtime: it has to initialise before libsunode_amd.so touches the devices (the
+        # arena-budget query below), or torch finds "no HIP GPUs" afterwards
+        import torch
+        torch.cuda.init()
+        if torch.cuda.device_count() <= max(devices):
+            raise SystemExit("bench.py: --devices %s but only %d GPU(s) visible" % (args.devices, torch.cuda.device_count()))
     name = args.workload
     prob = make_problem(name)
     w = WORKLOADS[name]

@@ -257,7 +257,10 @@ static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const do
         if (a < NI) {
             /* the matrix entries come from L2 (hundreds of cycles each): fetch a batch of MVB columns for every
                owned row BEFORE the dependent FMA chain consumes them, instead of one load per chain link */
-            constexpr int MVB = 13;
+#ifndef SA_MVB
+#define SA_MVB 25          /* (7 / 13 / 25 measured on network100: 58.8 / 58.2 / 57.6 ms backward) */
+#endif
+            constexpr int MVB = SA_MVB;
             constexpr int NT = (NI + 3) / 4;                 /* terms of one accumulator (at most) */
 #pragma unroll
             for (int t0 = 0; t0 < NT; t0 += MVB) {
@@ -1423,7 +1426,9 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
        slots below S hold finished rows (no work at all), slot S is masked by the lane, slots above S take part with
        every row. */
 #define LU_SLOT(PR) LU_SLOT_OF_BLOCK(PR)
+#ifndef LU_GC
 #define LU_GC 4
+#endif
     static_assert(LU_NB % LU_GC == 0, "panel width in whole column groups");
     /* the trailing update with panel p-1 of the register columns [C0, C1): step-outer, column-inner in groups of LU_GC
        columns -- the broadcasts of a group, then its FMAs, a scheduling barrier (left alone the scheduler hoists every
@@ -1448,9 +1453,11 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
             LU_UPD_GROUP(SP, c0, c1, kk)                                                                              \
         } SEND } SEND
     /* the published panel q (ring slot q mod SA_WAVES): words -> word[], multiplier columns of the slots >= SP -> lc */
+    /* (measured and not kept: reading the counter and the panel's data in ONE batch per spin turn -- one LDS round trip
+       less on the chain in theory, 58.65 against 58.4 ms in practice) */
 #define LU_READ(SP, Q)                                                                                              \
         const int slot_ = (Q) & (SA_WAVES - 1);                                                                       \
-        int nex_ = L.info[slot_ * LU_INFO + LU_NB], ierp_ = L.info[slot_ * LU_INFO + LU_NB + 1];                                              \
+        int nex_ = L.info[slot_ * LU_INFO + LU_NB], ierp_ = L.info[slot_ * LU_INFO + LU_NB + 1];                      \
         SFOR(r, SP, RS) { SFOR(kk, 0, LU_NB) lc[kk][r] = L.col[((slot_ * RS + r) * 64 + lane) * LU_NB + kk]; SEND } SEND \
         nex_ = __builtin_amdgcn_readfirstlane(nex_); ierp_ = __builtin_amdgcn_readfirstlane(ierp_);
     /* The row exchanges of a published panel (first row kq, pivot rows in slot SP) in the register columns [C0, C1)

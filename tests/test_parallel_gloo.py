@@ -155,8 +155,20 @@ def test_bench_single_process_launcher_two_devices(monkeypatch):
     monkeypatch.setattr(_native, "device_memory", lambda d: (200 << 30, 288 << 30))
     made = []
 
+    import threading
+    lock = threading.Lock()         # (the CPU oracle keeps the last forward solve in its handle: one step at a time)
+
     def factory(name, prob, batch, tol, device, arena_bytes=0):
         e = _OracleEngine(name, prob, batch, tol, device)
+        step = e.step
+
+        def locked_step():
+            with lock:
+                step()
+                e.kept = e.out
+        e.step = locked_step
+        res = e.results
+        e.results = lambda: (setattr(e, "out", e.kept), res())[1]
         made.append((device, arena_bytes, batch["y0"].shape[0], batch["ps"][0].copy()))
         return e
     args = bench.parse_args(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "12", "--single-process",

@@ -42,7 +42,8 @@ def main():
     for tag, stt in (("fwd", stats), ("bwd", statsb)):
         tot = stt[:, 15].mean() * 1e-5
         parts = ", ".join("%s %.1f" % (n, stt[:, 9 + i].mean() * 1e-5) for i, n in enumerate(names))
-        if tag == "bwd" and "PROFILE_PHASES" in os.environ.get("SA_KERNEL_DEFINES", "") and stt[:, 8].mean() > 1e4:
+        if tag == "bwd" and "PROFILE_PHASES" in os.environ.get("SA_KERNEL_DEFINES", "") and stt[:, 8].mean() > 1e4 \
+                and len(sys.argv) > 2 and sys.argv[2] == "seir":      # (lane-group builds: slot 8 = time in restarts)
             parts += ", restarts %.1f" % (stt[:, 8].mean() * 1e-5)
         if (stt[:, 8] & 0xffffffff).sum() > 0 and (stt[:, 8] >> 32).sum() == 0 and stt[:, 2].mean() > 0 and \
                 "PROFILE_PHASES" not in os.environ.get("SA_KERNEL_DEFINES", ""):      # workgroup LU: its own wall clock
