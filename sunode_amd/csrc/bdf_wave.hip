@@ -84,7 +84,13 @@ __shared__ uint8_t s_piv[KPW * W_PIV];              /* pivot rows (n <= 128 fits
 #define W_NOUT (W_NS > W_NQD ? W_NS : W_NQD)
 #define W_NOUTP (KPW > 1 ? (W_NOUT | 1) : W_NOUT)
 __shared__ double s_out[KPW * W_NOUTP];             /* output vector of the vector-valued callbacks */
-#if SA_LEAN && !defined(SA_HERMITE)
+/* (workgroup-per-instance build: the same two parking schemes for wavefront 0, -DSA_WG_TAB_LDS / -DSA_WG_COLD) */
+#if SA_GROUP >= 64 && defined(SA_WG_COLD)
+#define SA_COLD_PARK 1
+#else
+#define SA_COLD_PARK SA_LEAN
+#endif
+#if (SA_LEAN || (SA_GROUP >= 64 && defined(SA_WG_TAB_LDS))) && !defined(SA_HERMITE)
 /* the divided-difference record of the current interpolation index, copied from the arena when the index moves
    (20 + 6 n/G registers per lane otherwise).  Stride: even (16-byte rows) and not a multiple of 16 doubles. */
 #define SA_TAB_LDS 1
@@ -94,7 +100,7 @@ __shared__ double s_tab[KPW * W_TRECP];
 #else
 #define SA_TAB_LDS 0
 #endif
-#if SA_LEAN
+#if SA_COLD_PARK
 /* COLD per-lane state, parked in LDS across the Newton pass of a step attempt (callbacks, factorisation, solves): the
    Nordsieck columns 2..5, the saved correction and the whole quadrature history are only touched by predict / rescale
    / complete / order changes.  Lane-private slots [slot][lane]: no synchronisation, conflict-free. */
@@ -150,7 +156,10 @@ __shared__ double s_targ;
 __shared__ int s_rc[SA_WAVES];      /* (only s_nwaves is referenced by the single-wavefront builds: the rest costs them no LDS) */
 enum { CMD_EXIT = 0, CMD_RHS = 1, CMD_QUAD = 2, CMD_JAC = 3, CMD_GETRF = 4 };
 static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-#define SA_CHUNK_CALL(c, call) do { if (((c) % s_nwaves) == sa_wave_index()) bad |= call; } while (0)
+/* (s_nwaves is SA_WAVES in the integrator kernels and 1 in sa_k_eval: spelled out, both remainders are compile-time
+   -- a remainder by the run-time value costs ~25 instructions, several times per callback and wavefront) */
+#define SA_MOD_NWAVES(c) (s_nwaves == SA_WAVES ? (c) % SA_WAVES : (s_nwaves == 1 ? 0 : (c) % s_nwaves))
+#define SA_CHUNK_CALL(c, call) do { if (SA_MOD_NWAVES(c) == sa_wave_index()) bad |= call; } while (0)
 
 #ifdef SA_WAVE_INLINE_CALLBACKS      /* small callbacks: no call ABI between the integrator state and the callback */
 #define SA_FN static __device__ __forceinline__
@@ -234,7 +243,7 @@ static __device__ __forceinline__ double sa_touch(const gdouble *p, int n)
 __shared__ double s_mvp[4 * KPW * W_NS];
 #define SA_MV(tag, i) ((s_mvp[(0 * KPW + sa_grp()) * W_NS + (i)] + s_mvp[(1 * KPW + sa_grp()) * W_NS + (i)]) + \
                        (s_mvp[(2 * KPW + sa_grp()) * W_NS + (i)] + s_mvp[(3 * KPW + sa_grp()) * W_NS + (i)]))
-#define SA_OWNS(slot) (((slot) % s_nwaves) == sa_wave_index())
+#define SA_OWNS(slot) (SA_MOD_NWAVES(slot) == sa_wave_index())
 template <int NO, int NI>
 static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const double *v)
 {
@@ -242,15 +251,18 @@ static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const do
     constexpr int RSL = (NO + G - 1) / G;
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int li = lane & (G - 1), grp = (KPW == 1) ? 0 : lane / G;
-    const int nw = (SA_WAVES > 1) ? s_nwaves : 1;
-    const int w = (SA_WAVES > 1) ? sa_wave_index() : 0;
+    const bool full = (SA_WAVES > 1) && (s_nwaves == SA_WAVES);     /* (else: one wavefront, sa_k_eval) */
+    const int w = full ? sa_wave_index() : 0;
     /* work split: with nw >= 4 wavefronts, wavefront w takes accumulator w % 4 and the row slots r with
-       r % (nw / 4) == w / 4; with fewer, its accumulators w, w + nw, ... of every slot */
-    const int astep = nw >= 4 ? 4 : nw, sgroups = nw >= 4 ? nw / 4 : 1, sgrp = nw >= 4 ? w / 4 : 0;
+       r % (nw / 4) == w / 4; with fewer, its accumulators w, w + nw, ... of every slot.  (nw is SA_WAVES or 1: every
+       quotient and remainder below is by a compile-time constant) */
+    constexpr int NWF = SA_WAVES > 1 ? SA_WAVES : 1;
+    constexpr int ASTEP_F = NWF >= 4 ? 4 : NWF, SGROUPS_F = NWF >= 4 ? NWF / 4 : 1;
+    const int astep = full ? ASTEP_F : 1, sgroups = full ? SGROUPS_F : 1, sgrp = full ? (NWF >= 4 ? w / 4 : 0) : 0;
     int row[RSL];
 #pragma unroll
     for (int r = 0; r < RSL; r++) row[r] = (r * G + li < NO) ? r * G + li : 0;
-    for (int a = w % astep; a < 4; a += astep) {
+    for (int a = full ? w % ASTEP_F : 0; a < 4; a += astep) {
         double acc[RSL];
 #pragma unroll
         for (int r = 0; r < RSL; r++) acc[r] = 0.0;
@@ -271,7 +283,7 @@ static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const do
                     const int jc = (t0 + u < NT && j < NI) ? j : a;
                     vv[u] = v[jc];
 #pragma unroll
-                    for (int r = 0; r < RSL; r++) if (r % sgroups == sgrp) mm[u][r] = M[jc * NO + row[r]];
+                    for (int r = 0; r < RSL; r++) if (SGROUPS_F == 1 || r % sgroups == sgrp) mm[u][r] = M[jc * NO + row[r]];
                 }
 #pragma unroll
                 for (int u = 0; u < MVB; u++) {
@@ -279,7 +291,7 @@ static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const do
                     if (t0 + u < NT && j < NI) {
 #pragma unroll
                         for (int r = 0; r < RSL; r++) {
-                            if (r % sgroups == sgrp)
+                            if (SGROUPS_F == 1 || r % sgroups == sgrp)
                                 acc[r] = (t0 + u == 0) ? mm[u][r] * vv[u] : __builtin_fma(mm[u][r], vv[u], acc[r]);
                         }
                     }
@@ -288,7 +300,7 @@ static __device__ __forceinline__ void sa_matvec_coop(const gdouble *M, const do
         }
 #pragma unroll
         for (int r = 0; r < RSL; r++)
-            if (r % sgroups == sgrp && r * G + li < NO) s_mvp[(a * KPW + grp) * W_NS + r * G + li] = acc[r];
+            if ((SGROUPS_F == 1 || r % sgroups == sgrp) && r * G + li < NO) s_mvp[(a * KPW + grp) * W_NS + r * G + li] = acc[r];
     }
     if constexpr (SA_WAVES > 1) sa_barrier();
     else {
@@ -323,8 +335,8 @@ static __device__ __forceinline__ double sa_matfill_coop(const gdouble *M, const
     static_assert(N <= W_NS, "matrix block larger than the state vector");
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int li = lane & (G - 1), grp = (KPW == 1) ? 0 : lane / G;
-    const int nw = (SA_WAVES > 1) ? s_nwaves : 1;
-    const int w = (SA_WAVES > 1) ? sa_wave_index() : 0;
+    const int nw = (SA_WAVES > 1 && s_nwaves == SA_WAVES) ? SA_WAVES : 1;
+    const int w = (nw > 1) ? sa_wave_index() : 0;
     sa_group_sync();
     const double *uv = s_mvp + grp * W_NS;
     bool bad = false;
@@ -2314,7 +2326,7 @@ DEV int cv_lsetup(Cw<BWD> &m, int convfail)
 }
 
 
-#if SA_LEAN
+#if SA_COLD_PARK
 template <bool BWD>
 DEV void cold_store(const Cw<BWD> &m)
 {
