@@ -1304,7 +1304,7 @@ __shared__ double s_invp[W_NS];
 __shared__ __attribute__((aligned(16))) int s_luinfo[SA_WAVES * LU_INFO];     /* per ring slot: 4 pivot rows, #exchanges, zero-pivot step + 1 */
 __shared__ int s_luier, s_lunswaps, s_lupub;
 #ifdef SA_WAVE_PROFILE
-__shared__ int64_t s_luprof[10];           /* wavefront 0, cycles: panel factorisation, waiting, trailing update, whole function (ticks /
+__shared__ int64_t s_luprof[12];           /* wavefront 0, cycles: panel factorisation, waiting, trailing update, whole function (ticks /
                                               cycles), load + form, first barrier, write-back, last barrier */
 #endif
 #if defined(SA_WAVE_PROFILE) && defined(SA_LU_PROFILE_SEGMENTS)     /* (the inner timers cost ~800 cycles per panel themselves) */
@@ -1315,6 +1315,10 @@ __shared__ int64_t s_luprof[10];           /* wavefront 0, cycles: panel factori
 #define LUP_ADD(k, a, b)
 #endif
 #define LU_SING 0x100000
+/* place of row 64 * r + lane of column kk of the published panel in ring slot `slot`: a column's rows are contiguous
+   (lane stride 8 bytes: every ds_read / ds_write_b64 of a wavefront is bank-conflict free; with the four columns of a row
+   side by side -- 32 bytes from lane to lane -- each access was an 8-way conflict, ~600 cycles per panel on the owner's chain) */
+#define LU_PIDX(slot, r, kk) ((((slot) * LU_NB + (kk)) * RS + (r)) * 64 + lane)
 
 static __device__ __forceinline__ LuLds lu_lds()
 {
@@ -1342,6 +1346,13 @@ static __device__ __forceinline__ void lu_wait(lds_i32 *pub, int want)
 }
 
 static __device__ __forceinline__ void lu_pin(double &x) { asm volatile("" : "+v"(x)); }
+/* max(x, |y|) as the one instruction it is (fmax() adds a canonicalising v_max_f64 x, x per operand); a NaN operand loses */
+static __device__ __forceinline__ double vmax_abs(double x, double y)
+{
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 /* value of register slot `slot` (wave-uniform) of a column */
 #define LU_SEL(col, slot) (RS == 1 ? (col)[0] : ((slot) == 0 ? (col)[0] : (col)[RS - 1]))
 /* exchange rows (slot s1, lane l1) and (slot s2, lane l2) of a register column (rare path) */
@@ -1418,7 +1429,11 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
 #endif
     LUP_T(t_ld)
     sa_barrier();
+#ifdef SA_LU_PROFILE_TIMELINE
+    const int64_t t_loop = (int64_t)__builtin_readcyclecounter();
+#else
     LUP_T(t_loop)
+#endif
     LUP_ADD(5, t_in, t_ld) LUP_ADD(6, t_ld, t_loop)
     /* DATAFLOW over the panels p = 0, 1, ... (p = pr * SA_WAVES + o; the round pr -- which register columns the owner
        works on -- is unrolled, the SA_WAVES panels of a round are a run-time loop), no barrier inside:
@@ -1470,7 +1485,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
 #define LU_READ(SP, Q)                                                                                              \
         const int slot_ = (Q) & (SA_WAVES - 1);                                                                       \
         int nex_ = L.info[slot_ * LU_INFO + LU_NB], ierp_ = L.info[slot_ * LU_INFO + LU_NB + 1];                      \
-        SFOR(r, SP, RS) { SFOR(kk, 0, LU_NB) lc[kk][r] = L.col[((slot_ * RS + r) * 64 + lane) * LU_NB + kk]; SEND } SEND \
+        SFOR(r, SP, RS) { SFOR(kk, 0, LU_NB) lc[kk][r] = L.col[LU_PIDX(slot_, r, kk)]; SEND } SEND \
         nex_ = __builtin_amdgcn_readfirstlane(nex_); ierp_ = __builtin_amdgcn_readfirstlane(ierp_);
     /* The row exchanges of a published panel (first row kq, pivot rows in slot SP) in the register columns [C0, C1)
        and [C2, C3): the (at most four) exchanges are composed into ONE gather map per lane and slot -- src[r] = the
@@ -1531,6 +1546,8 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
             SFOR(kk, 0, LU_NB) own_word[kk] = 0; SEND
             if (wave == o) {
                 if (!first) { if (prev_round) { LU_UPD_SAME(SQ) } else { LU_UPD_SAME(S) } }
+                LUP_T(t_b1)
+                LUP_ADD(9, t_b, t_b1)
                 int pword[LU_NB];
                 double mults[LU_NB];
                 constexpr bool PARTIAL = (NS % LU_NB) != 0;     /* (a last panel with columns past n exists) */
@@ -1545,29 +1562,43 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                 if (!general) {
                     double keep[LU_NB][RS];
                     SFOR(kk, 0, LU_NB) { SFOR(r, S, RS) keep[kk][r] = a[pr * LU_NB + kk][r]; SEND } SEND
-                    bool beaten = false, zero = false;
+                    /* Costs that do not show in the instruction count (tools/ubench_issue.hip): a VALU compare consumed by
+                       the scalar unit stalls the wavefront ~20 cycles, an IEEE division is a 74-cycle chain.  So: "some
+                       row beats the diagonal" is accumulated on the VALU (max of |a(i,k)| - |a(k,k)|, one compare at the
+                       end), the pivot's sanity test is integer work on the scalar unit, and the reciprocal is the division's
+                       own expansion without the scaling / fix-up instructions -- v_rcp_f64 and six FMAs, the same bits as
+                       1.0 / x whenever nothing would be scaled (exponent within 2^-500 .. 2^500, checked: anything else,
+                       zero included, goes to the general code; 2^30 random operands compared in the micro-benchmark). */
+                    double over = 0.0;                          /* max(|a(i,k)| - |a(k,k)|) over the rows below the diagonal */
+                    int odd = 0;                                /* sign bit set: some pivot's exponent outside 2^-500 .. 2^500 */
                     SFOR(kk, 0, LU_NB) {
                         constexpr int kc = pr * LU_NB + kk;
                         const uint64_t abits = readlane_u64(a[kc][S], pl0 + kk);
                         const double akk = __builtin_bit_cast(double, abits);
-                        zero = zero || ((abits << 1) == 0);
-                        const double mult = 1.0 / akk;
+                        const int ex = (int)((uint32_t)(abits >> 52) & 0x7ffu);
+                        odd |= (ex - 523) | (1523 - ex);
+                        double mult = __builtin_amdgcn_rcp(akk), e_ = FMA(-akk, mult, 1.0);
+                        mult = FMA(mult, e_, mult); e_ = FMA(-akk, mult, 1.0);
+                        mult = FMA(mult, e_, mult); e_ = FMA(-akk, mult, 1.0);
+                        mult = FMA(e_, mult, mult);
                         mults[kk] = mult;
                         pword[kk] = (k0 + kk) & 0xff;
                         double akj[LU_NB];
                         SFOR(jj, kk + 1, LU_NB) akj[jj] = readlane_d(a[pr * LU_NB + jj][S], pl0 + kk); SEND
+                        double big = 0.0;                       /* largest |a(i,k)| below the diagonal, this lane */
                         SFOR(r, S + 1, RS) {
-                            beaten = beaten || (fabs(a[kc][r]) > fabs(akk));
+                            big = vmax_abs(big, a[kc][r]);
                             a[kc][r] = a[kc][r] * mult;
                             SFOR(jj, kk + 1, LU_NB) a[pr * LU_NB + jj][r] = FMA(-akj[jj], a[kc][r], a[pr * LU_NB + jj][r]); SEND
                         } SEND
                         if (lane > pl0 + kk) {                  /* the rows of slot S below the diagonal */
-                            beaten = beaten || (fabs(a[kc][S]) > fabs(akk));
+                            big = vmax_abs(big, a[kc][S]);
                             a[kc][S] = a[kc][S] * mult;
                             SFOR(jj, kk + 1, LU_NB) a[pr * LU_NB + jj][S] = FMA(-akj[jj], a[kc][S], a[pr * LU_NB + jj][S]); SEND
                         }
+                        over = vmax_abs(big - fabs(akk), over); /* (over >= 0 always; a NaN entry is ignored like the comparison ignores it) */
                     } SEND
-                    if (zero || __builtin_amdgcn_ballot_w64(beaten) != 0) {
+                    if (odd < 0 || __builtin_amdgcn_ballot_w64(over > 0.0) != 0) {
                         general = true;
                         SFOR(kk, 0, LU_NB) { SFOR(r, S, RS) a[pr * LU_NB + kk][r] = keep[kk][r]; SEND } SEND
                     }
@@ -1642,24 +1673,32 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                    column is zero; after a zero pivot: the factorisation has failed, nobody uses the result); the
                    pivot rows, the number of exchanges, the zero-pivot flag; then -- release -- the counter */
                 const int slot = p & (SA_WAVES - 1);
+                LUP_T(t_b2)
+                LUP_ADD(10, t_b1, t_b2)
                 SFOR(kk, 0, LU_NB) {
-                    L.col[((slot * RS + S) * 64 + lane) * LU_NB + kk] = (lane > pl0 + kk) ? a[pr * LU_NB + kk][S] : 0.0;
+                    L.col[LU_PIDX(slot, S, kk)] = (lane > pl0 + kk) ? a[pr * LU_NB + kk][S] : 0.0;
                 } SEND
                 SFOR(r, S + 1, RS) {
-                    SFOR(kk, 0, LU_NB) L.col[((slot * RS + r) * 64 + lane) * LU_NB + kk] = a[pr * LU_NB + kk][r]; SEND
+                    SFOR(kk, 0, LU_NB) L.col[LU_PIDX(slot, r, kk)] = a[pr * LU_NB + kk][r]; SEND
                 } SEND
                 if (lane == 0) {
                     SFOR(kk, 0, LU_NB) L.info[slot * LU_INFO + kk] = pword[kk]; SEND
                     L.info[slot * LU_INFO + LU_NB] = own_swaps;
                     L.info[slot * LU_INFO + LU_NB + 1] = ier;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) {
+                    *(volatile lds_i32 *)L.pub = p + 1;
+#ifdef SA_LU_PROFILE_TIMELINE       /* cycles from the first barrier to the publication of panel (workgroup index mod #panels) */
+                    if (p == (int)(blockIdx.x % LU_NPANEL)) L.prof[11] += (int64_t)__builtin_readcyclecounter() - t_loop;
+#endif
+                    /* (off the chain: the pivots are read by wavefront 0 only after the barrier at the end) */
                     if (k0 < NS && ier == 0) {
                         SFOR(kk, 0, LU_NB) {
                             if (!PARTIAL || k0 + kk < NS) { L.piv[k0 + kk] = (uint8_t)pword[kk]; L.invp[k0 + kk] = mults[kk]; }
                         } SEND
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) *(volatile lds_i32 *)L.pub = p + 1;
             }
             LUP_T(t_c)
             if (!first) {
@@ -2768,7 +2807,7 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     if (inst >= a.B) return;
     if (threadIdx.x == 0) s_nwaves = SA_WAVES;
 #if defined(SA_WAVE_PROFILE) && SA_WAVES > 1
-    if (threadIdx.x == 0) { for (int i = 0; i < 10; i++) s_luprof[i] = 0; }
+    if (threadIdx.x == 0) { for (int i = 0; i < 12; i++) s_luprof[i] = 0; }
 #endif
     if (sa_wave_index() != 0) {
         worker_loop<true>(a.pr + (int64_t)inst * a.rem_stride, ws_inst(a.ws, inst) + WS_OUT);
@@ -2926,6 +2965,10 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
         st[8] = s_luprof[3] + (s_luprof[4] << 32);                          /* ... prologue | epilogue << 32 */
 #ifdef SA_LU_PROFILE_SEGMENTS       /* load + form | first barrier | write-back | last barrier, cycles (replace the section slots) */
         st[9] = s_luprof[5]; st[10] = s_luprof[6]; st[11] = s_luprof[7]; st[12] = s_luprof[8];
+        st[13] = s_luprof[9]; st[14] = s_luprof[10];        /* owner block: update of its four columns | the four steps */
+#endif
+#ifdef SA_LU_PROFILE_TIMELINE
+        st[13] = s_luprof[11]; st[14] = blockIdx.x % LU_NPANEL;
 #endif
 #endif
 #endif

@@ -56,10 +56,19 @@ def main():
                   % tuple(stt[:, 5 + i].mean() / nlu / 1e3 for i in range(3))
                   + "; whole function %.1f us = %.1f kilo-cycles" % ((stt[:, 8] & 0xffffffff).mean() / nlu / 1e2,
                                                                    (stt[:, 8] >> 32).mean() / nlu / 1e3))
+        if "SA_LU_PROFILE_TIMELINE" in os.environ.get("SA_KERNEL_DEFINES", ""):
+            # publication time of panel p (cycles after the first barrier), averaged over the instances that recorded p
+            pan = stt[:, 14].astype(int)
+            tl = [(stt[pan == q, 13] / np.maximum(stt[pan == q, 2], 1)).mean() for q in range(pan.max() + 1)]
+            print("    LU timeline, kilo-cycles from the first barrier to the publication of panel p: "
+                  + " ".join("%.1f" % (v / 1e3) for v in tl))
+            print("    ... per panel: " + " ".join("%.1f" % ((b - a) / 1e3) for a, b in zip([0.0] + tl[:-1], tl)))
+            continue
         if "SA_LU_PROFILE_SEGMENTS" in os.environ.get("SA_KERNEL_DEFINES", ""):
             nlu = max(stt[:, 2].mean(), 1)
             print("    LU segments of wavefront 0, kilo-cycles per factorisation: load+form %.1f, first barrier %.1f, "
-                  "write-back %.1f, last barrier %.1f" % tuple(stt[:, 9 + i].mean() / nlu / 1e3 for i in range(4)))
+                  "write-back %.1f, last barrier %.1f; owner block: own four columns %.1f, four steps %.1f (rest: publication)"
+                  % tuple(stt[:, 9 + i].mean() / nlu / 1e3 for i in range(6)))
             continue
         print("%s per-instance ms: total %.1f | %s | nst %.0f nfe %.0f nsetups %.0f nje %.0f nni %.0f"
               % (tag, tot, parts, stt[:, 0].mean(), stt[:, 1].mean(), stt[:, 2].mean(), stt[:, 3].mean(),

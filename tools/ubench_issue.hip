@@ -88,20 +88,80 @@ __global__ void __launch_bounds__(64) k_bench(uint64_t *out, double seed)
                  "ds_bpermute_b32 %0, %5, %0\n ds_bpermute_b32 %1, %5, %1\n ds_bpermute_b32 %2, %5, %2\n ds_bpermute_b32 %3, %5, %3\n .endr\n s_waitcnt lgkmcnt(0)"
                  : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "n"(REP), "v"(p0));
     T1; if (threadIdx.x == 0) out[n] = t1 - t0; n++;
+    // 11: dependent chain of IEEE divisions 1.0 / x (the compiler's expansion: 2 v_div_scale, v_rcp, 6 fma / mul, v_div_fmas, v_div_fixup)
+    double x = seed + 2.5;
+    T0;
+#pragma unroll
+    for (int i = 0; i < REP; i++) { x = 1.0 / x; asm volatile("" : "+v"(x)); }
+    T1; if (threadIdx.x == 0) out[n] = t1 - t0; n++;
+    // 12: the same chain through the lean reciprocal (v_rcp + 6 fma: what the expansion computes when nothing is scaled)
+    T0;
+#pragma unroll
+    for (int i = 0; i < REP; i++) {
+        double r = __builtin_amdgcn_rcp(x), e = __builtin_fma(-x, r, 1.0);
+        r = __builtin_fma(r, e, r); e = __builtin_fma(-x, r, 1.0);
+        r = __builtin_fma(r, e, r); e = __builtin_fma(-x, r, 1.0);
+        x = __builtin_fma(e, r, r); asm volatile("" : "+v"(x));
+    }
+    T1; if (threadIdx.x == 0) out[n] = t1 - t0; n++;
+    // 13: v_rcp_f64 dependent chain
+    T0;
+#pragma unroll
+    for (int i = 0; i < REP; i++) { x = __builtin_amdgcn_rcp(x); asm volatile("" : "+v"(x)); }
+    T1; if (threadIdx.x == 0) out[n] = t1 - t0; n++;
+    // 14: v_cmp_gt_f64 -> s_or_b64 chain (VALU writes a scalar pair, the scalar unit consumes it), 2 instructions per link
+    T0;
+    asm volatile("s_mov_b64 s[20:21], 0\n .rept %c0\n v_cmp_gt_f64 s[22:23], %1, %2\n s_or_b64 s[20:21], s[20:21], s[22:23]\n"
+                 "v_cmp_gt_f64 s[22:23], %2, %1\n s_or_b64 s[20:21], s[20:21], s[22:23]\n"
+                 "v_cmp_gt_f64 s[22:23], %1, %2\n s_or_b64 s[20:21], s[20:21], s[22:23]\n"
+                 "v_cmp_gt_f64 s[22:23], %2, %1\n s_or_b64 s[20:21], s[20:21], s[22:23]\n .endr"
+                 :: "n"(REP), "v"(a1), "v"(a2) : "s20", "s21", "s22", "s23", "scc");
+    T1; if (threadIdx.x == 0) out[n] = t1 - t0; n++;
+    a0 += x;
     if (threadIdx.x == 0) out[15] = (uint64_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7) + i0 + i1 + i2 + i3;
+}
+
+// the lean reciprocal against the compiler's 1.0 / x, bit for bit, over random x with a biased exponent in [523, 1523]
+__global__ void k_check(unsigned long long *bad, int rounds)
+{
+    uint64_t h = (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    unsigned long long nb = 0;
+    for (int i = 0; i < rounds; i++) {
+        h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+        uint64_t e = 523 + (h >> 12) % 1001, bits = (h & 0x800fffffffffffffull) | (e << 52);
+        if ((i & 15) == 0) bits &= 0xfff0000000000000ull | (h >> 40);          /* (short mantissas: exact cases) */
+        if ((i & 15) == 1) bits |= 0x000fffffffffff00ull;                      /* (mantissas next to a power of two) */
+        double x = __builtin_bit_cast(double, bits);
+        double r = __builtin_amdgcn_rcp(x), q = __builtin_fma(-x, r, 1.0);
+        r = __builtin_fma(r, q, r); q = __builtin_fma(-x, r, 1.0);
+        r = __builtin_fma(r, q, r); q = __builtin_fma(-x, r, 1.0);
+        r = __builtin_fma(q, r, r);
+        double d = 1.0 / x;
+        nb += __builtin_bit_cast(uint64_t, d) != __builtin_bit_cast(uint64_t, r);
+    }
+    if (nb) atomicAdd(bad, nb);
 }
 
 int main()
 {
+    {
+        unsigned long long *db, hb = 0;
+        hipMalloc(&db, sizeof hb); hipMemset(db, 0, sizeof hb);
+        hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, 0, db, 1024);
+        hipMemcpy(&hb, db, sizeof hb, hipMemcpyDeviceToHost);
+        printf("lean reciprocal (v_rcp_f64 + 6 fma) against 1.0 / x over 2^30 random x, exponents 2^-500 .. 2^500: %llu differ\n", hb);
+    }
     uint64_t *d, h[16];
     hipMalloc(&d, sizeof h);
     for (int it = 0; it < 2; it++) { hipLaunchKernelGGL(k_bench, dim3(1), dim3(64), 0, 0, d, 1.0); hipDeviceSynchronize(); }
     hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
     const char *names[] = {"v_fma_f64 x8 independent", "v_fma_f64 dependent chain", "v_readlane_b32 independent",
                            "update mix (8 readlane + 8 fma)", "v_cndmask_b32 (dependent pairs)", "s_nop 0", "s_add_u32",
-                           "v_mul_f64 x8 independent", "readlane,readlane,s_nop 1,fma serial chain (4 instr)", "ds_bpermute_b32 x8 + wait"};
-    const int per[] = {8, 8, 8, 16, 8, 8, 8, 8, 8, 8};
-    for (int i = 0; i < 10; i++)
+                           "v_mul_f64 x8 independent", "readlane,readlane,s_nop 1,fma serial chain (4 instr)", "ds_bpermute_b32 x8 + wait",
+                           "1.0 / x dependent chain (per division)", "lean reciprocal chain (per reciprocal)", "v_rcp_f64 dependent chain",
+                           "v_cmp_gt_f64 -> s_or_b64 chain"};
+    const int per[] = {8, 8, 8, 16, 8, 8, 8, 8, 8, 8, 1, 1, 1, 8};
+    for (int i = 0; i < 14; i++)
         printf("%-56s %8.2f s_memtime ticks per instruction (%llu ticks / %d)\n", names[i], (double)h[i] / (REP * per[i]),
                (unsigned long long)h[i], REP * per[i]);
     int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
