@@ -1816,7 +1816,9 @@ DEV double bcast_vec(const double (&b)[RS], int k, int gbase)
    already solved, whose matrix entries belong to the other factor) are dead values in b by then.  Per step: two
    v_readlane, two v_writelane, one FMA per slot (before: two more v_readlane for a spilled lane mask and two
    v_cndmask).  Same operations on the same values for every component that is ever read. */
+#ifndef GETRS_BLOCK
 #define GETRS_BLOCK 4
+#endif
 template <int LANE>
 DEV double writelane_d(double old, double v)                   /* old with lane LANE replaced by the (wave-uniform) v */
 {
