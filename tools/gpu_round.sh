@@ -6,9 +6,10 @@ python __graft_entry__.py smoke 2>&1 | tail -1
 { echo "# SA_KERNEL_DEFINES=-DSA_WAVE_PROFILE python tools/profile_wave.py 1024   (network100 section timers; then -DSA_WAVE_PROFILE_PHASES; $tag, MI355X)";
   SA_KERNEL_DEFINES="-DSA_WAVE_PROFILE" timeout 600 python tools/profile_wave.py 1024 2>&1 | tail -5;
   SA_KERNEL_DEFINES="-DSA_WAVE_PROFILE -DSA_WAVE_PROFILE_PHASES" timeout 600 python tools/profile_wave.py 1024 2>&1 | tail -3;
-  echo "# the same with the LU's inner timers (-DSA_LU_PROFILE_SEGMENTS: ~800 cycles of overhead per panel)";
-  SA_KERNEL_DEFINES="-DSA_WAVE_PROFILE -DSA_LU_PROFILE_SEGMENTS" timeout 600 python tools/profile_wave.py 1024 2>&1 | tail -3; } > gpurun_out/${tag}_network100_sections.txt 2>&1
-tail -12 gpurun_out/${tag}_network100_sections.txt
+  echo "# the same with the LU's inner timers (-DSA_LU_PROFILE_SEGMENTS), then the publication timeline (-DSA_LU_PROFILE_TIMELINE)";
+  SA_KERNEL_DEFINES="-DSA_WAVE_PROFILE -DSA_LU_PROFILE_SEGMENTS" timeout 600 python tools/profile_wave.py 1024 2>&1 | tail -3;
+  SA_KERNEL_DEFINES="-DSA_WAVE_PROFILE -DSA_LU_PROFILE_TIMELINE" timeout 600 python tools/profile_wave.py 1024 2>&1 | tail -3; } > gpurun_out/${tag}_network100_sections.txt 2>&1
+tail -16 gpurun_out/${tag}_network100_sections.txt
 timeout 900 python tools/bench_small_batch.py > gpurun_out/${tag}_small_batch.json 2> gpurun_out/${tag}_small_batch.log; tail -c 600 gpurun_out/${tag}_small_batch.json
 timeout 600 python bench.py --gpus 2 --single-process --devices 0,0 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-configs > gpurun_out/${tag}_single_process_two_handles.json 2>&1; tail -c 400 gpurun_out/${tag}_single_process_two_handles.json
 timeout 1500 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.log; tail -c 1500 gpurun_out/${tag}_bench.json
