@@ -165,6 +165,6 @@ int main()
         printf("%-56s %8.2f s_memtime ticks per instruction (%llu ticks / %d)\n", names[i], (double)h[i] / (REP * per[i]),
                (unsigned long long)h[i], REP * per[i]);
     int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-    printf("device clock %d kHz; s_memtime counts a constant 100 MHz on gfx9: ticks x (clock / 100 MHz) = cycles\n", clk);
+    printf("device clock %d kHz; s_memtime ticks are shader cycles here (whole-function check in the LU: 79.6 k ticks = 33.4 us at 2.4 GHz)\n", clk);
     return 0;
 }
