@@ -664,6 +664,40 @@ def test_row_exchanges_in_the_dense_lu(variant, monkeypatch):
     np.testing.assert_array_equal(lam, lo)
 
 
+@pytest.mark.parametrize("variant", [None, "wave"])
+def test_pivots_beyond_the_lean_reciprocal_range(variant, monkeypatch):
+    """Diagonal entries of the Newton matrix around 1e200 (exactly-zero components with decay rates of 1e200, steps of
+    order 1): the workgroup LU's speculative panel factorisation computes reciprocals as v_rcp_f64 + 6 FMA, which
+    equals the IEEE division only while nothing is scaled -- pivots beyond 2^500 must be sent to the general code
+    (exponent guard) and the factors must still equal the oracle's bit for bit."""
+    from sunode_amd.solver import AdjointSolver
+    if variant:
+        monkeypatch.setenv("SA_FORCE_GROUP", variant)
+    prob = make_problem("huge_pivots")
+    B = 9
+    rng = np.random.RandomState(1)
+    ps = np.array([0.5, 0.3]) * np.exp(0.1 * rng.randn(B, 2))
+    pr = np.array([1e200, 3e199])
+    y0 = np.tile([0.5, 0.0, 0.0, 0.0, 0.0, 0.1], (B, 1))
+    tv = np.linspace(0, 10, 6)
+    grads = np.ones((6, 6)); grads[:, 1:5] = 0.0
+    kw = dict(abstol=1e-6, reltol=1e-6, backward_abstol=1e-6, backward_reltol=1e-6, quad_abstol=1e-6, quad_reltol=1e-6)
+    sol = AdjointSolver(prob, **kw)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, y0, ps, pr)
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("huge_pivots")
+    cfg = orc.config(rtol=1e-6, atol=1e-6, rtolB=1e-6, atolB=1e-6, rtolQB=1e-6, atolQB=1e-6)
+    yo, so, sto = orc.solve_forward(cfg, y0, ps, pr, 0.0, tv)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads)
+    assert (so == 0).all() and (sbo == 0).all() and (st == 0).all() and (stb == 0).all()
+    assert (yo[:, :, 1:5] == 0.0).all()                 # the stiff components never move: steps are set by the slow ones
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(statsb[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
 @pytest.mark.parametrize("variant", [None, "8", "wave", "mem"])
 def test_recoverable_rhs_failures_match_oracle(variant, monkeypatch):
     """x' = -k sqrt(x): draws that reach x = 0 inside the horizon hit a non-finite right-hand side; CVODES treats

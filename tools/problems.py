@@ -69,6 +69,17 @@ def misc_functions(t, y, p):
     }
 
 
+def huge_pivots(t, y, p):
+    """Decay rates of 1e200 on components that are exactly zero: the Newton matrix I - gamma*J has diagonal entries
+    around 1e200 (beyond 2^500) while the steps stay of order 1 -- the pivots' reciprocals leave the range in which the
+    workgroup LU's lean reciprocal is allowed (csrc/bdf_wave.hip, setup_lu_regs: exponent guard -> general code)."""
+    x = y.x
+    return {"x": [-p.k[0] * x[0] + 1.0,
+                  -p.w[0] * x[1], -p.w[0] * x[2] + p.w[1] * x[1],
+                  -p.w[0] * x[3] - p.k[1] * x[4], -p.w[0] * x[4],
+                  -x[5] + x[0]]}
+
+
 def pivoting(t, y, p):
     """Fast rotations far below the tolerances next to slow dynamics: once the step grows, I - gamma*J has
     off-diagonal entries far larger than its diagonal, so the dense LU must exchange rows."""
@@ -155,6 +166,12 @@ EXTRA_PROBLEMS = {
         states={"x": (24,)},
         rhs=make_network(24),
         derivative_params=[("scale",)],
+    ),
+    "huge_pivots": dict(
+        params={"k": (2,), "w": (2,)},
+        states={"x": (6,)},
+        rhs=huge_pivots,
+        derivative_params=[("k",)],
     ),
     "pivoting": dict(
         params={"k": (2,), "w": (2,)},
