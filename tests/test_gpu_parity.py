@@ -664,6 +664,38 @@ def test_row_exchanges_in_the_dense_lu(variant, monkeypatch):
     np.testing.assert_array_equal(lam, lo)
 
 
+def test_workgroup_lu_on_the_matrix_cores_is_bit_identical(monkeypatch):
+    """-DSA_LU_MFMA (experimental, slower: DESIGN section 7): the whole workgroup LU in the MFMA block layout, trailing
+    update = v_mfma_f64_16x16x4_f64.  The instruction accumulates like four sequential FMAs (tools/ubench_mfma_f64.hip),
+    so the factors -- and with them every step of the integration -- must equal the oracle's bit for bit, row exchanges
+    included."""
+    from sunode_amd.solver import AdjointSolver
+    monkeypatch.setenv("SA_KERNEL_DEFINES", "-DSA_LU_MFMA")
+    monkeypatch.setenv("SA_FORCE_GROUP", "wave")
+    prob = make_problem("pivoting")
+    B = 5
+    rng = np.random.RandomState(0)
+    ps = np.array([0.5, 0.3]) * np.exp(0.1 * rng.randn(B, 2))
+    pr = np.array([1000.0, 700.0])
+    y0 = np.tile([0.5, 1e-6, 0.0, 1e-6, 2e-6, 0.1], (B, 1))
+    tv = np.linspace(0, 20, 11)
+    grads = np.ones((11, 6)); grads[:, 1:5] = 0.0
+    kw = dict(abstol=1e-4, reltol=1e-5, backward_abstol=1e-4, backward_reltol=1e-5, quad_abstol=1e-4, quad_reltol=1e-5)
+    sol = AdjointSolver(prob, **kw)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, y0, ps, pr)
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("pivoting")
+    cfg = orc.config(rtol=1e-5, atol=1e-4, rtolB=1e-5, atolB=1e-4, rtolQB=1e-5, atolQB=1e-4)
+    yo, so, sto = orc.solve_forward(cfg, y0, ps, pr, 0.0, tv)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads)
+    assert (st == 0).all() and (stb == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(statsb[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
 @pytest.mark.parametrize("variant", [None, "wave"])
 def test_pivots_beyond_the_lean_reciprocal_range(variant, monkeypatch):
     """Diagonal entries of the Newton matrix around 1e200 (exactly-zero components with decay rates of 1e200, steps of
