@@ -120,6 +120,30 @@ void sa_solver_destroy(sa_solver *s);
 int sa_solver_set_options(sa_solver *s, const sa_options *opt);   /* tolerances / budgets */
 int sa_solver_sizes(const sa_solver *s, int32_t *n_states, int32_t *n_sub, int32_t *n_rem);
 
+/* Differential guard.  The reference accepts ANY sympy system (symode/problem.py:25-33): every user model is a new
+   code object, compiled by a toolchain whose AMDGPU back end was caught miscompiling this source family once
+   (SIOptimizeVGPRLiveRange, profiles/r04_sens_anomaly.txt) -- and a GPU box has no CPU oracle to notice.  So a handle
+   can be given the CONSERVATIVE build of the same source (sunode_amd._native.build_code_object(..., safe=True): the
+   pass off): on the first batch of each kind of call -- SA_GUARD_PLAIN sa_solve_batch, SA_GUARD_ADJOINT
+   sa_solve_forward_batch + sa_solve_backward_batch[_all], SA_GUARD_SENS sa_solve_sens_batch -- the library runs the
+   first min(B, n_sample) instances through BOTH code objects on two internal handles and compares statuses, all
+   counters and every fp64 output bit for bit.  Equal: the kind is verified (a check with fewer than 16 instances is
+   repeated on the next call, at most three times).  Any difference: the handle switches to the conservative code
+   object for good (sa_guard_state: using_safe) and, if the difference showed in the backward pass, repeats the
+   forward pass of the batch with it before it integrates backward.  `verified_kinds`: kinds a previous process
+   already verified for this pair of code objects (sunode_amd keeps that verdict in a file next to the code object).
+   Costs two extra launches of <= 64 instances per kind, once; synchronises the handle's stream while it runs. */
+#define SA_GUARD_PLAIN 1
+#define SA_GUARD_ADJOINT 2
+#define SA_GUARD_SENS 4
+int sa_solver_attach_guard(sa_solver *s, const char *safe_code_object_path, int32_t n_sample /* 0: 64 */,
+                           uint32_t verified_kinds);
+/* Any pointer may be NULL.  verified / differs: bit masks of SA_GUARD_*; n_sample[3]: instances of the largest check
+   per kind (plain, adjoint, sens); detail: text of the first difference ("" if none), valid until the next call on
+   the handle. */
+int sa_guard_state(sa_solver *s, uint32_t *pending, uint32_t *verified, uint32_t *differs, int32_t *using_safe,
+                   int32_t *n_sample, const char **detail);
+
 /* Solver.solve without sensitivities (solver.py:467-527): CVodeReInit + CVode(CV_NORMAL)
    per tval with <= max_retries_fwd CV_TOO_MUCH_WORK retries.
    y0 [B][n], ps [B][p], pr [B][r] (rem_stride = r) or [r] (rem_stride = 0), tvals [n_t],

@@ -130,9 +130,13 @@ SAFETY_CODEGEN_FLAGS = "-mllvm -amdgpu-opt-vgpr-liverange=0"
 SAFE_CODEGEN = False
 
 
-def _safety_flags():
-    off = os.environ.get("SA_VGPR_LIVERANGE_OPT") == "0" or (SAFE_CODEGEN and os.environ.get("SA_VGPR_LIVERANGE_OPT") != "1")
-    return SAFETY_CODEGEN_FLAGS.split() if off else []
+def all_builds_conservative() -> bool:
+    """SA_VGPR_LIVERANGE_OPT=0 (or ``SAFE_CODEGEN = True``): EVERY build is the conservative one."""
+    return os.environ.get("SA_VGPR_LIVERANGE_OPT") == "0" or (SAFE_CODEGEN and os.environ.get("SA_VGPR_LIVERANGE_OPT") != "1")
+
+
+def _safety_flags(safe: bool = False):
+    return SAFETY_CODEGEN_FLAGS.split() if (safe or all_builds_conservative()) else []
 
 
 def _extra_codegen_flags():
@@ -242,14 +246,14 @@ def _size_defines(native_source: str):
 
 
 def code_object_path(native_source: str, sens: bool = False, constraints: bool = False,
-                     hermite: bool = False, compact: bool = False) -> str:
+                     hermite: bool = False, compact: bool = False, safe: bool = False) -> str:
     fname, group = kernel_variant(native_source, sens, constraints, hermite)
     kern = os.path.join(_CSRC, fname)
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h", "bdf_core.h")]
     deps = [d for d in deps if os.path.exists(d)]
     extra = (native_source.encode() + " ".join(_extra_codegen_flags()).encode()
              + (WAVE_CODEGEN_FLAGS + ADJOINT_CODEGEN_FLAGS + SMALL_GROUP_CODEGEN_FLAGS).encode()
-             + " ".join(_safety_flags()).encode()
+             + " ".join(_safety_flags(safe)).encode()
              + b"G%d" % group + fname.encode()
              + os.environ.get("SA_KERNEL_DEFINES", "").encode() + os.environ.get("SA_WAVES_PER_EU", "").encode()
              + (b"SENS" if sens else b"") + (b"CONSTR" if constraints else b"") + (b"HERMITE" if hermite else b"")
@@ -260,12 +264,15 @@ def code_object_path(native_source: str, sens: bool = False, constraints: bool =
 
 
 def build_code_object(native_source: str, force: bool = False, keep_temps: bool = False,
-                      sens: bool = False, constraints: bool = False, hermite: bool = False, compact: bool = False) -> str:
+                      sens: bool = False, constraints: bool = False, hermite: bool = False, compact: bool = False,
+                      safe: bool = False) -> str:
     """Compile the integrator kernels for one problem to a gfx950 code object (cached).
     ``constraints=True`` builds the variant that enforces CVodeSetConstraints-style inequality
-    constraints (a separate code object: the default build carries no trace of them)."""
+    constraints (a separate code object: the default build carries no trace of them).
+    ``safe=True``: the CONSERVATIVE build -- same source, same defines, same flags, plus SAFETY_CODEGEN_FLAGS
+    (SIOptimizeVGPRLiveRange off): the partner of the default build in the differential guard (NativeSolver)."""
     os.makedirs(_CACHE, exist_ok=True)
-    out = code_object_path(native_source, sens, constraints, hermite, compact)
+    out = code_object_path(native_source, sens, constraints, hermite, compact, safe)
     if os.path.exists(out) and not force:
         return out
     fname, group = kernel_variant(native_source, sens, constraints, hermite)
@@ -306,20 +313,20 @@ def build_code_object(native_source: str, force: bool = False, keep_temps: bool 
         extra = _extra_codegen_flags()
         if "SA_CLANG_FLAGS" not in os.environ:
             if fname == "bdf_kernels.hip":
-                extra = extra + ([] if sens else ADJOINT_CODEGEN_FLAGS.split()) + _safety_flags()
+                extra = extra + ([] if sens else ADJOINT_CODEGEN_FLAGS.split())
             elif fname == "bdf_wave.hip":
                 extra = ([] if sens else (WAVE_CODEGEN_FLAGS + " " + ADJOINT_CODEGEN_FLAGS
-                                          + (" " + SMALL_GROUP_CODEGEN_FLAGS if group <= 8 else "")).split()) \
-                    + _safety_flags()
+                                          + (" " + SMALL_GROUP_CODEGEN_FLAGS if group <= 8 else "")).split())
             else:
                 extra = []
+        extra = extra + _safety_flags(safe)          # (also on top of SA_CLANG_FLAGS: the guard's partner of a tuning build)
         try:
             _run(base + extra + ["-c", "-o", obj])
         except NativeBuildError:
-            if not extra:
+            if extra == _safety_flags(safe):
                 raise
             # the non-default scheduler strategies crash clang on very large kernels: plain -O3 then
-            _run(base + ["-c", "-o", obj])
+            _run(base + _safety_flags(safe) + ["-c", "-o", obj])
         _run([os.path.join(LLVM_BIN, "ld.lld"), "-shared", obj, "-o", "%s.tmp%d" % (out, os.getpid())])
         os.replace("%s.tmp%d" % (out, os.getpid()), out)
     finally:
@@ -388,6 +395,52 @@ def check_code_object_budget(label: str, path: str, budget: dict) -> list:
     return bad
 
 
+# ----------------------------------------------------------------------------------------------
+# differential guard (include/sunode_amd.h: sa_solver_attach_guard)
+# ----------------------------------------------------------------------------------------------
+#: kinds of batch call the guard checks separately (bit masks of the C ABI)
+GUARD_KINDS = {"plain": 1, "adjoint": 2, "sens": 4}
+
+
+def guard_enabled() -> bool:
+    """The guard is ON unless SA_GUARD=0 -- or every build is the conservative one anyway."""
+    return os.environ.get("SA_GUARD", "1") != "0" and not all_builds_conservative()
+
+
+def guard_verdict_path(code_object: str) -> str:
+    return code_object[:-len(".hsaco")] + ".guard.json"
+
+
+def read_guard_verdict(code_object: str, safe_object: str) -> dict:
+    """{kind: {"verdict": "identical" | "differs", "n_sample": k}} recorded for this pair of code objects by an
+    earlier process (same toolchain), else {}."""
+    import json
+    try:
+        with open(guard_verdict_path(code_object)) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return {}
+    if doc.get("default") != os.path.basename(code_object) or doc.get("conservative") != os.path.basename(safe_object) \
+            or doc.get("toolchain") != toolchain_id()["hash"]:
+        return {}
+    return doc.get("kinds", {})
+
+
+def write_guard_verdict(code_object: str, safe_object: str, kinds: dict, detail: str = "") -> None:
+    import json
+    doc = {"default": os.path.basename(code_object), "conservative": os.path.basename(safe_object),
+           "toolchain": toolchain_id()["hash"], "kinds": kinds, "detail": detail,
+           "note": "differential guard: first instances of the first batch through both builds, statuses / counters / "
+                   "outputs compared bit for bit on the device (include/sunode_amd.h, sa_solver_attach_guard)"}
+    tmp = "%s.tmp%d" % (guard_verdict_path(code_object), os.getpid())
+    try:
+        with open(tmp, "w") as fh:
+            json.dump(doc, fh, indent=1, sort_keys=True)
+        os.replace(tmp, guard_verdict_path(code_object))
+    except OSError:
+        pass            # a read-only cache: the check simply runs again next time
+
+
 class _Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("device", ctypes.c_int32), ("rtol", ctypes.c_double),
                 ("atol", ctypes.POINTER(ctypes.c_double)), ("rtolB", ctypes.c_double), ("atolB", ctypes.c_double),
@@ -433,7 +486,11 @@ def load_library() -> ctypes.CDLL:
     L.sa_device_memory.argtypes = [i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.sa_set_stream.argtypes = [vp, vp]
     L.sa_synchronize.argtypes = [vp]
-    for name in ("sa_solver_create", "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
+    u32 = ctypes.c_uint32
+    L.sa_solver_attach_guard.argtypes = [vp, ctypes.c_char_p, i32, u32]
+    L.sa_guard_state.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32),
+                                 ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_char_p)]
+    for name in ("sa_solver_attach_guard", "sa_guard_state", "sa_solver_create", "sa_solver_set_options", "sa_solver_sizes", "sa_solve_batch", "sa_solve_sens_batch",
                  "sa_solve_forward_batch", "sa_solve_backward_batch", "sa_solve_backward_batch_all",
                  "sa_eval_callbacks", "sa_math_probe", "sa_last_kernel_ms", "sa_set_stream", "sa_synchronize",
                  "sa_arena_info", "sa_device_count", "sa_device_memory"):
@@ -447,7 +504,8 @@ EXPORTED_SYMBOLS = ["sa_abi_version", "sa_last_error", "sa_solver_create", "sa_s
                     "sa_solve_forward_batch",
                     "sa_solve_backward_batch", "sa_solve_backward_batch_all", "sa_eval_callbacks", "sa_math_probe",
                     "sa_last_kernel_ms", "sa_arena_info",
-                    "sa_set_stream", "sa_synchronize", "sa_device_count", "sa_device_memory"]
+                    "sa_set_stream", "sa_synchronize", "sa_device_count", "sa_device_memory",
+                    "sa_solver_attach_guard", "sa_guard_state"]
 
 
 class NativeError(RuntimeError):
@@ -491,10 +549,39 @@ class NativeSolver:
     def __init__(self, native_source: str, *, device: int = 0, rtol=1e-10, atol=1e-10, rtolB=1e-10,
                  atolB=1e-10, rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
                  max_retries_bwd=50, traj_capacity=500_001, n_states: Optional[int] = None, sens: bool = False,
-                 constraints=None, hermite: bool = False, arena_bytes: int = 0, compact: bool = False):
+                 constraints=None, hermite: bool = False, arena_bytes: int = 0, compact: bool = False,
+                 guard: Optional[bool] = None, guard_sample: int = 64):
+        """``guard`` (default: on, SA_GUARD=0 turns it off): the differential guard -- the conservative build of the
+        same source is compiled next to the default one and the first instances of the first batch of every kind of
+        call run through both on the device; any difference in statuses, counters or outputs makes the handle use
+        the conservative build (RuntimeWarning), and the verdict is kept next to the code object."""
         self.L = load_library()
-        self.code_object = build_code_object(native_source, sens=sens, constraints=constraints is not None,
-                                             hermite=hermite, compact=compact)
+        build_kw = dict(sens=sens, constraints=constraints is not None, hermite=hermite, compact=compact)
+        self._guard_open = False
+        self._guard_safe = None
+        self.guard_report = {"enabled": False}
+        if guard_enabled() if guard is None else bool(guard):
+            todo = [dict(build_kw), dict(build_kw, safe=True)]
+            if not all(os.path.exists(code_object_path(native_source, **kw)) for kw in todo):
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=2) as pool:          # both builds at once (compiler subprocesses)
+                    list(pool.map(lambda kw: build_code_object(native_source, **kw), todo))
+            self._guard_fast = build_code_object(native_source, **build_kw)
+            self._guard_safe = build_code_object(native_source, **todo[1])
+            self._guard_kinds = read_guard_verdict(self._guard_fast, self._guard_safe)
+            self.guard_report = {"enabled": True, "default": os.path.basename(self._guard_fast),
+                                 "conservative": os.path.basename(self._guard_safe), "kinds": dict(self._guard_kinds),
+                                 "using_conservative": False}
+        self.code_object = build_code_object(native_source, **build_kw)
+        if self._guard_safe and any(v.get("verdict") == "differs" for v in self._guard_kinds.values()):
+            import warnings
+            warnings.warn("sunode_amd: the default and the conservative build of this model gave different results in "
+                          "an earlier run (%s); using the conservative build %s"
+                          % (guard_verdict_path(self._guard_fast), os.path.basename(self._guard_safe)),
+                          RuntimeWarning, stacklevel=3)
+            self.code_object = self._guard_safe
+            self.guard_report["using_conservative"] = True
+            self._guard_safe = None                 # nothing left to compare
         self._h = ctypes.c_void_p()
         self._user_stream = False
         self._n_hint = n_states
@@ -509,6 +596,13 @@ class NativeSolver:
         self._check(self.L.sa_solver_sizes(self._h, ctypes.byref(n), ctypes.byref(p), ctypes.byref(r)))
         self.n, self.p, self.r = n.value, p.value, r.value
         self.set_options()
+        if self._guard_safe:
+            mask = sum(bit for kind, bit in GUARD_KINDS.items()
+                       if self._guard_kinds.get(kind, {}).get("verdict") == "identical")
+            self._check(self.L.sa_solver_attach_guard(self._h, self._guard_safe.encode(), int(guard_sample), mask))
+            self._guard_seen = (mask, 0)
+            self._guard_open = True
+            self._guard_poll()
 
     def _make_options(self, n):
         kw = self._opt_kw
@@ -537,6 +631,43 @@ class NativeSolver:
     def _check(self, rc):
         if rc != 0:
             raise NativeError("sunode_amd native call failed (%d): %s" % (rc, self.L.sa_last_error().decode()))
+
+    def guard_state(self):
+        """dict(pending, verified, differs: lists of kind names; using_conservative; n_sample {kind: k}; detail)."""
+        u32, i32 = ctypes.c_uint32, ctypes.c_int32
+        pend, ver, dif, safe = u32(), u32(), u32(), i32()
+        ns = (i32 * 3)()
+        detail = ctypes.c_char_p()
+        self._check(self.L.sa_guard_state(self._h, ctypes.byref(pend), ctypes.byref(ver), ctypes.byref(dif),
+                                          ctypes.byref(safe), ns, ctypes.byref(detail)))
+        names = lambda m: [k for k, bit in GUARD_KINDS.items() if m & bit]          # noqa: E731
+        return dict(pending=names(pend.value), verified=names(ver.value), differs=names(dif.value),
+                    using_conservative=bool(safe.value), n_sample=dict(zip(GUARD_KINDS, list(ns))),
+                    detail=(detail.value or b"").decode(), _masks=(ver.value, dif.value))
+
+    def _guard_poll(self):
+        """After a batch call while checks are pending: persist new verdicts, warn about a difference."""
+        if not self._guard_open:
+            return
+        st = self.guard_state()
+        if st["_masks"] != self._guard_seen:
+            self._guard_seen = st["_masks"]
+            for kind in st["verified"]:
+                if st["n_sample"][kind]:          # (kinds verified by an earlier process keep their record)
+                    self._guard_kinds[kind] = {"verdict": "identical", "n_sample": st["n_sample"][kind]}
+            for kind in st["differs"]:
+                self._guard_kinds[kind] = {"verdict": "differs", "n_sample": st["n_sample"][kind]}
+            write_guard_verdict(self._guard_fast, self._guard_safe, self._guard_kinds, st["detail"])
+            self.guard_report.update(kinds=dict(self._guard_kinds), using_conservative=st["using_conservative"],
+                                     detail=st["detail"])
+            if st["differs"]:
+                import warnings
+                warnings.warn("sunode_amd differential guard: %s -- this solver now runs the conservative build; the "
+                              "verdict is recorded in %s" % (st["detail"], guard_verdict_path(self._guard_fast)),
+                              RuntimeWarning, stacklevel=4)
+                self.code_object = self._guard_safe
+        if not st["pending"]:
+            self._guard_open = False
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -567,6 +698,8 @@ class NativeSolver:
                        n_t, _addr(y_out), _addr(status), _addr(stats)))
         if done:
             done()
+        if self._guard_open:
+            self._guard_poll()
 
     def solve_backward(self, mem, B, ps, pr, rem_stride, t0, tend, tvals, n_t, grads, grads_stride, grad_out,
                        lamda_out, status, stats, lamda_all=None, quad_all=None):
@@ -577,12 +710,16 @@ class NativeSolver:
             _addr(status), _addr(stats)))
         if done:
             done()
+        if self._guard_open:
+            self._guard_poll()
 
     def solve_sens(self, mem, ism, scaling, B, y0, ps, pr, rem_stride, sens0, t0, tvals, n_t, y_out, sens_out,
                    status, stats):
         self._check(self.L.sa_solve_sens_batch(self._h, mem, int(ism), _addr(scaling), B, _addr(y0), _addr(ps),
                                                _addr(pr), rem_stride, _addr(sens0), float(t0), _addr(tvals), n_t,
                                                _addr(y_out), _addr(sens_out), _addr(status), _addr(stats)))
+        if self._guard_open:
+            self._guard_poll()
 
     def eval_callbacks(self, t, y, lam, ps, pr):
         npts = len(t)

@@ -780,6 +780,9 @@ extern "C" __global__ void __launch_bounds__(64) SA_FWD_ATTR sa_k_forward(sa_fwd
     if (status != CV_SUCCESS) {
         for (int j = 0; j < a.n_t * NS; j++) yo[j] = SA_NAN;
     }
+#ifdef SA_TEST_PERTURB_FORWARD       /* tests/test_guard.py: a build that differs on purpose (never a default) */
+    else yo[(int64_t)(a.n_t - 1) * NS] += 1.0;
+#endif
     a.status[inst] = status;
     if (store) {
         a.traj_np[inst] = (status == CV_SUCCESS) ? np : 0;
@@ -1042,6 +1045,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
         SFOR(i, 0, NQ) quad_out[i] = SA_NAN; SEND
         SFOR(i, 0, NS) lam[i] = SA_NAN; SEND
     }
+#ifdef SA_TEST_PERTURB_BACKWARD      /* tests/test_guard.py: a build whose adjoint differs on purpose (never a default) */
+    lam[0] += 1.0;
+#endif
     SFOR(i, 0, NQ) a.grad_out[(int64_t)inst * NQ + i] = quad_out[i]; SEND
     SFOR(i, 0, NS) a.lamda_out[(int64_t)inst * NS + i] = lam[i]; SEND
     a.status[inst] = status;

@@ -42,6 +42,20 @@ static int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                               \
     } while (0)
 
+/* Select a device for the duration of a scope and give the calling thread its previous one back: construction,
+   destruction and queries run on the USER's thread (a torch / PyMC process whose own allocations follow the
+   current device); the compute entry points, documented to do so, leave their handle's device selected. */
+struct DeviceScope {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -64,7 +78,11 @@ struct DevBuf {
     }
 };
 
+struct Guard;
+
 struct sa_solver {
+    std::string path;              /* the code object this handle runs */
+    Guard *guard = nullptr;        /* differential guard (sa_solver_attach_guard); shadows have none */
     int device = 0;
     int n = 0, p = 0, r = 0;
     int group = 1;                 /* lanes per instance: 1 = thread-per-instance, 2^k = lane group / workgroup build */
@@ -170,7 +188,8 @@ extern "C" int sa_device_memory(int32_t device, int64_t *free_bytes, int64_t *to
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(SA_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    DeviceScope scope(device);     /* a query must not move the caller's current device */
+    if (!scope.ok) return fail(SA_ERR_HIP, "hipSetDevice(%d) failed", device);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (free_bytes) *free_bytes = (int64_t)free_b;
@@ -186,9 +205,11 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (opt->device < 0 || opt->device >= ndev)
         return fail(SA_ERR_ARG, "device %d out of range (%d visible)", opt->device, ndev);
-    HIP_TRY(hipSetDevice(opt->device));
+    DeviceScope scope(opt->device);
+    if (!scope.ok) return fail(SA_ERR_HIP, "hipSetDevice(%d) failed", opt->device);
     sa_solver *s = new sa_solver();
     s->device = opt->device;
+    s->path = path;
     hipError_t e = hipModuleLoad(&s->module, path);
     if (e != hipSuccess) {
         delete s;
@@ -255,10 +276,14 @@ extern "C" int sa_solver_create(const char *path, const sa_options *opt, sa_solv
     return SA_OK;
 }
 
+static void guard_free(sa_solver *s);
+static int guard_set_options(sa_solver *s, const sa_options *opt);
+
 extern "C" void sa_solver_destroy(sa_solver *s)
 {
     if (!s) return;
-    (void)hipSetDevice(s->device);
+    DeviceScope scope(s->device);
+    guard_free(s);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     DevBuf *bufs[] = {&s->d_atol, &s->traj, &s->traj_np, &s->fwd_status, &s->keep_y0, &s->keep_tvals,
                       &s->t_yout, &s->t_status, &s->t_stats, &s->t_np, &s->s_y0,
@@ -279,7 +304,9 @@ extern "C" int sa_solver_set_options(sa_solver *s, const sa_options *opt)
     HIP_TRY(hipStreamSynchronize(s->stream));
     sa_options o = *opt;
     o.device = s->device;
-    return apply_options(s, &o);
+    int rc = apply_options(s, &o);
+    if (rc) return rc;
+    return guard_set_options(s, &o);
 }
 
 extern "C" int sa_solver_sizes(const sa_solver *s, int32_t *n, int32_t *p, int32_t *r)
@@ -433,6 +460,10 @@ static int launch_forward(sa_solver *s, const FwdLaunch &f)
     return launch(s, s->k_forward, f.B, &a, sizeof a, s->group);
 }
 
+static int guard_forward(sa_solver *s, int mode, int32_t B, const double *d_y0, const double *d_ps, const double *d_pr,
+                         int32_t rem_stride, double t0, const double *d_tv, int32_t n_t);
+static bool guard_wants(const sa_solver *s, uint32_t kind);
+
 static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const double *y0, const double *ps,
                           const double *pr, int32_t rem_stride, double t0, const double *tvals, int32_t n_t,
                           double *y_out, int32_t *status, int64_t *stats)
@@ -459,6 +490,11 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
         if ((rc = s->s_stats.ensure(sizeof(int64_t) * nB * SA_N_STATS))) return rc; d_stats = (int64_t *)s->s_stats.p;
     } else if (mem != SA_MEM_DEVICE) {
         return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
+    }
+    if (guard_wants(s, mode == SA_MODE_PLAIN ? SA_GUARD_PLAIN : SA_GUARD_ADJOINT)) {
+        /* first batch of this kind on a code object nobody has compared yet: its first instances through the
+           default AND the conservative build, bit for bit ("differential guard" below) */
+        if ((rc = guard_forward(s, mode, B, d_y0, d_ps, d_pr, rem_stride, t0, d_tv, n_t))) return rc;
     }
     FwdLaunch f{mode, B, n_t, rem_stride, 2, 0, t0, d_y0, d_ps, d_pr, d_tv, d_yout, d_status, d_stats, nullptr};
     if (mode == SA_MODE_PLAIN) {
@@ -498,8 +534,10 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
         HIP_TRY(hipEventRecord(s->ev[1], s->stream));
         s->have_fwd_time = true;
         /* what a re-integration needs (the caller may reuse its buffers after this call) */
-        HIP_TRY(hipMemcpyAsync(s->keep_y0.p, d_y0, sizeof(double) * nB * s->n, hipMemcpyDeviceToDevice, s->stream));
-        HIP_TRY(hipMemcpyAsync(s->keep_tvals.p, d_tv, sizeof(double) * (size_t)n_t, hipMemcpyDeviceToDevice, s->stream));
+        if (s->keep_y0.p != (const void *)d_y0)       /* (the guard's repeat of a forward pass reads them in place) */
+            HIP_TRY(hipMemcpyAsync(s->keep_y0.p, d_y0, sizeof(double) * nB * s->n, hipMemcpyDeviceToDevice, s->stream));
+        if (s->keep_tvals.p != (const void *)d_tv)
+            HIP_TRY(hipMemcpyAsync(s->keep_tvals.p, d_tv, sizeof(double) * (size_t)n_t, hipMemcpyDeviceToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->fwd_status.p, d_status, sizeof(int32_t) * nB, hipMemcpyDeviceToDevice, s->stream));
         s->pending = true;
         s->tiled = !s->resident_attempt;
@@ -523,6 +561,10 @@ extern "C" int sa_solve_batch(sa_solver *s, int mem, int32_t B, const double *y0
 {
     return forward_common(s, SA_MODE_PLAIN, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats);
 }
+
+static int guard_sens(sa_solver *s, int ism, const double *scaling, int32_t B, const double *d_y0, const double *d_ps,
+                      const double *d_pr, int32_t rem_stride, const double *d_s0, double t0, const double *d_tv,
+                      int32_t n_t);
 
 extern "C" int sa_solve_sens_batch(sa_solver *s, int mem, int ism, const double *scaling, int32_t B,
                                    const double *y0, const double *ps, const double *pr, int32_t rem_stride,
@@ -559,6 +601,9 @@ extern "C" int sa_solve_sens_batch(sa_solver *s, int mem, int ism, const double 
         if ((rc = s->s_stats.ensure(sizeof(int64_t) * nB * SA_N_STATS))) return rc; d_stats = (int64_t *)s->s_stats.p;
     } else if (mem != SA_MEM_DEVICE) {
         return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
+    }
+    if (guard_wants(s, SA_GUARD_SENS)) {
+        if ((rc = guard_sens(s, ism, scaling, B, d_y0, d_ps, d_pr, rem_stride, d_s0, t0, d_tv, n_t))) return rc;
     }
     sa_sens_args a;
     memset(&a, 0, sizeof a);
@@ -633,6 +678,10 @@ static int resolve_forward(sa_solver *s)
     return SA_OK;
 }
 
+static int guard_backward(sa_solver *s, int32_t B, const double *d_ps, const double *d_pr, int32_t rem_stride,
+                          double t0, double tend, const double *d_tv, int32_t n_t, const double *d_g,
+                          int64_t grads_stride);
+
 extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const double *ps, const double *pr,
                                        int32_t rem_stride, double t0, double tend, const double *tvals,
                                        int32_t n_t, const double *grads, int64_t grads_stride, double *grad_out,
@@ -678,6 +727,9 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
         if ((rc = s->s_stats.ensure(sizeof(int64_t) * nB * SA_N_STATS))) return rc; d_stats = (int64_t *)s->s_stats.p;
     } else if (mem != SA_MEM_DEVICE) {
         return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
+    }
+    if (guard_wants(s, SA_GUARD_ADJOINT)) {
+        if ((rc = guard_backward(s, B, d_ps, d_pr, rem_stride, t0, tend, d_tv, n_t, d_g, grads_stride))) return rc;
     }
     sa_bwd_args a;
     memset(&a, 0, sizeof a);
@@ -802,6 +854,287 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
             HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(int64_t) * nB * SA_N_STATS, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
+    return SA_OK;
+}
+
+
+/* ---- differential guard ----------------------------------------------------------------------------
+ * include/sunode_amd.h, sa_solver_attach_guard.  Two shadow handles (the default and the conservative code object)
+ * integrate the first instances of the caller's batch from the caller's own device arrays -- the first k rows of a
+ * [B][...] array ARE the arrays of a k-instance batch -- into guard-owned output buffers; the host compares the bytes.
+ * The shadows are created when a check is due and destroyed when nothing is pending any more.
+ */
+struct Guard {
+    std::string safe_path;
+    sa_solver *fast = nullptr, *safe = nullptr;
+    int32_t want = 64;
+    uint32_t pending = 0, verified = 0, differs = 0;
+    int32_t checks[3] = {0, 0, 0}, best[3] = {0, 0, 0};
+    bool using_safe = false;
+    int32_t adj_k = 0;             /* adjoint check in flight: the shadows hold the forward pass of this many instances */
+    DevBuf out[2][4];
+    std::vector<unsigned char> host[2];
+    std::string detail;
+};
+static const int32_t SA_GUARD_MIN_SAMPLE = 16, SA_GUARD_MAX_SMALL_CHECKS = 3;
+
+static int kind_slot(uint32_t kind) { return kind == SA_GUARD_PLAIN ? 0 : kind == SA_GUARD_ADJOINT ? 1 : 2; }
+
+static bool guard_wants(const sa_solver *s, uint32_t kind) { return s->guard && (s->guard->pending & kind); }
+
+static void guard_drop_shadows(Guard *g)
+{
+    if (g->fast) sa_solver_destroy(g->fast);
+    if (g->safe) sa_solver_destroy(g->safe);
+    g->fast = g->safe = nullptr;
+    for (auto &row : g->out) for (DevBuf &b : row) b.release();
+    g->adj_k = 0;
+}
+
+static void guard_free(sa_solver *s)
+{
+    if (!s->guard) return;
+    guard_drop_shadows(s->guard);
+    delete s->guard;
+    s->guard = nullptr;
+}
+
+static sa_options shadow_options(const sa_solver *s)
+{
+    sa_options o = s->opt;
+    o.struct_size = (int32_t)sizeof(sa_options);
+    o.device = s->device;
+    o.atol = s->atol.data();
+    o.constraints = s->have_constraints ? s->constraints.data() : nullptr;
+    return o;
+}
+
+static int guard_set_options(sa_solver *s, const sa_options *)
+{
+    Guard *g = s->guard;
+    if (!g) return SA_OK;
+    sa_options o = shadow_options(s);
+    for (sa_solver *sh : {g->fast, g->safe})
+        if (sh) { int rc = apply_options(sh, &o); if (rc) return rc; }
+    return SA_OK;
+}
+
+static int guard_shadows(sa_solver *s)
+{
+    Guard *g = s->guard;
+    sa_options o = shadow_options(s);
+    int rc;
+    if (!g->fast && (rc = sa_solver_create(s->path.c_str(), &o, &g->fast))) return rc;
+    if (!g->safe && (rc = sa_solver_create(g->safe_path.c_str(), &o, &g->safe))) return rc;
+    for (sa_solver *sh : {g->fast, g->safe})
+        if (sh->n != s->n || sh->p != s->p || sh->r != s->r || sh->group != s->group || sh->ws_doubles != s->ws_doubles ||
+            sh->rec_doubles != s->rec_doubles || sh->point_major != s->point_major || (sh->k_sens != nullptr) != (s->k_sens != nullptr))
+            return fail(SA_ERR_MODULE, "guard: %s is not a build of the same source and options as %s",
+                        sh->path.c_str(), s->path.c_str());
+    return SA_OK;
+}
+
+/* the handle runs the conservative code object from now on */
+static void guard_switch(sa_solver *s)
+{
+    Guard *g = s->guard;
+    if (g->using_safe || !g->safe) return;
+    std::swap(s->module, g->safe->module);
+    std::swap(s->k_forward, g->safe->k_forward);
+    std::swap(s->k_backward, g->safe->k_backward);
+    std::swap(s->k_eval, g->safe->k_eval);
+    std::swap(s->k_math, g->safe->k_math);
+    std::swap(s->k_sens, g->safe->k_sens);
+    std::swap(s->path, g->safe->path);
+    g->using_safe = true;
+}
+
+struct GuardBuf { const char *name; size_t row_bytes; size_t cmp_bytes; };   /* per instance: stored / compared */
+
+/* bring the outputs of both shadows to the host and compare; *same = verdict */
+static int guard_compare(sa_solver *s, const char *what, int32_t k, const GuardBuf *bufs, int nbufs, bool *same)
+{
+    Guard *g = s->guard;
+    *same = true;
+    for (int b = 0; b < nbufs; b++) {
+        const size_t bytes = bufs[b].row_bytes * (size_t)k;
+        if (!bytes) continue;
+        sa_solver *sh[2] = {g->fast, g->safe};
+        for (int w = 0; w < 2; w++) {
+            g->host[w].resize(bytes);
+            HIP_TRY(hipMemcpyAsync(g->host[w].data(), g->out[w][b].p, bytes, hipMemcpyDeviceToHost, sh[w]->stream));
+            HIP_TRY(hipStreamSynchronize(sh[w]->stream));
+        }
+        for (int32_t i = 0; i < k && *same; i++) {
+            const unsigned char *x = g->host[0].data() + (size_t)i * bufs[b].row_bytes;
+            const unsigned char *y = g->host[1].data() + (size_t)i * bufs[b].row_bytes;
+            if (memcmp(x, y, bufs[b].cmp_bytes) != 0) {
+                size_t off = 0;
+                while (off < bufs[b].cmp_bytes && x[off] == y[off]) off++;
+                char msg[512];
+                snprintf(msg, sizeof msg, "%s: %s of instance %d differs between the default build %s and the "
+                         "conservative build %s (element %zu)", what, bufs[b].name, i, g->fast->path.c_str(),
+                         g->safe->path.c_str(), off / 8);
+                g->detail = msg;
+                *same = false;
+            }
+        }
+        if (!*same) break;
+    }
+    return SA_OK;
+}
+
+/* book a finished check of `kind` over k instances */
+static void guard_book(sa_solver *s, uint32_t kind, int32_t k, bool same)
+{
+    Guard *g = s->guard;
+    const int slot = kind_slot(kind);
+    g->checks[slot]++;
+    if (k > g->best[slot]) g->best[slot] = k;
+    if (!same) {
+        g->differs |= kind;
+        g->pending = 0;                       /* conservative code object from here on: nothing left to compare */
+        guard_switch(s);
+    } else if (k >= SA_GUARD_MIN_SAMPLE || k >= g->want || g->checks[slot] >= SA_GUARD_MAX_SMALL_CHECKS) {
+        g->verified |= kind;
+        g->pending &= ~kind;
+    }
+    if (!g->pending) guard_drop_shadows(g);
+}
+
+static int guard_forward(sa_solver *s, int mode, int32_t B, const double *d_y0, const double *d_ps, const double *d_pr,
+                         int32_t rem_stride, double t0, const double *d_tv, int32_t n_t)
+{
+    Guard *g = s->guard;
+    const int32_t k = B < g->want ? B : g->want;
+    int rc;
+    if ((rc = guard_shadows(s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));           /* the caller's (staged) inputs are in place */
+    const size_t nn = (size_t)(s->n > 0 ? s->n : 1);
+    const GuardBuf bufs[3] = {{"y_out", sizeof(double) * (size_t)n_t * nn, sizeof(double) * (size_t)n_t * (size_t)s->n},
+                              {"status", sizeof(int32_t), sizeof(int32_t)},
+                              {"the counters", sizeof(int64_t) * SA_N_STATS, sizeof(int64_t) * 15}};
+    sa_solver *sh[2] = {g->fast, g->safe};
+    for (int w = 0; w < 2; w++) {
+        for (int b = 0; b < 3; b++)
+            if ((rc = g->out[w][b].ensure(bufs[b].row_bytes * (size_t)k))) return rc;
+        if ((rc = forward_common(sh[w], mode, SA_MEM_DEVICE, k, d_y0, d_ps, d_pr, rem_stride, t0, d_tv, n_t,
+                                 (double *)g->out[w][0].p, (int32_t *)g->out[w][1].p, (int64_t *)g->out[w][2].p)))
+            return rc;
+    }
+    bool same = true;
+    if ((rc = guard_compare(s, mode == SA_MODE_PLAIN ? "forward solve" : "adjoint solve, forward pass", k, bufs, 3, &same)))
+        return rc;
+    if (mode == SA_MODE_PLAIN) guard_book(s, SA_GUARD_PLAIN, k, same);
+    else if (!same) guard_book(s, SA_GUARD_ADJOINT, k, false);
+    else g->adj_k = k;                                   /* the backward call finishes the check */
+    return SA_OK;
+}
+
+static int guard_sens(sa_solver *s, int ism, const double *scaling, int32_t B, const double *d_y0, const double *d_ps,
+                      const double *d_pr, int32_t rem_stride, const double *d_s0, double t0, const double *d_tv,
+                      int32_t n_t)
+{
+    Guard *g = s->guard;
+    const int32_t k = B < g->want ? B : g->want;
+    int rc;
+    if ((rc = guard_shadows(s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t nn = (size_t)(s->n > 0 ? s->n : 1), np_n = (size_t)s->p * (size_t)s->n;
+    const GuardBuf bufs[4] = {{"y_out", sizeof(double) * (size_t)n_t * nn, sizeof(double) * (size_t)n_t * (size_t)s->n},
+                              {"sens_out", sizeof(double) * (size_t)n_t * (np_n ? np_n : 1), sizeof(double) * (size_t)n_t * np_n},
+                              {"status", sizeof(int32_t), sizeof(int32_t)},
+                              {"the counters", sizeof(int64_t) * SA_N_STATS, sizeof(int64_t) * 15}};
+    sa_solver *sh[2] = {g->fast, g->safe};
+    for (int w = 0; w < 2; w++) {
+        for (int b = 0; b < 4; b++)
+            if ((rc = g->out[w][b].ensure(bufs[b].row_bytes * (size_t)k))) return rc;
+        if ((rc = sa_solve_sens_batch(sh[w], SA_MEM_DEVICE, ism, scaling, k, d_y0, d_ps, d_pr, rem_stride, d_s0, t0, d_tv,
+                                      n_t, (double *)g->out[w][0].p, (double *)g->out[w][1].p, (int32_t *)g->out[w][2].p,
+                                      (int64_t *)g->out[w][3].p)))
+            return rc;
+    }
+    bool same = true;
+    if ((rc = guard_compare(s, "forward-sensitivity solve", k, bufs, 4, &same))) return rc;
+    guard_book(s, SA_GUARD_SENS, k, same);
+    return SA_OK;
+}
+
+static int guard_backward(sa_solver *s, int32_t B, const double *d_ps, const double *d_pr, int32_t rem_stride,
+                          double t0, double tend, const double *d_tv, int32_t n_t, const double *d_g,
+                          int64_t grads_stride)
+{
+    Guard *g = s->guard;
+    const int32_t k = g->adj_k;
+    if (k <= 0 || k > B || !g->fast || !g->safe) return SA_OK;    /* no forward check in flight for this batch */
+    int rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t nn = (size_t)(s->n > 0 ? s->n : 1), pp = (size_t)(s->p > 0 ? s->p : 1);
+    const GuardBuf bufs[4] = {{"grad_out", sizeof(double) * pp, sizeof(double) * (size_t)s->p},
+                              {"lamda_out", sizeof(double) * nn, sizeof(double) * (size_t)s->n},
+                              {"status", sizeof(int32_t), sizeof(int32_t)},
+                              {"the counters", sizeof(int64_t) * SA_N_STATS, sizeof(int64_t) * 15}};
+    sa_solver *sh[2] = {g->fast, g->safe};
+    for (int w = 0; w < 2; w++) {
+        for (int b = 0; b < 4; b++)
+            if ((rc = g->out[w][b].ensure(bufs[b].row_bytes * (size_t)k))) return rc;
+        if ((rc = sa_solve_backward_batch_all(sh[w], SA_MEM_DEVICE, k, d_ps, d_pr, rem_stride, t0, tend, d_tv, n_t, d_g,
+                                              grads_stride, (double *)g->out[w][0].p, (double *)g->out[w][1].p, nullptr,
+                                              nullptr, (int32_t *)g->out[w][2].p, (int64_t *)g->out[w][3].p)))
+            return rc;
+    }
+    bool same = true;
+    if ((rc = guard_compare(s, "adjoint solve, backward pass", k, bufs, 4, &same))) return rc;
+    g->adj_k = 0;
+    guard_book(s, SA_GUARD_ADJOINT, k, same);
+    if (!same) {
+        /* the forward pass of THIS batch ran on the default build (whose first instances agreed with the conservative
+           build's): integrate it again with the code object the handle has just switched to, then go backward */
+        const size_t nB = (size_t)s->fwd_B;
+        if ((rc = s->t_yout.ensure(sizeof(double) * nB * (size_t)s->fwd_n_t * nn))) return rc;
+        if ((rc = s->t_status.ensure(sizeof(int32_t) * (size_t)round64(s->fwd_B)))) return rc;
+        if ((rc = s->t_stats.ensure(sizeof(int64_t) * (size_t)round64(s->fwd_B) * SA_N_STATS))) return rc;
+        if ((rc = forward_common(s, SA_MODE_ADJ_FWD, SA_MEM_DEVICE, s->fwd_B, (const double *)s->keep_y0.p, d_ps, d_pr,
+                                 rem_stride, s->fwd_t0, (const double *)s->keep_tvals.p, s->fwd_n_t,
+                                 (double *)s->t_yout.p, (int32_t *)s->t_status.p, (int64_t *)s->t_stats.p)))
+            return rc;
+        if ((rc = resolve_forward(s))) return rc;
+    }
+    return SA_OK;
+}
+
+extern "C" int sa_solver_attach_guard(sa_solver *s, const char *safe_path, int32_t n_sample, uint32_t verified_kinds)
+{
+    if (!s || !safe_path) return fail(SA_ERR_ARG, "null argument");
+    if (n_sample < 0) return fail(SA_ERR_ARG, "n_sample must be >= 0");
+    DeviceScope scope(s->device);
+    guard_free(s);
+    Guard *g = new Guard();
+    g->safe_path = safe_path;
+    g->want = n_sample > 0 ? n_sample : 64;
+    const uint32_t all = SA_GUARD_PLAIN | SA_GUARD_ADJOINT | (s->k_sens ? SA_GUARD_SENS : 0u);
+    g->verified = verified_kinds & all;
+    g->pending = all & ~g->verified;
+    s->guard = g;
+    if (g->pending) {                  /* fail HERE if the conservative code object is unusable, not in the first solve */
+        int rc = guard_shadows(s);
+        if (rc) { guard_free(s); return rc; }
+    }
+    return SA_OK;
+}
+
+extern "C" int sa_guard_state(sa_solver *s, uint32_t *pending, uint32_t *verified, uint32_t *differs,
+                              int32_t *using_safe, int32_t *n_sample, const char **detail)
+{
+    if (!s) return fail(SA_ERR_ARG, "null solver");
+    static const char *none = "";
+    Guard *g = s->guard;
+    if (pending) *pending = g ? g->pending : 0;
+    if (verified) *verified = g ? g->verified : 0;
+    if (differs) *differs = g ? g->differs : 0;
+    if (using_safe) *using_safe = g && g->using_safe ? 1 : 0;
+    if (n_sample) for (int i = 0; i < 3; i++) n_sample[i] = g ? g->best[i] : 0;
+    if (detail) *detail = g ? g->detail.c_str() : none;
     return SA_OK;
 }
 

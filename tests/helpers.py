@@ -1,14 +1,7 @@
 """Shared helpers for the test-suite (problem construction, oracle cache)."""
 import functools
 
-from sunode_amd import SympyProblem
-from tools.problems import EXTRA_PROBLEMS, PROBLEMS, network100
-
-
-@functools.lru_cache(maxsize=None)
-def make_problem(name):
-    spec = network100() if name == "network100" else {**PROBLEMS, **EXTRA_PROBLEMS}[name]
-    return SympyProblem(spec["params"], spec["states"], spec["rhs"], spec["derivative_params"])
+from tools.problem_cache import make_problem  # noqa: F401  (named problems, symbolic work cached on disk)
 
 
 @functools.lru_cache(maxsize=None)

@@ -28,7 +28,9 @@ def test_budget_file_covers_the_default_builds_of_every_baseline_problem():
 @pytest.mark.parametrize("label", ["lv", "robertson", "seir", "network24", "lv/sens", "robertson/sens", "seir/sens"])
 def test_current_builds_stay_within_budget(label):
     """(cross-compiles for gfx950 on the CPU box; cached after the first build)"""
-    assert cob.violations([label]) == []
+    hard, soft = cob.violations([label], split=True)
+    assert hard == []               # spill slots / scratch / LDS (+ slack); register counts only inform
+    assert all("exceeds" in m or "informational" in m for m in soft)
 
 
 def test_budget_check_notices_a_regression(tmp_path, monkeypatch):

@@ -35,7 +35,7 @@ FIELDS = ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", 
 
 
 def source_of(problem):
-    from tests.helpers import make_problem
+    from tools.problem_cache import make_problem
     return make_problem(problem).native_source()
 
 
@@ -56,16 +56,34 @@ def load():
         return json.load(fh)
 
 
-def violations(labels=None):
-    """[(label, message)] of every budget violation of the current builds."""
+#: fields whose excess fails the build (with SLACK on top of the recorded value); the register counts only inform
+HARD_FIELDS = ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size")
+SLACK = {"vgpr_spill_count": 16, "sgpr_spill_count": 16, "private_segment_fixed_size": 64, "group_segment_fixed_size": 0}
+#: environment overrides of the code generation: builds made under them are not the builds the budget describes
+OVERRIDES = ("SA_CLANG_FLAGS", "SA_KERNEL_DEFINES", "SA_VGPR_LIVERANGE_OPT", "SA_WAVES_PER_EU", "SA_FORCE_GROUP")
+
+
+def violations(labels=None, split=False):
+    """Messages of every budget violation of the current builds.  ``split=True``: (hard, soft) -- hard = a spill /
+    scratch / LDS ceiling (+ SLACK) exceeded by a build made with the recorded toolchain and without codegen
+    overrides in the environment; soft = everything else (register counts, other toolchain, overrides)."""
     from sunode_amd import _native
     doc = load()
-    bad = []
+    same_context = doc["toolchain"]["hash"] == _native.toolchain_id()["hash"] and \
+        not any(os.environ.get(k) for k in OVERRIDES)
+    hard, soft = [], []
     for label in (labels or doc["budgets"]):
         problem, kw = BUILDS[label]
         path = _native.build_code_object(source_of(problem), **kw)
-        bad += _native.check_code_object_budget(label, path, doc["budgets"][label])
-    return bad
+        limits = doc["budgets"][label]
+        strict = {k: {f: v + SLACK[f] for f, v in row.items() if f in HARD_FIELDS} for k, row in limits.items()}
+        loose = {k: {f: v for f, v in row.items() if f not in HARD_FIELDS} for k, row in limits.items()}
+        (hard if same_context else soft).extend(_native.check_code_object_budget(label, path, strict))
+        soft += _native.check_code_object_budget(label, path, loose)
+    if not same_context:
+        soft.append("toolchain %s / environment overrides differ from the recorded context (toolchain %s): "
+                    "informational only" % (_native.toolchain_id()["hash"], doc["toolchain"]["hash"]))
+    return (hard, soft) if split else hard + soft
 
 
 def main():

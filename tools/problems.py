@@ -270,3 +270,89 @@ def network_batch(B: int, n: int = 100, seed: int = SEED, idx=None):
     zx = std_normal(seed, 70, n)
     y0 = np.tile(np.exp(0.3 * zx), (len(z), 1))
     return dict(ps=ps, pr=K.ravel(), y0=y0, tvals=np.linspace(0, 10, 11), t0=0.0, rtol=1e-8, atol=1e-8)
+
+
+# --------------------------------------------------------------------------
+# generated model family for the shape sweep (tests/test_shape_sweep.py): any (n states, p differentiated parameters)
+# --------------------------------------------------------------------------
+def make_random_network(n: int, p: int, band: int = 0):
+    """Mass-action network with n states, a shared fixed rate matrix K (n x n) and p differentiated scales s:
+
+        x_i' = sum_j K_ij x_j  -  A_i x_i sum_j K_ji  -  B_i x_i T / (C + T)  +  D_i,      T = sum_j x_j
+
+    with A_i = sum of the s_k with k = i (mod n) (1 if there is none), B_i = s_{(i+1) mod p} / 2, C = 1 + s_{2 mod p},
+    D_i = s_{(3i+1) mod p} / 10 -- every parameter enters, with p > n several per equation, with p < n each one in
+    several equations.  ``band`` > 0: only the entries |i - j| <= band of K are used (sparse Jacobian, no dense
+    matrix-vector block for the code generator to find)."""
+    def rhs(t, y, par):
+        import sympy as sym
+        x = y.x
+        s = par.s
+        tot = sum(x)
+
+        def used(i, j):
+            return band <= 0 or abs(i - j) <= band
+        out = []
+        for i in range(n):
+            mine = [s[k] for k in range(p) if k % n == i]
+            a_i = sum(mine) if mine else sym.Integer(1)
+            inflow = sum(par.K[i, j] * x[j] for j in range(n) if used(i, j))
+            colsum = sum(par.K[j, i] for j in range(n) if used(j, i))
+            out.append(inflow - a_i * x[i] * colsum - s[(i + 1) % p] / 2 * x[i] * tot / (1 + s[2 % p] + tot)
+                       + s[(3 * i + 1) % p] / 10)
+        return {"x": out}
+    return rhs
+
+
+def random_network(n: int, p: int, band: int = 0):
+    """Problem specification (the dict ``SympyProblem`` is built from) of the (n, p) member of the family."""
+    return dict(params={"K": (n, n), "s": (p,)}, states={"x": (n,)}, rhs=make_random_network(n, p, band),
+                derivative_params=[("s",)])
+
+
+def lv12(t, y, p):
+    """Lotka-Volterra with saturating terms: 2 states, 12 differentiated parameters (few states, many parameters:
+    the quadrature history, not the state, decides the mapping)."""
+    h, l = y.hares, y.lynx
+    a, b, c = p.a, p.b, p.c
+    return {
+        "hares": a[0] * h - b[0] * h * l + a[1] * h / (1 + c[0] * h) - a[2] * h ** 2 / 10 + c[2] / 10,
+        "lynx": b[1] * h * l - a[3] * l + b[2] * l / (1 + c[1] * l) - b[3] * l ** 2 / 10 + c[3] / 10,
+    }
+
+
+LV12 = dict(params={"a": (4,), "b": (4,), "c": (4,)}, states={"hares": (), "lynx": ()}, rhs=lv12,
+            derivative_params=[("a",), ("b",), ("c",)])
+
+
+def random_network_batch(B: int, n: int, p: int, seed: int = SEED, idx=None):
+    """Draws for ``random_network(n, p)``: K shared (|N(0,1)| / n), s = s0 exp(0.2 z) per draw, y0 = exp(0.3 z') per
+    draw, per-instance cotangents; 6 output times on [0, 8]."""
+    stream = 1000 + 131 * n + p
+    K = np.abs(std_normal(seed, stream, n * n)).reshape(n, n) / n
+    s0 = 0.6 + 0.1 * (np.arange(p) % 7)
+    z = np.stack([std_normal(seed, stream + 1 + (k % 50), B, idx) for k in range(p)], axis=1) \
+        * (1.0 + 0.05 * (np.arange(p) // 50))
+    ps = s0 * np.exp(0.2 * z)
+    zx = np.stack([std_normal(seed, stream + 60 + (i % 40), B, idx) for i in range(n)], axis=1)
+    y0 = np.exp(0.3 * zx * (1.0 + 0.03 * (np.arange(n) // 40)))
+    tvals = np.array([0.0, 0.5, 1.5, 3.0, 5.0, 8.0])
+    k = np.arange(len(tvals))[None, :, None]
+    i = np.arange(n)[None, None, :]
+    b = np.arange(len(y0))[:, None, None] if idx is None else np.asarray(idx)[:, None, None]
+    grads = 1.0 + 0.5 * np.cos(1.7 * k + 0.9 * i + 0.37 * b)
+    return dict(ps=ps, pr=K.ravel(), y0=y0, tvals=tvals, t0=0.0, grads=grads, rtol=1e-8, atol=1e-8)
+
+
+def lv12_batch(B: int, seed: int = SEED, idx=None):
+    z = np.stack([std_normal(seed, 900 + k, B, idx) for k in range(12)], axis=1)
+    base = np.array([0.1, 0.05, 0.3, 0.3, 0.2, 0.4, 0.05, 0.2, 0.5, 0.5, 0.1, 0.1])
+    ps = base * np.exp(0.2 * z)
+    zy = np.stack([std_normal(seed, 920 + s, B, idx) for s in range(2)], axis=1)
+    y0 = np.array([1.0, 0.1]) * np.exp(0.1 * zy)
+    tvals = np.linspace(0, 10, 11)
+    k = np.arange(len(tvals))[None, :, None]
+    i = np.arange(2)[None, None, :]
+    b = np.arange(len(y0))[:, None, None] if idx is None else np.asarray(idx)[:, None, None]
+    grads = 1.0 + 0.5 * np.cos(1.3 * k + 0.7 * i + 0.21 * b)
+    return dict(ps=ps, pr=np.zeros(0), y0=y0, tvals=tvals, t0=0.0, grads=grads, rtol=1e-8, atol=1e-8)
