@@ -119,7 +119,7 @@ SMALL_GROUP_CODEGEN_FLAGS = "-mllvm -misched-cluster=0"
 #: machine CSE, no pre- / post-RA scheduler, no early if-conversion, sink splitting on / off, a hard barrier around the
 #: parked values) and disappears with exactly `-amdgpu-opt-vgpr-liverange=0`, with -O1, or when the source reads the
 #: parked values once more (which is why it looked like a heisenbug); the machine verifier is silent and the
-#: "group-uniform" values are uniform (diagnostic build -DSA_CTL_CHECK).  Reproducer: tools/repro_vgpr_liverange.sh,
+#: "group-uniform" values are uniform (round 4's diagnostic build).  Reproducer: tools/repro_vgpr_liverange.sh,
 #: record: profiles/r04_sens_anomaly.txt.  That configuration is NOT shipped (the sensitivity builds carry neither the
 #: parking nor -disable-machine-licm), and every shipped build agrees with the oracle bit for bit (163 GPU tests, all
 #: BASELINE batches at full size).  Building everything without the pass costs 10 % (LV) ... 27 % (SEIR) ... 57 %

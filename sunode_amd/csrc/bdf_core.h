@@ -505,8 +505,9 @@ DEV int cv_newton_pass(SA_STATE<BWD> &m, int callSetup, int jbad, int &convfail,
         m.nni++;
         SFOR(r, 0, RS) delta[r] = -1.0 * delta[r]; SEND
         dense_getrs(m, delta);
-        if (m.gamrat != 1.0) {
-            double s = 2.0 / (1.0 + m.gamrat);
+        {   /* cvLsSolve's scaling by 2 / (1 + gamrat) -- skipped by CVODES when gamrat == 1, where the factor is exactly
+               1.0: computed by every lane (x * 1.0 == x) instead of inside a divergent block of its own */
+            const double s = 2.0 / (1.0 + m.gamrat);
             SFOR(r, 0, RS) delta[r] *= s; SEND
         }
         SFOR(r, 0, RS) m.acor[r] = m.acor[r] + delta[r]; SEND
@@ -703,6 +704,19 @@ DEV void cv_prepare_next_step(SA_STATE<BWD> &m, double dsm)
        a decision (qwait != 0) or whose candidate is not defined discard the values through selects.  Values and
        written fields identical to the branching form. */
     const bool full = (m.qwait == 0);
+    if (!wave_any(full)) {
+        /* no lane of the wavefront is at an order decision (after a restart the lanes walk through qwait together):
+           what the block below leaves behind for full == false, without its two norms and two of its three powers */
+        const double p0 = rpower_nb<SA_POLY_CM(BWD)>(BIAS2 * dsm, inv_int(m.L));
+        const double etaq = 1.0 / (p0 + ADDON);
+        m.etaq = etaq;
+        m.qprime = m.q;
+        const bool small = etaq < THRESH;
+        const double capped = fmin(etaq, m.etamax);
+        m.hprime = small ? m.h : m.h * capped;
+        m.eta = small ? 1.0 : capped;
+        return;
+    }
     double znq[RS], znQq[RQ], tv[RS], tvQ[RQ];
     SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
     SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND

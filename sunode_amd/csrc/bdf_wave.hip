@@ -59,7 +59,7 @@
    16 instances x 2 KB would not fit next to the rest), the Jacobian callback writes straight to the saved copy in the
    workspace, and the cold per-instance state (interpolation table) lives in LDS instead of registers. */
 #define W_RS_PRE ((W_NS + G - 1) / G)
-#if SA_GROUP <= 8 && (W_NS * W_RS_PRE) <= 64 && !defined(SA_NO_LEAN)
+#if SA_GROUP <= 8 && (W_NS * W_RS_PRE) <= 64
 #define SA_LEAN 1
 #else
 #define SA_LEAN 0
@@ -84,13 +84,10 @@ __shared__ uint8_t s_piv[KPW * W_PIV];              /* pivot rows (n <= 128 fits
 #define W_NOUT (W_NS > W_NQD ? W_NS : W_NQD)
 #define W_NOUTP (KPW > 1 ? (W_NOUT | 1) : W_NOUT)
 __shared__ double s_out[KPW * W_NOUTP];             /* output vector of the vector-valued callbacks */
-/* (workgroup-per-instance build: the same two parking schemes for wavefront 0, -DSA_WG_TAB_LDS / -DSA_WG_COLD) */
-#if SA_GROUP >= 64 && defined(SA_WG_COLD)
-#define SA_COLD_PARK 1
-#else
+/* (the same two parking schemes for wavefront 0 of the workgroup-per-instance build were measured in round 4 -- 100 -> 42
+   spill slots, not faster: profiles/r04_network100_lu.txt -- and removed again) */
 #define SA_COLD_PARK SA_LEAN
-#endif
-#if (SA_LEAN || (SA_GROUP >= 64 && defined(SA_WG_TAB_LDS))) && !defined(SA_HERMITE)
+#if SA_LEAN && !defined(SA_HERMITE)
 /* the divided-difference record of the current interpolation index, copied from the arena when the index moves
    (20 + 6 n/G registers per lane otherwise).  Stride: even (16-byte rows) and not a multiple of 16 doubles. */
 #define SA_TAB_LDS 1
@@ -126,9 +123,6 @@ __shared__ double s_ctl[KPW * W_NCTL];
 #define SA_NO_CTL_PARK 1
 #endif
 #endif
-#ifdef SA_CTL_PRIVATE               /* experiment: every lane parks its own copy */
-__shared__ double s_ctlp[W_NCTL * 64];
-#endif
 #endif
 /* Workgroup barrier as ONE inline instruction sequence.  In this build pipeline (clang -O0 -> always-inline -> -O3)
    HIP's __syncthreads() stays a real function call: every call site spilled the caller's live VGPRs to scratch and
@@ -161,11 +155,7 @@ static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_
 #define SA_MOD_NWAVES(c) (s_nwaves == SA_WAVES ? (c) % SA_WAVES : (s_nwaves == 1 ? 0 : (c) % s_nwaves))
 #define SA_CHUNK_CALL(c, call) do { if (SA_MOD_NWAVES(c) == sa_wave_index()) bad |= call; } while (0)
 
-#ifdef SA_WAVE_INLINE_CALLBACKS      /* small callbacks: no call ABI between the integrator state and the callback */
-#define SA_FN static __device__ __forceinline__
-#else
 #define SA_FN static __device__ __attribute__((noinline))
-#endif
 #define SA_TEMPLATE template <class SinkT>
 #define SA_OUT_T SinkT
 #define SA_STORE(slot, value) out.template put<(slot)>(value)
@@ -176,24 +166,9 @@ static __device__ __forceinline__ int sa_wave_index() { return __builtin_amdgcn_
     const double *sa_pv = s_ps + sa_grp() * W_NQP; (void)sa_yv; (void)sa_lv; (void)sa_pv;
 typedef __attribute__((address_space(1))) double gdouble;      /* explicit global pointer: cannot alias LDS */
 #define SA_CONST_AS __attribute__((address_space(4)))
-#ifdef SA_WAVE_PR_SCALAR
-/* tuning alternative: remaining parameters through scalar loads of a wave-uniform constant-address-
-   space view.  Measured slower for large shared blocks (100 x 100 rate matrix): scalar loads return
-   out of order, every use waits for lgkmcnt(0), and the 16 KB scalar cache thrashes. */
-static __device__ __forceinline__ const SA_CONST_AS double *sa_uniform_const(const double *p)
-{
-    const uint64_t u = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-    return (const SA_CONST_AS double *)(((uint64_t)hi << 32) | (uint64_t)lo);
-}
-#define SA_PR(j) prc[j]
-#define SA_PROLOGUE SA_LDS_VIEWS const SA_CONST_AS double *prc = sa_uniform_const(pr);
-#else
 /* remaining parameters: broadcast global loads (all lanes read the same address; the vector memory
    pipe is otherwise idle during a callback and keeps dozens of loads in flight) */
 #define SA_PR(j) prg[j]
-#ifndef SA_WAVE_NO_PREFETCH
 /* A chunk function touches the parameter ranges it is about to read with ONE load per 8 KB (every lane a
    different 128-byte line); the values are parked in sa_pf[] and only consumed by the epilogue, so nothing
    waits for them -- but the statements' own broadcast loads then hit the L1 instead of paying the L2 latency
@@ -208,29 +183,18 @@ static __device__ __forceinline__ double sa_touch(const gdouble *p, int n)
 #define SA_PREFETCH_PR(k, lo, hi) sa_pf[k] = sa_touch(prg + (lo), (hi) - (lo) + 1)
 #define SA_EPILOGUE asm volatile("" :: "v"(sa_pf[0]), "v"(sa_pf[1]), "v"(sa_pf[2]), "v"(sa_pf[3]), \
                                  "v"(sa_pf[4]), "v"(sa_pf[5]), "v"(sa_pf[6]), "v"(sa_pf[7]));
-#else
-#define SA_PROLOGUE SA_LDS_VIEWS const gdouble *prg = (const gdouble *)pr;
-#endif
-#endif
 /* Small systems (config 4: n = 16): NO per-statement barriers.  With them every LDS / parameter load of a statement
    is waited for on the spot -- the SEIR adjoint right-hand side was 94 dependent memory round trips (32 of them
    global loads of the contact matrix), 11 k cycles per call; without them the scheduler batches the loads (8 global
    loads, one wait) and the whole SEIR solve is 21 % faster.  The barriers are for the thousands of statements of the
    n = 100 callbacks (below). */
-#if W_NS <= 32 && !defined(SA_WAVE_SCHED_BARRIER)
-#define SA_WAVE_NO_SCHED_BARRIER 1
-#endif
-#ifndef SA_WAVE_NO_SCHED_BARRIER
+#if W_NS > 32
 /* keep the instruction scheduler from hoisting the loads of later statements over earlier ones:
-   with thousands of independent statements that ends in tens of KB of spills */
-#ifdef SA_WAVE_NO_MEM_CLOBBER
-#define SA_STMT_END __builtin_amdgcn_sched_barrier(0);
-#else
-/* ... and a compiler-level memory barrier: without it the LDS reads of the state (and of the adjoint state)
+   with thousands of independent statements that ends in tens of KB of spills
+   ... and a compiler-level memory barrier: without it the LDS reads of the state (and of the adjoint state)
    are kept in registers across ALL statements of a chunk -- 2 x 100 doubles at n = 100 -- and the allocator
    spills them to scratch; re-reading LDS per statement is far cheaper */
 #define SA_STMT_END asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-#endif
 #endif
 
 /* Dense matrix-vector block of a callback (generated SA_MATVEC, see symode/codegen.py): out[i] = sum_j M[j*NO+i] v[j]
@@ -578,10 +542,6 @@ struct Cw {
     double f0[RS];                    /* f(t0, y0) of the first stored point */
 #endif
     int n_interp, n_rebuild;
-#ifdef SA_CTL_CHECK
-    int ctl_diff;                     /* (diagnostic build) bit i: l[i] differed between the lanes of the group when it was parked;
-                                         bits 8..: tau, bits 16..: tq */
-#endif
 #ifdef SA_SENS
     /* forward sensitivities (Solver(sens_mode=...), reference solver.py:360-392): the NQ sensitivity Nordsieck arrays
        and work vectors live in the workspace (SV(m, vector, parameter, slot)), streamed through registers phase by phase */
@@ -982,14 +942,7 @@ struct LuLds {
     lds_i64 *prof;
 };
 static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L);
-#if defined(SA_LU_MFMA) && SA_WAVES > 1
-static __device__ __attribute__((noinline)) void setup_lu_mfma(int wave, int lane, double c, int from_saved, double *sj, LuLds L);
-#define SA_LU_CALL setup_lu_mfma
-#define LU_RING_SLOTS 8
-#else
-#define SA_LU_CALL setup_lu_regs
 #define LU_RING_SLOTS SA_WAVES
-#endif
 static __device__ __forceinline__ LuLds lu_lds();
 
 template <bool BWD>
@@ -1002,7 +955,7 @@ DEV void worker_loop(const double *pr, double *obuf)
         const double t = s_targ;
         if (cmd == CMD_EXIT) break;
         if (cmd == CMD_GETRF) {
-            SA_LU_CALL(wave, lane, t, s_flag, obuf - WS_OUT + WS_SJ, lu_lds());
+            setup_lu_regs(wave, lane, t, s_flag, obuf - WS_OUT + WS_SJ, lu_lds());
         } else {
             const int rc = run_callback<BWD>(cmd, t, pr, obuf);
             if (lane == 0) s_rc[wave] = rc;
@@ -1344,13 +1297,22 @@ static __device__ __forceinline__ LuLds lu_lds()
     return L;
 }
 
-/* wait until `want` panels are published (the counter is written after a workgroup-scope release fence; the data
-   reads that follow are ordered behind it by the acquire fence) */
+/* wait until `want` panels are published.  Fence-to-fence synchronisation THROUGH AN ATOMIC (with a plain
+   volatile counter the ring accesses were formally a data race that only the AMDGPU lowering made work): the owner
+   writes the panel, issues a workgroup-scope release fence and stores the counter atomically (lu_publish); a reader
+   loads it atomically until it is large enough, then issues the acquire fence the panel reads are ordered behind.
+   Same instructions as before. */
 static __device__ __forceinline__ void lu_wait(lds_i32 *pub, int want)
 {
     /* (one wavefront per SIMD: a spinning wavefront takes nothing from anybody; with two per SIMD it yields) */
-    while (__builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)pub) < want) { if (SA_WAVES > 4) __builtin_amdgcn_s_sleep(1); }
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {
+        if (SA_WAVES > 4) __builtin_amdgcn_s_sleep(1);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+static __device__ __forceinline__ void lu_publish(lds_i32 *pub, int count)     /* after the release fence, by ONE lane */
+{
+    __hip_atomic_store(pub, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 static __device__ __forceinline__ void lu_pin(double &x) { asm volatile("" : "+v"(x)); }
@@ -1696,7 +1658,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) {
-                    *(volatile lds_i32 *)L.pub = p + 1;
+                    lu_publish(L.pub, p + 1);
 #ifdef SA_LU_PROFILE_TIMELINE       /* cycles from the first barrier to the publication of panel (workgroup index mod #panels) */
                     if (p == (int)(blockIdx.x % LU_NPANEL)) L.prof[11] += (int64_t)__builtin_readcyclecounter() - t_loop;
 #endif
@@ -1764,363 +1726,6 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
 #endif
 #undef LU_COL
 }
-#ifdef SA_LU_MFMA
-/* ---- EXPERIMENTAL (-DSA_LU_MFMA, off by default): the workgroup LU with the trailing update on the matrix cores ----
- * v_mfma_f64_16x16x4_f64 accumulates fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, c)))) bit for bit
- * (tools/ubench_mfma_f64.hip, profiles/r04_ubench_mfma_f64.txt): a rank-4 update of a 16 x 16 block is ONE instruction
- * with denseGETRF's operation order.  Layout: the matrix lives in MFMA blocks for the whole factorisation -- block
- * (I, J), register v of lane l = row 16 I + 4 v + l / 16, storage column l mod 16 of block column J; block columns are
- * dealt to the wavefronts (J mod SA_WAVES), and the COLUMNS are dealt to the block columns panel by panel (panel p = the
- * logical columns 4p .. 4p+3 lies in block column p mod NT at position p / NT) so that consecutive panels have
- * different owners and every block column keeps trailing columns to the end.
- * Per panel p: the owner transposes its four columns through LDS into the column layout (lane = row), factorises them
- * with the same two code paths as setup_lu_regs (speculative / general), writes the finished columns to s_A and
- * publishes the NEGATED multipliers (zero on and above the diagonal) in the ring; every wavefront then, per block column
- * it owns: the in-panel triangular solve of the four pivot rows as three MFMAs (A = one column of the strictly lower
- * 4 x 4 block each, B = the pivot rows themselves -- register v = (k0 mod 16) / 4, one row per 16-lane group: nothing
- * moves), then one MFMA per block row at or below the pivot rows.  B is masked to the columns of later panels, so
- * finished columns (multipliers!) and the panel itself are left alone.  Row exchanges (rare): every wavefront spills
- * its unfinished columns to their places in s_A, swaps the rows of all its columns there, reloads -- own columns only,
- * no synchronisation.  A zero A entry contributes fma(0, b, c) = c (only the sign of a zero can differ, as in
- * setup_lu_regs).
- * STATE (round 4, profiles/r04_network100_lu.txt): bit-identical to the oracle on the first run (network100 forward +
- * adjoint, DVODE counters, the row-exchange and huge-pivot cases) -- and 87 us per factorisation against 31.7: on
- * MI355X the fp64 matrix rate EQUALS the vector rate (78.6 TFLOP/s both: one 16x16x4 MFMA = 64 cycles = the 16 v_fma_f64
- * it replaces), so all an MFMA saves is the v_readlane broadcasts, and this first version gives that back several times
- * over: whole 16-column blocks are updated although on average half their columns are finished (the price of dealing
- * panels round-robin to block columns), four DEPENDENT MFMAs per block column and panel for the pivot rows, the owner's
- * transposition through LDS (1.7 k cycles measured, 0.5 k estimated) and a publication that also writes the finished
- * columns (1.5 k).  Kept as the starting point and as the executable proof of the accumulation order. */
-#define MT_NT ((NS + 15) / 16)
-#define MT_NTC ((MT_NT + SA_WAVES - 1) / SA_WAVES)
-#define MT_NPANEL ((NS + 3) / 4)
-#define MT_RING 8
-static_assert(MT_NT <= 7 && RS <= 2, "ring of 8 published panels: every wavefront owns a panel among any 7 consecutive ones");
-typedef double mt_v4 __attribute__((ext_vector_type(4)));
-__shared__ __attribute__((aligned(16))) double s_mtr[LU_NB][RS * 64];         /* the owner's panel on its way to the column layout */
-
-static __device__ __forceinline__ double mt_sel(const mt_v4 &x, int m)       /* x[m], m wave-uniform */
-{
-    double r = x[0];
-    r = (m == 1) ? x[1] : r; r = (m == 2) ? x[2] : r; r = (m == 3) ? x[3] : r;
-    return r;
-}
-
-/* the four columns of a panel in the column layout (a[kk][r] = row 64 r + lane): denseGETRF's steps k0 .. k0+3 on them.
-   S = register slot of the pivot rows.  Returns the number of row exchanges; pivot rows -> pword, reciprocal pivots ->
-   mults, zero pivot -> ier (k + 1) */
-template <int S>
-static __device__ __forceinline__ int mt_panel(double (&a)[LU_NB][RS], int lane, int k0, int &ier, int (&pword)[LU_NB],
-                                               double (&mults)[LU_NB], LuLds L)
-{
-    const int pl0 = k0 & 63;
-    constexpr bool PARTIAL = (NS % LU_NB) != 0;
-    int own_swaps = 0;
-    bool general = PARTIAL || (ier != 0);
-    if (!general) {
-        double keep[LU_NB][RS];
-        SFOR(kk, 0, LU_NB) { SFOR(r, S, RS) keep[kk][r] = a[kk][r]; SEND } SEND
-        double over = 0.0;
-        int odd = 0;
-        SFOR(kk, 0, LU_NB) {
-            const uint64_t abits = readlane_u64(a[kk][S], pl0 + kk);
-            const double akk = __builtin_bit_cast(double, abits);
-            const int ex = (int)((uint32_t)(abits >> 52) & 0x7ffu);
-            odd |= (ex - 523) | (1523 - ex);
-            double mult = __builtin_amdgcn_rcp(akk), e_ = FMA(-akk, mult, 1.0);
-            mult = FMA(mult, e_, mult); e_ = FMA(-akk, mult, 1.0);
-            mult = FMA(mult, e_, mult); e_ = FMA(-akk, mult, 1.0);
-            mult = FMA(e_, mult, mult);
-            mults[kk] = mult;
-            pword[kk] = (k0 + kk) & 0xff;
-            double akj[LU_NB];
-            SFOR(jj, kk + 1, LU_NB) akj[jj] = readlane_d(a[jj][S], pl0 + kk); SEND
-            double big = 0.0;
-            SFOR(r, S + 1, RS) {
-                big = vmax_abs(big, a[kk][r]);
-                a[kk][r] = a[kk][r] * mult;
-                SFOR(jj, kk + 1, LU_NB) a[jj][r] = FMA(-akj[jj], a[kk][r], a[jj][r]); SEND
-            } SEND
-            if (lane > pl0 + kk) {
-                big = vmax_abs(big, a[kk][S]);
-                a[kk][S] = a[kk][S] * mult;
-                SFOR(jj, kk + 1, LU_NB) a[jj][S] = FMA(-akj[jj], a[kk][S], a[jj][S]); SEND
-            }
-            over = vmax_abs(big - fabs(akk), over);
-        } SEND
-        if (odd < 0 || __builtin_amdgcn_ballot_w64(over > 0.0) != 0) {
-            general = true;
-            SFOR(kk, 0, LU_NB) { SFOR(r, S, RS) a[kk][r] = keep[kk][r]; SEND } SEND
-        }
-    }
-    if (general)
-    SFOR(kk, 0, LU_NB) {
-        const int k = k0 + kk;
-        const bool valid = (ier == 0) && (!PARTIAL || k < NS);
-        uint64_t abits = readlane_u64(a[kk][S], pl0 + kk);
-        double akk = __builtin_bit_cast(double, abits);
-        bool beaten = (lane > pl0 + kk) && (fabs(a[kk][S]) > fabs(akk));
-        SFOR(r, S + 1, RS) beaten = beaten || (fabs(a[kk][r]) > fabs(akk)); SEND
-        int l = k;
-        if (valid && __builtin_amdgcn_ballot_w64(beaten) != 0) {
-            double best = -1.0;
-            int bi = 1 << 20;
-            SFOR(r, S, RS) {
-                const int i = r * 64 + lane;
-                const double v = fabs(a[kk][r]);
-                if (i >= k && (v > best || (v == best && i < bi))) { best = v; bi = i; }
-            } SEND
-#pragma nounroll
-            for (int b = 0; b < 6; b++) {
-                const double ov = shfl_d(best, lane ^ (1 << b));
-                const int oi = shfl_i(bi, lane ^ (1 << b));
-                const bool take = (ov > best) || (ov == best && oi < bi);
-                best = take ? ov : best;
-                bi = take ? oi : bi;
-            }
-            l = __builtin_amdgcn_readfirstlane(bi);
-            if (l != k) {
-                own_swaps++;
-                const int ls = (RS == 1) ? 0 : (l >> 6), ll = l & 63;
-                SFOR(jj, 0, LU_NB) LU_SWAP_ROWS(a[jj], S, pl0 + kk, ls, ll); SEND
-                abits = readlane_u64(a[kk][S], pl0 + kk);
-                akk = __builtin_bit_cast(double, abits);
-            }
-        }
-        const bool nonzero = (abits << 1) != 0;
-        if (valid && !nonzero) {
-            ier = k + 1;
-            if (lane == 0) (*L.ier) = k + 1;
-        }
-        const bool ok = valid && nonzero;
-        const double mult = 1.0 / __builtin_bit_cast(double, ok ? abits : (uint64_t)0x3ff0000000000000ull);
-        pword[kk] = l & 0xff;
-        mults[kk] = mult;
-        double lcp[RS];
-        SFOR(r, 0, RS) lcp[r] = 0.0; SEND
-        {
-            const bool on = ok && (lane > pl0 + kk);
-            const double v = a[kk][S] * mult;
-            lcp[S] = on ? v : 0.0;
-            a[kk][S] = on ? v : a[kk][S];
-        }
-        SFOR(r, S + 1, RS) { const double v = a[kk][r] * mult; a[kk][r] = ok ? v : a[kk][r]; lcp[r] = ok ? v : 0.0; } SEND
-        SFOR(jj, kk + 1, LU_NB) {
-            const double akj = readlane_d(a[jj][S], pl0 + kk);
-            SFOR(r, S, RS) a[jj][r] = FMA(-akj, lcp[r], a[jj][r]); SEND
-        } SEND
-    } SEND
-    return own_swaps;
-}
-
-static __device__ __attribute__((noinline)) void setup_lu_mfma(int wave, int lane, double c, int from_saved, double *sj, LuLds L)
-{
-    typedef __attribute__((address_space(1))) double glb_f64;
-    glb_f64 *sjg = (glb_f64 *)sj;
-    wave = __builtin_amdgcn_readfirstlane(wave);
-#ifdef SA_WAVE_PROFILE
-    const int64_t w_in = (int64_t)wall_clock64();
-#endif
-    LUP_T(t_in)
-    const int q = lane >> 4, jl = lane & 15, cpos = jl >> 2, kq = jl & 3;
-    lds_f64 *tr = lds_opaque((lds_f64 *)&s_mtr[0][0]);
-    mt_v4 t[MT_NTC][MT_NT];
-    /* logical column of this lane in its block column jc, and whether it exists */
-    int col[MT_NTC], pcol[MT_NTC];
-    SFOR(jc, 0, MT_NTC) {
-        const int J = jc * SA_WAVES + wave;
-        pcol[jc] = cpos * MT_NT + J;
-        col[jc] = 4 * pcol[jc] + kq;
-        if (J >= MT_NT || pcol[jc] >= MT_NPANEL || col[jc] >= NS) { col[jc] = -1; pcol[jc] = -1; }
-    } SEND
-    /* load and form I - c J (padding: zero) */
-    SFOR(jc, 0, MT_NTC) {
-        const int cj = col[jc] < 0 ? 0 : col[jc];
-        SFOR(I, 0, MT_NT) {
-            SFOR(v, 0, 4) {
-                const int row = 16 * I + 4 * v + q, rr = row < NS ? row : NS - 1;
-                const double x = from_saved ? sjg[cj * NS + rr] : L.A[cj * NS + rr];
-                const double xs = (row < NS && col[jc] >= 0) ? x * c : 0.0;
-                t[jc][I][v] = (row == col[jc]) ? FMA(c, x, 1.0) : xs;
-            } SEND
-        } SEND
-    } SEND
-    if (!from_saved) {                              /* save J for later set-ups from the saved copy */
-        SFOR(jc, 0, MT_NTC) {
-            SFOR(I, 0, MT_NT) {
-                SFOR(v, 0, 4) {
-                    const int row = 16 * I + 4 * v + q;
-                    if (row < NS && col[jc] >= 0) sjg[col[jc] * NS + row] = L.A[col[jc] * NS + row];
-                } SEND
-            } SEND
-        } SEND
-    }
-    if (wave == 0 && lane == 0) { (*L.ier) = 0; (*L.pub) = 0; }
-    int nswaps = 0, ier = 0;
-    LUP_T(t_ld)
-    sa_barrier();
-    LUP_T(t_loop)
-    LUP_ADD(5, t_in, t_ld) LUP_ADD(6, t_ld, t_loop)
-    /* spill the columns of panels > pdone of block column jc to s_A / reload them (the exchange path) */
-#define MT_SPILL(jc, pdone) SFOR(I, 0, MT_NT) { SFOR(v, 0, 4) { const int row = 16 * I + 4 * v + q;                  \
-            if (row < NS && pcol[jc] > (pdone)) L.A[col[jc] * NS + row] = t[jc][I][v]; } SEND } SEND
-#define MT_RELOAD(jc, pdone) SFOR(I, 0, MT_NT) { SFOR(v, 0, 4) { const int row = 16 * I + 4 * v + q;                 \
-            if (row < NS && pcol[jc] > (pdone)) t[jc][I][v] = L.A[col[jc] * NS + row]; } SEND } SEND
-    /* the row exchanges of published panel pp (ring slot, first row kp) in every column of this wavefront but the
-       panel's own */
-#define MT_EXCHANGES(pp) {                                                                                          \
-        const int slotx_ = (pp) & (MT_RING - 1), kp_ = (pp) * LU_NB;                                                  \
-        SFOR(jc, 0, MT_NTC) MT_SPILL(jc, pp) SEND                                                                     \
-        if (q == 0) {                                                                                                 \
-            SFOR(jc, 0, MT_NTC) {                                                                                     \
-                if (col[jc] >= 0 && pcol[jc] != (pp)) {                                                               \
-                    for (int kk_ = 0; kk_ < LU_NB; kk_++) {                                                           \
-                        const int l_ = L.info[slotx_ * LU_INFO + kk_];                                                \
-                        if (kp_ + kk_ < NS && l_ != ((kp_ + kk_) & 0xff)) {                                           \
-                            const double x1_ = L.A[col[jc] * NS + kp_ + kk_], x2_ = L.A[col[jc] * NS + l_];           \
-                            L.A[col[jc] * NS + kp_ + kk_] = x2_; L.A[col[jc] * NS + l_] = x1_;                        \
-                        }                                                                                             \
-                    }                                                                                                 \
-                }                                                                                                     \
-            } SEND                                                                                                    \
-        }                                                                                                             \
-        SFOR(jc, 0, MT_NTC) MT_RELOAD(jc, pp) SEND }
-    /* the update of block column jc with the published panel p-1 (A operands in af[] / at[] / amain, pivot rows = register
-       M of block row I0).  No column mask: a finished column's registers are dead (it was written to s_A when its panel
-       was factorised, the exchange path spills later panels' columns only), and MFMA columns do not mix. */
-#define MT_UPDATE_M(jc, M) SFOR(I, 0, MT_NT) {                                                                       \
-            if (I == I0) {                                                                                            \
-                SFOR(ps, 0, LU_NB - 1) {                    /* the triangular solve of the pivot rows, step ps */      \
-                    t[jc][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[ps], t[jc][I][M], t[jc][I], 0, 0, 0);          \
-                } SEND                                                                                                \
-                bm = t[jc][I][M];                                                                                     \
-                t[jc][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(amain, bm, t[jc][I], 0, 0, 0);                        \
-            }                                                                                                         \
-        } SEND                                                                                                        \
-        SFOR(I, 0, MT_NT) {                                                                                           \
-            if (I > I0) t[jc][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[I], bm, t[jc][I], 0, 0, 0);                \
-        } SEND
-#define MT_UPDATE(jc, pp) {                                                                                         \
-        if (__builtin_amdgcn_ballot_w64(pcol[jc] > (pp)) != 0) {   /* (some column of a later panel lives here) */    \
-            if (m == 0) { MT_UPDATE_M(jc, 0) } else if (m == 1) { MT_UPDATE_M(jc, 1) }                                \
-            else if (m == 2) { MT_UPDATE_M(jc, 2) } else { MT_UPDATE_M(jc, 3) }                                       \
-        } }
-#pragma nounroll
-    for (int p = 0; p < MT_NPANEL; p++) {
-        const int k0 = p * LU_NB, J0 = p % MT_NT, c0 = p / MT_NT, owner = J0 & (SA_WAVES - 1), jc0 = J0 / SA_WAVES;
-        const bool own = (wave == owner);
-        double af[MT_NT];                               /* -l(16 I + l mod 16, 4 (p-1) + l / 16): the A operands of panel p-1 */
-        double bm = 0.0, at[LU_NB - 1], amain = 0.0;
-        int I0 = 0, m = 0;
-        SFOR(ps, 0, LU_NB - 1) at[ps] = 0.0; SEND
-        SFOR(I, 0, MT_NT) af[I] = 0.0; SEND
-        LUP_T(t_a)
-        if (p > 0) {
-            const int pp = p - 1, slot_ = pp & (MT_RING - 1);
-            I0 = (pp * LU_NB) >> 4; m = ((pp * LU_NB) & 15) >> 2;
-            lu_wait(L.pub, p);
-            LUP_T(t_w)
-            LUP_ADD(1, t_a, t_w)
-            int nex_ = L.info[slot_ * LU_INFO + LU_NB], ierp_ = L.info[slot_ * LU_INFO + LU_NB + 1];
-            SFOR(I, 0, MT_NT) {
-                const int row = 16 * I + jl;
-                af[I] = (row < RS * 64) ? L.col[(slot_ * LU_NB + q) * (RS * 64) + (row < RS * 64 ? row : 0)] : 0.0;
-            } SEND
-            nex_ = __builtin_amdgcn_readfirstlane(nex_); ierp_ = __builtin_amdgcn_readfirstlane(ierp_);
-            {   /* block row I0: one column of the strictly lower 4 x 4 block per solve step; the rows below the pivot rows */
-                double a0_ = 0.0;
-                SFOR(I, 0, MT_NT) a0_ = (I == I0) ? af[I] : a0_; SEND
-                SFOR(ps, 0, LU_NB - 1) at[ps] = (q == ps && (jl >> 2) == m) ? a0_ : 0.0; SEND
-                amain = ((jl >> 2) > m) ? a0_ : 0.0;
-            }
-            if (ierp_ != 0) ier = (ier == 0) ? ierp_ : ier;
-            if (nex_ != 0) { if (wave != ((pp % MT_NT) & (SA_WAVES - 1))) nswaps += nex_; MT_EXCHANGES(pp) }
-            if (own) { if (jc0 == 0) { MT_UPDATE(0, pp) } else if constexpr (MT_NTC > 1) { MT_UPDATE(MT_NTC - 1, pp) } }
-        }
-        LUP_T(t_b)
-        if (own) {
-            /* this panel's four columns -> column layout */
-            if (cpos == c0) {
-                SFOR(jc, 0, MT_NTC) {
-                    if (jc == jc0) {
-                        SFOR(I, 0, MT_NT) { SFOR(v, 0, 4) {
-                            if (16 * I + 4 * v < RS * 64) tr[kq * (RS * 64) + 16 * I + 4 * v + q] = t[jc][I][v];
-                        } SEND } SEND
-                    }
-                } SEND
-            }
-            double a[LU_NB][RS];
-            SFOR(kk, 0, LU_NB) { SFOR(r, 0, RS) a[kk][r] = (r * 64 + lane < 16 * MT_NT) ? tr[kk * (RS * 64) + r * 64 + lane] : 0.0; SEND } SEND
-            LUP_T(t_b1)
-            LUP_ADD(9, t_b, t_b1)
-            int pword[LU_NB];
-            double mults[LU_NB];
-            SFOR(kk, 0, LU_NB) { pword[kk] = 0; mults[kk] = 0.0; } SEND
-            int own_swaps;
-            if (RS == 1 || k0 < 64) own_swaps = mt_panel<0>(a, lane, k0, ier, pword, mults, L);
-            else own_swaps = mt_panel<RS - 1>(a, lane, k0, ier, pword, mults, L);
-            nswaps += own_swaps;
-            LUP_T(t_b2)
-            LUP_ADD(10, t_b1, t_b2)
-            const int slot = p & (MT_RING - 1);
-            SFOR(kk, 0, LU_NB) {
-                SFOR(r, 0, RS) {
-                    const int row = r * 64 + lane;
-                    L.col[(slot * LU_NB + kk) * (RS * 64) + row] = (row > k0 + kk && row < NS) ? -a[kk][r] : 0.0;
-                    if (row < NS && k0 + kk < NS) L.A[(k0 + kk) * NS + row] = a[kk][r];     /* the finished column */
-                } SEND
-            } SEND
-            if (lane == 0) {
-                SFOR(kk, 0, LU_NB) L.info[slot * LU_INFO + kk] = pword[kk]; SEND
-                L.info[slot * LU_INFO + LU_NB] = own_swaps;
-                L.info[slot * LU_INFO + LU_NB + 1] = ier;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) {
-                *(volatile lds_i32 *)L.pub = p + 1;
-                if (ier == 0) {
-                    SFOR(kk, 0, LU_NB) {
-                        if (k0 + kk < NS) { L.piv[k0 + kk] = (uint8_t)pword[kk]; L.invp[k0 + kk] = mults[kk]; }
-                    } SEND
-                }
-            }
-        }
-        LUP_T(t_c)
-        LUP_ADD(0, t_b, t_c)
-        if (p > 0) {
-            const int pp = p - 1;
-            SFOR(jc, 0, MT_NTC) {
-                if (!(own && jc == (jc0 == 0 ? 0 : MT_NTC - 1))) { MT_UPDATE(jc, pp) }
-            } SEND
-        }
-        LUP_T(t_d)
-        LUP_ADD(2, t_c, t_d)
-    }
-    LUP_T(t_out)
-    {   /* the row exchanges of the last panel (finished columns only: nothing is left in registers) */
-        constexpr int PL = MT_NPANEL - 1;
-        lu_wait(L.pub, PL + 1);
-        const int slot_ = PL & (MT_RING - 1);
-        int nex_ = __builtin_amdgcn_readfirstlane(L.info[slot_ * LU_INFO + LU_NB]);
-        int ierp_ = __builtin_amdgcn_readfirstlane(L.info[slot_ * LU_INFO + LU_NB + 1]);
-        if (ierp_ != 0) ier = (ier == 0) ? ierp_ : ier;
-        if (nex_ != 0) { if (wave != (PL % MT_NT) % SA_WAVES) nswaps += nex_; MT_EXCHANGES(PL) }
-    }
-#undef MT_UPDATE
-#undef MT_UPDATE_M
-#undef MT_EXCHANGES
-#undef MT_RELOAD
-#undef MT_SPILL
-    if (wave == 0 && lane == 0) (*L.nswaps) = nswaps;
-    LUP_T(t_wr)
-    sa_barrier();
-    LUP_T(t_end)
-    LUP_ADD(4, t_in, t_end) LUP_ADD(7, t_out, t_wr) LUP_ADD(8, t_wr, t_end)
-#ifdef SA_WAVE_PROFILE
-    if (wave == 0 && lane == 0) L.prof[3] += (int64_t)wall_clock64() - w_in;
-#endif
-}
-#endif
 #else
 static __device__ __forceinline__ LuLds lu_lds() { return LuLds{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
 static __device__ void setup_lu_regs(int, int, double, int, double *, LuLds) {}
@@ -2152,7 +1757,7 @@ DEV int setup_lu_workgroup(Cw<BWD> &m, double c, bool from_saved)
     PROF_T0
     if (m.li == 0) { s_cmd = CMD_GETRF; s_targ = c; s_flag = from_saved ? 1 : 0; }
     sa_barrier();
-    SA_LU_CALL(0, m.lane, c, from_saved ? 1 : 0, m.sj, lu_lds());
+    setup_lu_regs(0, m.lane, c, from_saved ? 1 : 0, m.sj, lu_lds());
     const int ier = s_luier;
     m.nswaps = s_lunswaps;
     SFOR(r, 0, RS) { const int i = r * 64 + m.lane; m.inv_piv[r] = (i < NS) ? s_invp[i < NS ? i : 0] : 0.0; } SEND
@@ -2597,11 +2202,7 @@ static_assert(SA_LEAN, "the sensitivity corrector of bdf_wave.hip exists in the 
 #define SLOOP_END }
 
 /* out[is] = J ys[is] + dp[is] for the rows of this lane; J, dp: workspace copies the callbacks just wrote */
-#ifdef SA_SENS_RHS_INLINE
-#define SENS_RHS_ATTR __forceinline__
-#else
 #define SENS_RHS_ATTR __attribute__((noinline))
-#endif
 static __device__ SENS_RHS_ATTR int sens_rhs_rows(double *sws, const gdouble *js, const gdouble *dp, int li,
                                                               int v_in, int v_out)
 {
@@ -2743,32 +2344,13 @@ DEV void cold_store(const Cw<BWD> &m)
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) c[(5 * RS + j * RQ + r) * 64] = m.znQ[j][r]; SEND } SEND
         SFOR(r, 0, RQ) c[(5 * RS + 6 * RQ + r) * 64] = m.zsaveQ[r]; SEND
     }
-#ifdef SA_CTL_CHECK
-    {   /* are the "group-uniform" coefficient vectors uniform?  every lane against lane 0 of its group */
-        int d = 0;
-        SFOR(i, 0, 6) { if (__builtin_bit_cast(uint64_t, m.l[i]) != __builtin_bit_cast(uint64_t, shfl_d(m.l[i], m.gbase))) d |= 1 << i; } SEND
-        SFOR(i, 1, 6) { if (__builtin_bit_cast(uint64_t, m.tau[i]) != __builtin_bit_cast(uint64_t, shfl_d(m.tau[i], m.gbase))) d |= 256 << i; } SEND
-        SFOR(i, 1, 6) { if (__builtin_bit_cast(uint64_t, m.tq[i]) != __builtin_bit_cast(uint64_t, shfl_d(m.tq[i], m.gbase))) d |= 65536 << i; } SEND
-        const_cast<Cw<BWD> &>(m).ctl_diff |= d;
-    }
-#endif
-#if defined(SA_CTL_PRIVATE) && !defined(SA_NO_CTL_PARK)
-    {
-        double *u = s_ctlp + m.lane;
-        SFOR(i, 0, 6) u[i * 64] = m.l[i]; SEND
-        SFOR(i, 1, 6) u[(5 + i) * 64] = m.tau[i]; SEND
-        u[11 * 64] = m.tq[1]; u[12 * 64] = m.tq[3]; u[13 * 64] = m.tq[5];
-    }
-#elif !defined(SA_NO_CTL_PARK)
+#if !defined(SA_NO_CTL_PARK)
     if (m.li == 0) {
         double *u = s_ctl + (m.lane / G) * W_NCTL;
         SFOR(i, 0, 6) u[i] = m.l[i]; SEND
         SFOR(i, 1, 6) u[5 + i] = m.tau[i]; SEND
         u[11] = m.tq[1]; u[12] = m.tq[3]; u[13] = m.tq[5];
     }
-#ifdef SA_COLD_HARD_SYNC             /* (experiment: a real barrier + a wait for every outstanding LDS operation) */
-    __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-#endif
     lds_sync();         /* lane 0 wrote what the other lanes of the group read back: the fence keeps the compiler from
                            moving their loads above the (for them absent) store */
 #endif
@@ -2783,18 +2365,8 @@ DEV void cold_load(Cw<BWD> &m)
         SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RQ) m.znQ[j][r] = c[(5 * RS + j * RQ + r) * 64]; SEND } SEND
         SFOR(r, 0, RQ) m.zsaveQ[r] = c[(5 * RS + 6 * RQ + r) * 64]; SEND
     }
-#if defined(SA_CTL_PRIVATE) && !defined(SA_NO_CTL_PARK)
+#if !defined(SA_NO_CTL_PARK)
     {
-        const double *u = s_ctlp + m.lane;
-        SFOR(i, 0, 6) m.l[i] = u[i * 64]; SEND
-        SFOR(i, 1, 6) m.tau[i] = u[(5 + i) * 64]; SEND
-        m.tq[1] = u[11 * 64]; m.tq[3] = u[12 * 64]; m.tq[5] = u[13 * 64];
-    }
-#elif !defined(SA_NO_CTL_PARK)
-    {
-#ifdef SA_COLD_HARD_SYNC
-        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-#endif
         lds_sync();
         const double *u = s_ctl + (m.lane / G) * W_NCTL;
         SFOR(i, 0, 6) m.l[i] = u[i]; SEND
@@ -2810,11 +2382,7 @@ DEV void cold_load(Cw<BWD> &m)
 #define COLD_LOAD(m)
 #endif
 
-#ifdef SA_POLY_CM_FORCE              /* (A/B switch: -DSA_POLY_CM_FORCE=0|1) */
-#define SA_POLY_CM(BWD) (SA_POLY_CM_FORCE)
-#else
 #define SA_POLY_CM(BWD) 1                   /* pow coefficients from constant memory (sa_common.h): SEIR +7 %, network100 +1 %, network24 +-0 */
-#endif
 #define SA_STATE Cw
 #include "bdf_core.h"
 
@@ -2923,9 +2491,6 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_forward(sa_fwd_
     m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
     m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
-#ifdef SA_CTL_CHECK
-    m.ctl_diff = 0;
-#endif
     m.traj = nullptr; m.trow = 0;
 
     double y0[RS], q0[RQ];
@@ -3066,9 +2631,6 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
     m.rtolQ = 0.0; m.atolQ = 1.0; m.tstop = 0.0;
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
     m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
-#ifdef SA_CTL_CHECK
-    m.ctl_diff = 0;
-#endif
     m.traj = nullptr; m.trow = 0;
     m.sensi = 1; m.ism = a.ism; m.pbar = a.pbar;
 
@@ -3148,10 +2710,6 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
         for (int j = m.li; j < a.n_t * NS; j += G) yo[j] = SA_NAN;
         for (int j = m.li; j < a.n_t * NQ * NS; j += G) so[j] = SA_NAN;
     }
-#ifdef SA_CTL_CHECK
-    int ctl_any = m.ctl_diff;
-    SFOR(b, 0, LOG2G) ctl_any |= shfl_i(ctl_any, m.lane ^ (1 << b)); SEND
-#endif
     if (m.li == 0) {
         a.status[inst] = status;
         int64_t st[SA_N_STATS];
@@ -3160,9 +2718,6 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
         /* sensitivity counters ride in the quadrature / interpolation slots of the adjoint path */
         st[ST_NFQE] = m.nfSe; st[ST_NETFQ] = m.netfS; st[ST_NINTERP] = m.nniS; st[ST_NREBUILD] = m.ncfnS;
         st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
-#ifdef SA_CTL_CHECK
-        st[15] = ctl_any;
-#endif
         SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
     }
 }
@@ -3201,9 +2756,6 @@ extern "C" __global__ void __launch_bounds__(64 * SA_WAVES) sa_k_backward(sa_bwd
     m.cur_idx = 0; m.tlo2 = 0.0; m.tlo = m.thi = 0.0;
     m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
     m.n_interp = 0; m.n_rebuild = 0;
-#ifdef SA_CTL_CHECK
-    m.ctl_diff = 0;
-#endif
 
     double *lam_g = a.lamda_out + (int64_t)inst * NS, *quad_g = a.grad_out + (int64_t)inst * NQ;
     {

@@ -121,6 +121,13 @@ enum { SV_ZN0 = 0, SV_ZSAVE = 6, SV_EWT = 7, SV_ACOR = 8, SV_TEMPV = 9, SV_FTEMP
 enum { ST_NST, ST_NFE, ST_NSETUPS, ST_NJE, ST_NNI, ST_NCFN, ST_NETF, ST_QLAST,
        ST_NPTS, ST_NFQE, ST_NETFQ, ST_NINTERP, ST_NREBUILD, ST_RETRIES, ST_ATTEMPTS, ST_RESERVED1 };
 
+/* Is `c` true for ANY active lane of the wavefront?  One VALU compare + one scalar test.  The controller uses it for
+   wave-uniform shortcuts around straight-line blocks whose results only SOME lanes keep (order decision, tq[1] / tq[3]):
+   when no lane needs them the whole block is jumped over by a scalar branch, when one does every lane runs the same
+   straight-line code as before -- values identical either way (round 5: a lone wavefront pays ~4 cycles for every
+   instruction it issues, needed by its lanes or not). */
+DEV bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+
 /* a / b for operands far from the exponent limits (cvSet's step-size ratios and BDF coefficients, det_log's reduced argument: all O(1)): the
    instruction sequence of the compiler's IEEE division (v_rcp_f64, two Newton steps on the reciprocal, quotient,
    residual correction) without its range scaling -- v_div_scale leaves such operands unscaled, v_div_fmas then is a
@@ -283,8 +290,8 @@ DEV void cv_set(M &m)
         const double A2 = FMA((double)q, A1, 1.0);
         m.tq[2] = fabs(fdiv(A1, alpha0 * A2));
         m.tq[5] = fabs(fdiv(A2 * xistar_inv, lq * xi_inv));
-        {
-            const bool w1 = (m.qwait == 1);
+        const bool w1 = (m.qwait == 1);
+        if (wave_any(w1)) {       /* tq[1] / tq[3] feed the order decision of the NEXT step: four divisions nobody reads otherwise */
             const double C = fdiv(xistar_inv, lq);
             const double A3 = alpha0 + inv_int(q);
             const double A4 = alpha0_hat + xi_inv;

@@ -83,6 +83,39 @@ def _rows(a: np.ndarray, lo: int, hi: int, per_instance) -> np.ndarray:
     return a[lo:hi] if per_instance else a
 
 
+class _OutputPool:
+    """Output arrays of the batch methods, recycled.
+
+    The reference API hands results back as numpy arrays, and a FRESH ``np.zeros`` of BASELINE config 2's ``y_out``
+    (52 MB) costs more than its PCIe transfer: every page is faulted in by the copy that first touches it --
+    tools/ubench_hostcopy.py on the MI355X box: device -> host into a fresh array 4.4 ms, into one that was touched
+    before 1.0 ms (= the pinned rate; the runtime pins on the fly).  So the solver keeps the arrays it handed out and
+    uses one again as soon as NOBODY ELSE holds a reference to it (the caller dropped the result of an earlier call --
+    the normal pattern of an Op's ``perform`` or a sampling loop); an array the caller still holds is never touched.
+    At most ``MAX_PER_KEY`` arrays per (shape, dtype) and ``MAX_BYTES`` in total are kept."""
+
+    MAX_PER_KEY = 3
+    MAX_BYTES = 1 << 30
+
+    def __init__(self):
+        self._arrays = {}
+        self._bytes = 0
+
+    def get(self, shape, dtype=np.float64):
+        import sys
+        key = (tuple(int(k) for k in shape), np.dtype(dtype).str)
+        held = self._arrays.setdefault(key, [])
+        for arr in held:
+            # references: the list, the loop variable, getrefcount's argument -- anything more is the caller's
+            if sys.getrefcount(arr) <= 3:
+                return arr
+        arr = np.empty(key[0], dtype=dtype)
+        if arr.nbytes >= (1 << 16) and len(held) < self.MAX_PER_KEY and self._bytes + arr.nbytes <= self.MAX_BYTES:
+            held.append(arr)
+            self._bytes += arr.nbytes
+        return arr
+
+
 def _is_device_tensor(x) -> bool:
     return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
 
@@ -120,6 +153,13 @@ class _EngineMixin:
         self._device = devices[0]
         self._natives = None
         self._pool = None
+        self._outputs = _OutputPool()
+
+    def _out(self, shape, dtype=np.float64):
+        """An output array the library overwrites completely (recycled: see _OutputPool)."""
+        if getattr(self, "_outputs", None) is None:         # (unpickled solvers)
+            self._outputs = _OutputPool()
+        return self._outputs.get(shape, dtype)
 
     def _arena_share(self, device: int) -> int:
         """arena_bytes of ONE handle on ``device``: the device's budget divided by the handles that share it.
@@ -386,10 +426,10 @@ class Solver(_EngineMixin):
         n, p = self._problem.n_states, self._problem.n_params
         sens0 = np.ascontiguousarray(np.broadcast_to(np.asarray(sens0, dtype=np.float64), (B, p, n)))
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
-        y_out = np.zeros((B, len(tvals), n))
-        sens_out = np.zeros((B, len(tvals), p, n))
-        status = np.zeros(B, np.int32)
-        stats = np.zeros((B, _native.N_STATS), np.int64)
+        y_out = self._out((B, len(tvals), n))
+        sens_out = self._out((B, len(tvals), p, n))
+        status = self._out((B,), np.int32)
+        stats = self._out((B, _native.N_STATS), np.int64)
         ism = 0 if self._sens_mode == "simultaneous" else 1
 
         def call(eng, lo, hi):
@@ -407,9 +447,9 @@ class Solver(_EngineMixin):
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         p = self._problem.n_params
-        y_out = np.zeros((B, len(tvals), self._problem.n_states))
-        status = np.zeros(B, np.int32)
-        stats = np.zeros((B, _native.N_STATS), np.int64)
+        y_out = self._out((B, len(tvals), self._problem.n_states))
+        status = self._out((B,), np.int32)
+        stats = self._out((B, _native.N_STATS), np.int64)
 
         def call(eng, lo, hi):
             eng.solve(_native.SA_MEM_HOST, hi - lo, y0[lo:hi], _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride),
@@ -546,9 +586,9 @@ class AdjointSolver(_EngineMixin):
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         p = self._problem.n_params
-        y_out = np.zeros((B, len(tvals), self._problem.n_states))
-        status = np.zeros(B, np.int32)
-        stats = np.zeros((B, _native.N_STATS), np.int64)
+        y_out = self._out((B, len(tvals), self._problem.n_states))
+        status = self._out((B,), np.int32)
+        stats = self._out((B, _native.N_STATS), np.int64)
         shards = self._shards(B)
 
         def call(eng, lo, hi):
@@ -579,12 +619,18 @@ class AdjointSolver(_EngineMixin):
             gstride = n_t * n
         else:
             raise ValueError(f"grads must have shape ({n_t}, {n}) or ({B}, {n_t}, {n})")
-        grad_out = np.zeros((B, max(p, 1)))
-        lamda_out = np.zeros((B, max(n, 1)))
-        status = np.zeros(B, np.int32)
-        stats = np.zeros((B, _native.N_STATS), np.int64)
-        lam_all = np.zeros((B, n_t, max(n, 1))) if return_all else None
-        quad_all = np.zeros((B, n_t, max(p, 1))) if return_all else None
+        grad_out = self._out((B, max(p, 1)))
+        lamda_out = self._out((B, max(n, 1)))
+        if not p:
+            grad_out.fill(0.0)          # (no differentiated parameter: the library writes nothing there)
+        if not n:
+            lamda_out.fill(0.0)
+        status = self._out((B,), np.int32)
+        stats = self._out((B, _native.N_STATS), np.int64)
+        lam_all = self._out((B, n_t, max(n, 1))) if return_all else None
+        quad_all = self._out((B, n_t, max(p, 1))) if return_all else None
+        if return_all and not p:
+            quad_all.fill(0.0)
 
         def call(eng, lo, hi):
             eng.solve_backward(_native.SA_MEM_HOST, hi - lo, _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride), stride,

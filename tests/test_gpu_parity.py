@@ -664,38 +664,6 @@ def test_row_exchanges_in_the_dense_lu(variant, monkeypatch):
     np.testing.assert_array_equal(lam, lo)
 
 
-def test_workgroup_lu_on_the_matrix_cores_is_bit_identical(monkeypatch):
-    """-DSA_LU_MFMA (experimental, slower: DESIGN section 7): the whole workgroup LU in the MFMA block layout, trailing
-    update = v_mfma_f64_16x16x4_f64.  The instruction accumulates like four sequential FMAs (tools/ubench_mfma_f64.hip),
-    so the factors -- and with them every step of the integration -- must equal the oracle's bit for bit, row exchanges
-    included."""
-    from sunode_amd.solver import AdjointSolver
-    monkeypatch.setenv("SA_KERNEL_DEFINES", "-DSA_LU_MFMA")
-    monkeypatch.setenv("SA_FORCE_GROUP", "wave")
-    prob = make_problem("pivoting")
-    B = 5
-    rng = np.random.RandomState(0)
-    ps = np.array([0.5, 0.3]) * np.exp(0.1 * rng.randn(B, 2))
-    pr = np.array([1000.0, 700.0])
-    y0 = np.tile([0.5, 1e-6, 0.0, 1e-6, 2e-6, 0.1], (B, 1))
-    tv = np.linspace(0, 20, 11)
-    grads = np.ones((11, 6)); grads[:, 1:5] = 0.0
-    kw = dict(abstol=1e-4, reltol=1e-5, backward_abstol=1e-4, backward_reltol=1e-5, quad_abstol=1e-4, quad_reltol=1e-5)
-    sol = AdjointSolver(prob, **kw)
-    y, st, stats = sol.solve_forward_batch(0.0, tv, y0, ps, pr)
-    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
-    orc = make_oracle("pivoting")
-    cfg = orc.config(rtol=1e-5, atol=1e-4, rtolB=1e-5, atolB=1e-4, rtolQB=1e-5, atolQB=1e-4)
-    yo, so, sto = orc.solve_forward(cfg, y0, ps, pr, 0.0, tv)
-    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads)
-    assert (st == 0).all() and (stb == 0).all()
-    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
-    np.testing.assert_array_equal(y, yo)
-    np.testing.assert_array_equal(statsb[:, CMP_B], stbo[:, CMP_B])
-    np.testing.assert_array_equal(g, go)
-    np.testing.assert_array_equal(lam, lo)
-
-
 @pytest.mark.parametrize("variant", [None, "wave"])
 def test_pivots_beyond_the_lean_reciprocal_range(variant, monkeypatch):
     """Diagonal entries of the Newton matrix around 1e200 (exactly-zero components with decay rates of 1e200, steps of
@@ -1186,3 +1154,42 @@ def test_conservative_build_without_the_vgpr_liverange_pass(name, monkeypatch):
         np.testing.assert_array_equal(ys, yso)
         np.testing.assert_array_equal(S, So)
 
+
+
+@pytest.mark.parametrize("name,mapping,defines", [
+    ("seir", None, "-DSA_WAVE_PROFILE"),
+    ("seir", None, "-DSA_WAVE_PROFILE -DSA_WAVE_PROFILE_PHASES"),
+    ("network24", "wave", "-DSA_WAVE_PROFILE"),
+    ("network24", "wave", "-DSA_WAVE_PROFILE -DSA_LU_PROFILE_SEGMENTS"),
+    ("network24", "wave", "-DSA_WAVE_PROFILE -DSA_LU_PROFILE_TIMELINE"),
+])
+def test_profiling_builds_integrate_like_the_default_build(name, mapping, defines, monkeypatch):
+    """The section-timer builds of bdf_wave.hip (tools/profile_wave.py; the numbers under profiles/*_sections.txt and
+    *_lu.txt come from them) put clock readings into the upper statistics slots and must change nothing else: states,
+    gradients and the CVODES counters equal the oracle's.  (Also: every conditional of the kernel file is reached by a
+    default build or by a GPU test.)"""
+    from sunode_amd.solver import AdjointSolver
+    monkeypatch.setenv("SA_KERNEL_DEFINES", defines)
+    if mapping:
+        monkeypatch.setenv("SA_FORCE_GROUP", mapping)
+    prob = make_problem(name)
+    B = 9
+    d = seir_batch(B) if name == "seir" else network_batch(B, n=24)
+    tv = d["tvals"][::10] if name == "seir" else d["tvals"][::2]
+    k = np.arange(len(tv))[:, None]; i = np.arange(prob.n_states)[None, :]
+    grads = 1.0 + 0.5 * np.cos(1.7 * k + 0.9 * i)
+    sol = AdjointSolver(prob, abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8,
+                        quad_abstol=1e-8, quad_reltol=1e-8)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], d["pr"])
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle(name)
+    cfg = orc.config(rtol=1e-8, atol=1e-8, rtolB=1e-8, atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (st == 0).all() and (stb == 0).all()
+    np.testing.assert_array_equal(stats[:, :5], sto[:, :5])          # (slots 5.. carry clock readings in these builds)
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(statsb[:, :5], stbo[:, :5])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+    assert statsb[:, 15].min() > 0                     # the timers did run

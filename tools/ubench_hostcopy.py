@@ -44,7 +44,10 @@ for mb in (1, 8, 52):
         hip.hipHostUnregister(pageable.ctypes.data)
     out["register + D2H + unregister"] = t(reg)
     out["np.zeros (fresh) + touch"] = t(lambda: np.zeros(n, np.uint8).__setitem__(slice(None, None, 4096), 1))
-    fresh = lambda: hip.hipMemcpy(np.empty(n, np.uint8).ctypes.data, d, n, D2H)     # noqa: E731
+    def fresh():
+        a = np.empty(n, np.uint8)           # (held until the copy is done)
+        hip.hipMemcpy(a.ctypes.data, d, n, D2H)
+        return a
     out["pageable D2H into a FRESH array"] = t(fresh)
     print("%3d MB: " % mb + "; ".join("%s %.2f ms" % kv for kv in out.items()))
     hip.hipHostFree(p)
