@@ -273,6 +273,9 @@ def run_single_process(args, *, make_engine=None):
     out = summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, res["failed"])
     out["config"]["parallelism"] = "instance-sharded x%d, one process, one host thread per device (devices %s)" \
         % (world, ",".join(map(str, devices)))
+    per_dev = [sum(e.kernel_ms()) for e in eng.engines]
+    out["rank_ms_per_step"] = {"min": min(per_dev), "max": max(per_dev), "imbalance": max(per_dev) / min(per_dev) - 1.0,
+                               "what": "kernel ms (forward + backward) of the last step per handle"}
     eng.close()
     return out
 
@@ -332,14 +335,20 @@ def run_rank(args, *, backend="nccl", make_engine=None):
         bwd_ms.append(b)
     eng.sync()
     elapsed = time.perf_counter() - t0
+    own = elapsed                                   # this rank's time before it waited for the others
     if use_dist:
         dist.barrier()
-    elapsed = all_reduce(elapsed, "MAX")
+    elapsed = all_reduce(own, "MAX")
+    fastest = all_reduce(own, "MIN")
     res = eng.results()
     failed = int(all_reduce(float(res["failed"]), "SUM"))
     out = None
     if rank == 0:
         out = summarise(name, prob, w, B, world, args, elapsed, fwd_ms, bwd_ms, res, failed)
+        # an imbalanced node (a slow GPU, a rank that drew the expensive instances) shows here the first time the
+        # driver has eight GPUs: the line's value follows the SLOWEST rank
+        out["rank_ms_per_step"] = {"min": 1e3 * fastest / args.steps, "max": 1e3 * elapsed / args.steps,
+                                   "imbalance": elapsed / fastest - 1.0 if fastest > 0 else None}
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -505,11 +505,18 @@ DEV int cv_newton_pass(SA_STATE<BWD> &m, int callSetup, int jbad, int &convfail,
         m.nni++;
         SFOR(r, 0, RS) delta[r] = -1.0 * delta[r]; SEND
         dense_getrs(m, delta);
+#ifdef SA_SENS
+        if (m.gamrat != 1.0) {
+            double s = 2.0 / (1.0 + m.gamrat);
+            SFOR(r, 0, RS) delta[r] *= s; SEND
+        }
+#else
         {   /* cvLsSolve's scaling by 2 / (1 + gamrat) -- skipped by CVODES when gamrat == 1, where the factor is exactly
                1.0: computed by every lane (x * 1.0 == x) instead of inside a divergent block of its own */
             const double s = 2.0 / (1.0 + m.gamrat);
             SFOR(r, 0, RS) delta[r] *= s; SEND
         }
+#endif
         SFOR(r, 0, RS) m.acor[r] = m.acor[r] + delta[r]; SEND
         double del = wrms_n(m, delta, m.ewt);
 #ifdef SA_SENS
@@ -704,7 +711,7 @@ DEV void cv_prepare_next_step(SA_STATE<BWD> &m, double dsm)
        a decision (qwait != 0) or whose candidate is not defined discard the values through selects.  Values and
        written fields identical to the branching form. */
     const bool full = (m.qwait == 0);
-    if (!wave_any(full)) {
+    if (!SA_SHORTCUT(full)) {
         /* no lane of the wavefront is at an order decision (after a restart the lanes walk through qwait together):
            what the block below leaves behind for full == false, without its two norms and two of its three powers */
         const double p0 = rpower_nb<SA_POLY_CM(BWD)>(BIAS2 * dsm, inv_int(m.L));
@@ -866,6 +873,22 @@ DEV int cv_first_call(SA_STATE<BWD> &m, double tout)
 template <bool BWD>
 DEV int cv_pre_step(SA_STATE<BWD> &m)
 {
+#if defined(SA_PRESTEP_FUSED) && !defined(SA_SENS)
+    /* Mappings that can hand over the MEAN SQUARE of a weighted vector (the argument of the WRMS norm's square root):
+       both weight vectors and the CV_TOO_MUCH_ACC test in one straight line -- no early returns (each one is a
+       divergent region of its own), no square roots.  UROUND * sqrt(x) > 1 with UROUND = 2^-52 and a correctly
+       rounded, monotone sqrt holds exactly for x >= 2^104 + 2^53 (the first double whose root rounds above 2^52), and
+       max(sqrt(a), sqrt(b)) exceeds the bound iff max(a, b) does; NaNs fail every comparison in both forms. */
+    int bad = ewt_set(m, m.zn[0], m.ewt);
+    double ms = wrms2_n(m, m.zn[0], m.ewt);
+    if (BWD) {
+        bad |= ewtQ_set(m, m.znQ[0], m.ewtQ);
+        const double mq = wrms2_q(m, m.znQ[0], m.ewtQ);
+        ms = ms > mq ? ms : mq;
+    }
+    const bool acc = ms >= 0x1.0000000000002p+104;
+    return bad ? CV_ILL_INPUT : (acc ? CV_TOO_MUCH_ACC : CV_SUCCESS);
+#endif
     if (ewt_set(m, m.zn[0], m.ewt) != 0) return CV_ILL_INPUT;
     if (BWD) { if (ewtQ_set(m, m.znQ[0], m.ewtQ) != 0) return CV_ILL_INPUT; }
 #ifdef SA_SENS

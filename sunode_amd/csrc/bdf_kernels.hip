@@ -432,6 +432,22 @@ DEV double wrms(const double *x, const double *w)
     }
 }
 
+/* mean square of the weighted vector: wrms<N>(x, w) == sqrt(wms<N>(x, w)), same tree, same division */
+template <int N>
+DEV double wms(const double *x, const double *w)
+{
+    if constexpr (N == 0) return 0.0;
+    else {
+        constexpr int P = next_pow2(N);
+        double leaf[P];
+        SFOR(i, 0, P) {
+            if constexpr (i < N) { double prod = x[i] * w[i]; leaf[i] = prod * prod; }
+            else leaf[i] = 0.0;
+        } SEND
+        return tree_sum<P>(leaf) / N;
+    }
+}
+
 template <bool BWD>
 DEV double quad_update_norm(const Cv<BWD> &m, double old_nrm, const double *xQ)
 {
@@ -582,10 +598,15 @@ DEV int cv_lsetup(Cv<BWD> &m, int convfail)
 #define PH_T0
 #define PH_ADD(m, k) PHASE(m, k);
 #define SA_RESCALE_ALWAYS 1          /* cv_attempt: the rescale runs for every lane (eta = 1: exact no-op), see there */
+#define SA_PRESTEP_FUSED 1           /* cv_pre_step: weights + accuracy test as one straight line (wrms2_n / wrms2_q below) */
 template <bool BWD>
 DEV double wrms_n(const Cv<BWD> &, const double (&x)[RS], const double (&w)[RS]) { return wrms<NS>(x, w); }
 template <bool BWD>
 DEV double wrms_q(const Cv<BWD> &, const double (&x)[RQ], const double (&w)[RQ]) { return wrms<NQ>(x, w); }
+template <bool BWD>
+DEV double wrms2_n(const Cv<BWD> &, const double (&x)[RS], const double (&w)[RS]) { return wms<NS>(x, w); }
+template <bool BWD>
+DEV double wrms2_q(const Cv<BWD> &, const double (&x)[RQ], const double (&w)[RQ]) { return wms<NQ>(x, w); }
 template <bool BWD>
 DEV void dense_getrs(const Cv<BWD> &m, double (&b)[RS]) { dense_getrs(m.A, m.piv, m.inv_piv, b); }
 #ifdef SA_SENS
@@ -908,7 +929,12 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
 /* ------------------------------------------------------------------------------------ */
 /* backward kernel: AdjointSolver.solve_backward (solver.py:723-784) over CVodeB semantics */
 /* ------------------------------------------------------------------------------------ */
-extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
+#ifdef SA_BWD_WAVES                  /* (experiment: cap the backward kernel's registers for SA_BWD_WAVES wavefronts per SIMD) */
+#define SA_BWD_ATTR __attribute__((amdgpu_waves_per_eu(SA_BWD_WAVES, SA_BWD_WAVES)))
+#else
+#define SA_BWD_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(64) SA_BWD_ATTR sa_k_backward(sa_bwd_args a)
 {
     __shared__ double ltab[TTAB * 64];        /* per-lane copy of the current divided-difference table */
     const int inst = blockIdx.x * 64 + threadIdx.x;

@@ -942,6 +942,7 @@ struct LuLds {
     lds_i64 *prof;
 };
 static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L);
+static __device__ __forceinline__ void setup_lu_regs_body(int wave, int lane, double c, int from_saved, double *sj, LuLds L);
 #define LU_RING_SLOTS SA_WAVES
 static __device__ __forceinline__ LuLds lu_lds();
 
@@ -955,7 +956,18 @@ DEV void worker_loop(const double *pr, double *obuf)
         const double t = s_targ;
         if (cmd == CMD_EXIT) break;
         if (cmd == CMD_GETRF) {
+            /* A CALL on purpose, also here.  As a call the function saves and restores its ~100 callee-saved vector
+               registers on every factorisation in every wavefront (11.8 GB of scratch writes per backward launch of
+               config 5, profiles/r04_network100_pmc.txt) although the workers have nothing live.  Inlining the body
+               here (-DSA_LU_INLINE_WORKERS: scratch per lane 256 -> 192 B, three quarters of those writes gone) was
+               measured in round 5 and is SLOWER: network100 15.84 -> 15.44 k solves/s (backward 55.05 -> 56.43 ms,
+               forward 9.51 -> 9.75): the scratch round trip overlaps with the first loads of the factorisation, the
+               second copy of the function costs instruction-cache misses and 60 more scalar spills in the kernel. */
+#ifdef SA_LU_INLINE_WORKERS
+            setup_lu_regs_body(wave, lane, t, s_flag, obuf - WS_OUT + WS_SJ, lu_lds());
+#else
             setup_lu_regs(wave, lane, t, s_flag, obuf - WS_OUT + WS_SJ, lu_lds());
+#endif
         } else {
             const int rc = run_callback<BWD>(cmd, t, pr, obuf);
             if (lane == 0) s_rc[wave] = rc;
@@ -1332,9 +1344,14 @@ static __device__ __forceinline__ double vmax_abs(double x, double y)
             (col)[r_] = (r_ == (s1) && lane == (l1)) ? v2_ : ((r_ == (s2) && lane == (l2)) ? v1_ : (col)[r_]); \
         } SEND } while (0)
 
-/* noinline on purpose: the 2*LU_NC matrix registers of a lane must not compete with the integrator state of
-   wavefront 0 (inlined, the pair spilled ~1.6 KB per lane to scratch); results come back through LDS */
+/* noinline for wavefront 0 on purpose: the 2*LU_NC matrix registers of a lane must not compete with its integrator
+   state (inlined, the pair spilled ~1.6 KB per lane to scratch); results come back through LDS.  The worker
+   wavefronts inline the body (worker_loop). */
 static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lane, double c, int from_saved, double *sj, LuLds L)
+{
+    setup_lu_regs_body(wave, lane, c, from_saved, sj, L);
+}
+static __device__ __forceinline__ void setup_lu_regs_body(int wave, int lane, double c, int from_saved, double *sj, LuLds L)
 {
     double a[LU_NC][RS];
     LUP_T(t_in)
@@ -1729,6 +1746,7 @@ static __device__ __attribute__((noinline)) void setup_lu_regs(int wave, int lan
 #else
 static __device__ __forceinline__ LuLds lu_lds() { return LuLds{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
 static __device__ void setup_lu_regs(int, int, double, int, double *, LuLds) {}
+static __device__ __forceinline__ void setup_lu_regs_body(int, int, double, int, double *, LuLds) {}
 #endif
 
 template <bool BWD>

@@ -127,6 +127,14 @@ enum { ST_NST, ST_NFE, ST_NSETUPS, ST_NJE, ST_NNI, ST_NCFN, ST_NETF, ST_QLAST,
    straight-line code as before -- values identical either way (round 5: a lone wavefront pays ~4 cycles for every
    instruction it issues, needed by its lanes or not). */
 DEV bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+/* The forward-sensitivity builds keep the plain straight-line forms: measured with the shortcuts LV 25.1 -> 24.5 M,
+   Robertson 0.91 -> 0.84 M, SEIR 43.9 -> 43.1 k sensitivity solves/s (their kernels live at the register limit:
+   Robertson's sa_k_sens 1136 -> 1397 spill slots); adjoint / plain builds: LV +4 %, Robertson +2 %, network100 +3 %. */
+#ifdef SA_SENS
+#define SA_SHORTCUT(c) true
+#else
+#define SA_SHORTCUT(c) wave_any(c)
+#endif
 
 /* a / b for operands far from the exponent limits (cvSet's step-size ratios and BDF coefficients, det_log's reduced argument: all O(1)): the
    instruction sequence of the compiler's IEEE division (v_rcp_f64, two Newton steps on the reciprocal, quotient,
@@ -291,7 +299,7 @@ DEV void cv_set(M &m)
         m.tq[2] = fabs(fdiv(A1, alpha0 * A2));
         m.tq[5] = fabs(fdiv(A2 * xistar_inv, lq * xi_inv));
         const bool w1 = (m.qwait == 1);
-        if (wave_any(w1)) {       /* tq[1] / tq[3] feed the order decision of the NEXT step: four divisions nobody reads otherwise */
+        if (SA_SHORTCUT(w1)) {       /* tq[1] / tq[3] feed the order decision of the NEXT step: four divisions nobody reads otherwise */
             const double C = fdiv(xistar_inv, lq);
             const double A3 = alpha0 + inv_int(q);
             const double A4 = alpha0_hat + xi_inv;

@@ -141,7 +141,8 @@ class _EngineMixin:
     # GIL for the duration of the native call) and the handles write into disjoint row ranges of the caller's
     # arrays.  An ordinal may appear more than once (two handles on one device: the arena budget of the device is
     # split between them).  Results are those of the one-handle call bit for bit (instances are independent).
-    def _init_devices(self, device, devices):
+    def _init_devices(self, device, devices, interleaved=False):
+        self._interleaved = bool(interleaved)
         if devices is None:
             devices = [int(device)]
         devices = [int(d) for d in devices]
@@ -190,14 +191,48 @@ class _EngineMixin:
         return self._engines()[0]
 
     def _shards(self, B: int):
-        """[(handle, lo, hi)] -- contiguous balanced instance ranges, empty ones dropped."""
+        """[(handle, lo, hi)] -- contiguous balanced instance ranges, empty ones dropped.  With ``interleaved=True``
+        the ranges refer to the batch in HANDLE-MAJOR order (see _gather / _scatter)."""
         from sunode_amd.parallel import shard_bounds
         engines = self._engines()
+        G = len(engines)
         out = []
+        pos = 0
         for r, eng in enumerate(engines):
-            lo, hi = shard_bounds(B, r, len(engines))
+            if self._interleaved and G > 1:
+                k = len(range(r, B, G))
+                lo, hi = pos, pos + k
+                pos = hi
+            else:
+                lo, hi = shard_bounds(B, r, G)
             if hi > lo:
                 out.append((eng, lo, hi))
+        return out
+
+    # ``interleaved=True`` (SURVEY.md section 8e: "if per-instance cost varies strongly (Robertson), interleaved assignment
+    # i mod G balances better than contiguous; keep output indexing stable"): handle r integrates the instances
+    # r, r + G, r + 2G, ...  The C entry points take contiguous arrays, so per-instance inputs are gathered into
+    # handle-major order once per call (strided copies) and the results scattered back to the caller's order.
+    def _reorders(self) -> bool:
+        return self._interleaved and len(self._engines()) > 1
+
+    def _gather(self, a: np.ndarray, per_instance=True) -> np.ndarray:
+        if not per_instance or not self._reorders():
+            return a
+        G = len(self._engines())
+        return np.concatenate([a[r::G] for r in range(G)], axis=0)
+
+    def _scatter(self, handle_major: np.ndarray) -> np.ndarray:
+        if not self._reorders():
+            return handle_major
+        G = len(self._engines())
+        B = handle_major.shape[0]
+        out = self._out(handle_major.shape, handle_major.dtype)
+        pos = 0
+        for r in range(G):
+            k = len(range(r, B, G))
+            out[r::G] = handle_major[pos:pos + k]
+            pos += k
         return out
 
     def _run_shards(self, shards, call):
@@ -303,7 +338,7 @@ class Solver(_EngineMixin):
     def __init__(self, problem, *, abstol: float = 1e-10, reltol: float = 1e-10, sens_mode: Optional[str] = None,
                  scaling_factors: Optional[np.ndarray] = None, constraints: Optional[np.ndarray] = None,
                  solver="BDF", linear_solver="dense", linear_solver_kwargs=None, mxsteps: int = 500,
-                 device: int = 0, devices=None):
+                 device: int = 0, devices=None, interleaved: bool = False):
         if sens_mode in (None, False):
             sens_mode = None
         elif sens_mode == "staggered1":
@@ -345,11 +380,11 @@ class Solver(_EngineMixin):
         self._compute_sens = sens_mode is not None
         self._scaling_factors = scaling_factors
         self._mxsteps = mxsteps
-        self._init_devices(device, devices)
+        self._init_devices(device, devices, interleaved)
         self._set_tolerances(abstol, reltol)
         self._state_names = ["_problem", "_user_data", "_constraints", "_abstol", "_reltol",
                              "_linear_solver_kind", "_linear_solver_kwargs", "_sens_mode", "_scaling_factors",
-                             "_mxsteps", "_device", "_devices", "_state_names"]
+                             "_mxsteps", "_device", "_devices", "_interleaved", "_state_names"]
         self._init_native()
 
     def _init_native(self):
@@ -426,6 +461,7 @@ class Solver(_EngineMixin):
         n, p = self._problem.n_states, self._problem.n_params
         sens0 = np.ascontiguousarray(np.broadcast_to(np.asarray(sens0, dtype=np.float64), (B, p, n)))
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
+        y0, ps, pr, sens0 = self._gather(y0), self._gather(ps, p), self._gather(pr, stride), self._gather(sens0)
         y_out = self._out((B, len(tvals), n))
         sens_out = self._out((B, len(tvals), p, n))
         status = self._out((B,), np.int32)
@@ -438,7 +474,7 @@ class Solver(_EngineMixin):
                            sens0[lo:hi] if sens0.size else np.zeros(1), t0, tvals, len(tvals), y_out[lo:hi],
                            sens_out[lo:hi] if sens_out.size else np.zeros(1), status[lo:hi], stats[lo:hi])
         self._run_shards(self._shards(B), call)
-        return y_out, sens_out, status, stats
+        return self._scatter(y_out), self._scatter(sens_out), self._scatter(status), self._scatter(stats)
 
     def solve_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5
                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -447,6 +483,7 @@ class Solver(_EngineMixin):
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         p = self._problem.n_params
+        y0, ps, pr = self._gather(y0), self._gather(ps, p), self._gather(pr, stride)
         y_out = self._out((B, len(tvals), self._problem.n_states))
         status = self._out((B,), np.int32)
         stats = self._out((B, _native.N_STATS), np.int64)
@@ -455,7 +492,7 @@ class Solver(_EngineMixin):
             eng.solve(_native.SA_MEM_HOST, hi - lo, y0[lo:hi], _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride),
                       stride, t0, tvals, len(tvals), y_out[lo:hi], status[lo:hi], stats[lo:hi])
         self._run_shards(self._shards(B), call)
-        return y_out, status, stats
+        return self._scatter(y_out), self._scatter(status), self._scatter(stats)
 
 
 class AdjointSolver(_EngineMixin):
@@ -480,7 +517,7 @@ class AdjointSolver(_EngineMixin):
                  constraints=None, solver="BDF", adjoint_solver="BDF", backward_abstol=1e-10,
                  backward_reltol=1e-10, quad_abstol=1e-10, quad_reltol=1e-10, mxsteps: int = 500,
                  max_steps: Optional[int] = None, arena_gib: Optional[float] = None, device: int = 0,
-                 compact_trajectory: Optional[bool] = None, devices=None):
+                 compact_trajectory: Optional[bool] = None, devices=None, interleaved: bool = False):
         if solver not in ("BDF", "ADAMS"):
             raise ValueError(f"Unknown solver {solver}.")
         if adjoint_solver not in ("BDF", "ADAMS"):
@@ -503,7 +540,7 @@ class AdjointSolver(_EngineMixin):
         self._max_steps = int(min(max_steps if max_steps is not None else checkpoint_n + 1, checkpoint_n + 1,
                                   2**31 - 1))
         self._arena_bytes = int(arena_gib * 2**30) if arena_gib else 0      # per DEVICE (handles sharing one split it)
-        self._init_devices(device, devices)
+        self._init_devices(device, devices, interleaved)
         self._source = problem.native_source()
         # (bdf_kernels.hip and bdf_wave.hip carry the compact-record option)
         if compact_trajectory is None:        # measured (profiles/r03_compact_trajectory.txt): pays from three states on
@@ -586,6 +623,7 @@ class AdjointSolver(_EngineMixin):
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         p = self._problem.n_params
+        y0, ps, pr = self._gather(y0), self._gather(ps, p), self._gather(pr, stride)
         y_out = self._out((B, len(tvals), self._problem.n_states))
         status = self._out((B,), np.int32)
         stats = self._out((B, _native.N_STATS), np.int64)
@@ -596,7 +634,7 @@ class AdjointSolver(_EngineMixin):
                       stride, t0, tvals, len(tvals), y_out[lo:hi], status[lo:hi], stats[lo:hi], adjoint=True)
         self._run_shards(shards, call)
         self._last_forward = (B, ps, pr, stride, shards)     # every handle keeps ITS shard's trajectories
-        return y_out, status, stats
+        return self._scatter(y_out), self._scatter(status), self._scatter(stats)
 
     def solve_backward_batch(self, t0, tend, tvals, grads, *, max_retries=50, return_all=False):
         """Adjoint pass for the batch of the last ``solve_forward_batch``.
@@ -619,6 +657,7 @@ class AdjointSolver(_EngineMixin):
             gstride = n_t * n
         else:
             raise ValueError(f"grads must have shape ({n_t}, {n}) or ({B}, {n_t}, {n})")
+        grads = self._gather(grads, gstride)                 # (ps / pr of the forward call are in handle order already)
         grad_out = self._out((B, max(p, 1)))
         lamda_out = self._out((B, max(n, 1)))
         if not p:
@@ -638,6 +677,9 @@ class AdjointSolver(_EngineMixin):
                                lamda_out[lo:hi], status[lo:hi], stats[lo:hi],
                                lam_all[lo:hi] if return_all else None, quad_all[lo:hi] if return_all else None)
         self._run_shards(shards, call)
+        grad_out, lamda_out, status, stats = (self._scatter(a) for a in (grad_out, lamda_out, status, stats))
+        if return_all:
+            lam_all, quad_all = self._scatter(lam_all), self._scatter(quad_all)
         if (status == -9001).any():
             import warnings
             warnings.warn("solve_backward: %d instance(s) returned SA_STATUS_ARENA_FULL (a 64-instance group of stored "

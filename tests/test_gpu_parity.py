@@ -1162,6 +1162,7 @@ def test_conservative_build_without_the_vgpr_liverange_pass(name, monkeypatch):
     ("network24", "wave", "-DSA_WAVE_PROFILE"),
     ("network24", "wave", "-DSA_WAVE_PROFILE -DSA_LU_PROFILE_SEGMENTS"),
     ("network24", "wave", "-DSA_WAVE_PROFILE -DSA_LU_PROFILE_TIMELINE"),
+    ("network24", "wave", "-DSA_LU_INLINE_WORKERS"),          # (measured, slower: see worker_loop)
 ])
 def test_profiling_builds_integrate_like_the_default_build(name, mapping, defines, monkeypatch):
     """The section-timer builds of bdf_wave.hip (tools/profile_wave.py; the numbers under profiles/*_sections.txt and
@@ -1187,9 +1188,10 @@ def test_profiling_builds_integrate_like_the_default_build(name, mapping, define
     yo, so, sto = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, tv, nthreads=8)
     go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
     assert (st == 0).all() and (stb == 0).all()
-    np.testing.assert_array_equal(stats[:, :5], sto[:, :5])          # (slots 5.. carry clock readings in these builds)
+    if "LU_PROFILE" not in defines:                                  # (the LU timers take more of the slots)
+        np.testing.assert_array_equal(stats[:, :5], sto[:, :5])      # (slots 5.. carry clock readings in these builds)
+        np.testing.assert_array_equal(statsb[:, :5], stbo[:, :5])
     np.testing.assert_array_equal(y, yo)
-    np.testing.assert_array_equal(statsb[:, :5], stbo[:, :5])
     np.testing.assert_array_equal(g, go)
     np.testing.assert_array_equal(lam, lo)
-    assert statsb[:, 15].min() > 0                     # the timers did run
+    assert "PROFILE" not in defines or statsb[:, 15].min() > 0        # the timers did run

@@ -209,3 +209,66 @@ def test_forward_solver_and_sensitivities_on_two_handles():
     assert _native.device_count() >= 1
     free_b, total_b = _native.device_memory(0)
     assert 0 < free_b <= total_b and total_b > (100 << 30)             # MI355X: 288 GB
+
+
+def test_interleaved_shards_keep_the_callers_order(fake_native):
+    """``interleaved=True``: handle r integrates the instances r, r + G, ...; inputs are gathered
+    into handle-major order, every result comes back in the caller's order, and the backward call hands every handle
+    the instances it integrated forward (the fake asserts that)."""
+    from sunode_amd.solver import AdjointSolver, Solver
+    prob = make_problem("lv")
+    B = 11
+    d, ps, pr = _lv_inputs(B)
+    sol = AdjointSolver(prob, devices=[0, 1, 2], interleaved=True, arena_gib=3)
+    y, st, stats = sol.solve_forward_batch(0.0, d["tvals"], d["y0"], ps, pr)
+    handles = fake_native.created
+    assert [h.calls[0][1] for h in handles] == [4, 4, 3]                 # instances 0,3,6,9 | 1,4,7,10 | 2,5,8
+    np.testing.assert_array_equal(handles[1].last_ps, ps[1::3])
+    np.testing.assert_array_equal(y, d["y0"][:, None, :] * (1.0 + d["tvals"][None, :, None]) + ps[:, :1, None])
+    np.testing.assert_array_equal(stats[:, 0], 100 + np.arange(B) % 3)  # which handle integrated which instance
+    grads = np.cos(np.arange(B * len(d["tvals"]) * 2.0)).reshape(B, len(d["tvals"]), 2)
+    g, lam, stb, _ = sol.solve_backward_batch(d["tvals"][-1], 0.0, d["tvals"], grads)
+    np.testing.assert_array_equal(g, ps * 2.0 + grads.sum(axis=(1, 2))[:, None])
+    np.testing.assert_array_equal(lam, np.tile(-1.0 - ps[:, :1], (1, 2)))
+    g2, _, _, _, la, qa = sol.solve_backward_batch(d["tvals"][-1], 0.0, d["tvals"], grads[0], return_all=True)
+    np.testing.assert_array_equal(g2, ps * 2.0)
+    assert la.shape == (B, len(d["tvals"]), 2) and (la == 7.0).all() and (qa == 8.0).all()
+    fake_native.created.clear()
+    fwd = Solver(prob, devices=[0, 1], interleaved=True, sens_mode="simultaneous")
+    y, S, st, _ = fwd.solve_sens_batch(0.0, d["tvals"], d["y0"], ps, pr, np.zeros((2, 2)))
+    np.testing.assert_array_equal(S, np.broadcast_to(ps[:, None, :, None], S.shape))
+    np.testing.assert_array_equal(y, np.broadcast_to(d["y0"][:, None, :], y.shape))
+    one = Solver(prob, devices=[0], interleaved=True)                    # one handle: nothing to reorder
+    y1, _, _ = one.solve_batch(0.0, d["tvals"], d["y0"], ps, pr)
+    np.testing.assert_array_equal(y1, d["y0"][:, None, :] * (1.0 + d["tvals"][None, :, None]) + ps[:, :1, None])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B", [("seir", 8 * 16384), ("network100", 8 * 64)])
+def test_eight_handles_carry_the_global_batch_of_an_eight_gpu_node(name, B):
+    """8-GPU readiness on the one-GPU box.  BASELINE config 4's GLOBAL batch (131 072 SEIR instances =
+    8 x 16 384) -- and 8 shards of the 100-state network -- through EIGHT handles on device 0 (eight streams, eight
+    arenas sharing the device's budget eight ways, eight host threads), contiguous and interleaved shards: statuses,
+    counters, states and gradients equal the one-handle run bit for bit."""
+    from sunode_amd.solver import AdjointSolver
+    from tools.problems import network_batch, seir_batch
+    prob = make_problem(name)
+    d = seir_batch(B) if name == "seir" else network_batch(B)
+    tv = d["tvals"]
+    k = np.arange(len(tv))[:, None]; i = np.arange(prob.n_states)[None, :]
+    grads = 1.0 + 0.5 * np.cos(1.7 * k + 0.9 * i)
+    tol = dict(abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8, quad_abstol=1e-8, quad_reltol=1e-8)
+    ref = None
+    for devs, inter in (([0], False), ([0] * 8, False), ([0] * 8, True)):
+        sol = AdjointSolver(prob, devices=devs, interleaved=inter, arena_gib=64, **tol)
+        y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], d["ps"], d["pr"])
+        g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+        assert (st == 0).all() and (stb == 0).all()
+        assert [e._opt_kw["arena_bytes"] for e in sol._engines()] == [(64 << 30) // len(devs)] * len(devs)
+        got = (y.copy(), stats[:, :9].copy(), g.copy(), lam.copy(), statsb[:, :8].copy())
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
+        del sol
