@@ -9,8 +9,11 @@
  *   bdf_kernels.hip   one lane per instance (n <= 5): a vector = NS doubles of one lane,
  *   bdf_wave.hip      G lanes per instance / a workgroup per instance: a vector = RS register slots per lane,
  * after each has defined its MAPPING -- the only things that differ between them:
- *   SA_STATE<BWD>     the state struct (fields named as in CVodeMem: zn, znQ, acor, ewt, tq, l, tau, ...),
+ *   SA_STATE<BWD>     the state struct (fields named as in CVodeMem: zn, znQ, acor, ewt, tq, l, tau, ...); a vector
+ *                     field is anything indexable as v[r] (register arrays, or views of an HBM workspace),
  *   RS, RQ            doubles of a state / quadrature vector held by one lane;  IDX(m, r) = component of slot r
+ *   VFOR(r) .. VEND / QFOR(r) .. QEND    loop over the slots of a state / quadrature vector: compile-time
+ *                     (SFOR over RS / RQ, the default in sa_common.h) or a run-time loop (bdf_mem.hip),
  *   wrms_n / wrms_q / quad_update_norm / ewt_set / ewtQ_set / wave_max    norms and reductions (in-lane trees or
  *                     cross-lane butterflies: the association is the oracle's balanced tree in both)
  *   cv_f / cv_fQ / cv_jac, cv_fS     generated callbacks (registers, or staged through LDS)
@@ -19,8 +22,10 @@
  *   SV / SLOOP_BEGIN / SLOOP_END      sensitivity vectors (registers, or streamed from the workspace)
  *   COLD_STORE / COLD_LOAD, PH_T0 / PH_ADD           optional hooks (LDS parking of cold state, phase timers)
  *   SA_POLY_CM(BWD)   whether the pow polynomials read their coefficients from constant memory (sa_common.h)
- * A controller change is an edit of THIS file; bit-equality with the oracle (tests -m gpu) covers both mappings.
- * (bdf_mem.hip, the memory-resident fall-back for n > 128, keeps its own loop-based restatement.)
+ * A controller change is an edit of THIS file; bit-equality with the oracle (tests -m gpu) covers every mapping.
+ * Since round 5 also included by
+ *   bdf_mem.hip       one lane per instance, every vector a strided view of an HBM workspace, run-time loops
+ *                     over the components (n > 128, and forward sensitivities beyond the lane groups).
  *
  * Reference call sites: /root/reference/sunode/solver.py:467-527, 682-784; CVODES digest: SURVEY.md Appendix A / B.
  */
@@ -36,11 +41,11 @@ DEV int sens_ewt_set(SA_STATE<BWD> &m)
     double bad = 0.0;
     SLOOP_BEGIN(is)
         const double pb = m.pbar[is];
-        SFOR(r, 0, RS) {
+        VFOR(r) {
             const double v = FMA(m.rtol, fabs(pb * SV(m, v_in, is, r)), m.atol[r]);
             bad = (IDX(m, r) < NS && v <= 0.0) ? 1.0 : bad;
             SV(m, v_out, is, r) = pb * (1.0 / v);
-        } SEND
+        } VEND
     SLOOP_END
     return wave_max(m.lane, bad) > 0.0 ? -1 : 0;
 }
@@ -52,7 +57,7 @@ DEV double sens_update_norm(const SA_STATE<BWD> &m, double old_nrm)
     double nrm = old_nrm;
     SLOOP_BEGIN(is)
         double x[RS], w[RS];
-        SFOR(r, 0, RS) { x[r] = SV(m, v_x, is, r); w[r] = SV(m, v_w, is, r); } SEND
+        VFOR(r) { x[r] = SV(m, v_x, is, r); w[r] = SV(m, v_w, is, r); } VEND
         const double snrm = wrms_n(m, x, w);
         nrm = snrm > nrm ? snrm : nrm;
     SLOOP_END
@@ -63,15 +68,15 @@ DEV double sens_update_norm(const SA_STATE<BWD> &m, double old_nrm)
 template <bool BWD>
 DEV int cv_nls_residual_sens(SA_STATE<BWD> &m)
 {
-    SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND SLOOP_END
+    SLOOP_BEGIN(is) VFOR(r) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); VEND SLOOP_END
     int retval = cv_fS<SV_Y, SV_FTEMP>(m, m.tn, m.y);
     if (retval < 0) return CV_SRHSFUNC_FAIL;
     if (retval > 0) return SRHSFUNC_RECVR;
     SLOOP_BEGIN(is)
-        SFOR(r, 0, RS) {
+        VFOR(r) {
             const double rr = FMA(m.rl1, SV(m, SV_ZN0 + 1, is, r), SV(m, SV_ACOR, is, r));
             SV(m, SV_DELTA, is, r) = FMA(-m.gamma, SV(m, SV_FTEMP, is, r), rr);
-        } SEND
+        } VEND
     SLOOP_END
     return CV_SUCCESS;
 }
@@ -82,30 +87,30 @@ DEV void cv_sens_newton_update(SA_STATE<BWD> &m)
 {
     SLOOP_BEGIN(is)
         double d[RS];
-        SFOR(r, 0, RS) d[r] = -1.0 * SV(m, SV_DELTA, is, r); SEND
+        VFOR(r) d[r] = -1.0 * SV(m, SV_DELTA, is, r); VEND
         dense_getrs(m, d);
         if (m.gamrat != 1.0) {
             double sc = 2.0 / (1.0 + m.gamrat);
-            SFOR(r, 0, RS) d[r] *= sc; SEND
+            VFOR(r) d[r] *= sc; VEND
         }
-        SFOR(r, 0, RS) { SV(m, SV_DELTA, is, r) = d[r]; SV(m, SV_ACOR, is, r) = SV(m, SV_ACOR, is, r) + d[r]; } SEND
+        VFOR(r) { SV(m, SV_DELTA, is, r) = d[r]; SV(m, SV_ACOR, is, r) = SV(m, SV_ACOR, is, r) + d[r]; } VEND
     SLOOP_END
 }
 #endif
 
 /* ---- CVodeInit / CVodeReInit ---- */
-template <bool BWD>
-DEV void cv_reinit(SA_STATE<BWD> &m, double t0, const double (&y0)[RS], const double (&q0)[RQ])
+template <bool BWD, class VY, class VQ>
+DEV void cv_reinit(SA_STATE<BWD> &m, double t0, const VY &y0, const VQ &q0)
 {
     m.tn = t0;
     m.q = 1; m.L = 2; m.qwait = 2; m.etamax = ETAMX1;
     m.qu = 0; m.hu = 0.0;
     SFOR(j, 0, (QMAX) + 1) {
-        SFOR(r, 0, RS) m.zn[j][r] = 0.0; SEND
-        SFOR(r, 0, RQ) m.znQ[j][r] = 0.0; SEND
+        VFOR(r) m.zn[j][r] = 0.0; VEND
+        QFOR(r) m.znQ[j][r] = 0.0; QEND
     } SEND
-    SFOR(r, 0, RS) m.zn[0][r] = y0[r]; SEND
-    if (BWD) { SFOR(r, 0, RQ) m.znQ[0][r] = q0[r]; SEND }
+    VFOR(r) m.zn[0][r] = y0[r]; VEND
+    if (BWD) { QFOR(r) m.znQ[0][r] = q0[r]; QEND }
     m.nst = m.nfe = m.ncfn = m.netf = m.nni = m.nsetups = 0;
     m.nje = 0; m.nstlp = 0; m.nstlj = 0; m.nfQe = m.netfQ = 0;
     m.h = 0.0; m.hprime = 0.0; m.hscale = 0.0; m.eta = 1.0;
@@ -115,8 +120,8 @@ DEV void cv_reinit(SA_STATE<BWD> &m, double t0, const double (&y0)[RS], const do
     m.jcur = 0; m.nls_jcur = 0;
     SFOR(i, 0, 7) { m.tau[i] = 0.0; m.l[i] = 0.0; } SEND
     SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
-    SFOR(r, 0, RS) { m.acor[r] = m.tempv[r] = m.ftemp[r] = m.y[r] = m.zsave[r] = 0.0; } SEND
-    SFOR(r, 0, RQ) { m.acorQ[r] = m.tempvQ[r] = m.zsaveQ[r] = 0.0; } SEND
+    VFOR(r) { m.acor[r] = m.tempv[r] = m.ftemp[r] = m.y[r] = m.zsave[r] = 0.0; } VEND
+    QFOR(r) { m.acorQ[r] = m.tempvQ[r] = m.zsaveQ[r] = 0.0; } QEND
 #ifdef SA_SENS
     m.crateS = 1.0; m.delpS = 0.0; m.acnrmS = 0.0;
     m.nfSe = m.nniS = m.ncfnS = m.netfS = m.nsetupsS = 0;
@@ -130,24 +135,24 @@ DEV double cv_upper_bound_h0(SA_STATE<BWD> &m, double tdist)
     double w[RS];
     ewt_set(m, m.zn[0], w);
     double loc = 0.0;
-    SFOR(r, 0, RS) {
+    VFOR(r) {
         const double t1 = FMA(HUB_FACTOR, fabs(m.zn[0][r]), 1.0 / w[r]);
         const double v = (IDX(m, r) < NS) ? fabs(m.zn[1][r]) / t1 : 0.0;
         loc = v > loc ? v : loc;
-    } SEND
+    } VEND
     double hub_inv = wave_max(m.lane, loc);
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         sens_ewt_set<SV_ZN0, SV_TEMPV>(m);
         double locS = 0.0;
         SLOOP_BEGIN(is)
-            SFOR(r, 0, RS) {
+            VFOR(r) {
                 const double t2 = fabs(SV(m, SV_ZN0, is, r));
                 double t1 = 1.0 / SV(m, SV_TEMPV, is, r);
                 t1 = FMA(HUB_FACTOR, t2, t1);
                 const double v = (IDX(m, r) < NS) ? fabs(SV(m, SV_ZN0 + 1, is, r)) / t1 : 0.0;
                 locS = v > locS ? v : locS;
-            } SEND
+            } VEND
         SLOOP_END
         const double hubS = wave_max(m.lane, locS);
         if (hubS > hub_inv) hub_inv = hubS;
@@ -157,11 +162,11 @@ DEV double cv_upper_bound_h0(SA_STATE<BWD> &m, double tdist)
         double wq[RQ];
         ewtQ_set(m, m.znQ[0], wq);
         double locq = 0.0;
-        SFOR(r, 0, RQ) {
+        QFOR(r) {
             const double t1q = FMA(HUB_FACTOR, fabs(m.znQ[0][r]), 1.0 / wq[r]);
             const double v = (IDX(m, r) < NQ) ? fabs(m.znQ[1][r]) / t1q : 0.0;
             locq = v > locq ? v : locq;
-        } SEND
+        } QEND
         const double hubQ_inv = wave_max(m.lane, locq);
         if (hubQ_inv > hub_inv) hub_inv = hubQ_inv;
     }
@@ -173,9 +178,9 @@ DEV double cv_upper_bound_h0(SA_STATE<BWD> &m, double tdist)
 template <bool BWD>
 DEV int cv_ydd_norm(SA_STATE<BWD> &m, double hg, double *yddnrm)
 {
-    SFOR(r, 0, RS) m.y[r] = FMA(hg, m.zn[1][r], m.zn[0][r]); SEND
+    VFOR(r) m.y[r] = FMA(hg, m.zn[1][r], m.zn[0][r]); VEND
 #ifdef SA_SENS
-    if (SENS_ON(m)) { SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_Y, is, r) = FMA(hg, SV(m, SV_ZN0 + 1, is, r), SV(m, SV_ZN0, is, r)); SEND SLOOP_END }
+    if (SENS_ON(m)) { SLOOP_BEGIN(is) VFOR(r) SV(m, SV_Y, is, r) = FMA(hg, SV(m, SV_ZN0 + 1, is, r), SV(m, SV_ZN0, is, r)); VEND SLOOP_END }
 #endif
     if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
     int retval = cv_f(m, m.tn + hg, m.y, m.tempv);
@@ -193,27 +198,27 @@ DEV int cv_ydd_norm(SA_STATE<BWD> &m, double hg, double *yddnrm)
         if (retval < 0) return CV_QRHSFUNC_FAIL;
         if (retval > 0) return QRHSFUNC_RECVR;
     }
-    SFOR(r, 0, RS) {
+    VFOR(r) {
         m.tempv[r] = m.tempv[r] - m.zn[1][r];
         m.tempv[r] = (1.0 / hg) * m.tempv[r];
-    } SEND
+    } VEND
     *yddnrm = wrms_n(m, m.tempv, m.ewt);
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
-            SFOR(r, 0, RS) {
+            VFOR(r) {
                 const double v = SV(m, SV_TEMPV, is, r) - SV(m, SV_ZN0 + 1, is, r);
                 SV(m, SV_TEMPV, is, r) = (1.0 / hg) * v;
-            } SEND
+            } VEND
         SLOOP_END
         *yddnrm = sens_update_norm<SV_TEMPV, SV_EWT>(m, *yddnrm);
     }
 #endif
     if (BWD) {
-        SFOR(r, 0, RQ) {
+        QFOR(r) {
             m.tempvQ[r] = m.tempvQ[r] - m.znQ[1][r];
             m.tempvQ[r] = (1.0 / hg) * m.tempvQ[r];
-        } SEND
+        } QEND
         *yddnrm = quad_update_norm(m, *yddnrm, m.tempvQ);
     }
     return CV_SUCCESS;
@@ -276,10 +281,10 @@ DEV void cv_rescale(SA_STATE<BWD> &m)
 {
     double factor = m.eta;
     SFOR(j, 1, (QMAX) + 1) {
-        SFOR(r, 0, RS) m.zn[j][r] *= factor; SEND
-        if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] *= factor; SEND }
+        VFOR(r) m.zn[j][r] *= factor; VEND
+        if (BWD) { QFOR(r) m.znQ[j][r] *= factor; QEND }
 #ifdef SA_SENS
-        if (SENS_ON(m)) { SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) *= factor; SEND SLOOP_END }
+        if (SENS_ON(m)) { SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ZN0 + j, is, r) *= factor; VEND SLOOP_END }
 #endif
         factor *= m.eta;
     } SEND
@@ -307,28 +312,28 @@ DEV void cv_increase_bdf(SA_STATE<BWD> &m)
     const double A1 = (-alpha0 - alpha1) / prod;
     const int L = m.L;
     double znL[RS], znQL[RQ];
-    SFOR(r, 0, RS) znL[r] = A1 * m.zsave[r]; SEND
-    SFOR(r, 0, RQ) znQL[r] = BWD ? A1 * m.zsaveQ[r] : 0.0; SEND
+    VFOR(r) znL[r] = A1 * m.zsave[r]; VEND
+    QFOR(r) znQL[r] = BWD ? A1 * m.zsaveQ[r] : 0.0; QEND
     SFOR(j, 2, (QMAX) + 1) {
         if (j == L) {
-            SFOR(r, 0, RS) m.zn[j][r] = znL[r]; SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = znQL[r]; SEND }
+            VFOR(r) m.zn[j][r] = znL[r]; VEND
+            if (BWD) { QFOR(r) m.znQ[j][r] = znQL[r]; QEND }
         }
     } SEND
     SFOR(j, 2, QMAX) {
         if (j <= m.q) {
-            SFOR(r, 0, RS) m.zn[j][r] = FMA(m.l[j], znL[r], m.zn[j][r]); SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(m.l[j], znQL[r], m.znQ[j][r]); SEND }
+            VFOR(r) m.zn[j][r] = FMA(m.l[j], znL[r], m.zn[j][r]); VEND
+            if (BWD) { QFOR(r) m.znQ[j][r] = FMA(m.l[j], znQL[r], m.znQ[j][r]); QEND }
         }
     } SEND
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
             double zl[RS];
-            SFOR(r, 0, RS) zl[r] = A1 * SV(m, SV_ZSAVE, is, r); SEND
-            SFOR(j, 2, (QMAX) + 1) { if (j == L) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = zl[r]; SEND } } SEND
+            VFOR(r) zl[r] = A1 * SV(m, SV_ZSAVE, is, r); VEND
+            SFOR(j, 2, (QMAX) + 1) { if (j == L) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = zl[r]; VEND } } SEND
             SFOR(j, 2, QMAX) {
-                if (j <= m.q) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], zl[r], SV(m, SV_ZN0 + j, is, r)); SEND }
+                if (j <= m.q) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], zl[r], SV(m, SV_ZN0 + j, is, r)); VEND }
             } SEND
         SLOOP_END
     }
@@ -349,24 +354,24 @@ DEV void cv_decrease_bdf(SA_STATE<BWD> &m)
         }
     } SEND
     double znq[RS], znQq[RQ];
-    SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
-    SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
+    VFOR(r) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } VEND
+    QFOR(r) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } QEND
     SFOR(j, 2, QMAX) {
         if (j < m.q) {
-            SFOR(r, 0, RS) m.zn[j][r] = FMA(-m.l[j], znq[r], m.zn[j][r]); SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(-m.l[j], znQq[r], m.znQ[j][r]); SEND }
+            VFOR(r) m.zn[j][r] = FMA(-m.l[j], znq[r], m.zn[j][r]); VEND
+            if (BWD) { QFOR(r) m.znQ[j][r] = FMA(-m.l[j], znQq[r], m.znQ[j][r]); QEND }
         }
     } SEND
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
             double zq[RS];
-            SFOR(r, 0, RS) {
+            VFOR(r) {
                 zq[r] = SV(m, SV_ZN0 + 2, is, r);
                 SFOR(k, 3, (QMAX) + 1) { if (m.q == k) zq[r] = SV(m, SV_ZN0 + k, is, r); } SEND
-            } SEND
+            } VEND
             SFOR(j, 2, QMAX) {
-                if (j < m.q) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(-m.l[j], zq[r], SV(m, SV_ZN0 + j, is, r)); SEND }
+                if (j < m.q) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = FMA(-m.l[j], zq[r], SV(m, SV_ZN0 + j, is, r)); VEND }
             } SEND
         SLOOP_END
     }
@@ -378,10 +383,10 @@ DEV void cv_clear_column(SA_STATE<BWD> &m, int q_old)
 {
     SFOR(j, 2, (QMAX) + 1) {
         if (j == q_old) {
-            SFOR(r, 0, RS) m.zn[j][r] = 0.0; SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = 0.0; SEND }
+            VFOR(r) m.zn[j][r] = 0.0; VEND
+            if (BWD) { QFOR(r) m.znQ[j][r] = 0.0; QEND }
 #ifdef SA_SENS
-            if (SENS_ON(m)) { SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = 0.0; SEND SLOOP_END }
+            if (SENS_ON(m)) { SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ZN0 + j, is, r) = 0.0; VEND SLOOP_END }
 #endif
         }
     } SEND
@@ -404,17 +409,17 @@ DEV void cv_predict(SA_STATE<BWD> &m)
     }
     SFOR(k, 1, (QMAX) + 1) {
         SFOR_DOWN(j, QMAX, k) {
-            SFOR(r, 0, RS) m.zn[j - 1][r] = m.zn[j - 1][r] + m.zn[j][r]; SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j - 1][r] = m.znQ[j - 1][r] + m.znQ[j][r]; SEND }
+            VFOR(r) m.zn[j - 1][r] = m.zn[j - 1][r] + m.zn[j][r]; VEND
+            if (BWD) { QFOR(r) m.znQ[j - 1][r] = m.znQ[j - 1][r] + m.znQ[j][r]; QEND }
         } SEND
     } SEND
 #ifdef SA_SENS
     if (SENS_ON(m)) {           /* the same Pascal-triangle pass, one load and one store per entry */
         SLOOP_BEGIN(is)
             double z[QMAX + 1][RS];
-            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) z[j][r] = SV(m, SV_ZN0 + j, is, r); SEND } SEND
-            SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { SFOR(r, 0, RS) z[j - 1][r] = z[j - 1][r] + z[j][r]; SEND } SEND } SEND
-            SFOR(j, 0, QMAX) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = z[j][r]; SEND } SEND
+            SFOR(j, 0, (QMAX) + 1) { VFOR(r) z[j][r] = SV(m, SV_ZN0 + j, is, r); VEND } SEND
+            SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { VFOR(r) z[j - 1][r] = z[j - 1][r] + z[j][r]; VEND } SEND } SEND
+            SFOR(j, 0, QMAX) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = z[j][r]; VEND } SEND
         SLOOP_END
     }
 #endif
@@ -426,17 +431,17 @@ DEV void cv_restore(SA_STATE<BWD> &m, double saved_t)
     m.tn = saved_t;
     SFOR(k, 1, (QMAX) + 1) {
         SFOR_DOWN(j, QMAX, k) {
-            SFOR(r, 0, RS) m.zn[j - 1][r] = m.zn[j - 1][r] - m.zn[j][r]; SEND
-            if (BWD) { SFOR(r, 0, RQ) m.znQ[j - 1][r] = m.znQ[j - 1][r] - m.znQ[j][r]; SEND }
+            VFOR(r) m.zn[j - 1][r] = m.zn[j - 1][r] - m.zn[j][r]; VEND
+            if (BWD) { QFOR(r) m.znQ[j - 1][r] = m.znQ[j - 1][r] - m.znQ[j][r]; QEND }
         } SEND
     } SEND
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
             double z[QMAX + 1][RS];
-            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) z[j][r] = SV(m, SV_ZN0 + j, is, r); SEND } SEND
-            SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { SFOR(r, 0, RS) z[j - 1][r] = z[j - 1][r] - z[j][r]; SEND } SEND } SEND
-            SFOR(j, 0, QMAX) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = z[j][r]; SEND } SEND
+            SFOR(j, 0, (QMAX) + 1) { VFOR(r) z[j][r] = SV(m, SV_ZN0 + j, is, r); VEND } SEND
+            SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { VFOR(r) z[j - 1][r] = z[j - 1][r] - z[j][r]; VEND } SEND } SEND
+            SFOR(j, 0, QMAX) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = z[j][r]; VEND } SEND
         SLOOP_END
     }
 #endif
@@ -461,17 +466,17 @@ DEV int cv_nls_lsetup(SA_STATE<BWD> &m, int jbad, int &convfail)
     return CV_SUCCESS;
 }
 
-template <bool BWD>
-DEV int cv_nls_residual(SA_STATE<BWD> &m, double (&res)[RS])
+template <bool BWD, class VR>
+DEV int cv_nls_residual(SA_STATE<BWD> &m, VR &res)
 {
-    SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
+    VFOR(r) m.y[r] = m.zn[0][r] + m.acor[r]; VEND
     int retval = cv_f(m, m.tn, m.y, m.ftemp);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return RHSFUNC_RECVR;
-    SFOR(r, 0, RS) {
+    VFOR(r) {
         res[r] = FMA(m.rl1, m.zn[1][r], m.acor[r]);
         res[r] = FMA(-m.gamma, m.ftemp[r], res[r]);
-    } SEND
+    } VEND
     return CV_SUCCESS;
 }
 
@@ -483,9 +488,9 @@ DEV int cv_newton_pass(SA_STATE<BWD> &m, int callSetup, int jbad, int &convfail,
     const bool sim = SENS_ON(m) && m.ism == 0;
 #endif
     in_loop = 0;
-    SFOR(r, 0, RS) m.acor[r] = 0.0; SEND
+    VFOR(r) m.acor[r] = 0.0; VEND
 #ifdef SA_SENS
-    if (sim) { SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND SLOOP_END }
+    if (sim) { SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ACOR, is, r) = 0.0; VEND SLOOP_END }
 #endif
     int retval = cv_nls_residual(m, delta);
     if (retval != CV_SUCCESS) return retval;
@@ -503,21 +508,21 @@ DEV int cv_newton_pass(SA_STATE<BWD> &m, int callSetup, int jbad, int &convfail,
     in_loop = 1;
     for (;;) {
         m.nni++;
-        SFOR(r, 0, RS) delta[r] = -1.0 * delta[r]; SEND
+        VFOR(r) delta[r] = -1.0 * delta[r]; VEND
         dense_getrs(m, delta);
 #ifdef SA_SENS
         if (m.gamrat != 1.0) {
             double s = 2.0 / (1.0 + m.gamrat);
-            SFOR(r, 0, RS) delta[r] *= s; SEND
+            VFOR(r) delta[r] *= s; VEND
         }
 #else
         {   /* cvLsSolve's scaling by 2 / (1 + gamrat) -- skipped by CVODES when gamrat == 1, where the factor is exactly
                1.0: computed by every lane (x * 1.0 == x) instead of inside a divergent block of its own */
             const double s = 2.0 / (1.0 + m.gamrat);
-            SFOR(r, 0, RS) delta[r] *= s; SEND
+            VFOR(r) delta[r] *= s; VEND
         }
 #endif
-        SFOR(r, 0, RS) m.acor[r] = m.acor[r] + delta[r]; SEND
+        VFOR(r) m.acor[r] = m.acor[r] + delta[r]; VEND
         double del = wrms_n(m, delta, m.ewt);
 #ifdef SA_SENS
         if (sim) {
@@ -556,7 +561,7 @@ template <bool BWD>
 DEV int cv_stgr_nls(SA_STATE<BWD> &m)
 {
     int callSetup = 0, jbad = 0, convfail = CV_FAIL_OTHER, retval;
-    SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND SLOOP_END
+    SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ACOR, is, r) = 0.0; VEND SLOOP_END
     for (;;) {
         retval = cv_nls_residual_sens(m);
         if (retval != CV_SUCCESS) break;
@@ -589,13 +594,13 @@ DEV int cv_stgr_nls(SA_STATE<BWD> &m)
         if ((retval > 0) && !m.nls_jcur) {
             callSetup = 1;
             jbad = 1;
-            SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = 0.0; SEND SLOOP_END
+            SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ACOR, is, r) = 0.0; VEND SLOOP_END
             continue;
         }
         break;
     }
     if (retval != CV_SUCCESS) return retval;
-    SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND SLOOP_END
+    SLOOP_BEGIN(is) VFOR(r) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); VEND SLOOP_END
     return CV_SUCCESS;
 }
 #endif
@@ -633,20 +638,20 @@ DEV int cv_error_test_failed(SA_STATE<BWD> &m, double saved_t, double dsm, int &
     int retval = cv_f(m, m.tn, m.zn[0], m.tempv);
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
-    SFOR(r, 0, RS) m.zn[1][r] = m.h * m.tempv[r]; SEND
+    VFOR(r) m.zn[1][r] = m.h * m.tempv[r]; VEND
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         retval = cv_fS<SV_ZN0, SV_TEMPV>(m, m.tn, m.zn[0]);
         if (retval < 0) return CV_SRHSFUNC_FAIL;
         if (retval > 0) return CV_UNREC_SRHSFUNC_ERR;
-        SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ZN0 + 1, is, r) = m.h * SV(m, SV_TEMPV, is, r); SEND SLOOP_END
+        SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ZN0 + 1, is, r) = m.h * SV(m, SV_TEMPV, is, r); VEND SLOOP_END
     }
 #endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, m.zn[0], m.tempvQ);
         if (retval < 0) return CV_QRHSFUNC_FAIL;
         if (retval > 0) return CV_UNREC_QRHSFUNC_ERR;
-        SFOR(r, 0, RQ) m.znQ[1][r] = m.h * m.tempvQ[r]; SEND
+        QFOR(r) m.znQ[1][r] = m.h * m.tempvQ[r]; QEND
     }
     return 0;
 }
@@ -661,24 +666,24 @@ DEV void cv_complete_step(SA_STATE<BWD> &m)
     m.tau[2] = ((m.q == 1) && (m.nst > 1)) ? m.tau[1] : m.tau[2];
     m.tau[1] = m.h;
     SFOR(j, 0, (QMAX) + 1) {
-        SFOR(r, 0, RS) m.zn[j][r] = FMA(m.l[j], m.acor[r], m.zn[j][r]); SEND
-        if (BWD) { SFOR(r, 0, RQ) m.znQ[j][r] = FMA(m.l[j], m.acorQ[r], m.znQ[j][r]); SEND }
+        VFOR(r) m.zn[j][r] = FMA(m.l[j], m.acor[r], m.zn[j][r]); VEND
+        if (BWD) { QFOR(r) m.znQ[j][r] = FMA(m.l[j], m.acorQ[r], m.znQ[j][r]); QEND }
     } SEND
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
             double ac[RS];
-            SFOR(r, 0, RS) ac[r] = SV(m, SV_ACOR, is, r); SEND
-            SFOR(j, 0, (QMAX) + 1) { SFOR(r, 0, RS) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], ac[r], SV(m, SV_ZN0 + j, is, r)); SEND } SEND
-            if ((m.qwait - 1 == 1) && (m.q != QMAX)) { SFOR(r, 0, RS) SV(m, SV_ZSAVE, is, r) = ac[r]; SEND }
+            VFOR(r) ac[r] = SV(m, SV_ACOR, is, r); VEND
+            SFOR(j, 0, (QMAX) + 1) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], ac[r], SV(m, SV_ZN0 + j, is, r)); VEND } SEND
+            if ((m.qwait - 1 == 1) && (m.q != QMAX)) { VFOR(r) SV(m, SV_ZSAVE, is, r) = ac[r]; VEND }
         SLOOP_END
     }
 #endif
     m.qwait--;
     {
         const bool sv = (m.qwait == 1) && (m.q != QMAX);
-        SFOR(r, 0, RS) m.zsave[r] = sv ? m.acor[r] : m.zsave[r]; SEND
-        if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = sv ? m.acorQ[r] : m.zsaveQ[r]; SEND }
+        VFOR(r) m.zsave[r] = sv ? m.acor[r] : m.zsave[r]; VEND
+        if (BWD) { QFOR(r) m.zsaveQ[r] = sv ? m.acorQ[r] : m.zsaveQ[r]; QEND }
         m.saved_tq5 = sv ? m.tq[5] : m.saved_tq5;
     }
 }
@@ -725,18 +730,18 @@ DEV void cv_prepare_next_step(SA_STATE<BWD> &m, double dsm)
         return;
     }
     double znq[RS], znQq[RQ], tv[RS], tvQ[RQ];
-    SFOR(r, 0, RS) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } SEND
-    SFOR(r, 0, RQ) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } SEND
+    VFOR(r) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } VEND
+    QFOR(r) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } QEND
     double ddn = wrms_n(m, znq, m.ewt);
     if (BWD) ddn = quad_update_norm(m, ddn, znQq);
 #ifdef SA_SENS
     if (SENS_ON(m) && full && m.q > 1) {            /* cvComputeEtaqm1: the sensitivities' column q takes part */
         SLOOP_BEGIN(is)
-            SFOR(r, 0, RS) {
+            VFOR(r) {
                 double v = SV(m, SV_ZN0 + 2, is, r);
                 SFOR(k, 3, (QMAX) + 1) { if (m.q == k) v = SV(m, SV_ZN0 + k, is, r); } SEND
                 SV(m, SV_TEMPV, is, r) = v;
-            } SEND
+            } VEND
         SLOOP_END
         ddn = sens_update_norm<SV_TEMPV, SV_EWT>(m, ddn);
     }
@@ -746,15 +751,15 @@ DEV void cv_prepare_next_step(SA_STATE<BWD> &m, double dsm)
     double pw = 1.0;
     SFOR(i, 1, (QMAX + 1) + 1) { pw = (i <= m.L) ? pw * base : pw; } SEND
     const double cquot = (m.tq[5] / m.saved_tq5) * pw;
-    SFOR(r, 0, RS) tv[r] = FMA(-cquot, m.zsave[r], m.acor[r]); SEND
+    VFOR(r) tv[r] = FMA(-cquot, m.zsave[r], m.acor[r]); VEND
     double dup = wrms_n(m, tv, m.ewt);
     if (BWD) {
-        SFOR(r, 0, RQ) tvQ[r] = FMA(-cquot, m.zsaveQ[r], m.acorQ[r]); SEND
+        QFOR(r) tvQ[r] = FMA(-cquot, m.zsaveQ[r], m.acorQ[r]); QEND
         dup = quad_update_norm(m, dup, tvQ);
     }
 #ifdef SA_SENS
     if (SENS_ON(m) && full && (m.q != QMAX) && (m.saved_tq5 != 0.0)) {     /* cvComputeEtaqp1 */
-        SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_TEMPV, is, r) = FMA(-cquot, SV(m, SV_ZSAVE, is, r), SV(m, SV_ACOR, is, r)); SEND SLOOP_END
+        SLOOP_BEGIN(is) VFOR(r) SV(m, SV_TEMPV, is, r) = FMA(-cquot, SV(m, SV_ZSAVE, is, r), SV(m, SV_ACOR, is, r)); VEND SLOOP_END
         dup = sens_update_norm<SV_TEMPV, SV_EWT>(m, dup);
     }
 #endif
@@ -776,10 +781,10 @@ DEV void cv_prepare_next_step(SA_STATE<BWD> &m, double dsm)
     const bool up = full && !c0 && !c1 && !c2;
     m.eta = full ? eta_f : etaq;
     m.qprime = full ? qp_f : m.q;
-    SFOR(r, 0, RS) m.zsave[r] = up ? m.acor[r] : m.zsave[r]; SEND
-    if (BWD) { SFOR(r, 0, RQ) m.zsaveQ[r] = up ? m.acorQ[r] : m.zsaveQ[r]; SEND }
+    VFOR(r) m.zsave[r] = up ? m.acor[r] : m.zsave[r]; VEND
+    if (BWD) { QFOR(r) m.zsaveQ[r] = up ? m.acorQ[r] : m.zsaveQ[r]; QEND }
 #ifdef SA_SENS
-    if (SENS_ON(m) && up) { SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ZSAVE, is, r) = SV(m, SV_ACOR, is, r); SEND SLOOP_END }
+    if (SENS_ON(m) && up) { SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ZSAVE, is, r) = SV(m, SV_ACOR, is, r); VEND SLOOP_END }
 #endif
     {   /* cvSetEta */
         const bool small = m.eta < THRESH;
@@ -789,8 +794,8 @@ DEV void cv_prepare_next_step(SA_STATE<BWD> &m, double dsm)
     }
 }
 
-template <bool BWD>
-DEV int cv_get_dky0(const SA_STATE<BWD> &m, double t, double (&dky)[RS], double (&dkyQ)[RQ])
+template <bool BWD, class VD, class VDQ>
+DEV int cv_get_dky0(const SA_STATE<BWD> &m, double t, VD &&dky, VDQ &&dkyQ)
 {
     double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.hu));
     if (m.hu < 0.0) tfuzz = -tfuzz;
@@ -801,17 +806,17 @@ DEV int cv_get_dky0(const SA_STATE<BWD> &m, double t, double (&dky)[RS], double 
     double pw[QMAX + 1];
     pw[0] = 1.0;
     SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
-    SFOR(r, 0, RS) {
+    VFOR(r) {
         double acc = pw[QMAX] * m.zn[QMAX][r];
         SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.zn[j][r], acc); SEND
         dky[r] = acc;
-    } SEND
+    } VEND
     if (BWD) {
-        SFOR(r, 0, RQ) {
+        QFOR(r) {
             double acc = pw[QMAX] * m.znQ[QMAX][r];
             SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], m.znQ[j][r], acc); SEND
             dkyQ[r] = acc;
-        } SEND
+        } QEND
     }
     return CV_SUCCESS;
 }
@@ -822,7 +827,7 @@ DEV int cv_first_call(SA_STATE<BWD> &m, double tout)
 #ifdef SA_CONSTRAINTS
     if (!BWD && m.constr) {
         double bad = 0.0;
-        SFOR(r, 0, RS) bad = ((IDX(m, r) < NS) && constr_violated(m.cons[r], m.zn[0][r])) ? 1.0 : bad; SEND
+        VFOR(r) bad = ((IDX(m, r) < NS) && constr_violated(m.cons[r], m.zn[0][r])) ? 1.0 : bad; VEND
         if (wave_max(m.lane, bad) > 0.0) return CV_ILL_INPUT;
     }
 #endif
@@ -836,7 +841,7 @@ DEV int cv_first_call(SA_STATE<BWD> &m, double tout)
     if (retval < 0) return CV_RHSFUNC_FAIL;
     if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
 #ifdef SA_HERMITE
-    SFOR(r, 0, RS) m.f0[r] = m.zn[1][r]; SEND
+    VFOR(r) m.f0[r] = m.zn[1][r]; VEND
 #endif
     if (BWD) {
         retval = cv_fQ(m, m.tn, m.zn[0], m.znQ[1]);
@@ -862,10 +867,10 @@ DEV int cv_first_call(SA_STATE<BWD> &m, double tout)
     }
     m.hscale = m.h;
     m.hprime = m.h;
-    SFOR(r, 0, RS) m.zn[1][r] = m.h * m.zn[1][r]; SEND
-    if (BWD) { SFOR(r, 0, RQ) m.znQ[1][r] = m.h * m.znQ[1][r]; SEND }
+    VFOR(r) m.zn[1][r] = m.h * m.zn[1][r]; VEND
+    if (BWD) { QFOR(r) m.znQ[1][r] = m.h * m.znQ[1][r]; QEND }
 #ifdef SA_SENS
-    if (SENS_ON(m)) { SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ZN0 + 1, is, r) = m.h * SV(m, SV_ZN0 + 1, is, r); SEND SLOOP_END }
+    if (SENS_ON(m)) { SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ZN0 + 1, is, r) = m.h * SV(m, SV_ZN0 + 1, is, r); VEND SLOOP_END }
 #endif
     return CV_SUCCESS;
 }
@@ -1003,33 +1008,33 @@ DEV int cv_attempt(SA_STATE<BWD> &m, StepCtl &c)
     c.redo = 0;
     if (nls != CV_SUCCESS) { COLD_LOAD(m); return cv_handle_nflag_failed(m, c, nls, c.ncf, m.ncfn); }
 
-    SFOR(r, 0, RS) m.y[r] = m.zn[0][r] + m.acor[r]; SEND
+    VFOR(r) m.y[r] = m.zn[0][r] + m.acor[r]; VEND
 #ifdef SA_CONSTRAINTS
     if (!BWD && m.constr) {             /* cvCheckConstraints (see the oracle) */
         double mm[RS], v[RS];
         double anyv = 0.0;
-        SFOR(r, 0, RS) {
+        VFOR(r) {
             const bool bad = (IDX(m, r) < NS) && constr_violated(m.cons[r], m.y[r]);
             mm[r] = bad ? 1.0 : 0.0;
             anyv = bad ? 1.0 : anyv;
-        } SEND
+        } VEND
         if (wave_max(m.lane, anyv) > 0.0) {
-            SFOR(r, 0, RS) {
+            VFOR(r) {
                 const double aa = (fabs(m.cons[r]) >= 1.5) ? 1.0 : 0.0;
                 double tmp = (aa * m.cons[r]) / m.ewt[r];
                 tmp = FMA(-0.1, tmp, m.y[r]);
                 v[r] = (IDX(m, r) < NS) ? tmp * mm[r] : 0.0;
-            } SEND
+            } VEND
             const double vnorm = wrms_n(m, v, m.ewt);
             if (vnorm * m.tq[4] <= 1.0) {
-                SFOR(r, 0, RS) m.acor[r] = m.acor[r] - v[r]; SEND
+                VFOR(r) m.acor[r] = m.acor[r] - v[r]; VEND
             } else {
                 double q = 1e308;
-                SFOR(r, 0, RS) {
+                VFOR(r) {
                     const double d = mm[r] * (m.zn[0][r] - m.y[r]);
                     const double qv = (IDX(m, r) < NS && d != 0.0) ? m.zn[0][r] / d : 1e308;
                     q = qv < q ? qv : q;
-                } SEND
+                } VEND
                 const double minq = -wave_max(m.lane, -q);
                 m.eta = fmax(0.9 * minq, 0.1);
                 COLD_LOAD(m);
@@ -1045,7 +1050,7 @@ DEV int cv_attempt(SA_STATE<BWD> &m, StepCtl &c)
         return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
     }
 #ifdef SA_SENS
-    if (SENS_ON(m) && m.ism == 0) { SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); SEND SLOOP_END }
+    if (SENS_ON(m) && m.ism == 0) { SLOOP_BEGIN(is) VFOR(r) SV(m, SV_Y, is, r) = SV(m, SV_ZN0, is, r) + SV(m, SV_ACOR, is, r); VEND SLOOP_END }
     if (SENS_ON(m) && m.ism == 1) {      /* CV_STAGGERED: sensitivities after the state passed (oracle cv_step) */
         c.ncf = c.nef = 0;
         int retval = cv_f(m, m.tn, m.y, m.ftemp);
@@ -1068,10 +1073,10 @@ DEV int cv_attempt(SA_STATE<BWD> &m, StepCtl &c)
         int retval = cv_fQ(m, m.tn, m.y, m.acorQ);
         COLD_LOAD(m);
         if (retval != 0) return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR, c.ncf, m.ncfn);
-        SFOR(r, 0, RQ) {
+        QFOR(r) {
             m.acorQ[r] = FMA(m.h, m.acorQ[r], -m.znQ[1][r]);
             m.acorQ[r] = m.rl1 * m.acorQ[r];
-        } SEND
+        } QEND
         double acnrmQ = wrms_q(m, m.acorQ, m.ewtQ);
         double dsmQ = acnrmQ * m.tq[2];
         if (dsmQ > 1.0) {
@@ -1086,10 +1091,10 @@ DEV int cv_attempt(SA_STATE<BWD> &m, StepCtl &c)
     cv_complete_step(m);
     cv_prepare_next_step(m, dsm);
     m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
-    SFOR(r, 0, RS) m.acor[r] = m.tq[2] * m.acor[r]; SEND
-    if (BWD) { SFOR(r, 0, RQ) m.acorQ[r] = m.tq[2] * m.acorQ[r]; SEND }
+    VFOR(r) m.acor[r] = m.tq[2] * m.acor[r]; VEND
+    if (BWD) { QFOR(r) m.acorQ[r] = m.tq[2] * m.acorQ[r]; QEND }
 #ifdef SA_SENS
-    if (SENS_ON(m)) { SLOOP_BEGIN(is) SFOR(r, 0, RS) SV(m, SV_ACOR, is, r) = m.tq[2] * SV(m, SV_ACOR, is, r); SEND SLOOP_END }
+    if (SENS_ON(m)) { SLOOP_BEGIN(is) VFOR(r) SV(m, SV_ACOR, is, r) = m.tq[2] * SV(m, SV_ACOR, is, r); VEND SLOOP_END }
 #endif
     c.in_step = 0;
     PH_ADD(m, 5)

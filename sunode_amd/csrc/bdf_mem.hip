@@ -1,5 +1,6 @@
 /*
- * bdf_mem.hip -- memory-resident thread-per-instance integrator for large systems (n > 64).
+ * bdf_mem.hip -- memory-resident thread-per-instance MAPPING for large systems (n > 128) and for forward
+ * sensitivities beyond the lane groups.
  *
  * One lane = one integrator as in bdf_kernels.hip, but the vectors, the Nordsieck array, the Newton
  * matrix / saved Jacobian and the LU live in an HBM workspace laid out [field element][instance]
@@ -8,10 +9,15 @@
  * coalesced 512-byte transaction served by L1/L2.  Control scalars (h, q, tau, l, tq, counters) stay
  * in registers.  Loops over components are real loops (code size independent of n); the generated
  * callbacks read the state through SA_Y / SA_LAM and write through SA_STORE with the workspace
- * stride, and run with full lane utilisation (each lane evaluates its own instance), which is what
- * makes this mapping preferable to a cooperative one when the callbacks dominate (n = 100: the
- * dense Jacobian has 10^4 entries).  The dense LU is the serial denseGETRF per lane; its n^3/3
- * multiply-adds stream through L2.
+ * stride, and run with full lane utilisation (each lane evaluates its own instance).  The dense LU
+ * is the serial denseGETRF per lane; its n^3/3 multiply-adds stream through L2.
+ *
+ * Round 5: this file is a MAPPING of csrc/bdf_core.h like bdf_kernels.hip and bdf_wave.hip -- the
+ * controller (cvHin, Nordsieck updates, Newton loop, error tests, order selection, sensitivity
+ * correctors, cv_attempt) is that one header; here a vector field of the state is a strided VIEW of
+ * the workspace (m.zn[j][r], m.acor[r], ... index HBM), the loops over vector slots are run-time loops
+ * (VFOR / QFOR), and the hooks below are the norms, the callbacks, the dense LU and the interpolation.
+ * Until round 4 the file carried its own loop-based restatement of the controller (1 805 lines).
  *
  * Same algorithm, operation order and rounding as the CPU oracle (restated CVODES 5.x; reference call
  * sites /root/reference/sunode/solver.py:467-527, 682-784): explicit FMAs, reciprocal pivots,
@@ -35,6 +41,11 @@
 #include SA_PROBLEM_HEADER
 #undef sa_ystride
 #include "sa_device_abi.h"
+/* bdf_core.h's loops over the slots of a vector: real loops over the n (p) components */
+#define VFOR(r) _Pragma("nounroll") for (int r = 0; r < NS; r++) {
+#define VEND }
+#define QFOR(r) _Pragma("nounroll") for (int r = 0; r < NQ; r++) {
+#define QEND }
 #include "sa_common.h"
 
 #define TREC (8 + 6 * NS)
@@ -45,14 +56,15 @@ constexpr int next_pow2_c(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 /* workspace field offsets (in elements; element e of the lane's instance is w[e * S]) */
 #define O_ZN 0
 #define O_ZNQ (O_ZN + 6 * NS)
-#define O_EWT (O_ZNQ + 6 * NQ)
+#define O_ZSAVE (O_ZNQ + 6 * NQ)
+#define O_ZSAVEQ (O_ZSAVE + NS)
+#define O_EWT (O_ZSAVEQ + NQ)
 #define O_ACOR (O_EWT + NS)
 #define O_TEMPV (O_ACOR + NS)
 #define O_FTEMP (O_TEMPV + NS)
 #define O_Y (O_FTEMP + NS)
 #define O_YTMP (O_Y + NS)
-#define O_DELTA (O_YTMP + NS)
-#define O_EWTQ (O_DELTA + NS)
+#define O_EWTQ (O_YTMP + NS)
 #define O_ACORQ (O_EWTQ + NQ)
 #define O_TEMPVQ (O_ACORQ + NQ)
 #define O_LAM (O_TEMPVQ + NQ)
@@ -63,20 +75,13 @@ constexpr int next_pow2_c(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 #define O_PIV (O_SJ + NS * NS)
 #define O_INVP (O_PIV + NS)
 #define O_HY (O_INVP + NS)
-#define O_TREE (O_HY + 6 * NS)
-#ifdef SA_SENS      /* forward sensitivities: Nordsieck arrays and work vectors of the NQ sensitivity systems */
-#define O_ZNS (O_TREE + PS_TREE)
-#define O_EWTS (O_ZNS + 6 * NQ * NS)
-#define O_ACORS (O_EWTS + NQ * NS)
-#define O_TEMPVS (O_ACORS + NQ * NS)
-#define O_FTEMPS (O_TEMPVS + NQ * NS)
-#define O_YS (O_FTEMPS + NQ * NS)
-#define O_DELTAS (O_YS + NQ * NS)
-#define O_DP (O_DELTAS + NQ * NS)
+#define O_F0 (O_HY + 6 * NS)
+#define O_TREE (O_F0 + NS)
+#ifdef SA_SENS      /* forward sensitivities: the SV_COUNT vectors of the NQ sensitivity systems (sa_common.h), J and df/dp */
+#define O_SV (O_TREE + PS_TREE)
+#define O_DP (O_SV + SV_COUNT * NQ * NS)
 #define O_JT (O_DP + NQ * NS)
 #define WS_DOUBLES (O_JT + NS * NS)
-#define ZNS(m, j, is, i) W(m, O_ZNS, ((j) * NQ + (is)) * NS + (i))
-#define VS(m, off, is, i) W(m, off, (is) * NS + (i))
 #else
 #define WS_DOUBLES (O_TREE + PS_TREE)
 #endif
@@ -89,12 +94,33 @@ struct StrideSink {
     __device__ __forceinline__ void put_dyn(int slot, double x) const { p[(int64_t)slot * stride] = x; }
 };
 
+/* a vector of the instance: element r at p[r * S] (workspace: S = instance stride; caller arrays: S = 1) */
+struct Vec {
+    double *p;
+    int64_t S;
+    __device__ __forceinline__ double &operator[](int r) const { return p[(int64_t)r * S]; }
+};
+/* the Nordsieck arrays: column j = the vector starting n elements further on */
+struct Cols {
+    double *p;
+    int64_t S;
+    int n;
+    __device__ __forceinline__ Vec operator[](int j) const { return Vec{p + (int64_t)j * n * S, S}; }
+};
+/* absolute tolerances: a per-component vector (forward problem) or one scalar (backward problem) */
+struct Atol {
+    const double *p;
+    double s;
+    __device__ __forceinline__ double operator[](int r) const { return p ? p[r] : s; }
+};
+
 template <bool BWD>
 struct Cm {
     double *w;                 /* workspace, pre-offset to the lane's instance */
     int64_t S;                 /* instance stride of the workspace */
-    double atol_s;             /* backward: scalar atol; forward: per-component vector via atol_p */
-    const double *atol_p;
+    Cols zn, znQ;
+    Vec zsave, zsaveQ, ewt, acor, tempv, ftemp, y, ytmp, ewtQ, acorQ, tempvQ, f0;
+    Atol atol;
     double rtol, rtolQ, atolQ;
     double tn, h, hprime, hscale, eta, etamax, hu;
     int q, qprime, L, qwait, qu;
@@ -112,97 +138,98 @@ struct Cm {
     int ilast, newdata, have_last, cur_idx;
     double last_t, tlo, thi, tlo2;
     int n_interp, n_rebuild;
-    /* forward sensitivities (only the SA_SENS build sets sensi) */
     const double *cons;        /* CVodeSetConstraints vector (global) or nullptr */
+    int constr;
+    int lane;                  /* (unused: one lane = one instance) */
+    /* forward sensitivities (only the SA_SENS build sets sensi) */
     int sensi, ism;
     double pbar[NQD], crateS, delpS, acnrmS;
     int nfSe, nniS, ncfnS, netfS, nsetupsS;
 };
 
 #define W(m, off, i) (m).w[(int64_t)((off) + (i)) * (m).S]
-#define ZN(m, j, i) W(m, O_ZN, (j) * NS + (i))
-#define ZNQ(m, j, i) W(m, O_ZNQ, (j) * NQ + (i))
+template <bool BWD>
+DEV Vec wvec(const Cm<BWD> &m, int off) { return Vec{m.w + (int64_t)off * m.S, m.S}; }
+
+/* point the vector fields of the state at the lane's workspace */
+template <bool BWD>
+DEV void bind_workspace(Cm<BWD> &m, double *ws, int64_t stride, int inst)
+{
+    m.S = stride;
+    m.w = ws + inst;
+    m.lane = 0;
+    m.zn = Cols{m.w + (int64_t)O_ZN * m.S, m.S, NS};
+    m.znQ = Cols{m.w + (int64_t)O_ZNQ * m.S, m.S, NQ};
+    m.zsave = wvec(m, O_ZSAVE); m.zsaveQ = wvec(m, O_ZSAVEQ); m.ewt = wvec(m, O_EWT); m.acor = wvec(m, O_ACOR);
+    m.tempv = wvec(m, O_TEMPV); m.ftemp = wvec(m, O_FTEMP); m.y = wvec(m, O_Y); m.ytmp = wvec(m, O_YTMP);
+    m.ewtQ = wvec(m, O_EWTQ); m.acorQ = wvec(m, O_ACORQ); m.tempvQ = wvec(m, O_TEMPVQ); m.f0 = wvec(m, O_F0);
+}
+
+/* ---- the mapping bdf_core.h needs (see its header) ---- */
+#define SA_STATE Cm
+#define RS (NS > 0 ? NS : 1)
+#define RQ NQD
+#define IDX(m, r) (r)
+#define wave_max(lane, x) (x)
+#define COLD_STORE(m)
+#define COLD_LOAD(m)
+#define PH_T0
+#define PH_ADD(m, k)
+#define SA_POLY_CM(BWD) false
+#ifdef SA_SENS
+#define SENS_ON(m) (!BWD && (m).sensi)
+#define SV(m, v, is, r) W(m, O_SV, (((v) * NQ + (is)) * NS) + (r))
+#define SLOOP_BEGIN(is) for (int is = 0; is < NQ; is++) {
+#define SLOOP_END }
+#endif
 
 /* ---- norms: balanced tree over the zero-padded power-of-two array, as in the oracle ---- */
-template <bool BWD>
-DEV double wrms_off(Cm<BWD> &m, int xoff, int woff, int n)
+template <bool BWD, class X, class Wt>
+DEV double wrms_gen(const Cm<BWD> &m, const X &x, const Wt &w, int n)
 {
     if (n == 0) return 0.0;
     int P = 1;
     while (P < n) P <<= 1;
     for (int i = 0; i < P; i++) {
-        double prod = (i < n) ? W(m, xoff, i) * W(m, woff, i) : 0.0;
+        double prod = (i < n) ? x[i] * w[i] : 0.0;
         W(m, O_TREE, i) = prod * prod;
     }
     for (int s = 1; s < P; s <<= 1)
         for (int i = 0; i < P; i += 2 * s) W(m, O_TREE, i) = W(m, O_TREE, i) + W(m, O_TREE, i + s);
     return sqrt(W(m, O_TREE, 0) / n);
 }
-
-template <bool BWD> DEV double wrms_n(Cm<BWD> &m, int xoff) { return wrms_off(m, xoff, O_EWT, NS); }
-template <bool BWD> DEV double wrms_q(Cm<BWD> &m, int xoff) { return wrms_off(m, xoff, O_EWTQ, NQ); }
-
-template <bool BWD>
-DEV double quad_update_norm(Cm<BWD> &m, double old_nrm, int xoff)
+template <bool BWD, class X, class Wt> DEV double wrms_n(const Cm<BWD> &m, const X &x, const Wt &w) { return wrms_gen(m, x, w, NS); }
+template <bool BWD, class X, class Wt> DEV double wrms_q(const Cm<BWD> &m, const X &x, const Wt &w) { return wrms_gen(m, x, w, NQ); }
+template <bool BWD, class X>
+DEV double quad_update_norm(const Cm<BWD> &m, double old_nrm, const X &xQ)
 {
-    double qnrm = wrms_q(m, xoff);
+    double qnrm = wrms_q(m, xQ, m.ewtQ);
     return old_nrm > qnrm ? old_nrm : qnrm;
 }
 
-template <bool BWD> DEV double atol_of(const Cm<BWD> &m, int i) { return BWD ? m.atol_s : m.atol_p[i]; }
-
-template <bool BWD>
-DEV int ewt_set(Cm<BWD> &m, int yoff, int woff)
+template <bool BWD, class Y, class Wt>
+DEV int ewt_set(const Cm<BWD> &m, const Y &ycur, Wt &&w)
 {
     int bad = 0;
     for (int i = 0; i < NS; i++) {
-        double v = FMA(m.rtol, fabs(W(m, yoff, i)), atol_of(m, i));
+        double v = FMA(m.rtol, fabs(ycur[i]), m.atol[i]);
         bad |= (v <= 0.0);
-        W(m, woff, i) = 1.0 / v;
+        w[i] = 1.0 / v;
     }
     return bad ? -1 : 0;
 }
 
-template <bool BWD>
-DEV int ewtQ_set(Cm<BWD> &m, int qoff, int woff)
+template <bool BWD, class Q, class Wt>
+DEV int ewtQ_set(const Cm<BWD> &m, const Q &qcur, Wt &&w)
 {
     int bad = 0;
     for (int i = 0; i < NQ; i++) {
-        double v = FMA(m.rtolQ, fabs(W(m, qoff, i)), m.atolQ);
+        double v = FMA(m.rtolQ, fabs(qcur[i]), m.atolQ);
         bad |= (v <= 0.0);
-        W(m, woff, i) = 1.0 / v;
+        w[i] = 1.0 / v;
     }
     return bad ? -1 : 0;
 }
-
-#ifdef SA_SENS
-/* cvSensEwtSetEE / cvSensUpdateNorm (see the oracle) */
-template <bool BWD>
-DEV int sens_ewt_set(Cm<BWD> &m, int ysoff, int woff)
-{
-    int bad = 0;
-    for (int is = 0; is < NQ; is++) {
-        const double pb = pick(m.pbar, is);
-        for (int i = 0; i < NS; i++) {
-            double v = FMA(m.rtol, fabs(pb * VS(m, ysoff, is, i)), atol_of(m, i));
-            bad |= (v <= 0.0);
-            VS(m, woff, is, i) = pb * (1.0 / v);
-        }
-    }
-    return bad ? -1 : 0;
-}
-
-template <bool BWD>
-DEV double sens_update_norm(Cm<BWD> &m, double old_nrm, int xoff, int woff)
-{
-    double nrm = old_nrm;
-    for (int is = 0; is < NQ; is++) {
-        double snrm = wrms_off(m, xoff + is * NS, woff + is * NS, NS);
-        if (snrm > nrm) nrm = snrm;
-    }
-    return nrm;
-}
-#endif
 
 /* ---- stored trajectory (records as in bdf_kernels.hip, read straight from global memory) ---- */
 template <bool BWD>
@@ -261,7 +288,7 @@ DEV int interp_y(Cm<BWD> &m, double t)
     m.have_last = 1;
     m.last_t = t;
     if (indx == 0) {
-        for (int i = 0; i < NS; i++) W(m, O_YTMP, i) = rec(m, 0, 8 + i);
+        for (int i = 0; i < NS; i++) m.ytmp[i] = rec(m, 0, 8 + i);
         return CV_SUCCESS;
     }
 #ifdef SA_HERMITE
@@ -288,7 +315,7 @@ DEV int interp_y(Cm<BWD> &m, double t)
             double acc = FMA(factor1, rec(m, indx - 1, 8 + NS + i), rec(m, indx - 1, 8 + i));
             acc = FMA(factor2, W(m, O_HY, i), acc);
             acc = FMA(factor3, W(m, O_HY, NS + i), acc);
-            W(m, O_YTMP, i) = acc;
+            m.ytmp[i] = acc;
         }
         return CV_SUCCESS;
     }
@@ -309,55 +336,55 @@ DEV int interp_y(Cm<BWD> &m, double t)
         for (int k = 0; k < NS; k++) {
             double acc = cvals[0] * rec(m, ci, 8 + k);
             SFOR(i, 1, (QMAX) + 1) if (i <= order) acc = FMA(cvals[i], rec(m, ci, 8 + i * NS + k), acc); SEND
-            W(m, O_YTMP, k) = acc;
+            m.ytmp[k] = acc;
         }
     }
     return CV_SUCCESS;
 }
 
-/* ---- callbacks through strided views of the workspace ---- */
+/* ---- callbacks through strided views of the workspace (inputs and outputs are workspace vectors: one stride) ---- */
 template <bool BWD>
-DEV int cv_f(Cm<BWD> &m, double t, int yoff, int outoff)
+DEV int cv_f(Cm<BWD> &m, double t, const Vec &y, const Vec &out)
 {
     m.nfe++;
-    StrideSink sink{&W(m, outoff, 0), m.S};
-    if (BWD) return sa_adj_rhs(t, &W(m, O_YTMP, 0), &W(m, yoff, 0), m.ps, m.pr, sink);
-    return sa_rhs(t, &W(m, yoff, 0), m.ps, m.pr, sink);
+    StrideSink sink{out.p, out.S};
+    if (BWD) return sa_adj_rhs(t, m.ytmp.p, y.p, m.ps, m.pr, sink);
+    return sa_rhs(t, y.p, m.ps, m.pr, sink);
 }
 
 template <bool BWD>
-DEV int cv_fQ(Cm<BWD> &m, double t, int yoff, int outoff)
+DEV int cv_fQ(Cm<BWD> &m, double t, const Vec &y, const Vec &out)
 {
     m.nfQe++;
-    StrideSink sink{&W(m, outoff, 0), m.S};
-    return sa_quad_rhs(t, &W(m, O_YTMP, 0), &W(m, yoff, 0), m.ps, m.pr, sink);
+    StrideSink sink{out.p, out.S};
+    return sa_quad_rhs(t, m.ytmp.p, y.p, m.ps, m.pr, sink);
 }
 
 template <bool BWD>
-DEV int cv_jac(Cm<BWD> &m, double t, int yoff)
+DEV int cv_jac(Cm<BWD> &m, double t, const Vec &y)
 {
     StrideSink sink{&W(m, O_A, 0), m.S};
-    if (BWD) return sa_adj_jac(t, &W(m, O_YTMP, 0), m.ps, m.pr, sink);
-    return sa_jac(t, &W(m, yoff, 0), m.ps, m.pr, sink);
+    if (BWD) return sa_adj_jac(t, m.ytmp.p, m.ps, m.pr, sink);
+    return sa_jac(t, y.p, m.ps, m.pr, sink);
 }
 
 #ifdef SA_SENS
-/* sensitivity right-hand side for all parameters: out[is] = J(t,y) yS[is] + df/dp_is (oracle cv_fS) */
-template <bool BWD>
-DEV int cv_fS(Cm<BWD> &m, double t, int yoff, int ysoff, int outoff)
+/* sensitivity right-hand side for all parameters: SV(v_out)[is] = J(t,y) SV(v_in)[is] + df/dp_is (oracle cv_fS) */
+template <int v_in, int v_out, bool BWD>
+DEV int cv_fS(Cm<BWD> &m, double t, const Vec &y)
 {
     m.nfSe++;
     StrideSink sj{&W(m, O_JT, 0), m.S}, sp{&W(m, O_DP, 0), m.S};
-    int rc = sa_jac(t, &W(m, yoff, 0), m.ps, m.pr, sj);
+    int rc = sa_jac(t, y.p, m.ps, m.pr, sj);
     if (rc != 0) return rc;
-    rc = sa_dydp(t, &W(m, yoff, 0), m.ps, m.pr, sp);
+    rc = sa_dydp(t, y.p, m.ps, m.pr, sp);
     int bad = 0;
     for (int is = 0; is < NQ; is++)
         for (int i = 0; i < NS; i++) {
-            double acc = W(m, O_JT, 0 * NS + i) * VS(m, ysoff, is, 0);
-            for (int j = 1; j < NS; j++) acc = FMA(W(m, O_JT, j * NS + i), VS(m, ysoff, is, j), acc);
-            acc = acc + VS(m, O_DP, is, i);
-            VS(m, outoff, is, i) = acc;
+            double acc = W(m, O_JT, 0 * NS + i) * SV(m, v_in, is, 0);
+            for (int j = 1; j < NS; j++) acc = FMA(W(m, O_JT, j * NS + i), SV(m, v_in, is, j), acc);
+            acc = acc + W(m, O_DP, is * NS + i);
+            SV(m, v_out, is, i) = acc;
             bad |= !(acc * 0.0 == 0.0);
         }
     return (rc != 0 || bad) ? 1 : 0;
@@ -399,318 +426,26 @@ DEV int dense_getrf(Cm<BWD> &m)
     return 0;
 }
 
-template <bool BWD>
-DEV void dense_getrs(Cm<BWD> &m, int boff)
+template <bool BWD, class B>
+DEV void dense_getrs(const Cm<BWD> &m, B &b)
 {
     for (int k = 0; k < NS; k++) {
         int pk = (int)W(m, O_PIV, k);
-        if (pk != k) { double tmp = W(m, boff, k); W(m, boff, k) = W(m, boff, pk); W(m, boff, pk) = tmp; }
+        if (pk != k) { double tmp = b[k]; b[k] = b[pk]; b[pk] = tmp; }
     }
     for (int k = 0; k < NS - 1; k++) {
-        double bk = W(m, boff, k);
-        for (int i = k + 1; i < NS; i++) W(m, boff, i) = FMA(-AE(m, i, k), bk, W(m, boff, i));
+        double bk = b[k];
+        for (int i = k + 1; i < NS; i++) b[i] = FMA(-AE(m, i, k), bk, b[i]);
     }
     for (int k = NS - 1; k > 0; k--) {
-        double bk = W(m, boff, k) * W(m, O_INVP, k);
-        W(m, boff, k) = bk;
-        for (int i = 0; i < k; i++) W(m, boff, i) = FMA(-AE(m, i, k), bk, W(m, boff, i));
+        double bk = b[k] * W(m, O_INVP, k);
+        b[k] = bk;
+        for (int i = 0; i < k; i++) b[i] = FMA(-AE(m, i, k), bk, b[i]);
     }
-    if (NS > 0) W(m, boff, 0) = W(m, boff, 0) * W(m, O_INVP, 0);
+    if (NS > 0) b[0] = b[0] * W(m, O_INVP, 0);
 }
 
-/* ---- CVodeInit / CVodeReInit (y0 / q0 already stored in zn[0] / znQ[0] by the caller) ---- */
-template <bool BWD>
-DEV void cv_reinit(Cm<BWD> &m, double t0)
-{
-    m.tn = t0;
-    m.q = 1; m.L = 2; m.qwait = 2; m.etamax = ETAMX1;
-    m.qu = 0; m.hu = 0.0;
-    m.nst = m.nfe = m.ncfn = m.netf = m.nni = m.nsetups = 0;
-    m.nje = 0; m.nstlp = 0; m.nstlj = 0; m.nfQe = m.netfQ = 0;
-    m.h = 0.0; m.hprime = 0.0; m.hscale = 0.0; m.eta = 1.0;
-    m.qprime = 1;
-    m.gamma = m.gammap = 0.0; m.gamrat = 1.0; m.crate = 1.0; m.delp = 0.0;
-    m.acnrm = 0.0; m.saved_tq5 = 0.0;
-    m.jcur = 0; m.nls_jcur = 0;
-    m.crateS = 1.0; m.delpS = 0.0; m.acnrmS = 0.0;
-    m.nfSe = m.nniS = m.ncfnS = m.netfS = m.nsetupsS = 0;
-    SFOR(i, 0, 7) { m.tau[i] = 0.0; m.l[i] = 0.0; } SEND
-    SFOR(i, 0, 6) m.tq[i] = 0.0; SEND
-}
-
-/* ---- cvHin ---- */
-template <bool BWD>
-DEV double cv_upper_bound_h0(Cm<BWD> &m, double tdist)
-{
-    double hub_inv = 0.0;
-    ewt_set(m, O_ZN, O_TEMPV);                         /* temp1 = ewt(zn[0]) */
-    for (int i = 0; i < NS; i++) {
-        double t2 = fabs(ZN(m, 0, i));
-        double t1 = 1.0 / W(m, O_TEMPV, i);
-        t1 = FMA(HUB_FACTOR, t2, t1);
-        double v = fabs(ZN(m, 1, i)) / t1;
-        if (v > hub_inv) hub_inv = v;
-    }
-    if (BWD) {
-        ewtQ_set(m, O_ZNQ, O_TEMPVQ);
-        double hubQ_inv = 0.0;
-        for (int i = 0; i < NQ; i++) {
-            double t2 = fabs(ZNQ(m, 0, i));
-            double t1 = 1.0 / W(m, O_TEMPVQ, i);
-            t1 = FMA(HUB_FACTOR, t2, t1);
-            double v = fabs(ZNQ(m, 1, i)) / t1;
-            if (v > hubQ_inv) hubQ_inv = v;
-        }
-        if (hubQ_inv > hub_inv) hub_inv = hubQ_inv;
-    }
-#ifdef SA_SENS
-    if (m.sensi) {
-        sens_ewt_set(m, O_ZNS, O_TEMPVS);
-        for (int is = 0; is < NQ; is++)
-            for (int i = 0; i < NS; i++) {
-                double t2 = fabs(ZNS(m, 0, is, i));
-                double t1 = 1.0 / VS(m, O_TEMPVS, is, i);
-                t1 = FMA(HUB_FACTOR, t2, t1);
-                double v = fabs(ZNS(m, 1, is, i)) / t1;
-                if (v > hub_inv) hub_inv = v;
-            }
-    }
-#endif
-    double hub = HUB_FACTOR * tdist;
-    if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
-    return hub;
-}
-
-template <bool BWD>
-DEV int cv_ydd_norm(Cm<BWD> &m, double hg, double *yddnrm)
-{
-    for (int i = 0; i < NS; i++) W(m, O_Y, i) = FMA(hg, ZN(m, 1, i), ZN(m, 0, i));
-    if (BWD) { if (interp_y(m, m.tn + hg) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-#ifdef SA_SENS
-    if (m.sensi)
-        for (int is = 0; is < NQ; is++)
-            for (int i = 0; i < NS; i++) VS(m, O_YS, is, i) = FMA(hg, ZNS(m, 1, is, i), ZNS(m, 0, is, i));
-#endif
-    int retval = cv_f(m, m.tn + hg, O_Y, O_TEMPV);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return RHSFUNC_RECVR;
-#ifdef SA_SENS
-    if (m.sensi) {
-        retval = cv_fS(m, m.tn + hg, O_Y, O_YS, O_TEMPVS);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return SRHSFUNC_RECVR;
-    }
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn + hg, O_Y, O_TEMPVQ);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return QRHSFUNC_RECVR;
-    }
-    for (int i = 0; i < NS; i++) {
-        double v = W(m, O_TEMPV, i) - ZN(m, 1, i);
-        W(m, O_TEMPV, i) = (1.0 / hg) * v;
-    }
-    *yddnrm = wrms_n(m, O_TEMPV);
-    if (BWD) {
-        for (int i = 0; i < NQ; i++) {
-            double v = W(m, O_TEMPVQ, i) - ZNQ(m, 1, i);
-            W(m, O_TEMPVQ, i) = (1.0 / hg) * v;
-        }
-        *yddnrm = quad_update_norm(m, *yddnrm, O_TEMPVQ);
-    }
-#ifdef SA_SENS
-    if (m.sensi) {
-        for (int is = 0; is < NQ; is++)
-            for (int i = 0; i < NS; i++) {
-                double v = VS(m, O_TEMPVS, is, i) - ZNS(m, 1, is, i);
-                VS(m, O_TEMPVS, is, i) = (1.0 / hg) * v;
-            }
-        *yddnrm = sens_update_norm(m, *yddnrm, O_TEMPVS, O_EWTS);
-    }
-#endif
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_hin(Cm<BWD> &m, double tout)
-{
-    double tdiff = tout - m.tn;
-    if (tdiff == 0.0) return CV_TOO_CLOSE;
-    double sign = (tdiff > 0.0) ? 1.0 : -1.0;
-    double tdist = fabs(tdiff);
-    double tround = UROUND * fmax(fabs(m.tn), fabs(tout));
-    if (tdist < 2.0 * tround) return CV_TOO_CLOSE;
-    double hlb = HLB_FACTOR * tround;
-    double hub = cv_upper_bound_h0(m, tdist);
-    double hg = sqrt(hlb * hub);
-    if (hub < hlb) {
-        m.h = (sign < 0.0) ? -hg : hg;
-        return CV_SUCCESS;
-    }
-    double hs = hg, hnew = hg, yddnrm = 0.0;
-    int result = 1;
-    for (int count1 = 1; count1 <= HIN_MAX_ITERS && result == 1; count1++) {
-        int hgOK = 0;
-        for (int count2 = 1; count2 <= HIN_MAX_ITERS; count2++) {
-            double hgs = hg * sign;
-            int retval = cv_ydd_norm(m, hgs, &yddnrm);
-            if (retval < 0) { result = CV_RHSFUNC_FAIL; break; }
-            if (retval == CV_SUCCESS) { hgOK = 1; break; }
-            hg *= 0.2;
-        }
-        if (result != 1) break;
-        if (!hgOK) {
-            if (count1 <= 2) { result = CV_REPTD_RHSFUNC_ERR; break; }
-            hnew = hs;
-            result = 0;
-            break;
-        }
-        hs = hg;
-        hnew = (yddnrm * hub * hub > 2.0) ? sqrt(2.0 / yddnrm) : sqrt(hg * hub);
-        if (count1 == HIN_MAX_ITERS) { result = 0; break; }
-        double hrat = hnew / hg;
-        if ((hrat > 0.5) && (hrat < 2.0)) { result = 0; break; }
-        if ((count1 > 1) && (hrat > 2.0)) { hnew = hg; result = 0; break; }
-        hg = hnew;
-    }
-    if (result < 0) return result;
-    double h0 = H_BIAS * hnew;
-    if (h0 < hlb) h0 = hlb;
-    if (h0 > hub) h0 = hub;
-    if (sign < 0.0) h0 = -h0;
-    m.h = h0;
-    return CV_SUCCESS;
-}
-
-/* ---- Nordsieck array manipulation (oracle form: columns 1..q, saved correction in zn[qmax]) ---- */
-template <bool BWD>
-DEV void cv_rescale(Cm<BWD> &m)
-{
-    double factor = m.eta;
-    for (int j = 1; j <= m.q; j++) {
-        for (int i = 0; i < NS; i++) ZN(m, j, i) *= factor;
-        if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j, i) *= factor;
-#ifdef SA_SENS
-        if (m.sensi) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) ZNS(m, j, is, i) *= factor;
-#endif
-        factor *= m.eta;
-    }
-    m.h = m.hscale * m.eta;
-    m.hscale = m.h;
-}
-
-template <bool BWD>
-DEV void cv_increase_bdf(Cm<BWD> &m)
-{
-    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
-    double alpha1 = 1.0, prod = 1.0, xiold = 1.0, alpha0 = -1.0, hsum = m.hscale;
-    m.l[2] = 1.0;
-    SFOR(j, 1, QMAX - 1) {
-        if (j < m.q) {
-            hsum += m.tau[j + 1];
-            double xi = hsum / m.hscale;
-            prod *= xi;
-            alpha0 -= 1.0 / (j + 1);
-            alpha1 += 1.0 / xi;
-            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xiold, m.l[i - 1]); SEND
-            xiold = xi;
-        }
-    } SEND
-    const double A1 = (-alpha0 - alpha1) / prod;
-    const int L = m.L;
-    for (int i = 0; i < NS; i++) ZN(m, L, i) = A1 * ZN(m, QMAX, i);
-    for (int j = 2; j <= m.q; j++) {
-        const double lj = pick(m.l, j);
-        for (int i = 0; i < NS; i++) ZN(m, j, i) = FMA(lj, ZN(m, L, i), ZN(m, j, i));
-    }
-    if (BWD) {
-        for (int i = 0; i < NQ; i++) ZNQ(m, L, i) = A1 * ZNQ(m, QMAX, i);
-        for (int j = 2; j <= m.q; j++) {
-            const double lj = pick(m.l, j);
-            for (int i = 0; i < NQ; i++) ZNQ(m, j, i) = FMA(lj, ZNQ(m, L, i), ZNQ(m, j, i));
-        }
-    }
-#ifdef SA_SENS
-    if (m.sensi)
-        for (int is = 0; is < NQ; is++) {
-            for (int i = 0; i < NS; i++) ZNS(m, L, is, i) = A1 * ZNS(m, QMAX, is, i);
-            for (int j = 2; j <= m.q; j++) {
-                const double lj = pick(m.l, j);
-                for (int i = 0; i < NS; i++) ZNS(m, j, is, i) = FMA(lj, ZNS(m, L, is, i), ZNS(m, j, is, i));
-            }
-        }
-#endif
-}
-
-template <bool BWD>
-DEV void cv_decrease_bdf(Cm<BWD> &m)
-{
-    SFOR(i, 0, (QMAX) + 1) m.l[i] = 0.0; SEND
-    m.l[2] = 1.0;
-    double hsum = 0.0;
-    SFOR(j, 1, (QMAX - 2) + 1) {
-        if (j <= m.q - 2) {
-            hsum += m.tau[j];
-            double xi = hsum / m.hscale;
-            SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xi, m.l[i - 1]); SEND
-        }
-    } SEND
-    for (int j = 2; j < m.q; j++) {
-        const double lj = pick(m.l, j);
-        for (int i = 0; i < NS; i++) ZN(m, j, i) = FMA(-lj, ZN(m, m.q, i), ZN(m, j, i));
-        if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j, i) = FMA(-lj, ZNQ(m, m.q, i), ZNQ(m, j, i));
-#ifdef SA_SENS
-        if (m.sensi)
-            for (int is = 0; is < NQ; is++)
-                for (int i = 0; i < NS; i++) ZNS(m, j, is, i) = FMA(-lj, ZNS(m, m.q, is, i), ZNS(m, j, is, i));
-#endif
-    }
-}
-
-template <bool BWD>
-DEV void cv_adjust_order(Cm<BWD> &m, int deltaq)
-{
-    if ((m.q == 2) && (deltaq != 1)) return;
-    if (deltaq == 1) cv_increase_bdf(m);
-    else if (deltaq == -1) cv_decrease_bdf(m);
-}
-
-template <bool BWD>
-DEV void cv_predict(Cm<BWD> &m)
-{
-    m.tn += m.h;
-    if (BWD) {
-        if ((m.tn - m.tstop) * m.h > 0.0) m.tn = m.tstop;
-    }
-    for (int k = 1; k <= m.q; k++)
-        for (int j = m.q; j >= k; j--) {
-            for (int i = 0; i < NS; i++) ZN(m, j - 1, i) = ZN(m, j - 1, i) + ZN(m, j, i);
-            if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j - 1, i) = ZNQ(m, j - 1, i) + ZNQ(m, j, i);
-#ifdef SA_SENS
-            if (m.sensi)
-                for (int is = 0; is < NQ; is++)
-                    for (int i = 0; i < NS; i++) ZNS(m, j - 1, is, i) = ZNS(m, j - 1, is, i) + ZNS(m, j, is, i);
-#endif
-        }
-}
-
-template <bool BWD>
-DEV void cv_restore(Cm<BWD> &m, double saved_t)
-{
-    m.tn = saved_t;
-    for (int k = 1; k <= m.q; k++)
-        for (int j = m.q; j >= k; j--) {
-            for (int i = 0; i < NS; i++) ZN(m, j - 1, i) = ZN(m, j - 1, i) - ZN(m, j, i);
-            if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j - 1, i) = ZNQ(m, j - 1, i) - ZNQ(m, j, i);
-#ifdef SA_SENS
-            if (m.sensi)
-                for (int is = 0; is < NQ; is++)
-                    for (int i = 0; i < NS; i++) ZNS(m, j - 1, is, i) = ZNS(m, j - 1, is, i) - ZNS(m, j, is, i);
-#endif
-        }
-}
-
-/* ---- linear solver interface ---- */
+/* cvLsSetup on SUNLinSol_Dense: Jacobian (fresh or saved), I - gamma J, LU */
 template <bool BWD>
 DEV int cv_lsetup(Cm<BWD> &m, int convfail)
 {
@@ -726,7 +461,7 @@ DEV int cv_lsetup(Cm<BWD> &m, int convfail)
         m.nje++;
         m.nstlj = m.nst;
         m.jcur = 1;
-        jret = cv_jac(m, m.tn, O_Y);
+        jret = cv_jac(m, m.tn, m.y);
         if (jret == 0) { for (int i = 0; i < NS * NS; i++) W(m, O_SJ, i) = W(m, O_A, i); }
     }
     if (jret < 0) return -1;
@@ -741,624 +476,7 @@ DEV int cv_lsetup(Cm<BWD> &m, int convfail)
     return ier > 0 ? 1 : 0;
 }
 
-template <bool BWD>
-DEV int cv_nls_lsetup(Cm<BWD> &m, int jbad, int &convfail)
-{
-    if (jbad) convfail = CV_FAIL_BAD_J;
-    int retval = cv_lsetup(m, convfail);
-    m.nsetups++;
-    m.nls_jcur = m.jcur;
-    m.gamrat = 1.0;
-    m.gammap = m.gamma;
-    m.crate = 1.0;
-    m.crateS = 1.0;
-    m.nstlp = m.nst;
-    if (retval < 0) return CV_LSETUP_FAIL;
-    if (retval > 0) return NLS_CONV_RECVR;
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_nls_residual(Cm<BWD> &m)          /* res -> O_DELTA */
-{
-    for (int i = 0; i < NS; i++) W(m, O_Y, i) = ZN(m, 0, i) + W(m, O_ACOR, i);
-    int retval = cv_f(m, m.tn, O_Y, O_FTEMP);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return RHSFUNC_RECVR;
-    for (int i = 0; i < NS; i++) {
-        double r = FMA(m.rl1, ZN(m, 1, i), W(m, O_ACOR, i));
-        W(m, O_DELTA, i) = FMA(-m.gamma, W(m, O_FTEMP, i), r);
-    }
-    return CV_SUCCESS;
-}
-
-#ifdef SA_SENS
-/* cvNlsResidualSensSim: residuals of the sensitivity systems -> O_DELTAS */
-template <bool BWD>
-DEV int cv_nls_residual_sens(Cm<BWD> &m)
-{
-    for (int is = 0; is < NQ; is++)
-        for (int i = 0; i < NS; i++) VS(m, O_YS, is, i) = ZNS(m, 0, is, i) + VS(m, O_ACORS, is, i);
-    int retval = cv_fS(m, m.tn, O_Y, O_YS, O_FTEMPS);
-    if (retval < 0) return CV_SRHSFUNC_FAIL;
-    if (retval > 0) return SRHSFUNC_RECVR;
-    for (int is = 0; is < NQ; is++)
-        for (int i = 0; i < NS; i++) {
-            double r = FMA(m.rl1, ZNS(m, 1, is, i), VS(m, O_ACORS, is, i));
-            VS(m, O_DELTAS, is, i) = FMA(-m.gamma, VS(m, O_FTEMPS, is, i), r);
-        }
-    return CV_SUCCESS;
-}
-
-/* one Newton update of every sensitivity system with the current factorisation */
-template <bool BWD>
-DEV void cv_sens_newton_update(Cm<BWD> &m)
-{
-    for (int is = 0; is < NQ; is++) {
-        for (int i = 0; i < NS; i++) VS(m, O_DELTAS, is, i) = -1.0 * VS(m, O_DELTAS, is, i);
-        dense_getrs(m, O_DELTAS + is * NS);
-        if (m.gamrat != 1.0) {
-            double s = 2.0 / (1.0 + m.gamrat);
-            for (int i = 0; i < NS; i++) VS(m, O_DELTAS, is, i) *= s;
-        }
-        for (int i = 0; i < NS; i++) VS(m, O_ACORS, is, i) = VS(m, O_ACORS, is, i) + VS(m, O_DELTAS, is, i);
-    }
-}
-#endif
-
-template <bool BWD>
-DEV int cv_newton_pass(Cm<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
-{
-#ifdef SA_SENS
-    const bool sim = m.sensi && m.ism == 0;
-#else
-    const bool sim = false;
-#endif
-    in_loop = 0;
-    for (int i = 0; i < NS; i++) W(m, O_ACOR, i) = 0.0;
-#ifdef SA_SENS
-    if (sim) for (int j = 0; j < NQ * NS; j++) W(m, O_ACORS, j) = 0.0;
-#endif
-    int retval = cv_nls_residual(m);
-    if (retval != CV_SUCCESS) return retval;
-#ifdef SA_SENS
-    if (sim) {
-        retval = cv_nls_residual_sens(m);
-        if (retval != CV_SUCCESS) return retval;
-    }
-#endif
-    if (callSetup) {
-        retval = cv_nls_lsetup(m, jbad, convfail);
-        if (retval != CV_SUCCESS) return retval;
-    }
-    int curiter = 0;
-    in_loop = 1;
-    for (;;) {
-        m.nni++;
-        for (int i = 0; i < NS; i++) W(m, O_DELTA, i) = -1.0 * W(m, O_DELTA, i);
-        dense_getrs(m, O_DELTA);
-        if (m.gamrat != 1.0) {
-            double s = 2.0 / (1.0 + m.gamrat);
-            for (int i = 0; i < NS; i++) W(m, O_DELTA, i) *= s;
-        }
-        for (int i = 0; i < NS; i++) W(m, O_ACOR, i) = W(m, O_ACOR, i) + W(m, O_DELTA, i);
-        double del = wrms_n(m, O_DELTA);
-#ifdef SA_SENS
-        if (sim) {
-            cv_sens_newton_update(m);
-            del = sens_update_norm(m, del, O_DELTAS, O_EWTS);
-        }
-#endif
-        if (curiter > 0) m.crate = fmax(CRDOWN * m.crate, del / m.delp);
-        double dcon = del * fmin(1.0, m.crate) * m.tq[4];
-        if (dcon <= 1.0) {
-            if (curiter == 0) m.acnrm = del;
-            else {
-                m.acnrm = wrms_n(m, O_ACOR);
-#ifdef SA_SENS
-                if (sim) m.acnrm = sens_update_norm(m, m.acnrm, O_ACORS, O_EWTS);
-#endif
-            }
-            m.nls_jcur = 0;
-            return CV_SUCCESS;
-        }
-        if ((curiter >= 1) && (del > RDIV * m.delp)) return NLS_CONV_RECVR;
-        m.delp = del;
-        curiter++;
-        if (curiter >= NLS_MAXCOR) return NLS_CONV_RECVR;
-        retval = cv_nls_residual(m);
-        if (retval != CV_SUCCESS) return retval;
-#ifdef SA_SENS
-        if (sim) {
-            retval = cv_nls_residual_sens(m);
-            if (retval != CV_SUCCESS) return retval;
-        }
-#endif
-    }
-}
-
-#ifdef SA_SENS
-/* cvStgrNls (ism = CV_STAGGERED): Newton on the sensitivity systems with the state fixed */
-template <bool BWD>
-DEV int cv_stgr_nls(Cm<BWD> &m)
-{
-    int callSetup = 0, jbad = 0, convfail = CV_FAIL_OTHER, retval;
-    for (int j = 0; j < NQ * NS; j++) W(m, O_ACORS, j) = 0.0;
-    for (;;) {
-        retval = cv_nls_residual_sens(m);
-        if (retval != CV_SUCCESS) break;
-        if (callSetup) {
-            retval = cv_nls_lsetup(m, jbad, convfail);
-            m.nsetupsS++;
-            if (retval != CV_SUCCESS) break;
-        }
-        int curiter = 0;
-        for (;;) {
-            m.nniS++;
-            cv_sens_newton_update(m);
-            double del = sens_update_norm(m, 0.0, O_DELTAS, O_EWTS);
-            if (curiter > 0) m.crateS = fmax(CRDOWN * m.crateS, del / m.delpS);
-            double dcon = del * fmin(1.0, m.crateS) * m.tq[4];
-            if (dcon <= 1.0) {
-                m.acnrmS = (curiter == 0) ? del : sens_update_norm(m, 0.0, O_ACORS, O_EWTS);
-                retval = CV_SUCCESS;
-                m.nls_jcur = 0;
-                break;
-            }
-            if ((curiter >= 1) && (del > RDIV * m.delpS)) { retval = NLS_CONV_RECVR; break; }
-            m.delpS = del;
-            curiter++;
-            if (curiter >= NLS_MAXCOR) { retval = NLS_CONV_RECVR; break; }
-            retval = cv_nls_residual_sens(m);
-            if (retval != CV_SUCCESS) break;
-        }
-        if (retval == CV_SUCCESS) break;
-        if ((retval > 0) && !m.nls_jcur) {
-            callSetup = 1;
-            jbad = 1;
-            for (int j = 0; j < NQ * NS; j++) W(m, O_ACORS, j) = 0.0;
-            continue;
-        }
-        break;
-    }
-    if (retval != CV_SUCCESS) return retval;
-    for (int is = 0; is < NQ; is++)
-        for (int i = 0; i < NS; i++) VS(m, O_YS, is, i) = ZNS(m, 0, is, i) + VS(m, O_ACORS, is, i);
-    return CV_SUCCESS;
-}
-#endif
-
-template <bool BWD>
-DEV int cv_error_test_failed(Cm<BWD> &m, double saved_t, double dsm, int &nef, int &netf_counter)
-{
-    nef++;
-    netf_counter++;
-    cv_restore(m, saved_t);
-    if (nef == MXNEF) return CV_ERR_FAILURE;
-    m.etamax = 1.0;
-    if (nef <= MXNEF1) {
-        m.eta = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
-        m.eta = fmax(ETAMIN, m.eta);
-        if (nef >= SMALL_NEF) m.eta = fmin(m.eta, ETAMXF);
-        cv_rescale(m);
-        return 0;
-    }
-    if (m.q > 1) {
-        m.eta = ETAMIN;
-        cv_adjust_order(m, -1);
-        m.L = m.q;
-        m.q--;
-        m.qwait = m.L;
-        cv_rescale(m);
-        return 0;
-    }
-    m.eta = ETAMIN;
-    m.h *= m.eta;
-    m.hscale = m.h;
-    m.qwait = LONG_WAIT;
-    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-    int retval = cv_f(m, m.tn, O_ZN, O_TEMPV);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return CV_UNREC_RHSFUNC_ERR;
-    for (int i = 0; i < NS; i++) ZN(m, 1, i) = m.h * W(m, O_TEMPV, i);
-#ifdef SA_SENS
-    if (m.sensi) {
-        retval = cv_fS(m, m.tn, O_ZN, O_ZNS, O_TEMPVS);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return CV_UNREC_SRHSFUNC_ERR;
-        for (int is = 0; is < NQ; is++)
-            for (int i = 0; i < NS; i++) ZNS(m, 1, is, i) = m.h * VS(m, O_TEMPVS, is, i);
-    }
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn, O_ZN, O_TEMPVQ);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return CV_UNREC_QRHSFUNC_ERR;
-        for (int i = 0; i < NQ; i++) ZNQ(m, 1, i) = m.h * W(m, O_TEMPVQ, i);
-    }
-    return 0;
-}
-
-template <bool BWD>
-DEV void cv_complete_step(Cm<BWD> &m)
-{
-    m.nst++;
-    m.hu = m.h;
-    m.qu = m.q;
-    SFOR_DOWN(i, QMAX, 2) m.tau[i] = (i <= m.q) ? m.tau[i - 1] : m.tau[i]; SEND
-    m.tau[2] = ((m.q == 1) && (m.nst > 1)) ? m.tau[1] : m.tau[2];
-    m.tau[1] = m.h;
-    for (int j = 0; j <= m.q; j++) {
-        const double lj = pick(m.l, j);
-        for (int i = 0; i < NS; i++) ZN(m, j, i) = FMA(lj, W(m, O_ACOR, i), ZN(m, j, i));
-        if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, j, i) = FMA(lj, W(m, O_ACORQ, i), ZNQ(m, j, i));
-    }
-#ifdef SA_SENS
-    if (m.sensi)
-        for (int is = 0; is < NQ; is++)
-            for (int j = 0; j <= m.q; j++) {
-                const double lj = pick(m.l, j);
-                for (int i = 0; i < NS; i++) ZNS(m, j, is, i) = FMA(lj, VS(m, O_ACORS, is, i), ZNS(m, j, is, i));
-            }
-#endif
-    m.qwait--;
-    if ((m.qwait == 1) && (m.q != QMAX)) {
-#ifdef SA_SENS
-        if (m.sensi) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) ZNS(m, QMAX, is, i) = VS(m, O_ACORS, is, i);
-#endif
-        for (int i = 0; i < NS; i++) ZN(m, QMAX, i) = W(m, O_ACOR, i);
-        if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, QMAX, i) = W(m, O_ACORQ, i);
-        m.saved_tq5 = m.tq[5];
-    }
-}
-
-template <bool BWD>
-DEV void cv_set_eta(Cm<BWD> &m)
-{
-    if (m.eta < THRESH) {
-        m.eta = 1.0;
-        m.hprime = m.h;
-    } else {
-        m.eta = fmin(m.eta, m.etamax);
-        m.hprime = m.h * m.eta;
-    }
-}
-
-template <bool BWD>
-DEV void cv_prepare_next_step(Cm<BWD> &m, double dsm)
-{
-    if (m.etamax == 1.0) {
-        m.qwait = m.qwait > 2 ? m.qwait : 2;
-        m.qprime = m.q;
-        m.hprime = m.h;
-        m.eta = 1.0;
-        return;
-    }
-    m.etaq = 1.0 / (rpower_r(BIAS2 * dsm, inv_int(m.L)) + ADDON);
-    if (m.qwait != 0) {
-        m.eta = m.etaq;
-        m.qprime = m.q;
-        cv_set_eta(m);
-        return;
-    }
-    m.qwait = 2;
-    m.etaqm1 = 0.0;
-    if (m.q > 1) {
-        double ddn = wrms_off(m, O_ZN + m.q * NS, O_EWT, NS);
-        if (BWD) { double dq = wrms_off(m, O_ZNQ + m.q * NQ, O_EWTQ, NQ); ddn = ddn > dq ? ddn : dq; }
-#ifdef SA_SENS
-        if (m.sensi) ddn = sens_update_norm(m, ddn, O_ZNS + m.q * NQ * NS, O_EWTS);
-#endif
-        ddn = ddn * m.tq[1];
-        m.etaqm1 = 1.0 / (rpower_r(BIAS1 * ddn, inv_int(m.q)) + ADDON);
-    }
-    m.etaqp1 = 0.0;
-    if (m.q != QMAX) {
-        if (m.saved_tq5 != 0.0) {
-            double base = m.h / m.tau[2];
-            double pw = 1.0;
-            SFOR(i, 1, (QMAX + 1) + 1) { if (i <= m.L) pw *= base; } SEND
-            double cquot = (m.tq[5] / m.saved_tq5) * pw;
-            for (int i = 0; i < NS; i++) W(m, O_TEMPV, i) = FMA(-cquot, ZN(m, QMAX, i), W(m, O_ACOR, i));
-            double dup = wrms_n(m, O_TEMPV);
-            if (BWD) {
-                for (int i = 0; i < NQ; i++) W(m, O_TEMPVQ, i) = FMA(-cquot, ZNQ(m, QMAX, i), W(m, O_ACORQ, i));
-                dup = quad_update_norm(m, dup, O_TEMPVQ);
-            }
-#ifdef SA_SENS
-            if (m.sensi) {
-                for (int is = 0; is < NQ; is++)
-                    for (int i = 0; i < NS; i++)
-                        VS(m, O_TEMPVS, is, i) = FMA(-cquot, ZNS(m, QMAX, is, i), VS(m, O_ACORS, is, i));
-                dup = sens_update_norm(m, dup, O_TEMPVS, O_EWTS);
-            }
-#endif
-            dup = dup * m.tq[3];
-            m.etaqp1 = 1.0 / (rpower_r(BIAS3 * dup, inv_int(m.L + 1)) + ADDON);
-        }
-    }
-    double etam = fmax(m.etaqm1, fmax(m.etaq, m.etaqp1));
-    if (etam < THRESH) {
-        m.eta = 1.0;
-        m.qprime = m.q;
-    } else if (etam == m.etaq) {
-        m.eta = m.etaq;
-        m.qprime = m.q;
-    } else if (etam == m.etaqm1) {
-        m.eta = m.etaqm1;
-        m.qprime = m.q - 1;
-    } else {
-        m.eta = m.etaqp1;
-        m.qprime = m.q + 1;
-        for (int i = 0; i < NS; i++) ZN(m, QMAX, i) = W(m, O_ACOR, i);
-        if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, QMAX, i) = W(m, O_ACORQ, i);
-#ifdef SA_SENS
-        if (m.sensi) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) ZNS(m, QMAX, is, i) = VS(m, O_ACORS, is, i);
-#endif
-    }
-    cv_set_eta(m);
-}
-
-/* CVodeGetDky (k = 0): oracle form, sum from column q down to 0 */
-template <bool BWD>
-DEV int cv_get_dky0(Cm<BWD> &m, double t, double *dky, int64_t dstride, int qoff_out)
-{
-    double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.hu));
-    if (m.hu < 0.0) tfuzz = -tfuzz;
-    double tp = m.tn - m.hu - tfuzz;
-    double tn1 = m.tn + tfuzz;
-    if ((t - tp) * (t - tn1) > 0.0) return CV_BAD_T;
-    double s = (t - m.tn) / m.h;
-    double pw[QMAX + 1];
-    pw[0] = 1.0;
-    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
-    const double pq = pick(pw, m.q);
-    for (int i = 0; i < NS; i++) {
-        double acc = pq * ZN(m, m.q, i);
-        for (int j = m.q - 1; j >= 0; j--) acc = FMA(pick(pw, j), ZN(m, j, i), acc);
-        dky[(int64_t)i * dstride] = acc;
-    }
-    if (BWD) {
-        for (int i = 0; i < NQ; i++) {
-            double acc = pq * ZNQ(m, m.q, i);
-            for (int j = m.q - 1; j >= 0; j--) acc = FMA(pick(pw, j), ZNQ(m, j, i), acc);
-            W(m, qoff_out, i) = acc;
-        }
-    }
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_first_call(Cm<BWD> &m, double tout)
-{
-#ifdef SA_CONSTRAINTS
-    if (!BWD && m.cons) {
-        if (m.sensi && m.ism == 0) return CV_ILL_INPUT;       /* CVODES: no constraints with the simultaneous corrector */
-        for (int i = 0; i < NS; i++) if (constr_violated(m.cons[i], ZN(m, 0, i))) return CV_ILL_INPUT;
-    }
-#endif
-    if (ewt_set(m, O_ZN, O_EWT) != 0) return CV_ILL_INPUT;
-    if (BWD) { if (ewtQ_set(m, O_ZNQ, O_EWTQ) != 0) return CV_ILL_INPUT; }
-#ifdef SA_SENS
-    if (m.sensi) { if (sens_ewt_set(m, O_ZNS, O_EWTS) != 0) return CV_ILL_INPUT; }
-#endif
-    if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-    int retval = cv_f(m, m.tn, O_ZN, O_ZN + NS);
-    if (retval < 0) return CV_RHSFUNC_FAIL;
-    if (retval > 0) return CV_FIRST_RHSFUNC_ERR;
-#ifdef SA_HERMITE
-    if (!BWD) for (int i = 0; i < NS; i++) W(m, O_HY, 5 * NS + i) = ZN(m, 1, i);
-#endif
-#ifdef SA_SENS
-    if (m.sensi) {
-        retval = cv_fS(m, m.tn, O_ZN, O_ZNS, O_ZNS + NQ * NS);
-        if (retval < 0) return CV_SRHSFUNC_FAIL;
-        if (retval > 0) return CV_FIRST_SRHSFUNC_ERR;
-    }
-#endif
-    if (BWD) {
-        retval = cv_fQ(m, m.tn, O_ZN, O_ZNQ + NQ);
-        if (retval < 0) return CV_QRHSFUNC_FAIL;
-        if (retval > 0) return CV_FIRST_QRHSFUNC_ERR;
-    }
-    double tout_hin = tout;
-    if (BWD) {
-        if ((m.tstop - m.tn) * (tout - m.tn) <= 0.0) return CV_ILL_INPUT;
-        if ((tout - m.tn) * (tout - m.tstop) > 0.0) tout_hin = m.tstop;
-    }
-    int hflag = cv_hin(m, tout_hin);
-    if (hflag != CV_SUCCESS) return hflag;
-    if (BWD) {
-        if ((m.tn + m.h - m.tstop) * m.h > 0.0) m.h = (m.tstop - m.tn) * (1.0 - 4.0 * UROUND);
-    }
-    m.hscale = m.h;
-    m.hprime = m.h;
-    for (int i = 0; i < NS; i++) ZN(m, 1, i) = m.h * ZN(m, 1, i);
-    if (BWD) for (int i = 0; i < NQ; i++) ZNQ(m, 1, i) = m.h * ZNQ(m, 1, i);
-#ifdef SA_SENS
-    if (m.sensi) for (int is = 0; is < NQ; is++) for (int i = 0; i < NS; i++) ZNS(m, 1, is, i) = m.h * ZNS(m, 1, is, i);
-#endif
-    return CV_SUCCESS;
-}
-
-template <bool BWD>
-DEV int cv_pre_step(Cm<BWD> &m)
-{
-    if (ewt_set(m, O_ZN, O_EWT) != 0) return CV_ILL_INPUT;
-    if (BWD) { if (ewtQ_set(m, O_ZNQ, O_EWTQ) != 0) return CV_ILL_INPUT; }
-#ifdef SA_SENS
-    if (m.sensi) { if (sens_ewt_set(m, O_ZNS, O_EWTS) != 0) return CV_ILL_INPUT; }
-#endif
-    double nrm = wrms_n(m, O_ZN);
-    if (BWD) nrm = quad_update_norm(m, nrm, O_ZNQ);
-#ifdef SA_SENS
-    if (m.sensi) nrm = sens_update_norm(m, nrm, O_ZNS, O_EWTS);
-#endif
-    if (UROUND * nrm > 1.0) return CV_TOO_MUCH_ACC;
-    return CV_SUCCESS;
-}
-
-struct StepCtl {
-    int in_step, redo, nflag, ncf, nef, nefQ, convfail, ncfS, nefS;
-    double saved_t;
-};
-
-template <bool BWD>
-DEV int cv_handle_nflag_failed(Cm<BWD> &m, StepCtl &c, int nflag, int &ncf, int &ncfn)
-{
-    ncfn++;
-    cv_restore(m, c.saved_t);
-    if (nflag < 0) return nflag;
-    ncf++;
-    m.etamax = 1.0;
-    if (ncf == MXNCF) {
-        if (nflag == NLS_CONV_RECVR) return CV_CONV_FAILURE;
-        if (nflag == RHSFUNC_RECVR) return CV_REPTD_RHSFUNC_ERR;
-        if (nflag == SRHSFUNC_RECVR) return CV_REPTD_SRHSFUNC_ERR;
-        if (nflag == CONSTR_RECVR) return CV_CONSTR_FAIL;
-        return CV_REPTD_QRHSFUNC_ERR;
-    }
-    if (nflag != CONSTR_RECVR) m.eta = ETACF;         /* CONSTR_RECVR: eta was set by the constraint check */
-    c.nflag = PREV_CONV_FAIL;
-    cv_rescale(m);
-    return 0;
-}
-
-template <bool BWD>
-DEV int cv_attempt(Cm<BWD> &m, StepCtl &c)
-{
-    if (!c.in_step) {
-        c.saved_t = m.tn;
-        c.ncf = c.nef = c.nefQ = 0;
-        c.ncfS = c.nefS = 0;
-        c.nflag = FIRST_CALL;
-        c.redo = 0;
-        if ((m.nst > 0) && (m.hprime != m.h)) {
-            if (m.qprime != m.q) {
-                cv_adjust_order(m, m.qprime - m.q);
-                m.q = m.qprime;
-                m.L = m.q + 1;
-                m.qwait = m.L;
-            }
-            cv_rescale(m);
-        }
-        c.in_step = 1;
-    }
-    int callSetup, jbad;
-    if (!c.redo) {
-        cv_predict(m);
-        cv_set(m);
-        if (BWD) { if (interp_y(m, m.tn) != CV_SUCCESS) { m.nfe++; return CV_RHSFUNC_FAIL; } }
-        c.convfail = ((c.nflag == FIRST_CALL) || (c.nflag == PREV_ERR_FAIL)) ? CV_NO_FAILURES : CV_FAIL_OTHER;
-        callSetup = (c.nflag == PREV_CONV_FAIL) || (c.nflag == PREV_ERR_FAIL) || (m.nst == 0) ||
-                    (m.nst >= m.nstlp + MSBP) || (fabs(m.gamrat - 1.0) > DGMAX);
-        jbad = 0;
-    } else {
-        callSetup = 1;
-        jbad = 1;
-    }
-    int in_loop;
-    int nls = cv_newton_pass(m, callSetup, jbad, c.convfail, in_loop);
-    if ((nls > 0) && in_loop && !m.nls_jcur) {
-        c.redo = 1;
-        return 0;
-    }
-    c.redo = 0;
-    if (nls != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nls, c.ncf, m.ncfn);
-
-    for (int i = 0; i < NS; i++) W(m, O_Y, i) = ZN(m, 0, i) + W(m, O_ACOR, i);
-#ifdef SA_CONSTRAINTS
-    if (!BWD && m.cons) {               /* cvCheckConstraints (see the oracle); mask in O_FTEMP, v in O_TEMPV */
-        bool any = false;
-        for (int i = 0; i < NS; i++) {
-            const bool bad = constr_violated(m.cons[i], W(m, O_Y, i));
-            W(m, O_FTEMP, i) = bad ? 1.0 : 0.0;
-            any = any || bad;
-        }
-        if (any) {
-            for (int i = 0; i < NS; i++) {
-                const double aa = (fabs(m.cons[i]) >= 1.5) ? 1.0 : 0.0;
-                double tmp = (aa * m.cons[i]) / W(m, O_EWT, i);
-                tmp = FMA(-0.1, tmp, W(m, O_Y, i));
-                W(m, O_TEMPV, i) = tmp * W(m, O_FTEMP, i);
-            }
-            const double vnorm = wrms_n(m, O_TEMPV);
-            if (vnorm * m.tq[4] <= 1.0) {
-                for (int i = 0; i < NS; i++) W(m, O_ACOR, i) = W(m, O_ACOR, i) - W(m, O_TEMPV, i);
-            } else {
-                double minq = 1e308;
-                for (int i = 0; i < NS; i++) {
-                    const double d = W(m, O_FTEMP, i) * (ZN(m, 0, i) - W(m, O_Y, i));
-                    if (d != 0.0) { const double qv = ZN(m, 0, i) / d; if (qv < minq) minq = qv; }
-                }
-                m.eta = fmax(0.9 * minq, 0.1);
-                return cv_handle_nflag_failed(m, c, CONSTR_RECVR, c.ncf, m.ncfn);
-            }
-        }
-    }
-#endif
-    double dsm = m.acnrm * m.tq[2];
-    if (dsm > 1.0) {
-        c.nflag = PREV_ERR_FAIL;
-        return cv_error_test_failed(m, c.saved_t, dsm, c.nef, m.netf);
-    }
-#ifdef SA_SENS
-    if (m.sensi && m.ism == 0) {
-        for (int is = 0; is < NQ; is++)
-            for (int i = 0; i < NS; i++) VS(m, O_YS, is, i) = ZNS(m, 0, is, i) + VS(m, O_ACORS, is, i);
-    }
-    if (m.sensi && m.ism == 1) {         /* CV_STAGGERED: sensitivities after the state passed (oracle cv_step) */
-        c.ncf = c.nef = 0;
-        int retval = cv_f(m, m.tn, O_Y, O_FTEMP);
-        if (retval < 0) return CV_RHSFUNC_FAIL;
-        if (retval > 0) { c.nflag = PREV_CONV_FAIL; return 0; }
-        const int nflagS = cv_stgr_nls(m);
-        if (nflagS != CV_SUCCESS) return cv_handle_nflag_failed(m, c, nflagS, c.ncfS, m.ncfnS);
-        m.acnrmS = sens_update_norm(m, 0.0, O_ACORS, O_EWTS);
-        const double dsmS = m.acnrmS * m.tq[2];
-        if (dsmS > 1.0) {
-            c.nflag = PREV_ERR_FAIL;
-            return cv_error_test_failed(m, c.saved_t, dsmS, c.nefS, m.netfS);
-        }
-        if (dsmS > dsm) dsm = dsmS;
-    }
-#endif
-    if (BWD) {
-        c.ncf = c.nef = 0;
-        int retval = cv_fQ(m, m.tn, O_Y, O_ACORQ);
-        if (retval != 0)
-            return cv_handle_nflag_failed(m, c, retval < 0 ? CV_QRHSFUNC_FAIL : QRHSFUNC_RECVR, c.ncf, m.ncfn);
-        for (int i = 0; i < NQ; i++) {
-            double v = FMA(m.h, W(m, O_ACORQ, i), -ZNQ(m, 1, i));
-            W(m, O_ACORQ, i) = m.rl1 * v;
-        }
-        double acnrmQ = wrms_q(m, O_ACORQ);
-        double dsmQ = acnrmQ * m.tq[2];
-        if (dsmQ > 1.0) {
-            c.nflag = PREV_ERR_FAIL;
-            return cv_error_test_failed(m, c.saved_t, dsmQ, c.nefQ, m.netfQ);
-        }
-        if (dsmQ > dsm) dsm = dsmQ;
-    }
-    cv_complete_step(m);
-    cv_prepare_next_step(m, dsm);
-    m.etamax = (m.nst <= SMALL_NST) ? ETAMX2 : ETAMX3;
-    for (int i = 0; i < NS; i++) W(m, O_ACOR, i) = m.tq[2] * W(m, O_ACOR, i);
-    if (BWD) for (int i = 0; i < NQ; i++) W(m, O_ACORQ, i) = m.tq[2] * W(m, O_ACORQ, i);
-#ifdef SA_SENS
-    if (m.sensi) for (int j = 0; j < NQ * NS; j++) W(m, O_ACORS, j) = m.tq[2] * W(m, O_ACORS, j);
-#endif
-    c.in_step = 0;
-    return 1;
-}
-
-template <bool BWD>
-DEV void accumulate_stats(const Cm<BWD> &m, int64_t *acc)
-{
-    acc[ST_NST] += m.nst; acc[ST_NFE] += m.nfe; acc[ST_NSETUPS] += m.nsetups; acc[ST_NJE] += m.nje;
-    acc[ST_NNI] += m.nni; acc[ST_NCFN] += m.ncfn; acc[ST_NETF] += m.netf; acc[ST_QLAST] = m.qu;
-    acc[ST_NFQE] += m.nfQe; acc[ST_NETFQ] += m.netfQ;
-}
+#include "bdf_core.h"
 
 /* forward: build the divided-difference record of the newest point from the history in O_HY
    (hY[j] = point s-j) directly in the trajectory record (see bdf_kernels.hip::store_table) */
@@ -1389,11 +507,26 @@ DEV void store_hermite(Cm<BWD> &m, double *r, int64_t tS, double t, bool first)
     r[(int64_t)1 * tS] = 1.0;
     r[(int64_t)2 * tS] = t;
     for (int i = 0; i < NS; i++) {
-        r[(int64_t)(8 + i) * tS] = ZN(m, 0, i);
-        r[(int64_t)(8 + NS + i) * tS] = first ? W(m, O_HY, 5 * NS + i) : (1.0 / m.h) * ZN(m, 1, i);
+        r[(int64_t)(8 + i) * tS] = m.zn[0][i];
+        r[(int64_t)(8 + NS + i) * tS] = first ? m.f0[i] : (1.0 / m.h) * m.zn[1][i];
     }
 }
 #endif
+
+/* common part of the kernels' set-up */
+template <bool BWD>
+DEV void init_state(Cm<BWD> &m, double *ws, int64_t ws_stride, int inst, const double *ps, const double *pr, int rem_stride)
+{
+    bind_workspace(m, ws, ws_stride, inst);
+    SFOR(i, 0, NQ) m.ps[i] = ps[(int64_t)inst * NQ + i]; SEND
+    m.pr = pr + (int64_t)inst * rem_stride;
+    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
+    m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
+    m.traj = nullptr; m.tS = 0;
+    m.sensi = 0; m.ism = 0; m.cons = nullptr; m.constr = 0;
+    m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
+    for (int i = 0; i < NS; i++) m.ytmp[i] = 0.0;
+}
 
 /* ------------------------------------------------------------------------------------ */
 extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
@@ -1401,24 +534,13 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
     Cm<false> m;
-    m.sensi = 0; m.ism = 0; m.cons = a.constraints;
-    m.S = a.ws_stride;
-    m.w = a.ws + inst;
-    SFOR(i, 0, NQ) m.ps[i] = a.ps[(int64_t)inst * NQ + i]; SEND
-    m.pr = a.pr + (int64_t)inst * a.rem_stride;
-    m.rtol = a.rtol; m.atol_p = a.atol; m.atol_s = 0.0;
-    m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
-    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
-    m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
-    m.traj = nullptr; m.tS = 0;
+    init_state(m, a.ws, a.ws_stride, inst, a.ps, a.pr, a.rem_stride);
+    m.cons = a.constraints; m.constr = (a.constraints != nullptr);
+    m.rtol = a.rtol; m.atol = Atol{a.atol, 0.0};
 
-    const double *y0 = a.y0 + (int64_t)inst * NS;
-    for (int j = 0; j <= QMAX; j++) for (int i = 0; i < NS; i++) ZN(m, j, i) = 0.0;
-    for (int i = 0; i < NS; i++) {
-        ZN(m, 0, i) = y0[i];
-        W(m, O_ACOR, i) = 0.0; W(m, O_TEMPV, i) = 0.0; W(m, O_FTEMP, i) = 0.0; W(m, O_Y, i) = 0.0;
-    }
-    cv_reinit(m, a.t0);
+    const Vec y0{const_cast<double *>(a.y0) + (int64_t)inst * NS, 1};
+    const Vec q0 = wvec(m, O_QUAD);                       /* (no quadratures in the forward problem: never read) */
+    cv_reinit(m, a.t0, y0, q0);
 
     /* store: CVodeF semantics (every step is a data point, no mxstep budget); wr: the points are written to the
        arena (SA_MODE_ADJ_COUNT runs the identical pass and only counts them, see sunode_amd.cpp) */
@@ -1446,7 +568,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
             if (wr) store_hermite(m, trec, tS, m.tn, true);
 #else
             hT[0] = m.tn;
-            for (int i = 0; i < NS; i++) W(m, O_HY, i) = ZN(m, 0, i);
+            for (int i = 0; i < NS; i++) W(m, O_HY, i) = m.zn[0][i];
             if (wr) store_table(m, trec, tS, 0, 1.0, hT);
 #endif
             np = 1;
@@ -1479,7 +601,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                         hT[0] = m.tn;
                         for (int j = QMAX; j >= 1; j--)
                             for (int i = 0; i < NS; i++) W(m, O_HY, j * NS + i) = W(m, O_HY, (j - 1) * NS + i);
-                        for (int i = 0; i < NS; i++) W(m, O_HY, i) = ZN(m, 0, i);
+                        for (int i = 0; i < NS; i++) W(m, O_HY, i) = m.zn[0][i];
                         if (wr && np < a.traj_cap) store_table(m, trec + (int64_t)np * TREC * tS, tS, m.qu, fabs(hT[0] - hT[1]), hT);
 #endif
                         np++;
@@ -1491,7 +613,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_forward(sa_fwd_args a)
                         for (int i = 0; i < NS; i++) yo[(int64_t)k * NS + i] = y0[i];
                         k++;
                     } else if ((m.tn - tout) * m.h >= 0.0) {
-                        cv_get_dky0(m, tout, yo + (int64_t)k * NS, 1, O_QOUT);
+                        cv_get_dky0(m, tout, Vec{yo + (int64_t)k * NS, 1}, wvec(m, O_QOUT));
                         k++;
                         nstloc = 0; retries = 0;
                     } else break;
@@ -1528,43 +650,30 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
     if (a.fwd_status[inst] != CV_SUCCESS || np < 2) status = CV_NO_FWD;
 
     Cm<true> m;
-    m.sensi = 0; m.ism = 0; m.cons = nullptr;
-    m.S = a.ws_stride;
-    m.w = a.ws + inst;
-    SFOR(i, 0, NQ) m.ps[i] = a.ps[(int64_t)inst * NQ + i]; SEND
-    m.pr = a.pr + (int64_t)inst * a.rem_stride;
-    m.rtol = a.rtolB; m.atol_s = a.atolB; m.atol_p = nullptr;
+    init_state(m, a.ws, a.ws_stride, inst, a.ps, a.pr, a.rem_stride);
+    m.rtol = a.rtolB; m.atol = Atol{nullptr, a.atolB};
     m.rtolQ = a.rtolQB; m.atolQ = a.atolQB;
     m.tstop = a.tinitial;
     m.traj = a.traj + inst;
     m.tS = a.traj_stride;
     m.np = np;
     m.tfinal = (status == CV_SUCCESS) ? rec(m, np - 1, 2) : a.tinitial;
-    m.cur_idx = 0; m.tlo2 = 0.0; m.tlo = m.thi = 0.0;
-    m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
-    m.n_interp = 0; m.n_rebuild = 0;
+    m.newdata = 1;
 
-    for (int i = 0; i < NS; i++) { W(m, O_LAM, i) = 0.0; W(m, O_YTMP, i) = 0.0; }
-    for (int i = 0; i < NQ; i++) { W(m, O_QUAD, i) = 0.0; W(m, O_QOUT, i) = 0.0; }
-    for (int j = 0; j <= QMAX; j++) {
-        for (int i = 0; i < NS; i++) ZN(m, j, i) = 0.0;
-        for (int i = 0; i < NQ; i++) ZNQ(m, j, i) = 0.0;
-    }
-    for (int i = 0; i < NS; i++) { W(m, O_ACOR, i) = 0.0; W(m, O_TEMPV, i) = 0.0; W(m, O_FTEMP, i) = 0.0; W(m, O_Y, i) = 0.0; }
-    for (int i = 0; i < NQ; i++) { W(m, O_ACORQ, i) = 0.0; W(m, O_TEMPVQ, i) = 0.0; }
+    const Vec lam = wvec(m, O_LAM), quad = wvec(m, O_QUAD), quad_out = wvec(m, O_QOUT);
+    for (int i = 0; i < NS; i++) lam[i] = 0.0;
+    for (int i = 0; i < NQ; i++) { quad[i] = 0.0; quad_out[i] = 0.0; }
     const double *g = a.grads + (int64_t)inst * a.grads_stride;
     bool first_call = true;
     int total_retries = 0, attempts = 0;
-    cv_reinit(m, a.t0);
+    cv_reinit(m, a.t0, lam, quad);
 
     for (int iv = 0; iv <= a.n_t; iv++) {
         const double t_upper = (iv == 0) ? a.t0 : a.tvals[a.n_t - iv];
         const double t_lower = (iv == a.n_t) ? a.tend : a.tvals[a.n_t - 1 - iv];
         if (t_lower < t_upper) {
             if (status == CV_SUCCESS) {
-                for (int i = 0; i < NS; i++) ZN(m, 0, i) = W(m, O_LAM, i);        /* CVodeReInitB */
-                for (int i = 0; i < NQ; i++) ZNQ(m, 0, i) = W(m, O_QUAD, i);      /* CVodeQuadReInitB */
-                cv_reinit(m, t_upper);
+                cv_reinit(m, t_upper, lam, quad);          /* CVodeReInitB + CVodeQuadReInitB */
                 if (first_call) {
                     if ((t_upper - a.tinitial) < 0.0 || (m.tfinal - t_upper) < 0.0) status = CV_BAD_TB0;
                     first_call = false;
@@ -1603,7 +712,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
                         double troundoff = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.h));
                         if (fabs(m.tn - m.tstop) <= troundoff) m.tn = m.tstop;
                         if ((m.tn - t_lower) * m.h >= 0.0) {
-                            cv_get_dky0(m, t_lower, &W(m, O_LAM, 0), m.S, O_QOUT);
+                            cv_get_dky0(m, t_lower, lam, quad_out);
                             idone = true;
                         } else {
                             troundoff = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.h));
@@ -1617,22 +726,22 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
                 }
             }
             if (status == CV_SUCCESS || m.nst > 0) accumulate_stats(m, st);
-            if (status == CV_SUCCESS) { for (int i = 0; i < NQ; i++) W(m, O_QUAD, i) = W(m, O_QOUT, i); }
+            if (status == CV_SUCCESS) { for (int i = 0; i < NQ; i++) quad[i] = quad_out[i]; }
         }
         if (iv < a.n_t && status == CV_SUCCESS) {
             const double *gi = g + (int64_t)(a.n_t - 1 - iv) * NS;
-            for (int i = 0; i < NS; i++) W(m, O_LAM, i) -= gi[i];
+            for (int i = 0; i < NS; i++) lam[i] -= gi[i];
             const int64_t row = (int64_t)inst * a.n_t + (iv == 0 ? 0 : a.n_t - iv);
-            if (a.lamda_all) for (int i = 0; i < NS; i++) a.lamda_all[row * NS + i] = W(m, O_LAM, i);
-            if (a.quad_all) for (int i = 0; i < NQ; i++) a.quad_all[row * NQ + i] = W(m, O_QUAD, i);
+            if (a.lamda_all) for (int i = 0; i < NS; i++) a.lamda_all[row * NS + i] = lam[i];
+            if (a.quad_all) for (int i = 0; i < NQ; i++) a.quad_all[row * NQ + i] = quad[i];
         }
     }
     if (status != CV_SUCCESS) {
         if (a.lamda_all) for (int j = 0; j < a.n_t * NS; j++) a.lamda_all[(int64_t)inst * a.n_t * NS + j] = SA_NAN;
         if (a.quad_all) for (int j = 0; j < a.n_t * NQ; j++) a.quad_all[(int64_t)inst * a.n_t * NQ + j] = SA_NAN;
     }
-    for (int i = 0; i < NQ; i++) a.grad_out[(int64_t)inst * NQ + i] = (status == CV_SUCCESS) ? W(m, O_QOUT, i) : SA_NAN;
-    for (int i = 0; i < NS; i++) a.lamda_out[(int64_t)inst * NS + i] = (status == CV_SUCCESS) ? W(m, O_LAM, i) : SA_NAN;
+    for (int i = 0; i < NQ; i++) a.grad_out[(int64_t)inst * NQ + i] = (status == CV_SUCCESS) ? quad_out[i] : SA_NAN;
+    for (int i = 0; i < NS; i++) a.lamda_out[(int64_t)inst * NS + i] = (status == CV_SUCCESS) ? lam[i] : SA_NAN;
     a.status[inst] = status;
     st[ST_NPTS] = np; st[ST_NINTERP] = m.n_interp; st[ST_NREBUILD] = m.n_rebuild;
     st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
@@ -1640,29 +749,6 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_backward(sa_bwd_args a)
 }
 
 #ifdef SA_SENS
-/* CVodeGetSensDky(k = 0) for all parameters -> dst[is * NS + i] */
-template <bool BWD>
-DEV int cv_get_sens_dky0(Cm<BWD> &m, double t, double *dst)
-{
-    double tfuzz = FUZZ_FACTOR * UROUND * (fabs(m.tn) + fabs(m.hu));
-    if (m.hu < 0.0) tfuzz = -tfuzz;
-    double tp = m.tn - m.hu - tfuzz;
-    double tn1 = m.tn + tfuzz;
-    if ((t - tp) * (t - tn1) > 0.0) return CV_BAD_T;
-    double s = (t - m.tn) / m.h;
-    double pw[QMAX + 1];
-    pw[0] = 1.0;
-    SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * s; SEND
-    const double pq = pick(pw, m.q);
-    for (int is = 0; is < NQ; is++)
-        for (int i = 0; i < NS; i++) {
-            double acc = pq * ZNS(m, m.q, is, i);
-            for (int j = m.q - 1; j >= 0; j--) acc = FMA(pick(pw, j), ZNS(m, j, is, i), acc);
-            dst[is * NS + i] = acc;
-        }
-    return CV_SUCCESS;
-}
-
 /* Solver(sens_mode).solve (reference solver.py:467-527): CVodeReInit + CVodeSensReInit, then per output
    time CVode(NORMAL) with the mxstep x max_retries budget, CVodeGetSens */
 extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
@@ -1670,33 +756,17 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
     Cm<false> m;
-    m.S = a.ws_stride;
-    m.w = a.ws + inst;
-    SFOR(i, 0, NQ) { m.ps[i] = a.ps[(int64_t)inst * NQ + i]; m.pbar[i] = a.pbar[i]; } SEND
-    m.pr = a.pr + (int64_t)inst * a.rem_stride;
-    m.rtol = a.rtol; m.atol_p = a.atol; m.atol_s = 0.0;
-    m.rtolQ = 0.0; m.atolQ = 0.0; m.tstop = 0.0;
-    m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0; m.cur_idx = 0;
-    m.last_t = 0.0; m.tlo = m.thi = m.tlo2 = 0.0; m.n_interp = 0; m.n_rebuild = 0;
-    m.traj = nullptr; m.tS = 0;
-    m.sensi = 1; m.ism = a.ism; m.cons = nullptr;
+    init_state(m, a.ws, a.ws_stride, inst, a.ps, a.pr, a.rem_stride);
+    SFOR(i, 0, NQ) m.pbar[i] = a.pbar[i]; SEND
+    m.rtol = a.rtol; m.atol = Atol{a.atol, 0.0};
+    m.sensi = 1; m.ism = a.ism;
 
-    const double *y0 = a.y0 + (int64_t)inst * NS;
+    const Vec y0{const_cast<double *>(a.y0) + (int64_t)inst * NS, 1};
     const double *s0 = a.sens0 + (int64_t)inst * NQ * NS;
-    for (int j = 0; j <= QMAX; j++) {
-        for (int i = 0; i < NS; i++) ZN(m, j, i) = 0.0;
-        for (int k = 0; k < NQ * NS; k++) W(m, O_ZNS, j * NQ * NS + k) = 0.0;
-    }
-    for (int i = 0; i < NS; i++) {
-        ZN(m, 0, i) = y0[i];
-        W(m, O_ACOR, i) = 0.0; W(m, O_TEMPV, i) = 0.0; W(m, O_FTEMP, i) = 0.0; W(m, O_Y, i) = 0.0;
-    }
-    for (int k = 0; k < NQ * NS; k++) {
-        W(m, O_ZNS, k) = s0[k];
-        W(m, O_ACORS, k) = 0.0; W(m, O_TEMPVS, k) = 0.0; W(m, O_FTEMPS, k) = 0.0; W(m, O_YS, k) = 0.0;
-        W(m, O_EWTS, k) = 0.0;
-    }
-    cv_reinit(m, a.t0);
+    cv_reinit(m, a.t0, y0, wvec(m, O_QUAD));
+    for (int v = 0; v < SV_COUNT; v++)
+        for (int is = 0; is < NQ; is++)
+            for (int i = 0; i < NS; i++) SV(m, v, is, i) = (v == SV_ZN0) ? s0[is * NS + i] : 0.0;
 
     double *yo = a.y_out + (int64_t)inst * a.n_t * NS;
     double *so = a.sens_out + (int64_t)inst * a.n_t * NQ * NS;
@@ -1738,8 +808,19 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
                         for (int j = 0; j < NQ * NS; j++) so[(int64_t)k * NQ * NS + j] = s0[j];
                         k++;
                     } else if ((m.tn - tout) * m.h >= 0.0) {
-                        cv_get_dky0(m, tout, yo + (int64_t)k * NS, 1, O_QOUT);
-                        cv_get_sens_dky0(m, tout, so + (int64_t)k * NQ * NS);
+                        cv_get_dky0(m, tout, Vec{yo + (int64_t)k * NS, 1}, wvec(m, O_QOUT));
+                        {   /* CVodeGetSensDky, k = 0, all parameters (t validated by cv_get_dky0; bdf_kernels.hip's form) */
+                            const double sx = (tout - m.tn) / m.h;
+                            double pw[QMAX + 1];
+                            pw[0] = 1.0;
+                            SFOR(j, 1, (QMAX) + 1) pw[j] = pw[j - 1] * sx; SEND
+                            for (int is = 0; is < NQ; is++)
+                                for (int i = 0; i < NS; i++) {
+                                    double acc = pw[QMAX] * SV(m, SV_ZN0 + QMAX, is, i);
+                                    SFOR_DOWN(j, QMAX - 1, 0) acc = FMA(pw[j], SV(m, SV_ZN0 + j, is, i), acc); SEND
+                                    so[((int64_t)k * NQ + is) * NS + i] = acc;
+                                }
+                        }
                         k++;
                         nstloc = 0; retries = 0;
                     } else break;

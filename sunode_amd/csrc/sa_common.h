@@ -39,6 +39,15 @@ DEV void sfor_down(F &&f)          /* B, B-1, ..., E (inclusive) */
 #define SFOR_DOWN(var, B, E) sfor_down<(B), (E)>([&](auto var##_ic) __attribute__((always_inline)) { constexpr int var = decltype(var##_ic)::value;
 #define SEND });
 
+/* loops over the slots of a state / quadrature vector in bdf_core.h: compile-time unless the mapping says otherwise
+   (bdf_mem.hip: run-time loops over n components in HBM) */
+#ifndef VFOR
+#define VFOR(r) SFOR(r, 0, RS)
+#define VEND SEND
+#define QFOR(r) SFOR(r, 0, RQ)
+#define QEND SEND
+#endif
+
 /* CVODES return codes (16_cvodes.h:45-106) */
 #define CV_SUCCESS 0
 #define CV_TSTOP_RETURN 1
