@@ -56,6 +56,18 @@
 #ifndef SA_SJ_LDS
 #define SA_SJ_LDS (NS >= 3)
 #endif
+/* The divided-difference table of the current interpolation index: an LDS column per lane (the default from three
+   states on: 20 + 6n register pairs are worth more there) or, for two states, 20 doubles in REGISTERS -- the backward
+   kernel of Lotka-Volterra has 120 registers to spare at its one wavefront per SIMD, and a lone wavefront waits out
+   every LDS round trip of the 20 reads per interpolation (round 5). */
+#ifndef SA_TAB_REGS
+#define SA_TAB_REGS (NS <= 2)
+#endif
+#if SA_TAB_REGS
+#define LT_(m, f) (m).tabr[f]
+#else
+#define LT_(m, f) (m).ltab[(f) * 64]
+#endif
 #if SA_SJ_LDS
 __shared__ double s_savedJ[NS * NS * 64];
 #define SAVEDJ(m, i) s_savedJ[(i) * 64 + threadIdx.x]
@@ -108,6 +120,9 @@ struct Cv {
     double f0[NSD];                   /* f(t0, y0) of the first stored point */
 #endif
     double *ltab;                     /* this lane's column of the LDS table copy: ltab[field * 64] */
+#if SA_TAB_REGS
+    double tabr[8 + 6 * NS];          /* ... or the table in registers (see SA_TAB_REGS) */
+#endif
     double tlo2;                      /* t[ilast-2] */
     int np;
     double tfinal;
@@ -172,6 +187,7 @@ struct Cv {
 #define TREC_Y 8
 #endif
 #define TTAB (8 + 6 * NS)            /* the table in LDS: {order, dt, T[6], Y[6][n]} */
+#define LT(m, f) LT_(m, f)
 
 template <bool BWD>
 DEV double point_time(const Cv<BWD> &m, int s) { return m.traj[(int64_t)s * m.trow + TREC_T]; }
@@ -308,30 +324,29 @@ DEV int interp_y(Cv<BWD> &m, double t)
             } SEND
             const double dt = fabs(hT[0] - hT[1]);
             build_table(order, dt, hT, Y);
-            m.ltab[0] = (double)order;
-            m.ltab[64] = dt;
-            SFOR(j, 0, (QMAX) + 1) m.ltab[(2 + j) * 64] = hT[j]; SEND
-            SFOR(j, 0, (QMAX) + 1) { SFOR(k, 0, NS) m.ltab[(8 + j * NS + k) * 64] = Y[j][k]; SEND } SEND
+            LT(m, 0) = (double)order;
+            LT(m, 1) = dt;
+            SFOR(j, 0, (QMAX) + 1) LT(m, 2 + j) = hT[j]; SEND
+            SFOR(j, 0, (QMAX) + 1) { SFOR(k, 0, NS) LT(m, 8 + j * NS + k) = Y[j][k]; SEND } SEND
             const double *rn = r - (indx > QMAX + 1 ? (QMAX + 1) * m.trow : 0);     /* the point the next move adds */
             m.pf[0] = rn[0]; m.pf[1] = rn[TREC - 1]; m.pf[2] = m.pf[0]; m.pf[3] = m.pf[1];
         }
 #else
-        SFOR(f, 0, TREC) m.ltab[f * 64] = r[f]; SEND
+        SFOR(f, 0, TREC) LT(m, f) = r[f]; SEND
         {   /* touch the record of the next index to the left so that it is L2-resident when needed */
             const double *rn = r - (indx > 0 ? m.trow : 0);
             m.pf[0] = rn[0]; m.pf[1] = rn[TREC / 3]; m.pf[2] = rn[2 * TREC / 3]; m.pf[3] = rn[TREC - 1];
         }
 #endif
-        if (m.ltab[0] > (double)indx) return CV_GETY_BADT;   /* CVODES would shift the base; cannot occur */
-        if (indx == m.ilast) m.tlo2 = m.ltab[4 * 64];        /* T[2] = t[ilast-2] for the next move */
+        if (LT(m, 0) > (double)indx) return CV_GETY_BADT;    /* CVODES would shift the base; cannot occur */
+        if (indx == m.ilast) m.tlo2 = LT(m, 4);              /* T[2] = t[ilast-2] for the next move */
     }
     {
         /* every LDS read of the record up front, in ONE batch: with the reads inside the conditional expressions
            the compiler built a branch chain around them -- seven dependent LDS round trips per interpolation */
-        const double *lt = m.ltab;
         double hdr[8], Yt[QMAX + 1][NSD];
-        SFOR(f, 0, 8) hdr[f] = lt[f * 64]; SEND
-        SFOR(i, 0, (QMAX) + 1) { SFOR(k, 0, NS) Yt[i][k] = lt[(8 + i * NS + k) * 64]; SEND } SEND
+        SFOR(f, 0, 8) hdr[f] = LT(m, f); SEND
+        SFOR(i, 0, (QMAX) + 1) { SFOR(k, 0, NS) Yt[i][k] = LT(m, 8 + i * NS + k); SEND } SEND
         const int order = (int)hdr[0];
         const double inv_dt = 1.0 / hdr[1];
         double cvals[QMAX + 1];
@@ -936,7 +951,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
 #endif
 extern "C" __global__ void __launch_bounds__(64) SA_BWD_ATTR sa_k_backward(sa_bwd_args a)
 {
+#if !SA_TAB_REGS
     __shared__ double ltab[TTAB * 64];        /* per-lane copy of the current divided-difference table */
+#endif
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
     int64_t st[SA_N_STATS];
@@ -961,9 +978,13 @@ extern "C" __global__ void __launch_bounds__(64) SA_BWD_ATTR sa_k_backward(sa_bw
     SFOR(k, 0, 8) m.prof[k] = 0; SEND
     m.prof_last = __builtin_readcyclecounter(); m.prof_cur = 7;
 #endif
+#if SA_TAB_REGS
+    m.ltab = nullptr;
+#else
     m.ltab = ltab + threadIdx.x;
-    SFOR(f, 0, TTAB) m.ltab[f * 64] = 0.0; SEND
-    m.ltab[64] = 1.0;
+#endif
+    SFOR(f, 0, TTAB) LT(m, f) = 0.0; SEND
+    LT(m, 1) = 1.0;
     m.ilast = 0; m.newdata = 1; m.have_last = 0; m.last_t = 0.0;
     m.tlo = 0.0; m.thi = 0.0;
     m.n_interp = 0; m.n_rebuild = 0;
