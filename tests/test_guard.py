@@ -107,6 +107,36 @@ def test_guard_verifies_a_clean_model_and_keeps_the_verdict(monkeypatch):
     assert e3.guard_state()["verified"] == ["plain", "adjoint"] and e3.guard_state()["n_sample"]["plain"] == 5
 
 
+@pytest.mark.gpu
+def test_guard_finds_no_difference_on_any_shape_of_the_sweep(monkeypatch):
+    """Default build == conservative build, bit for bit on the device, for every shape of tests/test_shape_sweep.py
+    (every kernel family, both sides of every mapping boundary): the guard verifies all 29 models -- no false alarm,
+    and no default mapping depends on the pass round 4 caught."""
+    from sunode_amd.solver import AdjointSolver
+    from tools.sweep_cases import ADJOINT_CASES, batch_of
+    monkeypatch.setenv("SA_GUARD", "1")
+    seen = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                  # a RuntimeWarning of the guard fails the test
+        for name, B in ADJOINT_CASES:
+            prob = make_problem(name)
+            d = batch_of(name, B)
+            src = prob.native_source()
+            from sunode_amd import _native
+            _forget_verdict(src, compact=_native.default_compact_trajectory(src))
+            tol = dict(abstol=d["atol"], reltol=d["rtol"], backward_abstol=d["atol"], backward_reltol=d["rtol"],
+                       quad_abstol=d["atol"], quad_reltol=d["rtol"])
+            sol = AdjointSolver(prob, **tol)
+            tv = d["tvals"]
+            for _ in range(3 if B < 16 else 1):         # (a check with fewer than 16 instances is repeated twice)
+                sol.solve_forward_batch(d["t0"], tv, d["y0"], d["ps"], d["pr"])
+                sol.solve_backward_batch(tv[-1], d["t0"], tv, d["grads"])
+            st = sol._engine().guard_state()
+            seen[name] = (st["verified"], st["differs"], st["n_sample"]["adjoint"])
+            del sol
+    assert all(v == (["adjoint"], [], min(B, 64)) for (name, B), v in zip(ADJOINT_CASES, seen.values())), seen
+
+
 def _attach_other_build(monkeypatch, prob, define):
     """A NativeSolver on the default LV build whose guard partner is a build that differs ON PURPOSE."""
     from sunode_amd import _native

@@ -27,6 +27,8 @@ def _compile(name, kind):
         out = build_oracle_library(src, name)
     elif kind == "sens":
         out = _native.build_code_object(src, sens=True)
+    elif kind == "conservative":        # the differential guard's partner build (tests/test_guard.py runs the sweep's shapes through it)
+        out = _native.build_code_object(src, compact=_native.default_compact_trajectory(src), safe=True)
     else:
         out = _native.build_code_object(src, compact=_native.default_compact_trajectory(src))
     return "%s [%s]" % (name, kind), out, time.time() - t
@@ -43,7 +45,8 @@ def build(names=None, verbose=True):
         for name, dt in pool.map(_symbolic, every[::-1]):
             if verbose and dt > 5:
                 print("problem [%s]: %.0f s of sympy" % (name, dt))
-    jobs = [(n, "oracle") for n in every] + [(n, "adjoint") for n in adj] + [(n, "sens") for n in sens]
+    jobs = [(n, "oracle") for n in every] + [(n, "adjoint") for n in adj] + [(n, "sens") for n in sens] \
+        + [(n, "conservative") for n in adj]
     failed = []
     with ThreadPoolExecutor(max_workers=workers) as pool:           # compiler subprocesses: threads
         futs = [(j, pool.submit(_compile, *j)) for j in jobs]
