@@ -30,6 +30,18 @@
 #include <stdint.h>
 
 #define SA_FN static __device__ __forceinline__
+/* lane families of the generated callbacks (symode/codegen.py find_lane_families): this mapping has ONE lane per
+   instance and keeps the callback inputs in register arrays, so the loop over the M members of a family is unrolled at
+   compile time -- every index stays a constant (same expression text as in every other mapping) */
+template <int I> struct sa_fam_ic { static constexpr int value = I; };
+template <int B, int E, class F>
+static __device__ __forceinline__ void sa_fam_for(F &&f) { if constexpr (B < E) { f(sa_fam_ic<B>{}); sa_fam_for<B + 1, E>(f); } }
+constexpr int sa_tau_c(int f, int j) { return j == 0 ? f : (j == f ? 0 : j); }
+#define SA_FAM_BEGIN(M) sa_fam_for<0, (M)>([&](auto sa_fic_) __attribute__((always_inline)) { constexpr int sa_f = decltype(sa_fic_)::value;
+#define SA_F sa_f
+#define SA_TAU(j) sa_tau_c(sa_f, (j))
+#define SA_FAM_STORE(S0, value) { const double v_ = (value); out[(S0) + sa_f] = v_; chk += v_ * 0.0; }
+#define SA_FAM_END });
 #include SA_PROBLEM_HEADER
 #include "sa_device_abi.h"
 

@@ -393,6 +393,33 @@ static __device__ __forceinline__ double sa_rolled_coop(F body)      /* body(i) 
 #define SA_UVEC_ROLLED(tag, N, expr) \
     chk += sa_rolled_coop<N>([&](int i_) __attribute__((always_inline)) -> double { const double v_ = (expr); SA_UVEC_SET(tag, i_, v_); return v_; })
 
+/* Lane families of the generated callbacks (symode/codegen.py find_lane_families): a model with M groups whose outputs
+   for group f are those of group 0 under the relabelling SA_TAU.  With M == G lanes per instance (SEIR: four age groups
+   on the four lanes of a lean group) every lane evaluates ONE member -- its inputs are LDS reads with a lane-dependent
+   index, its outputs land in the slots S0 + f -- instead of all M x K outputs in every lane (round-3 / round-4 review:
+   "callback outputs distributed over the lanes of a group"); M a multiple of G: the members li, li + G, ... per lane; G a
+   multiple of M: member li mod M (lanes beyond M repeat a member: same value into the same slot); otherwise -- and in
+   the workgroup-per-instance build -- a plain loop over the members.  The non-finite check of the members is combined
+   over the group's lanes. */
+static __device__ __forceinline__ double sa_fam_any(double chk)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint64_t any = __builtin_amdgcn_ballot_w64(!(chk == 0.0));
+    const uint64_t mask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << (lane & ~(G - 1)));
+    return (any & mask) ? __builtin_nan("") : 0.0;
+}
+#define SA_FAM_BEGIN(M) { constexpr bool sa_many_ = (SA_WAVES == 1) && ((M) % G == 0);         /* members li, li + G, ... */ \
+    constexpr bool sa_one_ = (SA_WAVES == 1) && !sa_many_ && (G % (M) == 0);                 /* member li mod M     */ \
+    constexpr bool sa_dist_ = sa_many_ || sa_one_; \
+    const int sa_li_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & (G - 1); \
+    const int sa_lo_ = sa_many_ ? sa_li_ : (sa_one_ ? sa_li_ % (M) : 0); \
+    const int sa_hi_ = sa_one_ ? sa_lo_ + 1 : (M); \
+    for (int sa_f = sa_lo_; sa_f < sa_hi_; sa_f += (sa_many_ ? G : 1)) {
+#define SA_F sa_f
+#define SA_TAU(j) ((j) == 0 ? sa_f : ((j) == sa_f ? 0 : (j)))
+#define SA_FAM_STORE(S0, value) { const double v_ = (value); out.put_dyn((S0) + sa_f, v_); chk += v_ * 0.0; }
+#define SA_FAM_END } if (sa_dist_) chk = sa_fam_any(chk); }
+
 #include SA_PROBLEM_HEADER
 #include "sa_device_abi.h"
 #include "sa_common.h"

@@ -166,6 +166,22 @@ HELPERS_C = r"""
 #define SA_ROLLED(N, S0, S1, expr) \
     for (int i_ = 0; i_ < (N); i_++) { const double v_ = (expr); SA_STORE_DYN((S0) + (S1) * i_, v_); chk += v_ * 0.0; }
 #endif
+/* Lane families (codegen.find_lane_families): a model written as loops over M groups -- compartments x age groups,
+   species x sites -- is equivariant under a relabelling of the groups, so the outputs of group f are the outputs of
+   group 0 with every group index j replaced by SA_TAU(j), the transposition (0 f).  Such outputs are emitted ONCE,
+   for group 0, inside
+     SA_FAM_BEGIN(M) ... SA_FAM_STORE(S0, expr); ... SA_FAM_END
+   where SA_F is the member index, SA_TAU(j) its relabelling of a group coordinate j and slot S0 + SA_F receives `expr`.
+   Default: a plain loop over the M members (oracle, one-lane mappings through a compile-time loop); a kernel with M
+   lanes per instance evaluates ONE member per lane (bdf_wave.hip) instead of all outputs in every lane.  The
+   expression text -- operand order included -- is the same for all members and all mappings. */
+#ifndef SA_FAM_BEGIN
+#define SA_FAM_BEGIN(M) for (int sa_f = 0; sa_f < (M); sa_f++) {
+#define SA_F sa_f
+#define SA_TAU(j) ((j) == 0 ? sa_f : ((j) == sa_f ? 0 : (j)))
+#define SA_FAM_STORE(S0, value) { const double v_ = (value); SA_STORE_DYN((S0) + sa_f, v_); chk += v_ * 0.0; }
+#define SA_FAM_END }
+#endif
 SA_FN double sa_logaddexp(double a, double b) {
     double lo = fmin(a, b), hi = fmax(a, b);
     return hi + log1p(exp(lo - hi));
@@ -482,6 +498,104 @@ class Roller:
         return keep, hoist(sym.sympify(skel))
 
 
+#: group sizes tried for lane families (lanes per instance of the lean lane groups are 4 and 8)
+FAMILY_SIZES = (4, 8, 2, 3, 5, 6, 7)
+
+
+def find_lane_families(flat, out_index, n_out, symbol_map, leaf_axes, out_array):
+    """Group structure of a vector callback -> (M, [slot0, ...], relabelled symbol map) or None.
+
+    ``flat[k]`` is the expression of output slot ``out_index[k]``; the outputs are laid out like the array
+    ``out_array`` ("SA_Y": like the state; "SA_PS": like the differentiated parameters).  A FAMILY is a 1-D leaf of
+    length M of that array whose member f equals member 0 with all group coordinates relabelled by the transposition
+    (0 f) -- on every axis of length M of every state / adjoint-state / parameter leaf at once.  Checked symbolically
+    (``xreplace`` + sympy's canonical form), so a symbol may play the "own group" and the "summed over all groups" role
+    in the same expression.  Expressions with generated symbols (hoisted values, matrix-vector results) are left alone."""
+    if leaf_axes is None or n_out < 2 or list(out_index) != list(range(n_out)):
+        return None
+    by_slot = {(arr, idx): (name, axes) for name, (arr, idx, axes) in leaf_axes.items()}
+    known = set(leaf_axes)
+    free = set().union(*[e.free_symbols for e in flat]) if flat else set()
+    if any(sy.name not in known and sy.name != "time" for sy in free):
+        return None
+    symbols = {sy.name: sy for sy in free}
+    for M in FAMILY_SIZES:
+        leaves = []                # (slot0 of a 1-D output leaf of length M)
+        for (arr, idx), (name, axes) in by_slot.items():
+            if arr == out_array and len(axes) == 1 and axes[0][2] == M and axes[0][1] == 0 and idx + M <= n_out:
+                leaves.append(idx)
+        if not leaves:
+            continue
+
+        def relabel(f):
+            sub = {}
+            for name, sy in symbols.items():
+                if name == "time":
+                    continue
+                arr, idx, axes = leaf_axes[name]
+                new = idx
+                for stride, coord, length in axes:
+                    if length == M:
+                        t = f if coord == 0 else (0 if coord == f else coord)
+                        new += stride * (t - coord)
+                if new != idx:
+                    other = by_slot.get((arr, new))
+                    if other is None:
+                        return None
+                    sub[sy] = sym.Symbol(other[0], **sy.assumptions0)
+            return sub
+        subs = [relabel(f) for f in range(M)]
+        if any(sub is None for sub in subs):
+            continue
+        good = [s0 for s0 in sorted(leaves)
+                if all(sym.sympify(flat[s0]).xreplace(subs[f]) == sym.sympify(flat[s0 + f]) for f in range(1, M))
+                and any(sym.sympify(flat[s0 + f]) != 0 for f in range(M))]
+        if not good:
+            continue
+        fam_map = dict(symbol_map)
+        for name, (arr, idx, axes) in leaf_axes.items():
+            grouped = [(stride, coord) for stride, coord, length in axes if length == M]
+            if grouped:
+                base = idx - sum(stride * coord for stride, coord in grouped)
+                terms = ["%d" % base] if base else []
+                terms += [("SA_TAU(%d)" % coord) if stride == 1 else "%d*SA_TAU(%d)" % (stride, coord)
+                          for stride, coord in grouped]
+                fam_map[name] = "%s(%s)" % (arr, " + ".join(terms))
+        return M, good, fam_map
+    return None
+
+
+def _emit_families(name, signature, flat, n_out, symbol_map, names, fam):
+    """Callback with lane families: the outputs outside the families as ordinary statements, then every family
+    once (member 0) inside SA_FAM_BEGIN .. SA_FAM_END."""
+    M, starts, fam_map = fam
+    in_family = {s0 + f for s0 in starts for f in range(M)}
+    rest_slots = [k for k in range(n_out) if k not in in_family]
+    printer = HipExprPrinter(symbol_map)
+    fprinter = HipExprPrinter(fam_map)
+    lines = ["SA_TEMPLATE SA_FN int %s(%s) {" % (name, signature), "    SA_PROLOGUE", "    double chk = 0.0;"]
+    if rest_slots:
+        assigns, reduced = sym.cse([flat[k] for k in rest_slots], symbols=names, order="canonical")
+        lines += ["    const double %s = %s; SA_STMT_END" % (v.name, printer.doprint(val)) for v, val in assigns]
+        for k, value in zip(rest_slots, reduced):
+            if value == 0:
+                lines.append("    SA_STORE(%d, 0.0);" % k)
+            else:
+                lines.append("    { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; } SA_STMT_END"
+                             % (printer.doprint(value), k))
+    assigns, reduced = sym.cse([flat[s0] for s0 in starts], symbols=names, order="canonical")
+    lines.append("    SA_FAM_BEGIN(%d)" % M)
+    lines += ["        const double %s = %s; SA_STMT_END" % (v.name, fprinter.doprint(val)) for v, val in assigns]
+    for s0, value in zip(starts, reduced):
+        lines.append("        SA_FAM_STORE(%d, %s); SA_STMT_END" % (s0, fprinter.doprint(value)))
+    lines.append("    SA_FAM_END")
+    lines.append("    (void)t; (void)y; (void)ps; (void)pr; (void)out;")
+    lines.append("    SA_EPILOGUE")
+    lines.append("    return (chk == 0.0) ? 0 : 1;")
+    lines.append("}")
+    return "\n".join(lines)
+
+
 def _closure(needed, deps, order):
     """CSE temporaries (in definition order) that the expressions using ``needed`` depend on."""
     seen = set()
@@ -537,6 +651,8 @@ def emit_function(
     symbol_map: Dict[str, str],
     prefix: str,
     matvec: Optional[Dict[str, object]] = None,
+    leaf_axes=None,
+    out_array: Optional[str] = None,
 ) -> str:
     """One callback.  ``expr`` is ravelled; ``out_index[k]`` is the flat output
     slot of ``expr.ravel()[k]`` (lets the caller pick column-major storage).
@@ -545,6 +661,11 @@ def emit_function(
     output statements carry ``SA_OWNS(slot)`` guards (the kernels split those between wavefronts)."""
     flat = [sym.sympify(e) for e in np.asarray(expr, dtype=object).ravel()]
     names = (sym.Symbol("%s%d" % (prefix, i)) for i in count())
+    # group structure: one member per lane (SA_FAM_BEGIN); small callbacks only -- the large ones have their own forms
+    if out_array is not None and matvec is None and n_out <= 64:
+        fam = find_lane_families(flat, out_index, n_out, symbol_map, leaf_axes, out_array)
+        if fam is not None:
+            return _emit_families(name, signature, flat, n_out, symbol_map, names, fam)
     # re-rolling (Roller): long sums of isomorphic terms -> SA_SUM, isomorphic outputs -> SA_ROLLED
     if len(flat) * max((len(sym.Add.make_args(e)) for e in flat), default=0) >= ROLL_MIN and any(
             len(sym.Add.make_args(a)) >= ROLL_MIN for e in flat for a in sym.preorder_traversal(e) if a.is_Add) \
@@ -732,6 +853,7 @@ def generate_problem_source(
     description: str = "",
     matvec: Optional[Dict[str, Dict[str, object]]] = None,
     matfill: Optional[Dict[str, Dict[str, object]]] = None,
+    leaf_axes=None,
 ) -> str:
     """Full generated header: sizes + helpers + the five callbacks of the adjoint path and the
     parameter derivative of the right-hand side (forward sensitivities)."""
@@ -757,14 +879,14 @@ def generate_problem_source(
         "#define SA_N_REM %d" % n_rem,
         HELPERS_C,
         emit_function("sa_rhs", base, np.asarray(dydt, dtype=object).ravel(),
-                      list(range(n)), n, symbol_map, "r_", matvec=mv("f")),
+                      list(range(n)), n, symbol_map, "r_", matvec=mv("f"), leaf_axes=leaf_axes, out_array="SA_Y"),
         (emit_matfill_function("sa_jac", base, n, matfill["j"], symbol_map, "j_", "j") if "j" in matfill else
          emit_function("sa_jac", base, jac, col_major, n * n, symbol_map, "j_")),
         emit_function("sa_adj_rhs", adj, np.asarray(dlamdadt, dtype=object).ravel(),
-                      list(range(n)), n, symbol_map, "a_", matvec=mv("a")).replace(
+                      list(range(n)), n, symbol_map, "a_", matvec=mv("a"), leaf_axes=leaf_axes, out_array="SA_Y").replace(
                           "(void)pr;", "(void)pr; (void)lam;"),
         emit_function("sa_quad_rhs", adj, np.asarray(quad, dtype=object).ravel(),
-                      list(range(n_sub)), n_sub, symbol_map, "q_").replace(
+                      list(range(n_sub)), n_sub, symbol_map, "q_", leaf_axes=leaf_axes, out_array="SA_PS").replace(
                           "(void)pr;", "(void)pr; (void)lam;"),
         (emit_matfill_function("sa_adj_jac", base, n, matfill["b"], symbol_map, "b_", "b") if "b" in matfill else
          emit_function("sa_adj_jac", base, adj_jac, col_major, n * n, symbol_map, "b_")),

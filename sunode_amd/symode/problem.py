@@ -211,6 +211,7 @@ class SympyProblem:
 
         state_syms = self._declare(self.state_subset, "state", positive=True)
         param_syms = self._declare(self.params_subset, "params", real=True)
+        self._state_syms, self._param_syms = state_syms, param_syms
 
         sub_paths = set(self.params_subset.subset_paths)
         deriv = [param_syms[p].ravel() for p in self.params_subset.paths if p in sub_paths]
@@ -575,6 +576,32 @@ class SympyProblem:
             self._native_cache = (packed_arrays, slots)
         return self._native_cache
 
+    def _leaf_axes(self) -> Dict[str, Tuple[str, int, Tuple[Tuple[int, int, int], ...]]]:
+        """symbol name -> (array macro, flat slot, ((stride, coordinate, axis length), ...)) for every state, adjoint
+        state and user parameter symbol: where the symbol sits inside its leaf array.  The code generator uses it to
+        recognise GROUP structure (codegen.find_lane_families): a model written as loops over M groups is equivariant
+        under a relabelling of the groups, which acts on all axes of length M of all leaves at once."""
+        out: Dict[str, Tuple[str, int, Tuple[Tuple[int, int, int], ...]]] = {}
+
+        def add(symbols_by_path, subset, arr_of_slot):
+            for path, arr in symbols_by_path.items():
+                shape = tuple(subset.flat_shapes[path])
+                strides = [int(np.prod(shape[k + 1:], dtype=int)) for k in range(len(shape))]
+                for idx in product(*[range(k) for k in shape]):
+                    name = arr[idx].name
+                    text = self._c_slots.get(name)
+                    m = codegen._LEAF_RE.match(text) if text else None
+                    if m:
+                        out[name] = (m.group(1), int(m.group(2)),
+                                     tuple((strides[k], idx[k], shape[k]) for k in range(len(shape))))
+        add(self._state_syms, self.state_subset, None)
+        add(self._param_syms, self.params_subset, None)
+        for name, info in list(out.items()):
+            if info[0] == "SA_Y":           # the adjoint state mirrors the state's layout
+                lam = self._sym_lamda[info[1]].name
+                out[lam] = ("SA_LAM", info[1], info[2])
+        return out
+
     @property
     def n_remainder_native(self) -> int:
         """Length of the remainder vector the native code reads (user part + hoisted values)."""
@@ -624,6 +651,7 @@ class SympyProblem:
                 n_states=self.n_states, n_sub=self.n_params, n_rem=self.n_remainder_native,
                 symbol_map=slots, dydt=dydt, jac=jac, dlamdadt=dlamdadt, quad=quad, dydp_t=dydp_t,
                 description=desc, matvec=self._matvec, matfill=self._matfill,
+                leaf_axes=None if os.environ.get("SA_NO_LANE_FAMILIES") else self._leaf_axes(),
             )
         return self._native_source
 

@@ -1195,3 +1195,45 @@ def test_profiling_builds_integrate_like_the_default_build(name, mapping, define
     np.testing.assert_array_equal(g, go)
     np.testing.assert_array_equal(lam, lo)
     assert "PROFILE" not in defines or statsb[:, 15].min() > 0        # the timers did run
+
+
+@pytest.mark.parametrize("mapping", [None, "4", "mem"])
+def test_lane_family_callbacks_in_the_one_lane_and_other_mappings(mapping, monkeypatch):
+    """Two age groups x (S, I): the generated callbacks are lane families of two members (symode/codegen.py
+    find_lane_families).  The one-lane-per-instance kernel unrolls the member loop at compile time (register arrays),
+    4 lanes per instance give lanes 0..1 / 2..3 the members 0 / 1, the memory-resident mapping loops: callbacks equal
+    the host build bit for bit, and the whole forward + adjoint solve equals the oracle."""
+    from sunode_amd import _native
+    from sunode_amd.solver import AdjointSolver
+    if mapping:
+        monkeypatch.setenv("SA_FORCE_GROUP", mapping)
+    prob = make_problem("sir2")
+    assert _native.kernel_variant(prob.native_source())[0] == {None: "bdf_kernels.hip", "4": "bdf_wave.hip", "mem": "bdf_mem.hip"}[mapping]
+    rng = np.random.RandomState(11)
+    B = 37
+    y0 = np.tile([900.0, 700.0, 3.0, 1.0], (B, 1)) * np.exp(0.05 * rng.randn(B, 4))
+    ps = np.array([0.4, 0.3, 0.15]) * np.exp(0.2 * rng.randn(B, 3))
+    pr = np.array([1.0, 0.3, 0.2, 1.0, 50.0, 30.0])
+    tv = np.linspace(0.0, 40.0, 9)
+    grads = 1.0 + 0.5 * np.cos(1.1 * np.arange(9)[:, None] + 0.7 * np.arange(4)[None, :])
+    tol = dict(abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8, quad_abstol=1e-8, quad_reltol=1e-8)
+    sol = AdjointSolver(prob, **tol)
+    orc = make_oracle("sir2")
+    tpts, lam5 = np.linspace(0.0, 1.0, 5), rng.randn(5, 4)
+    got = sol._engine().eval_callbacks(tpts, y0[:5], lam5, ps[:5], np.tile(pr, (5, 1)))
+    for i in range(5):
+        host = orc.eval(tpts[i], y0[i], lam5[i], ps[i], pr)
+        for key in ("rhs", "adj", "quad"):
+            np.testing.assert_array_equal(got[key][i], host[key])
+    y, st, stats = sol.solve_forward_batch(0.0, tv, y0, ps, pr)
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    cfg = orc.config(rtol=1e-8, atol=1e-8, rtolB=1e-8, atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
+    yo, so, sto = orc.solve_forward(cfg, y0, ps, pr, 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (st == 0).all() and (stb == 0).all() and (so == 0).all() and (sbo == 0).all()
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(statsb[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+    assert np.abs(g).max() > 0

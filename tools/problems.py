@@ -145,8 +145,24 @@ def switched(t, y, p):
             "z": y.x - y.z}
 
 
+def sir_two_groups(t, y, p):
+    """Two age groups x (S, I): the smallest model with GROUP structure (the code generator emits its callbacks as lane
+    families, symode/codegen.py find_lane_families); four states: runs in the one-lane-per-instance kernel, where the
+    family loop is unrolled at compile time."""
+    n = [y.S[i] + y.I[i] + p.pop[i] for i in range(2)]
+    force = [sum(p.beta[i] * p.C[i, j] * y.I[j] / n[j] for j in range(2)) for i in range(2)]
+    return {"S": [-force[i] * y.S[i] + p.gamma * y.I[i] / 4 for i in range(2)],
+            "I": [force[i] * y.S[i] - p.gamma * y.I[i] for i in range(2)]}
+
+
 #: test-only problems without reference-generated golden fixtures
 EXTRA_PROBLEMS = {
+    "sir2": dict(
+        params={"beta": (2,), "C": (2, 2), "gamma": (), "pop": (2,)},
+        states={"S": (2,), "I": (2,)},
+        rhs=sir_two_groups,
+        derivative_params=[("beta",), ("gamma",)],
+    ),
     "switched": dict(
         params={"k": (), "a": ()},
         states={"x": (), "z": ()},
