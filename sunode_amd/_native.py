@@ -432,7 +432,9 @@ def write_guard_verdict(code_object: str, safe_object: str, kinds: dict, detail:
            "toolchain": toolchain_id()["hash"], "kinds": kinds, "detail": detail,
            "note": "differential guard: first instances of the first batch through both builds, statuses / counters / "
                    "outputs compared bit for bit on the device (include/sunode_amd.h, sa_solver_attach_guard)"}
-    tmp = "%s.tmp%d" % (guard_verdict_path(code_object), os.getpid())
+    import threading
+    # (several handles of one solver object report from their own host threads: private temporaries, atomic renames)
+    tmp = "%s.tmp%d_%d" % (guard_verdict_path(code_object), os.getpid(), threading.get_ident())
     try:
         with open(tmp, "w") as fh:
             json.dump(doc, fh, indent=1, sort_keys=True)
