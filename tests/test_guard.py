@@ -137,6 +137,33 @@ def test_guard_finds_no_difference_on_any_shape_of_the_sweep(monkeypatch):
     assert all(v == (["adjoint"], [], min(B, 64)) for (name, B), v in zip(ADJOINT_CASES, seen.values())), seen
 
 
+@pytest.mark.gpu
+def test_guard_under_several_handles_of_one_solver(monkeypatch):
+    """AdjointSolver(devices=[0, 0, 0]): every handle carries its own guard and reports from its own host thread; the
+    three checks agree, the verdict file stays valid JSON, the results are the one-handle results."""
+    from sunode_amd.solver import AdjointSolver
+    monkeypatch.setenv("SA_GUARD", "1")
+    prob, d, ps, pr = _lv(600)
+    verdict = _forget_verdict(prob.native_source())
+    tv = d["tvals"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        sol = AdjointSolver(prob, devices=[0, 0, 0], interleaved=True, arena_gib=6, **TOL)
+        y, st, _ = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+        g, lam, stb, _ = sol.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 2)))
+    for eng in sol._engines():
+        state = eng.guard_state()
+        assert state["verified"] == ["adjoint"] and not state["differs"] and state["n_sample"]["adjoint"] == 64
+    assert json.load(open(verdict))["kinds"]["adjoint"]["verdict"] == "identical"
+    monkeypatch.setenv("SA_GUARD", "0")
+    one = AdjointSolver(prob, **TOL)
+    y1, _, _ = one.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+    g1, lam1, _, _ = one.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 2)))
+    np.testing.assert_array_equal(y, y1)
+    np.testing.assert_array_equal(g, g1)
+    np.testing.assert_array_equal(lam, lam1)
+
+
 def _attach_other_build(monkeypatch, prob, define):
     """A NativeSolver on the default LV build whose guard partner is a build that differs ON PURPOSE."""
     from sunode_amd import _native
