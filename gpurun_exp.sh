@@ -1,3 +1,2 @@
-export SA_GUARD=0
-SA_KERNEL_DEFINES=-DSA_ABLATE_PROFILE python tools/profile_lv.py 65536 lv 2>&1 | tail -4
-SA_KERNEL_DEFINES=-DSA_ABLATE_PROFILE python tools/profile_lv.py 262144 robertson 2>&1 | tail -4
+(time python -m pytest tests -m gpu -q --timeout 1500 --durations=8 2>&1 | tail -16) > gpurun_out/r05_gputests.log 2>&1; tail -5 gpurun_out/r05_gputests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
