@@ -125,17 +125,29 @@ int sa_solver_sizes(const sa_solver *s, int32_t *n_states, int32_t *n_sub, int32
    (SIOptimizeVGPRLiveRange, profiles/r04_sens_anomaly.txt) -- and a GPU box has no CPU oracle to notice.  So a handle
    can be given the CONSERVATIVE build of the same source (sunode_amd._native.build_code_object(..., safe=True): the
    pass off): on the first batch of each kind of call -- SA_GUARD_PLAIN sa_solve_batch, SA_GUARD_ADJOINT
-   sa_solve_forward_batch + sa_solve_backward_batch[_all], SA_GUARD_SENS sa_solve_sens_batch -- the library runs the
-   first min(B, n_sample) instances through BOTH code objects on two internal handles and compares statuses, all
-   counters and every fp64 output bit for bit.  Equal: the kind is verified (a check with fewer than 16 instances is
-   repeated on the next call, at most three times).  Any difference: the handle switches to the conservative code
-   object for good (sa_guard_state: using_safe) and, if the difference showed in the backward pass, repeats the
-   forward pass of the batch with it before it integrates backward.  `verified_kinds`: kinds a previous process
-   already verified for this pair of code objects (sunode_amd keeps that verdict in a file next to the code object).
-   Costs two extra launches of <= 64 instances per kind, once; synchronises the handle's stream while it runs. */
+   sa_solve_forward_batch + sa_solve_backward_batch[_all], SA_GUARD_SENS sa_solve_sens_batch -- the library runs a
+   SAMPLE of min(B, n_sample) instances through BOTH code objects on two internal handles (created when the first
+   check is due) and compares statuses, all counters and every fp64 output bit for bit.  The sample is chosen after the
+   batch's own launch, from its statuses and counters: the first 16 instances, one instance per failure code, the
+   instances with the most steps / error-test failures / convergence failures / set-ups / Jacobian evaluations /
+   retries, and an even stride over the rest -- rarely taken paths are compared if any instance of the batch takes
+   them.  Equal: the kind is verified (a check with fewer than 16 instances is repeated on the next call, at most
+   three times).  Any difference: the handle switches to the conservative code object for good (sa_guard_state:
+   using_safe) and, if the difference showed in the backward pass, repeats the forward pass of the batch with it
+   before it integrates backward (the forward OUTPUTS the caller already received are not recomputed).
+   While a kind is verified, SA_MEM_HOST calls -- whose statuses / counters reach the host anyway -- are scanned for a
+   status code, a first error-test / convergence failure or a doubled step count the verified sample never showed;
+   the first such batch within the next 32 calls of the kind is checked again, once (sa_guard_state reports
+   SA_GUARD_RECHECK_OPEN in `pending` while that window is open).  Forward passes of the adjoint kind that no backward
+   call follows are checked at most twice; the check resumes with the first forward call after a backward call.
+   `verified_kinds`: kinds NOT to check -- those a previous process already verified for this pair of code objects
+   (sunode_amd keeps that verdict in a file next to the code object) and those the caller will never run on this
+   handle (an AdjointSolver never calls sa_solve_batch).
+   Costs two extra launches of <= n_sample instances per kind, once; synchronises the handle's stream while it runs. */
 #define SA_GUARD_PLAIN 1
 #define SA_GUARD_ADJOINT 2
 #define SA_GUARD_SENS 4
+#define SA_GUARD_RECHECK_OPEN 0x80000000u   /* sa_guard_state, `pending`: a verified kind may still be re-checked */
 int sa_solver_attach_guard(sa_solver *s, const char *safe_code_object_path, int32_t n_sample /* 0: 64 */,
                            uint32_t verified_kinds);
 /* Any pointer may be NULL.  verified / differs: bit masks of SA_GUARD_*; n_sample[3]: instances of the largest check

@@ -400,6 +400,8 @@ def check_code_object_budget(label: str, path: str, budget: dict) -> list:
 # ----------------------------------------------------------------------------------------------
 #: kinds of batch call the guard checks separately (bit masks of the C ABI)
 GUARD_KINDS = {"plain": 1, "adjoint": 2, "sens": 4}
+GUARD_RECHECK_OPEN = 0x80000000     # sa_guard_state `pending`: a verified kind may still be re-checked
+GUARD_PERSIST_MIN = 16              # smallest sample whose "identical" verdict is written next to the code object
 
 
 def guard_enabled() -> bool:
@@ -552,11 +554,14 @@ class NativeSolver:
                  atolB=1e-10, rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
                  max_retries_bwd=50, traj_capacity=500_001, n_states: Optional[int] = None, sens: bool = False,
                  constraints=None, hermite: bool = False, arena_bytes: int = 0, compact: bool = False,
-                 guard: Optional[bool] = None, guard_sample: int = 64):
+                 guard: Optional[bool] = None, guard_sample: int = 64, guard_kinds=None):
         """``guard`` (default: on, SA_GUARD=0 turns it off): the differential guard -- the conservative build of the
-        same source is compiled next to the default one and the first instances of the first batch of every kind of
-        call run through both on the device; any difference in statuses, counters or outputs makes the handle use
-        the conservative build (RuntimeWarning), and the verdict is kept next to the code object."""
+        same source is compiled next to the default one and a sample of the first batch of every kind of call (chosen
+        from the batch's own statuses and counters, include/sunode_amd.h) runs through both on the device; any
+        difference in statuses, counters or outputs makes the handle use the conservative build (RuntimeWarning), and
+        the verdict is kept next to the code object.  ``guard_kinds``: the kinds of call this handle will make
+        (``("adjoint",)`` under an AdjointSolver, ``("plain",)`` / ``("sens",)`` under a Solver; default: all) --
+        kinds it never runs are not left pending, so the shadow handles go away once the used kind is verified."""
         self.L = load_library()
         build_kw = dict(sens=sens, constraints=constraints is not None, hermite=hermite, compact=compact)
         self._guard_open = False
@@ -599,10 +604,17 @@ class NativeSolver:
         self.n, self.p, self.r = n.value, p.value, r.value
         self.set_options()
         if self._guard_safe:
-            mask = sum(bit for kind, bit in GUARD_KINDS.items()
-                       if self._guard_kinds.get(kind, {}).get("verdict") == "identical")
-            self._check(self.L.sa_solver_attach_guard(self._h, self._guard_safe.encode(), int(guard_sample), mask))
-            self._guard_seen = (mask, 0)
+            used = set(GUARD_KINDS) if guard_kinds is None else set(guard_kinds)
+            if not used <= set(GUARD_KINDS):
+                raise ValueError("guard_kinds must be some of %s" % sorted(GUARD_KINDS))
+            verified = sum(bit for kind, bit in GUARD_KINDS.items()
+                           if self._guard_kinds.get(kind, {}).get("verdict") == "identical")
+            unused = sum(bit for kind, bit in GUARD_KINDS.items() if kind not in used)
+            self.guard_report["checked_kinds"] = sorted(used)
+            self._check(self.L.sa_solver_attach_guard(self._h, self._guard_safe.encode(), int(guard_sample),
+                                                      verified | unused))
+            self._guard_unused = unused
+            self._guard_seen = (verified | unused, 0)
             self._guard_open = True
             self._guard_poll()
 
@@ -643,8 +655,10 @@ class NativeSolver:
         self._check(self.L.sa_guard_state(self._h, ctypes.byref(pend), ctypes.byref(ver), ctypes.byref(dif),
                                           ctypes.byref(safe), ns, ctypes.byref(detail)))
         names = lambda m: [k for k, bit in GUARD_KINDS.items() if m & bit]          # noqa: E731
-        return dict(pending=names(pend.value), verified=names(ver.value), differs=names(dif.value),
+        unused = getattr(self, "_guard_unused", 0)
+        return dict(pending=names(pend.value), verified=names(ver.value & ~unused), differs=names(dif.value),
                     using_conservative=bool(safe.value), n_sample=dict(zip(GUARD_KINDS, list(ns))),
+                    recheck_open=bool(pend.value & GUARD_RECHECK_OPEN),
                     detail=(detail.value or b"").decode(), _masks=(ver.value, dif.value))
 
     def _guard_poll(self):
@@ -659,16 +673,23 @@ class NativeSolver:
                     self._guard_kinds[kind] = {"verdict": "identical", "n_sample": st["n_sample"][kind]}
             for kind in st["differs"]:
                 self._guard_kinds[kind] = {"verdict": "differs", "n_sample": st["n_sample"][kind]}
-            write_guard_verdict(self._guard_fast, self._guard_safe, self._guard_kinds, st["detail"])
+            # on disk: a difference always; "identical" only from a sample of at least GUARD_PERSIST_MIN instances
+            # (a verdict from three batches of one draw stays with this process -- ADVICE r5)
+            keep = {k: v for k, v in self._guard_kinds.items()
+                    if v["verdict"] == "differs" or v.get("n_sample", 0) >= GUARD_PERSIST_MIN}
+            if keep:
+                write_guard_verdict(self._guard_fast, self._guard_safe, keep, st["detail"])
             self.guard_report.update(kinds=dict(self._guard_kinds), using_conservative=st["using_conservative"],
                                      detail=st["detail"])
             if st["differs"]:
                 import warnings
-                warnings.warn("sunode_amd differential guard: %s -- this solver now runs the conservative build; the "
-                              "verdict is recorded in %s" % (st["detail"], guard_verdict_path(self._guard_fast)),
-                              RuntimeWarning, stacklevel=4)
+                warnings.warn("sunode_amd differential guard: %s -- this solver now runs the conservative build (a "
+                              "difference found in a backward pass repeats this batch's forward pass internally; "
+                              "forward outputs already returned to the caller came from the default build and are "
+                              "not recomputed); the verdict is recorded in %s"
+                              % (st["detail"], guard_verdict_path(self._guard_fast)), RuntimeWarning, stacklevel=4)
                 self.code_object = self._guard_safe
-        if not st["pending"]:
+        if not st["pending"] and not st["recheck_open"]:
             self._guard_open = False
 
     def close(self):

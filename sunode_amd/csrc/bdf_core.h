@@ -21,6 +21,7 @@
  *   interp_y          forward state at t from the stored trajectory (backward problem)
  *   SV / SLOOP_BEGIN / SLOOP_END      sensitivity vectors (registers, or streamed from the workspace)
  *   COLD_STORE / COLD_LOAD, PH_T0 / PH_ADD           optional hooks (LDS parking of cold state, phase timers)
+ *   TMPV / TMPQ / TMPV2                              optional: where the controller's vector temporaries live
  *   SA_POLY_CM(BWD)   whether the pow polynomials read their coefficients from constant memory (sa_common.h)
  * A controller change is an edit of THIS file; bit-equality with the oracle (tests -m gpu) covers every mapping.
  * Since round 5 also included by
@@ -31,6 +32,17 @@
  */
 #ifndef SA_BDF_CORE_H
 #define SA_BDF_CORE_H
+
+/* state- / quadrature-sized temporaries of the controller: per-lane register arrays, unless the mapping keeps its
+   vectors elsewhere (bdf_mem.hip: numbered slots of the HBM workspace -- an n-sized array per lane would be
+   O(n) scratch per lane there).  Slots live at the same time never share a number. */
+#ifndef TMPV
+#define TMPV(m, name, slot) double name[RS]
+#define TMPQ(m, name, slot) double name[RQ]
+#define TMPV2(m, name, rows, slot) double name[rows][RS]
+#endif
+#define SA_TMPV_SLOTS 20
+#define SA_TMPQ_SLOTS 5
 
 #ifdef SA_SENS
 /* ---- forward sensitivities: the parts of the corrector that do not depend on the mapping ---- */
@@ -56,7 +68,7 @@ DEV double sens_update_norm(const SA_STATE<BWD> &m, double old_nrm)
 {
     double nrm = old_nrm;
     SLOOP_BEGIN(is)
-        double x[RS], w[RS];
+        TMPV(m, x, 0); TMPV(m, w, 1);
         VFOR(r) { x[r] = SV(m, v_x, is, r); w[r] = SV(m, v_w, is, r); } VEND
         const double snrm = wrms_n(m, x, w);
         nrm = snrm > nrm ? snrm : nrm;
@@ -86,7 +98,7 @@ template <bool BWD>
 DEV void cv_sens_newton_update(SA_STATE<BWD> &m)
 {
     SLOOP_BEGIN(is)
-        double d[RS];
+        TMPV(m, d, 2);
         VFOR(r) d[r] = -1.0 * SV(m, SV_DELTA, is, r); VEND
         dense_getrs(m, d);
         if (m.gamrat != 1.0) {
@@ -132,7 +144,7 @@ DEV void cv_reinit(SA_STATE<BWD> &m, double t0, const VY &y0, const VQ &q0)
 template <bool BWD>
 DEV double cv_upper_bound_h0(SA_STATE<BWD> &m, double tdist)
 {
-    double w[RS];
+    TMPV(m, w, 3);
     ewt_set(m, m.zn[0], w);
     double loc = 0.0;
     VFOR(r) {
@@ -159,7 +171,7 @@ DEV double cv_upper_bound_h0(SA_STATE<BWD> &m, double tdist)
     }
 #endif
     if (BWD) {
-        double wq[RQ];
+        TMPQ(m, wq, 4);
         ewtQ_set(m, m.znQ[0], wq);
         double locq = 0.0;
         QFOR(r) {
@@ -311,7 +323,7 @@ DEV void cv_increase_bdf(SA_STATE<BWD> &m)
     } SEND
     const double A1 = (-alpha0 - alpha1) / prod;
     const int L = m.L;
-    double znL[RS], znQL[RQ];
+    TMPV(m, znL, 4); TMPQ(m, znQL, 0);
     VFOR(r) znL[r] = A1 * m.zsave[r]; VEND
     QFOR(r) znQL[r] = BWD ? A1 * m.zsaveQ[r] : 0.0; QEND
     SFOR(j, 2, (QMAX) + 1) {
@@ -329,7 +341,7 @@ DEV void cv_increase_bdf(SA_STATE<BWD> &m)
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
-            double zl[RS];
+            TMPV(m, zl, 5);
             VFOR(r) zl[r] = A1 * SV(m, SV_ZSAVE, is, r); VEND
             SFOR(j, 2, (QMAX) + 1) { if (j == L) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = zl[r]; VEND } } SEND
             SFOR(j, 2, QMAX) {
@@ -353,7 +365,7 @@ DEV void cv_decrease_bdf(SA_STATE<BWD> &m)
             SFOR_DOWN(i, j + 2, 2) m.l[i] = FMA(m.l[i], xi, m.l[i - 1]); SEND
         }
     } SEND
-    double znq[RS], znQq[RQ];
+    TMPV(m, znq, 6); TMPQ(m, znQq, 1);
     VFOR(r) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } VEND
     QFOR(r) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } QEND
     SFOR(j, 2, QMAX) {
@@ -365,7 +377,7 @@ DEV void cv_decrease_bdf(SA_STATE<BWD> &m)
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
-            double zq[RS];
+            TMPV(m, zq, 7);
             VFOR(r) {
                 zq[r] = SV(m, SV_ZN0 + 2, is, r);
                 SFOR(k, 3, (QMAX) + 1) { if (m.q == k) zq[r] = SV(m, SV_ZN0 + k, is, r); } SEND
@@ -416,7 +428,7 @@ DEV void cv_predict(SA_STATE<BWD> &m)
 #ifdef SA_SENS
     if (SENS_ON(m)) {           /* the same Pascal-triangle pass, one load and one store per entry */
         SLOOP_BEGIN(is)
-            double z[QMAX + 1][RS];
+            TMPV2(m, z, (QMAX) + 1, 8);
             SFOR(j, 0, (QMAX) + 1) { VFOR(r) z[j][r] = SV(m, SV_ZN0 + j, is, r); VEND } SEND
             SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { VFOR(r) z[j - 1][r] = z[j - 1][r] + z[j][r]; VEND } SEND } SEND
             SFOR(j, 0, QMAX) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = z[j][r]; VEND } SEND
@@ -438,7 +450,7 @@ DEV void cv_restore(SA_STATE<BWD> &m, double saved_t)
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
-            double z[QMAX + 1][RS];
+            TMPV2(m, z, (QMAX) + 1, 8);
             SFOR(j, 0, (QMAX) + 1) { VFOR(r) z[j][r] = SV(m, SV_ZN0 + j, is, r); VEND } SEND
             SFOR(k, 1, (QMAX) + 1) { SFOR_DOWN(j, QMAX, k) { VFOR(r) z[j - 1][r] = z[j - 1][r] - z[j][r]; VEND } SEND } SEND
             SFOR(j, 0, QMAX) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = z[j][r]; VEND } SEND
@@ -483,7 +495,7 @@ DEV int cv_nls_residual(SA_STATE<BWD> &m, VR &res)
 template <bool BWD>
 DEV int cv_newton_pass(SA_STATE<BWD> &m, int callSetup, int jbad, int &convfail, int &in_loop)
 {
-    double delta[RS];
+    TMPV(m, delta, 14);
 #ifdef SA_SENS
     const bool sim = SENS_ON(m) && m.ism == 0;
 #endif
@@ -672,7 +684,7 @@ DEV void cv_complete_step(SA_STATE<BWD> &m)
 #ifdef SA_SENS
     if (SENS_ON(m)) {
         SLOOP_BEGIN(is)
-            double ac[RS];
+            TMPV(m, ac, 15);
             VFOR(r) ac[r] = SV(m, SV_ACOR, is, r); VEND
             SFOR(j, 0, (QMAX) + 1) { VFOR(r) SV(m, SV_ZN0 + j, is, r) = FMA(m.l[j], ac[r], SV(m, SV_ZN0 + j, is, r)); VEND } SEND
             if ((m.qwait - 1 == 1) && (m.q != QMAX)) { VFOR(r) SV(m, SV_ZSAVE, is, r) = ac[r]; VEND }
@@ -729,7 +741,7 @@ DEV void cv_prepare_next_step(SA_STATE<BWD> &m, double dsm)
         m.eta = small ? 1.0 : capped;
         return;
     }
-    double znq[RS], znQq[RQ], tv[RS], tvQ[RQ];
+    TMPV(m, znq, 16); TMPQ(m, znQq, 2); TMPV(m, tv, 17); TMPQ(m, tvQ, 3);
     VFOR(r) { znq[r] = m.zn[0][r]; SFOR(j, 1, (QMAX) + 1) znq[r] = (m.q == j) ? m.zn[j][r] : znq[r]; SEND } VEND
     QFOR(r) { znQq[r] = m.znQ[0][r]; SFOR(j, 1, (QMAX) + 1) znQq[r] = (m.q == j) ? m.znQ[j][r] : znQq[r]; SEND } QEND
     double ddn = wrms_n(m, znq, m.ewt);
@@ -1011,7 +1023,7 @@ DEV int cv_attempt(SA_STATE<BWD> &m, StepCtl &c)
     VFOR(r) m.y[r] = m.zn[0][r] + m.acor[r]; VEND
 #ifdef SA_CONSTRAINTS
     if (!BWD && m.constr) {             /* cvCheckConstraints (see the oracle) */
-        double mm[RS], v[RS];
+        TMPV(m, mm, 18); TMPV(m, v, 19);
         double anyv = 0.0;
         VFOR(r) {
             const bool bad = (IDX(m, r) < NS) && constr_violated(m.cons[r], m.y[r]);

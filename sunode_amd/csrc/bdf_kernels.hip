@@ -842,6 +842,10 @@ extern "C" __global__ void __launch_bounds__(64) SA_FWD_ATTR sa_k_forward(sa_fwd
     SFOR(i, 0, SA_N_STATS) st[i] = 0; SEND
     accumulate_stats(m, st);
     st[ST_NPTS] = np; st[ST_RETRIES] = total_retries; st[ST_ATTEMPTS] = attempts;
+#ifdef SA_TEST_PERTURB_NETF          /* tests/test_guard.py: a build that differs ONLY for instances with that many error-test
+                                       failures -- a difference a prefix sample would never see (never a default) */
+    if (status == CV_SUCCESS && st[ST_NETF] >= SA_TEST_PERTURB_NETF) yo[(int64_t)(a.n_t - 1) * NS] += 1.0;
+#endif
     SFOR(i, 0, SA_N_STATS) a.stats[(int64_t)inst * SA_N_STATS + i] = st[i]; SEND
 }
 

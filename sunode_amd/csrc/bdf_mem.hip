@@ -77,13 +77,17 @@ constexpr int next_pow2_c(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 #define O_HY (O_INVP + NS)
 #define O_F0 (O_HY + 6 * NS)
 #define O_TREE (O_F0 + NS)
+/* the controller's vector temporaries (bdf_core.h TMPV / TMPQ: 20 state-sized + 5 quadrature-sized slots) */
+#define O_TMP (O_TREE + PS_TREE)
+#define O_TMPQ (O_TMP + 20 * NS)
+#define O_TMP_END (O_TMPQ + 5 * NQ)
 #ifdef SA_SENS      /* forward sensitivities: the SV_COUNT vectors of the NQ sensitivity systems (sa_common.h), J and df/dp */
-#define O_SV (O_TREE + PS_TREE)
+#define O_SV O_TMP_END
 #define O_DP (O_SV + SV_COUNT * NQ * NS)
 #define O_JT (O_DP + NQ * NS)
 #define WS_DOUBLES (O_JT + NS * NS)
 #else
-#define WS_DOUBLES (O_TREE + PS_TREE)
+#define WS_DOUBLES O_TMP_END
 #endif
 
 /* strided sink for the generated callbacks: slot k of the output lives at p[k * stride] */
@@ -176,6 +180,10 @@ DEV void bind_workspace(Cm<BWD> &m, double *ws, int64_t stride, int inst)
 #define PH_T0
 #define PH_ADD(m, k)
 #define SA_POLY_CM(BWD) false
+/* vector temporaries of the controller: slots of the workspace, not n-sized arrays in every lane's scratch */
+#define TMPV(m, name, slot) const Vec name = wvec(m, O_TMP + (slot) * NS)
+#define TMPQ(m, name, slot) const Vec name = wvec(m, O_TMPQ + (slot) * NQ)
+#define TMPV2(m, name, rows, slot) const Cols name{(m).w + (int64_t)(O_TMP + (slot) * NS) * (m).S, (m).S, NS}
 #ifdef SA_SENS
 #define SENS_ON(m) (!BWD && (m).sensi)
 #define SV(m, v, is, r) W(m, O_SV, (((v) * NQ + (is)) * NS) + (r))
@@ -477,6 +485,7 @@ DEV int cv_lsetup(Cm<BWD> &m, int convfail)
 }
 
 #include "bdf_core.h"
+static_assert(SA_TMPV_SLOTS == 20 && SA_TMPQ_SLOTS == 5, "O_TMP / O_TMPQ reserve 20 + 5 slots");
 
 /* forward: build the divided-difference record of the newest point from the history in O_HY
    (hY[j] = point s-j) directly in the trajectory record (see bdf_kernels.hip::store_table) */

@@ -9,6 +9,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
@@ -461,8 +463,11 @@ static int launch_forward(sa_solver *s, const FwdLaunch &f)
 }
 
 static int guard_forward(sa_solver *s, int mode, int32_t B, const double *d_y0, const double *d_ps, const double *d_pr,
-                         int32_t rem_stride, double t0, const double *d_tv, int32_t n_t);
+                         int32_t rem_stride, double t0, const double *d_tv, int32_t n_t, const int32_t *d_status,
+                         const int64_t *d_stats);
 static bool guard_wants(const sa_solver *s, uint32_t kind);
+static bool guard_recheck_due(sa_solver *s, uint32_t kind, int32_t B, const int32_t *status, const int64_t *stats);
+static bool guard_switched(sa_solver *s);
 
 static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const double *y0, const double *ps,
                           const double *pr, int32_t rem_stride, double t0, const double *tvals, int32_t n_t,
@@ -491,11 +496,7 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
     } else if (mem != SA_MEM_DEVICE) {
         return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
     }
-    if (guard_wants(s, mode == SA_MODE_PLAIN ? SA_GUARD_PLAIN : SA_GUARD_ADJOINT)) {
-        /* first batch of this kind on a code object nobody has compared yet: its first instances through the
-           default AND the conservative build, bit for bit ("differential guard" below) */
-        if ((rc = guard_forward(s, mode, B, d_y0, d_ps, d_pr, rem_stride, t0, d_tv, n_t))) return rc;
-    }
+    const uint32_t gkind = mode == SA_MODE_PLAIN ? SA_GUARD_PLAIN : SA_GUARD_ADJOINT;
     FwdLaunch f{mode, B, n_t, rem_stride, 2, 0, t0, d_y0, d_ps, d_pr, d_tv, d_yout, d_status, d_stats, nullptr};
     if (mode == SA_MODE_PLAIN) {
         HIP_TRY(hipEventRecord(s->ev[0], s->stream));
@@ -552,6 +553,15 @@ static int forward_common(sa_solver *s, int mode, int mem, int32_t B, const doub
             HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(int64_t) * nB * SA_N_STATS, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
+    /* differential guard ("differential guard" below): the first batch of this kind on a code object nobody has
+       compared yet -- or a later host-memory batch that shows a status code / failure regime the verified sample never
+       had -- goes through the default AND the conservative build: a sample chosen from the statuses and counters the
+       main launch has just produced, compared bit for bit */
+    if (guard_wants(s, gkind) || (mem == SA_MEM_HOST && guard_recheck_due(s, gkind, B, status, stats))) {
+        if ((rc = guard_forward(s, mode, B, d_y0, d_ps, d_pr, rem_stride, t0, d_tv, n_t, d_status, d_stats))) return rc;
+        if (guard_switched(s))      /* the builds differ: THIS batch again, with the conservative code object */
+            return forward_common(s, mode, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats);
+    }
     return SA_OK;
 }
 
@@ -564,7 +574,7 @@ extern "C" int sa_solve_batch(sa_solver *s, int mem, int32_t B, const double *y0
 
 static int guard_sens(sa_solver *s, int ism, const double *scaling, int32_t B, const double *d_y0, const double *d_ps,
                       const double *d_pr, int32_t rem_stride, const double *d_s0, double t0, const double *d_tv,
-                      int32_t n_t);
+                      int32_t n_t, const int32_t *d_status, const int64_t *d_stats);
 
 extern "C" int sa_solve_sens_batch(sa_solver *s, int mem, int ism, const double *scaling, int32_t B,
                                    const double *y0, const double *ps, const double *pr, int32_t rem_stride,
@@ -602,9 +612,6 @@ extern "C" int sa_solve_sens_batch(sa_solver *s, int mem, int ism, const double 
     } else if (mem != SA_MEM_DEVICE) {
         return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
     }
-    if (guard_wants(s, SA_GUARD_SENS)) {
-        if ((rc = guard_sens(s, ism, scaling, B, d_y0, d_ps, d_pr, rem_stride, d_s0, t0, d_tv, n_t))) return rc;
-    }
     sa_sens_args a;
     memset(&a, 0, sizeof a);
     a.B = B; a.n_t = n_t; a.ism = ism; a.mxstep = s->opt.mxstep; a.max_retries = s->opt.max_retries_fwd;
@@ -625,6 +632,13 @@ extern "C" int sa_solve_sens_batch(sa_solver *s, int mem, int ism, const double 
             HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(int64_t) * nB * SA_N_STATS, hipMemcpyDeviceToHost, s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));      /* pbar staging buffer is host-owned */
+    if (guard_wants(s, SA_GUARD_SENS) || (mem == SA_MEM_HOST && guard_recheck_due(s, SA_GUARD_SENS, B, status, stats))) {
+        if ((rc = guard_sens(s, ism, scaling, B, d_y0, d_ps, d_pr, rem_stride, d_s0, t0, d_tv, n_t, d_status, d_stats)))
+            return rc;
+        if (guard_switched(s))      /* the builds differ: THIS batch again, with the conservative code object */
+            return sa_solve_sens_batch(s, mem, ism, scaling, B, y0, ps, pr, rem_stride, sens0, t0, tvals, n_t, y_out,
+                                       sens_out, status, stats);
+    }
     return SA_OK;
 }
 
@@ -681,6 +695,7 @@ static int resolve_forward(sa_solver *s)
 static int guard_backward(sa_solver *s, int32_t B, const double *d_ps, const double *d_pr, int32_t rem_stride,
                           double t0, double tend, const double *d_tv, int32_t n_t, const double *d_g,
                           int64_t grads_stride);
+static bool guard_backward_due(const sa_solver *s);
 
 extern "C" int sa_solve_backward_batch(sa_solver *s, int mem, int32_t B, const double *ps, const double *pr,
                                        int32_t rem_stride, double t0, double tend, const double *tvals,
@@ -728,7 +743,7 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
     } else if (mem != SA_MEM_DEVICE) {
         return fail(SA_ERR_ARG, "mem must be SA_MEM_HOST or SA_MEM_DEVICE");
     }
-    if (guard_wants(s, SA_GUARD_ADJOINT)) {
+    if (guard_backward_due(s)) {
         if ((rc = guard_backward(s, B, d_ps, d_pr, rem_stride, t0, tend, d_tv, n_t, d_g, grads_stride))) return rc;
     }
     sa_bwd_args a;
@@ -860,10 +875,24 @@ extern "C" int sa_solve_backward_batch_all(sa_solver *s, int mem, int32_t B, con
 
 /* ---- differential guard ----------------------------------------------------------------------------
  * include/sunode_amd.h, sa_solver_attach_guard.  Two shadow handles (the default and the conservative code object)
- * integrate the first instances of the caller's batch from the caller's own device arrays -- the first k rows of a
- * [B][...] array ARE the arrays of a k-instance batch -- into guard-owned output buffers; the host compares the bytes.
+ * integrate a SAMPLE of the caller's batch into guard-owned output buffers; the host compares the bytes.
+ *
+ * The sample (<= n_sample instances) is chosen AFTER the main launch of the batch, from its own statuses and counters
+ * (guard_select): the first 16 instances, one instance per failure code, the instances with the most steps, error-test
+ * failures, convergence failures, linear set-ups, Jacobian evaluations and retries, and an even stride over the rest
+ * of the batch -- a miscompiled block that only rarely-taken paths reach (order reduction after repeated error-test
+ * failures, the recoverable-rhs retry, the general-pivot LU) is compared if ANY instance of the batch takes it, not
+ * only if one of the first 64 does.  The sample's rows are gathered into guard-owned device arrays (a prefix of the
+ * batch is used in place).  While a kind is verified, host-memory calls (whose statuses / counters are on the host
+ * anyway) are scanned for a status code or a failure-counter regime the verified sample never showed; the first such
+ * batch is checked again, once per kind, within the first SA_GUARD_RECHECK_CALLS calls.
  * The shadows are created when a check is due and destroyed when nothing is pending any more.
  */
+struct GuardSeen {                  /* what the verified sample of a kind covered */
+    std::vector<int32_t> codes;
+    int64_t max_nst = 0, max_netf = 0, max_ncfn = 0;
+    bool valid = false;
+};
 struct Guard {
     std::string safe_path;
     sa_solver *fast = nullptr, *safe = nullptr;
@@ -871,16 +900,32 @@ struct Guard {
     uint32_t pending = 0, verified = 0, differs = 0;
     int32_t checks[3] = {0, 0, 0}, best[3] = {0, 0, 0};
     bool using_safe = false;
+    bool just_switched = false;    /* set by guard_switch, consumed by the entry point that repeats its batch */
     int32_t adj_k = 0;             /* adjoint check in flight: the shadows hold the forward pass of this many instances */
+    int32_t fwd_only = 0;          /* adjoint-kind forward checks that no backward call completed */
+    bool wait_backward = false;    /* ... after two of them: no further forward check until a backward call was seen */
+    std::vector<int32_t> idx;      /* the sample of the batch under check (ascending instance indices) */
+    bool prefix = true;            /* idx == 0..k-1: the caller's arrays are used in place */
+    DevBuf in[5];                  /* gathered rows of the sample: y0, ps, pr, sens0, grads */
+    GuardSeen seen[3];
+    int32_t recheck_left[3] = {1, 1, 1}, window[3] = {0, 0, 0};
+    std::vector<int32_t> h_status;
+    std::vector<int64_t> h_stats;
     DevBuf out[2][4];
     std::vector<unsigned char> host[2];
     std::string detail;
 };
-static const int32_t SA_GUARD_MIN_SAMPLE = 16, SA_GUARD_MAX_SMALL_CHECKS = 3;
+static const int32_t SA_GUARD_MIN_SAMPLE = 16, SA_GUARD_MAX_SMALL_CHECKS = 3, SA_GUARD_RECHECK_CALLS = 32,
+                     SA_GUARD_MAX_FWD_ONLY = 2;
 
 static int kind_slot(uint32_t kind) { return kind == SA_GUARD_PLAIN ? 0 : kind == SA_GUARD_ADJOINT ? 1 : 2; }
 
 static bool guard_wants(const sa_solver *s, uint32_t kind) { return s->guard && (s->guard->pending & kind); }
+
+static bool guard_backward_due(const sa_solver *s)
+{
+    return s->guard && ((s->guard->pending & SA_GUARD_ADJOINT) || s->guard->wait_backward);
+}
 
 static void guard_drop_shadows(Guard *g)
 {
@@ -888,6 +933,7 @@ static void guard_drop_shadows(Guard *g)
     if (g->safe) sa_solver_destroy(g->safe);
     g->fast = g->safe = nullptr;
     for (auto &row : g->out) for (DevBuf &b : row) b.release();
+    for (DevBuf &b : g->in) b.release();
     g->adj_k = 0;
 }
 
@@ -919,6 +965,8 @@ static int guard_set_options(sa_solver *s, const sa_options *)
     return SA_OK;
 }
 
+/* the shadow handles, created when the first check is due (not at attach: a handle whose kinds are all verified, or
+   that never runs the kind still pending, never pays for two extra modules, streams and buffer sets) */
 static int guard_shadows(sa_solver *s)
 {
     Guard *g = s->guard;
@@ -947,6 +995,109 @@ static void guard_switch(sa_solver *s)
     std::swap(s->k_sens, g->safe->k_sens);
     std::swap(s->path, g->safe->path);
     g->using_safe = true;
+    g->just_switched = true;
+}
+
+static bool guard_switched(sa_solver *s)
+{
+    if (!s->guard || !s->guard->just_switched) return false;
+    s->guard->just_switched = false;
+    return true;
+}
+
+/* ---- the sample ---- */
+static void guard_take(std::vector<char> &in, std::vector<int32_t> &idx, int32_t i, int32_t k)
+{
+    if ((int32_t)idx.size() < k && !in[(size_t)i]) { in[(size_t)i] = 1; idx.push_back(i); }
+}
+
+/* the `count` instances with the largest positive stats[slot] (ties: lowest index) */
+static void guard_take_top(std::vector<char> &in, std::vector<int32_t> &idx, int32_t B, const int64_t *stats, int slot,
+                           int count, int32_t k, bool positive_only)
+{
+    for (int c = 0; c < count; c++) {
+        int32_t arg = -1;
+        int64_t bestv = positive_only ? 0 : -1;
+        for (int32_t i = 0; i < B; i++) {
+            const int64_t v = stats[(size_t)i * SA_N_STATS + slot];
+            if (!in[(size_t)i] && v > bestv) { bestv = v; arg = i; }
+        }
+        if (arg < 0) return;
+        guard_take(in, idx, arg, k);
+    }
+}
+
+static void guard_select(Guard *g, int32_t B, const int32_t *status, const int64_t *stats)
+{
+    const int32_t k = B < g->want ? B : g->want;
+    g->idx.clear();
+    std::vector<char> in((size_t)B, 0);
+    for (int32_t i = 0; i < B && i < 16; i++) guard_take(in, g->idx, i, k);
+    if (k < B && status) {                       /* one instance per failure code, then more failures (<= 8) */
+        std::vector<int32_t> codes;
+        int taken = 0;
+        for (int32_t i = 0; i < B && taken < 8; i++)
+            if (status[i] != 0 && std::find(codes.begin(), codes.end(), status[i]) == codes.end()) {
+                codes.push_back(status[i]);
+                if (!in[(size_t)i]) { guard_take(in, g->idx, i, k); taken++; }
+            }
+        for (int32_t i = 0; i < B && taken < 8; i++)
+            if (status[i] != 0 && !in[(size_t)i]) { guard_take(in, g->idx, i, k); taken++; }
+    }
+    if (k < B && stats) {
+        guard_take_top(in, g->idx, B, stats, SA_ST_NST, 4, k, false);
+        guard_take_top(in, g->idx, B, stats, SA_ST_NETF, 8, k, true);
+        guard_take_top(in, g->idx, B, stats, SA_ST_NCFN, 8, k, true);
+        guard_take_top(in, g->idx, B, stats, SA_ST_NSETUPS, 4, k, false);
+        guard_take_top(in, g->idx, B, stats, SA_ST_NJE, 4, k, false);
+        guard_take_top(in, g->idx, B, stats, SA_ST_RETRIES, 4, k, true);
+    }
+    const int32_t rest = k - (int32_t)g->idx.size();     /* an even stride over the whole batch */
+    for (int32_t j = 0; j < rest; j++) guard_take(in, g->idx, (int32_t)(((int64_t)2 * j + 1) * B / ((int64_t)2 * rest)), k);
+    for (int32_t i = 0; i < B && (int32_t)g->idx.size() < k; i++) guard_take(in, g->idx, i, k);
+    std::sort(g->idx.begin(), g->idx.end());
+    g->prefix = true;
+    for (size_t j = 0; j < g->idx.size(); j++) if (g->idx[j] != (int32_t)j) g->prefix = false;
+}
+
+/* rows idx[] of a [B][row_bytes] device array -> buf (runs of consecutive rows in one copy); a prefix sample, a shared
+   array (per_instance false) or a NULL array is used in place */
+static int guard_gather(sa_solver *s, DevBuf &buf, const void *src, size_t row_bytes, bool per_instance, const void **out)
+{
+    Guard *g = s->guard;
+    *out = src;
+    if (!src || !per_instance || g->prefix || !row_bytes) return SA_OK;
+    int rc;
+    if ((rc = buf.ensure(row_bytes * g->idx.size()))) return rc;
+    for (size_t j = 0; j < g->idx.size();) {
+        size_t e = j + 1;
+        while (e < g->idx.size() && g->idx[e] == g->idx[e - 1] + 1) e++;
+        HIP_TRY(hipMemcpyAsync((char *)buf.p + j * row_bytes, (const char *)src + (size_t)g->idx[j] * row_bytes,
+                               (e - j) * row_bytes, hipMemcpyDeviceToDevice, s->stream));
+        j = e;
+    }
+    *out = buf.p;
+    return SA_OK;
+}
+
+/* statuses / counters of the finished main launch on the host, the sample chosen from them */
+static int guard_sample(sa_solver *s, int32_t B, const int32_t *d_status, const int64_t *d_stats)
+{
+    Guard *g = s->guard;
+    g->h_status.clear();
+    g->h_stats.clear();
+    HIP_TRY(hipStreamSynchronize(s->stream));            /* the main launch (and the staged inputs) are complete */
+    const bool need = B > g->want;
+    if (need && d_status) {
+        g->h_status.resize((size_t)B);
+        HIP_TRY(hipMemcpy(g->h_status.data(), d_status, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    }
+    if (need && d_stats) {
+        g->h_stats.resize((size_t)B * SA_N_STATS);
+        HIP_TRY(hipMemcpy(g->h_stats.data(), d_stats, sizeof(int64_t) * (size_t)B * SA_N_STATS, hipMemcpyDeviceToHost));
+    }
+    guard_select(g, B, g->h_status.empty() ? nullptr : g->h_status.data(), g->h_stats.empty() ? nullptr : g->h_stats.data());
+    return SA_OK;
 }
 
 struct GuardBuf { const char *name; size_t row_bytes; size_t cmp_bytes; };   /* per instance: stored / compared */
@@ -973,7 +1124,8 @@ static int guard_compare(sa_solver *s, const char *what, int32_t k, const GuardB
                 while (off < bufs[b].cmp_bytes && x[off] == y[off]) off++;
                 char msg[512];
                 snprintf(msg, sizeof msg, "%s: %s of instance %d differs between the default build %s and the "
-                         "conservative build %s (element %zu)", what, bufs[b].name, i, g->fast->path.c_str(),
+                         "conservative build %s (element %zu)", what, bufs[b].name,
+                         (size_t)i < g->idx.size() ? g->idx[(size_t)i] : i, g->fast->path.c_str(),
                          g->safe->path.c_str(), off / 8);
                 g->detail = msg;
                 *same = false;
@@ -981,6 +1133,27 @@ static int guard_compare(sa_solver *s, const char *what, int32_t k, const GuardB
         }
         if (!*same) break;
     }
+    return SA_OK;
+}
+
+/* what the sample of a passed check covered (shadow `fast` outputs are still in g->host[0] only for the last buffer:
+   re-read status and counters of the default shadow) */
+static int guard_remember(sa_solver *s, uint32_t kind, int32_t k, int status_buf, int stats_buf)
+{
+    Guard *g = s->guard;
+    GuardSeen &seen = g->seen[kind_slot(kind)];
+    std::vector<int32_t> st((size_t)k);
+    std::vector<int64_t> ct((size_t)k * SA_N_STATS);
+    HIP_TRY(hipMemcpy(st.data(), g->out[0][status_buf].p, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ct.data(), g->out[0][stats_buf].p, sizeof(int64_t) * (size_t)k * SA_N_STATS, hipMemcpyDeviceToHost));
+    for (int32_t i = 0; i < k; i++) {
+        if (std::find(seen.codes.begin(), seen.codes.end(), st[(size_t)i]) == seen.codes.end()) seen.codes.push_back(st[(size_t)i]);
+        const int64_t *c = ct.data() + (size_t)i * SA_N_STATS;
+        if (c[SA_ST_NST] > seen.max_nst) seen.max_nst = c[SA_ST_NST];
+        if (c[SA_ST_NETF] > seen.max_netf) seen.max_netf = c[SA_ST_NETF];
+        if (c[SA_ST_NCFN] > seen.max_ncfn) seen.max_ncfn = c[SA_ST_NCFN];
+    }
+    seen.valid = true;
     return SA_OK;
 }
 
@@ -993,24 +1166,71 @@ static void guard_book(sa_solver *s, uint32_t kind, int32_t k, bool same)
     if (k > g->best[slot]) g->best[slot] = k;
     if (!same) {
         g->differs |= kind;
+        g->verified &= ~kind;
         g->pending = 0;                       /* conservative code object from here on: nothing left to compare */
+        for (int i = 0; i < 3; i++) g->recheck_left[i] = 0;
         guard_switch(s);
     } else if (k >= SA_GUARD_MIN_SAMPLE || k >= g->want || g->checks[slot] >= SA_GUARD_MAX_SMALL_CHECKS) {
         g->verified |= kind;
         g->pending &= ~kind;
+        g->window[slot] = g->recheck_left[slot] > 0 ? SA_GUARD_RECHECK_CALLS : 0;
     }
     if (!g->pending) guard_drop_shadows(g);
 }
 
-static int guard_forward(sa_solver *s, int mode, int32_t B, const double *d_y0, const double *d_ps, const double *d_pr,
-                         int32_t rem_stride, double t0, const double *d_tv, int32_t n_t)
+/* a verified kind, a host-memory call: does this batch show a status code or a failure regime the verified sample
+   never had?  Then the kind is pending again (once) and the caller runs the check on THIS batch. */
+static bool guard_recheck_due(sa_solver *s, uint32_t kind, int32_t B, const int32_t *status, const int64_t *stats)
 {
     Guard *g = s->guard;
-    const int32_t k = B < g->want ? B : g->want;
+    if (!g || g->using_safe || !(g->verified & kind)) return false;
+    const int slot = kind_slot(kind);
+    if (g->recheck_left[slot] <= 0 || g->window[slot] <= 0) return false;
+    g->window[slot]--;
+    const GuardSeen &seen = g->seen[slot];
+    if (!seen.valid || !status) return false;
+    bool due = false;
+    for (int32_t i = 0; i < B && !due; i++) {
+        if (std::find(seen.codes.begin(), seen.codes.end(), status[i]) == seen.codes.end()) due = true;
+        if (stats && !due) {
+            const int64_t *c = stats + (size_t)i * SA_N_STATS;
+            due = (c[SA_ST_NETF] > 0 && seen.max_netf == 0) || (c[SA_ST_NCFN] > 0 && seen.max_ncfn == 0) ||
+                  (c[SA_ST_NST] > 2 * seen.max_nst && seen.max_nst > 0);
+        }
+    }
+    if (!due) return false;
+    g->recheck_left[slot]--;
+    g->window[slot] = 0;
+    g->verified &= ~kind;
+    g->pending |= kind;
+    g->checks[slot] = 0;
+    return true;
+}
+
+/* after the main forward launch of a batch of `mode`: its sample through both shadows */
+static int guard_forward(sa_solver *s, int mode, int32_t B, const double *d_y0, const double *d_ps, const double *d_pr,
+                         int32_t rem_stride, double t0, const double *d_tv, int32_t n_t, const int32_t *d_status,
+                         const int64_t *d_stats)
+{
+    Guard *g = s->guard;
+    if (mode != SA_MODE_PLAIN) {
+        /* a forward pass nobody followed with a backward pass cannot finish the adjoint check: after
+           SA_GUARD_MAX_FWD_ONLY of them stop paying for the shadows until a backward call has been seen */
+        if (g->adj_k > 0) g->fwd_only++;
+        g->adj_k = 0;
+        if (g->wait_backward) return SA_OK;
+        if (g->fwd_only >= SA_GUARD_MAX_FWD_ONLY) { g->wait_backward = true; guard_drop_shadows(g); return SA_OK; }
+    }
     int rc;
     if ((rc = guard_shadows(s))) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));           /* the caller's (staged) inputs are in place */
+    if ((rc = guard_sample(s, B, d_status, d_stats))) return rc;
+    const int32_t k = (int32_t)g->idx.size();
     const size_t nn = (size_t)(s->n > 0 ? s->n : 1);
+    const void *in_y0, *in_ps, *in_pr;
+    if ((rc = guard_gather(s, g->in[0], d_y0, sizeof(double) * (size_t)s->n, true, &in_y0))) return rc;
+    if ((rc = guard_gather(s, g->in[1], d_ps, sizeof(double) * (size_t)s->p, true, &in_ps))) return rc;
+    if ((rc = guard_gather(s, g->in[2], d_pr, sizeof(double) * (size_t)s->r, rem_stride != 0, &in_pr))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
     const GuardBuf bufs[3] = {{"y_out", sizeof(double) * (size_t)n_t * nn, sizeof(double) * (size_t)n_t * (size_t)s->n},
                               {"status", sizeof(int32_t), sizeof(int32_t)},
                               {"the counters", sizeof(int64_t) * SA_N_STATS, sizeof(int64_t) * 15}};
@@ -1018,13 +1238,15 @@ static int guard_forward(sa_solver *s, int mode, int32_t B, const double *d_y0, 
     for (int w = 0; w < 2; w++) {
         for (int b = 0; b < 3; b++)
             if ((rc = g->out[w][b].ensure(bufs[b].row_bytes * (size_t)k))) return rc;
-        if ((rc = forward_common(sh[w], mode, SA_MEM_DEVICE, k, d_y0, d_ps, d_pr, rem_stride, t0, d_tv, n_t,
+        if ((rc = forward_common(sh[w], mode, SA_MEM_DEVICE, k, (const double *)in_y0, (const double *)in_ps,
+                                 (const double *)in_pr, rem_stride, t0, d_tv, n_t,
                                  (double *)g->out[w][0].p, (int32_t *)g->out[w][1].p, (int64_t *)g->out[w][2].p)))
             return rc;
     }
     bool same = true;
     if ((rc = guard_compare(s, mode == SA_MODE_PLAIN ? "forward solve" : "adjoint solve, forward pass", k, bufs, 3, &same)))
         return rc;
+    if (same && (rc = guard_remember(s, mode == SA_MODE_PLAIN ? SA_GUARD_PLAIN : SA_GUARD_ADJOINT, k, 1, 2))) return rc;
     if (mode == SA_MODE_PLAIN) guard_book(s, SA_GUARD_PLAIN, k, same);
     else if (!same) guard_book(s, SA_GUARD_ADJOINT, k, false);
     else g->adj_k = k;                                   /* the backward call finishes the check */
@@ -1033,14 +1255,20 @@ static int guard_forward(sa_solver *s, int mode, int32_t B, const double *d_y0, 
 
 static int guard_sens(sa_solver *s, int ism, const double *scaling, int32_t B, const double *d_y0, const double *d_ps,
                       const double *d_pr, int32_t rem_stride, const double *d_s0, double t0, const double *d_tv,
-                      int32_t n_t)
+                      int32_t n_t, const int32_t *d_status, const int64_t *d_stats)
 {
     Guard *g = s->guard;
-    const int32_t k = B < g->want ? B : g->want;
     int rc;
     if ((rc = guard_shadows(s))) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    if ((rc = guard_sample(s, B, d_status, d_stats))) return rc;
+    const int32_t k = (int32_t)g->idx.size();
     const size_t nn = (size_t)(s->n > 0 ? s->n : 1), np_n = (size_t)s->p * (size_t)s->n;
+    const void *in_y0, *in_ps, *in_pr, *in_s0;
+    if ((rc = guard_gather(s, g->in[0], d_y0, sizeof(double) * (size_t)s->n, true, &in_y0))) return rc;
+    if ((rc = guard_gather(s, g->in[1], d_ps, sizeof(double) * (size_t)s->p, true, &in_ps))) return rc;
+    if ((rc = guard_gather(s, g->in[2], d_pr, sizeof(double) * (size_t)s->r, rem_stride != 0, &in_pr))) return rc;
+    if ((rc = guard_gather(s, g->in[3], d_s0, sizeof(double) * np_n, true, &in_s0))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
     const GuardBuf bufs[4] = {{"y_out", sizeof(double) * (size_t)n_t * nn, sizeof(double) * (size_t)n_t * (size_t)s->n},
                               {"sens_out", sizeof(double) * (size_t)n_t * (np_n ? np_n : 1), sizeof(double) * (size_t)n_t * np_n},
                               {"status", sizeof(int32_t), sizeof(int32_t)},
@@ -1049,13 +1277,15 @@ static int guard_sens(sa_solver *s, int ism, const double *scaling, int32_t B, c
     for (int w = 0; w < 2; w++) {
         for (int b = 0; b < 4; b++)
             if ((rc = g->out[w][b].ensure(bufs[b].row_bytes * (size_t)k))) return rc;
-        if ((rc = sa_solve_sens_batch(sh[w], SA_MEM_DEVICE, ism, scaling, k, d_y0, d_ps, d_pr, rem_stride, d_s0, t0, d_tv,
+        if ((rc = sa_solve_sens_batch(sh[w], SA_MEM_DEVICE, ism, scaling, k, (const double *)in_y0, (const double *)in_ps,
+                                      (const double *)in_pr, rem_stride, (const double *)in_s0, t0, d_tv,
                                       n_t, (double *)g->out[w][0].p, (double *)g->out[w][1].p, (int32_t *)g->out[w][2].p,
                                       (int64_t *)g->out[w][3].p)))
             return rc;
     }
     bool same = true;
     if ((rc = guard_compare(s, "forward-sensitivity solve", k, bufs, 4, &same))) return rc;
+    if (same && (rc = guard_remember(s, SA_GUARD_SENS, k, 2, 3))) return rc;
     guard_book(s, SA_GUARD_SENS, k, same);
     return SA_OK;
 }
@@ -1065,11 +1295,17 @@ static int guard_backward(sa_solver *s, int32_t B, const double *d_ps, const dou
                           int64_t grads_stride)
 {
     Guard *g = s->guard;
+    if (g->wait_backward) { g->wait_backward = false; g->fwd_only = 0; }       /* the next forward call checks again */
     const int32_t k = g->adj_k;
-    if (k <= 0 || k > B || !g->fast || !g->safe) return SA_OK;    /* no forward check in flight for this batch */
+    if (k <= 0 || k > B || !g->fast || !g->safe || (int32_t)g->idx.size() != k) return SA_OK;    /* no forward check in flight for this batch */
     int rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
     const size_t nn = (size_t)(s->n > 0 ? s->n : 1), pp = (size_t)(s->p > 0 ? s->p : 1);
+    /* the sample's parameters were gathered by the forward check (g->in[1], g->in[2]); its cotangents now */
+    const void *in_ps = g->prefix ? (const void *)d_ps : g->in[1].p;
+    const void *in_pr = (g->prefix || rem_stride == 0) ? (const void *)d_pr : g->in[2].p;
+    const void *in_g;
+    if ((rc = guard_gather(s, g->in[4], d_g, sizeof(double) * (size_t)n_t * (size_t)s->n, grads_stride != 0, &in_g))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
     const GuardBuf bufs[4] = {{"grad_out", sizeof(double) * pp, sizeof(double) * (size_t)s->p},
                               {"lamda_out", sizeof(double) * nn, sizeof(double) * (size_t)s->n},
                               {"status", sizeof(int32_t), sizeof(int32_t)},
@@ -1078,7 +1314,8 @@ static int guard_backward(sa_solver *s, int32_t B, const double *d_ps, const dou
     for (int w = 0; w < 2; w++) {
         for (int b = 0; b < 4; b++)
             if ((rc = g->out[w][b].ensure(bufs[b].row_bytes * (size_t)k))) return rc;
-        if ((rc = sa_solve_backward_batch_all(sh[w], SA_MEM_DEVICE, k, d_ps, d_pr, rem_stride, t0, tend, d_tv, n_t, d_g,
+        if ((rc = sa_solve_backward_batch_all(sh[w], SA_MEM_DEVICE, k, (const double *)in_ps, (const double *)in_pr,
+                                              rem_stride, t0, tend, d_tv, n_t, (const double *)in_g,
                                               grads_stride, (double *)g->out[w][0].p, (double *)g->out[w][1].p, nullptr,
                                               nullptr, (int32_t *)g->out[w][2].p, (int64_t *)g->out[w][3].p)))
             return rc;
@@ -1086,10 +1323,14 @@ static int guard_backward(sa_solver *s, int32_t B, const double *d_ps, const dou
     bool same = true;
     if ((rc = guard_compare(s, "adjoint solve, backward pass", k, bufs, 4, &same))) return rc;
     g->adj_k = 0;
+    g->fwd_only = 0;
     guard_book(s, SA_GUARD_ADJOINT, k, same);
     if (!same) {
-        /* the forward pass of THIS batch ran on the default build (whose first instances agreed with the conservative
-           build's): integrate it again with the code object the handle has just switched to, then go backward */
+        (void)guard_switched(s);
+        /* the forward pass of THIS batch ran on the default build (whose sample agreed with the conservative
+           build's): integrate it again with the code object the handle has just switched to, then go backward.
+           (The y_out / status the caller received from that forward call came from the default build and are NOT
+           recomputed -- sunode_amd's RuntimeWarning says so.) */
         const size_t nB = (size_t)s->fwd_B;
         if ((rc = s->t_yout.ensure(sizeof(double) * nB * (size_t)s->fwd_n_t * nn))) return rc;
         if ((rc = s->t_status.ensure(sizeof(int32_t) * (size_t)round64(s->fwd_B)))) return rc;
@@ -1109,6 +1350,12 @@ extern "C" int sa_solver_attach_guard(sa_solver *s, const char *safe_path, int32
     if (n_sample < 0) return fail(SA_ERR_ARG, "n_sample must be >= 0");
     DeviceScope scope(s->device);
     guard_free(s);
+    {   /* fail HERE if the conservative code object is missing, not in the first solve (the module itself is loaded
+           when the first check is due) */
+        FILE *fh = fopen(safe_path, "rb");
+        if (!fh) return fail(SA_ERR_MODULE, "guard: cannot read the conservative code object %s", safe_path);
+        fclose(fh);
+    }
     Guard *g = new Guard();
     g->safe_path = safe_path;
     g->want = n_sample > 0 ? n_sample : 64;
@@ -1116,10 +1363,6 @@ extern "C" int sa_solver_attach_guard(sa_solver *s, const char *safe_path, int32
     g->verified = verified_kinds & all;
     g->pending = all & ~g->verified;
     s->guard = g;
-    if (g->pending) {                  /* fail HERE if the conservative code object is unusable, not in the first solve */
-        int rc = guard_shadows(s);
-        if (rc) { guard_free(s); return rc; }
-    }
     return SA_OK;
 }
 
@@ -1129,7 +1372,10 @@ extern "C" int sa_guard_state(sa_solver *s, uint32_t *pending, uint32_t *verifie
     if (!s) return fail(SA_ERR_ARG, "null solver");
     static const char *none = "";
     Guard *g = s->guard;
-    if (pending) *pending = g ? g->pending : 0;
+    uint32_t open = 0;
+    if (g && !g->using_safe)
+        for (int i = 0; i < 3; i++) if (g->recheck_left[i] > 0 && g->window[i] > 0) open = SA_GUARD_RECHECK_OPEN;
+    if (pending) *pending = g ? (g->pending | open) : 0;
     if (verified) *verified = g ? g->verified : 0;
     if (differs) *differs = g ? g->differs : 0;
     if (using_safe) *using_safe = g && g->using_safe ? 1 : 0;

@@ -84,35 +84,33 @@ def _rows(a: np.ndarray, lo: int, hi: int, per_instance) -> np.ndarray:
 
 
 class _OutputPool:
-    """Output arrays of the batch methods, recycled.
+    """Output arrays of the batch methods, recycled -- OPT-IN (``reuse_outputs=True``).
 
-    The reference API hands results back as numpy arrays, and a FRESH ``np.zeros`` of BASELINE config 2's ``y_out``
-    (52 MB) costs more than its PCIe transfer: every page is faulted in by the copy that first touches it --
-    tools/ubench_hostcopy.py on the MI355X box: device -> host into a fresh array 4.4 ms, into one that was touched
-    before 1.0 ms (= the pinned rate; the runtime pins on the fly).  So the solver keeps the arrays it handed out and
-    uses one again as soon as NOBODY ELSE holds a reference to it (the caller dropped the result of an earlier call --
-    the normal pattern of an Op's ``perform`` or a sampling loop); an array the caller still holds is never touched.
-    At most ``MAX_PER_KEY`` arrays per (shape, dtype) and ``MAX_BYTES`` in total are kept."""
+    A FRESH output array of BASELINE config 2's ``y_out`` (52 MB) costs more than its PCIe transfer: every page is
+    faulted in by the copy that first touches it -- tools/ubench_hostcopy.py on the MI355X box: device -> host into a
+    fresh array 4.4 ms, into one that was touched before 1.0 ms (= the pinned rate; the runtime pins on the fly).
+    The reference's convention avoids that by construction: the CALLER allocates the outputs once and the solver
+    writes in place (/root/reference/sunode/solver.py:682,723-724) -- the batch methods take ``out=`` for exactly that,
+    and it is the recommended way.  With ``reuse_outputs=True`` the solver does it for the caller: ONE array per
+    (method slot, shape, dtype), handed out again by the next call of the same method.  The contract is explicit
+    (no reference counting: a caller may hold an array through a raw pointer the interpreter cannot see): a result
+    of a batch call is valid until the next call of the same method on the same solver; copy what must live longer.
+    Without the option every call returns fresh arrays."""
 
-    MAX_PER_KEY = 3
-    MAX_BYTES = 1 << 30
+    MAX_BYTES = 1 << 31
 
     def __init__(self):
         self._arrays = {}
         self._bytes = 0
 
-    def get(self, shape, dtype=np.float64):
-        import sys
-        key = (tuple(int(k) for k in shape), np.dtype(dtype).str)
-        held = self._arrays.setdefault(key, [])
-        for arr in held:
-            # references: the list, the loop variable, getrefcount's argument -- anything more is the caller's
-            if sys.getrefcount(arr) <= 3:
-                return arr
-        arr = np.empty(key[0], dtype=dtype)
-        if arr.nbytes >= (1 << 16) and len(held) < self.MAX_PER_KEY and self._bytes + arr.nbytes <= self.MAX_BYTES:
-            held.append(arr)
-            self._bytes += arr.nbytes
+    def get(self, slot, shape, dtype=np.float64):
+        key = (slot, tuple(int(k) for k in shape), np.dtype(dtype).str)
+        arr = self._arrays.get(key)
+        if arr is None:
+            arr = np.empty(key[1], dtype=dtype)
+            if self._bytes + arr.nbytes <= self.MAX_BYTES:
+                self._arrays[key] = arr
+                self._bytes += arr.nbytes
         return arr
 
 
@@ -154,13 +152,56 @@ class _EngineMixin:
         self._device = devices[0]
         self._natives = None
         self._pool = None
-        self._outputs = _OutputPool()
+        self._outputs = _OutputPool() if getattr(self, "_reuse_outputs", False) else None
 
-    def _out(self, shape, dtype=np.float64):
-        """An output array the library overwrites completely (recycled: see _OutputPool)."""
-        if getattr(self, "_outputs", None) is None:         # (unpickled solvers)
-            self._outputs = _OutputPool()
-        return self._outputs.get(shape, dtype)
+    def _out(self, slot, shape, dtype=np.float64, given=None, small=False):
+        """(work, final) arrays of one output of a batch call.  ``final`` is what the caller receives: the array it
+        passed through ``out=`` (checked: exact shape, dtype, C-contiguous, writeable -- the library writes through
+        the raw pointer), else a fresh one (or the solver's recycled one, ``reuse_outputs=True``).  ``work`` is what
+        the library writes: ``final`` itself, or -- with ``interleaved=True`` over several handles -- a handle-major
+        temporary that ``_scatter`` copies into ``final``.  ``small`` outputs (status, counters) start zeroed: the
+        library returns early without touching them for an empty time grid."""
+        shape = tuple(int(k) for k in shape)
+        dtype = np.dtype(dtype)
+
+        def fresh(tag):
+            pool = getattr(self, "_outputs", None)
+            arr = pool.get((slot, tag), shape, dtype) if pool is not None else np.empty(shape, dtype=dtype)
+            if small:
+                arr.fill(0)
+            return arr
+        if given is not None:
+            if not isinstance(given, np.ndarray) or given.shape != shape or given.dtype != dtype \
+                    or not given.flags.c_contiguous or not given.flags.writeable:
+                raise ValueError("out[%r] must be a writeable C-contiguous %s array of shape %s" % (slot, dtype, shape))
+            if small:
+                given.fill(0)
+            final = given
+        else:
+            final = fresh("final")
+        work = fresh("work") if self._reorders() else final
+        return work, final
+
+    @staticmethod
+    def _zero_width(given, shape):
+        if given is not None and tuple(given.shape) != tuple(shape):
+            raise ValueError("out= array of shape %s where %s is expected" % (given.shape, shape))
+        return given if given is not None else np.zeros(shape)
+
+    @staticmethod
+    def _out_arg(out, k: int, names):
+        """``out=`` of the batch methods: None, a dict keyed by the output's name, or a sequence in return order
+        (entries may be None: allocated by the solver)."""
+        if out is None:
+            return None
+        if isinstance(out, dict):
+            unknown = set(out) - set(names)
+            if unknown:
+                raise ValueError("out= has unknown entries %s (expected some of %s)" % (sorted(unknown), list(names)))
+            return out.get(names[k])
+        if len(out) > len(names):
+            raise ValueError("out= has %d entries, the call returns %d arrays" % (len(out), len(names)))
+        return out[k] if k < len(out) else None
 
     def _arena_share(self, device: int) -> int:
         """arena_bytes of ONE handle on ``device``: the device's budget divided by the handles that share it.
@@ -222,12 +263,13 @@ class _EngineMixin:
         G = len(self._engines())
         return np.concatenate([a[r::G] for r in range(G)], axis=0)
 
-    def _scatter(self, handle_major: np.ndarray) -> np.ndarray:
-        if not self._reorders():
-            return handle_major
+    def _scatter(self, pair) -> np.ndarray:
+        """(work, final) of ``_out`` after the call: ``final`` in the caller's instance order."""
+        handle_major, out = pair
+        if out is handle_major:
+            return out
         G = len(self._engines())
         B = handle_major.shape[0]
-        out = self._out(handle_major.shape, handle_major.dtype)
         pos = 0
         for r in range(G):
             k = len(range(r, B, G))
@@ -338,7 +380,7 @@ class Solver(_EngineMixin):
     def __init__(self, problem, *, abstol: float = 1e-10, reltol: float = 1e-10, sens_mode: Optional[str] = None,
                  scaling_factors: Optional[np.ndarray] = None, constraints: Optional[np.ndarray] = None,
                  solver="BDF", linear_solver="dense", linear_solver_kwargs=None, mxsteps: int = 500,
-                 device: int = 0, devices=None, interleaved: bool = False):
+                 device: int = 0, devices=None, interleaved: bool = False, reuse_outputs: bool = False):
         if sens_mode in (None, False):
             sens_mode = None
         elif sens_mode == "staggered1":
@@ -380,11 +422,12 @@ class Solver(_EngineMixin):
         self._compute_sens = sens_mode is not None
         self._scaling_factors = scaling_factors
         self._mxsteps = mxsteps
+        self._reuse_outputs = bool(reuse_outputs)
         self._init_devices(device, devices, interleaved)
         self._set_tolerances(abstol, reltol)
         self._state_names = ["_problem", "_user_data", "_constraints", "_abstol", "_reltol",
                              "_linear_solver_kind", "_linear_solver_kwargs", "_sens_mode", "_scaling_factors",
-                             "_mxsteps", "_device", "_devices", "_interleaved", "_state_names"]
+                             "_mxsteps", "_device", "_devices", "_interleaved", "_reuse_outputs", "_state_names"]
         self._init_native()
 
     def _init_native(self):
@@ -396,13 +439,16 @@ class Solver(_EngineMixin):
         self._pool = None
 
     def _engine_kwargs(self):
-        return dict(self._native_kwargs(), sens=self._compute_sens, constraints=self._constraints)
+        return dict(self._native_kwargs(), sens=self._compute_sens, constraints=self._constraints,
+                    guard_kinds=("sens",) if self._compute_sens else ("plain",))
 
     def __getstate__(self):
         return {name: self.__dict__[name] for name in self._state_names}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self._reuse_outputs = state.get("_reuse_outputs", False)
+        self._outputs = _OutputPool() if self._reuse_outputs else None
         self._compute_sens = self._sens_mode is not None
         self._set_tolerances(self._abstol, self._reltol)
         self._init_native()
@@ -450,10 +496,11 @@ class Solver(_EngineMixin):
         if self._compute_sens:
             sens_out[...] = so[0]
 
-    def solve_sens_batch(self, t0, tvals, y0, params_sub, params_rem, sens0, *, max_retries=5
+    def solve_sens_batch(self, t0, tvals, y0, params_sub, params_rem, sens0, *, max_retries=5, out=None
                          ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
         """Forward solve + forward sensitivities for B draws (``sens_mode`` must be set): returns
-        (y_out [B,n_t,n], sens_out [B,n_t,p,n], status [B], stats [B,16]); ``sens0`` is [B,p,n] or [p,n]."""
+        (y_out [B,n_t,n], sens_out [B,n_t,p,n], status [B], stats [B,16]); ``sens0`` is [B,p,n] or [p,n].
+        ``out``: caller-allocated outputs (see ``solve_batch``), names ``y_out, sens_out, status, stats``."""
         if not self._compute_sens:
             raise ValueError("construct the Solver with sens_mode='simultaneous' or 'staggered'")
         self._set_retries(max_retries_fwd=max_retries)
@@ -462,10 +509,12 @@ class Solver(_EngineMixin):
         sens0 = np.ascontiguousarray(np.broadcast_to(np.asarray(sens0, dtype=np.float64), (B, p, n)))
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         y0, ps, pr, sens0 = self._gather(y0), self._gather(ps, p), self._gather(pr, stride), self._gather(sens0)
-        y_out = self._out((B, len(tvals), n))
-        sens_out = self._out((B, len(tvals), p, n))
-        status = self._out((B,), np.int32)
-        stats = self._out((B, _native.N_STATS), np.int64)
+        names = ("y_out", "sens_out", "status", "stats")
+        y_pair = self._out("sens.y_out", (B, len(tvals), n), given=self._out_arg(out, 0, names))
+        s_pair = self._out("sens.sens_out", (B, len(tvals), p, n), given=self._out_arg(out, 1, names))
+        st_pair = self._out("sens.status", (B,), np.int32, self._out_arg(out, 2, names), small=True)
+        sa_pair = self._out("sens.stats", (B, _native.N_STATS), np.int64, self._out_arg(out, 3, names), small=True)
+        y_out, sens_out, status, stats = y_pair[0], s_pair[0], st_pair[0], sa_pair[0]
         ism = 0 if self._sens_mode == "simultaneous" else 1
 
         def call(eng, lo, hi):
@@ -474,25 +523,32 @@ class Solver(_EngineMixin):
                            sens0[lo:hi] if sens0.size else np.zeros(1), t0, tvals, len(tvals), y_out[lo:hi],
                            sens_out[lo:hi] if sens_out.size else np.zeros(1), status[lo:hi], stats[lo:hi])
         self._run_shards(self._shards(B), call)
-        return self._scatter(y_out), self._scatter(sens_out), self._scatter(status), self._scatter(stats)
+        return self._scatter(y_pair), self._scatter(s_pair), self._scatter(st_pair), self._scatter(sa_pair)
 
-    def solve_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5
+    def solve_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5, out=None
                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """``solve`` for B parameter draws at once: returns (y_out [B,n_t,n], status [B], stats [B,16])."""
+        """``solve`` for B parameter draws at once: returns (y_out [B,n_t,n], status [B], stats [B,16]).
+
+        ``out``: caller-allocated output arrays, written in place and returned -- the reference's convention
+        (``solve(t0, tvals, y0, y_out)``, /root/reference/sunode/solver.py:467) carried over to the batch: a dict
+        ``{"y_out": ..., "status": ..., "stats": ...}`` or a sequence in return order, entries may be missing / None.
+        Arrays must be C-contiguous float64 (status int32, stats int64) of the exact shape."""
         self._set_retries(max_retries_fwd=max_retries)
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         p = self._problem.n_params
         y0, ps, pr = self._gather(y0), self._gather(ps, p), self._gather(pr, stride)
-        y_out = self._out((B, len(tvals), self._problem.n_states))
-        status = self._out((B,), np.int32)
-        stats = self._out((B, _native.N_STATS), np.int64)
+        names = ("y_out", "status", "stats")
+        y_pair = self._out("solve.y_out", (B, len(tvals), self._problem.n_states), given=self._out_arg(out, 0, names))
+        st_pair = self._out("solve.status", (B,), np.int32, self._out_arg(out, 1, names), small=True)
+        sa_pair = self._out("solve.stats", (B, _native.N_STATS), np.int64, self._out_arg(out, 2, names), small=True)
+        y_out, status, stats = y_pair[0], st_pair[0], sa_pair[0]
 
         def call(eng, lo, hi):
             eng.solve(_native.SA_MEM_HOST, hi - lo, y0[lo:hi], _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride),
                       stride, t0, tvals, len(tvals), y_out[lo:hi], status[lo:hi], stats[lo:hi])
         self._run_shards(self._shards(B), call)
-        return self._scatter(y_out), self._scatter(status), self._scatter(stats)
+        return self._scatter(y_pair), self._scatter(st_pair), self._scatter(sa_pair)
 
 
 class AdjointSolver(_EngineMixin):
@@ -517,7 +573,8 @@ class AdjointSolver(_EngineMixin):
                  constraints=None, solver="BDF", adjoint_solver="BDF", backward_abstol=1e-10,
                  backward_reltol=1e-10, quad_abstol=1e-10, quad_reltol=1e-10, mxsteps: int = 500,
                  max_steps: Optional[int] = None, arena_gib: Optional[float] = None, device: int = 0,
-                 compact_trajectory: Optional[bool] = None, devices=None, interleaved: bool = False):
+                 compact_trajectory: Optional[bool] = None, devices=None, interleaved: bool = False,
+                 reuse_outputs: bool = False):
         if solver not in ("BDF", "ADAMS"):
             raise ValueError(f"Unknown solver {solver}.")
         if adjoint_solver not in ("BDF", "ADAMS"):
@@ -540,6 +597,7 @@ class AdjointSolver(_EngineMixin):
         self._max_steps = int(min(max_steps if max_steps is not None else checkpoint_n + 1, checkpoint_n + 1,
                                   2**31 - 1))
         self._arena_bytes = int(arena_gib * 2**30) if arena_gib else 0      # per DEVICE (handles sharing one split it)
+        self._reuse_outputs = bool(reuse_outputs)
         self._init_devices(device, devices, interleaved)
         self._source = problem.native_source()
         # (bdf_kernels.hip and bdf_wave.hip carry the compact-record option)
@@ -554,7 +612,7 @@ class AdjointSolver(_EngineMixin):
 
     def _engine_kwargs(self):
         return dict(self._native_kwargs(), constraints=self._constraints, hermite=self._hermite,
-                    compact=self._compact)
+                    compact=self._compact, guard_kinds=("adjoint",))
 
     def _set_tolerances(self, atol=None, rtol=None):
         atol, rtol = np.array(atol, dtype=float), np.array(rtol, dtype=float)
@@ -617,16 +675,22 @@ class AdjointSolver(_EngineMixin):
             quad_all_out[...] = res[5][0]
 
     # -- batch API -------------------------------------------------------------------------
-    def solve_forward_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5):
-        """B forward solves with stored trajectories: (y_out [B,n_t,n], status [B], stats [B,16])."""
+    def solve_forward_batch(self, t0, tvals, y0, params_sub, params_rem, *, max_retries=5, out=None):
+        """B forward solves with stored trajectories: (y_out [B,n_t,n], status [B], stats [B,16]).
+
+        ``out``: caller-allocated outputs written in place (the reference's convention,
+        /root/reference/sunode/solver.py:682: ``solve_forward(t0, tvals, y0, y_out)``): a dict with some of
+        ``y_out, status, stats`` or a sequence in return order; see ``Solver.solve_batch``."""
         self._set_retries(max_retries_fwd=max_retries)
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         p = self._problem.n_params
         y0, ps, pr = self._gather(y0), self._gather(ps, p), self._gather(pr, stride)
-        y_out = self._out((B, len(tvals), self._problem.n_states))
-        status = self._out((B,), np.int32)
-        stats = self._out((B, _native.N_STATS), np.int64)
+        names = ("y_out", "status", "stats")
+        y_pair = self._out("fwd.y_out", (B, len(tvals), self._problem.n_states), given=self._out_arg(out, 0, names))
+        st_pair = self._out("fwd.status", (B,), np.int32, self._out_arg(out, 1, names), small=True)
+        sa_pair = self._out("fwd.stats", (B, _native.N_STATS), np.int64, self._out_arg(out, 2, names), small=True)
+        y_out, status, stats = y_pair[0], st_pair[0], sa_pair[0]
         shards = self._shards(B)
 
         def call(eng, lo, hi):
@@ -634,15 +698,18 @@ class AdjointSolver(_EngineMixin):
                       stride, t0, tvals, len(tvals), y_out[lo:hi], status[lo:hi], stats[lo:hi], adjoint=True)
         self._run_shards(shards, call)
         self._last_forward = (B, ps, pr, stride, shards)     # every handle keeps ITS shard's trajectories
-        return self._scatter(y_out), self._scatter(status), self._scatter(stats)
+        return self._scatter(y_pair), self._scatter(st_pair), self._scatter(sa_pair)
 
-    def solve_backward_batch(self, t0, tend, tvals, grads, *, max_retries=50, return_all=False):
+    def solve_backward_batch(self, t0, tend, tvals, grads, *, max_retries=50, return_all=False, out=None):
         """Adjoint pass for the batch of the last ``solve_forward_batch``.
 
         ``grads``: [B, n_t, n] or [n_t, n] (shared).  Returns (grad_out [B,p] = dL/dp,
         lamda_out [B,n] = -dL/dy0, status [B], stats [B,16]); with ``return_all`` also
         (lamda_all [B,n_t,n], quad_all [B,n_t,p]): adjoint state and accumulated quadrature right
-        after every jump, rows ordered as the reference's ``lamda_all_out[-i]`` (solver.py:778-781)."""
+        after every jump, rows ordered as the reference's ``lamda_all_out[-i]`` (solver.py:778-781).
+        ``out``: caller-allocated outputs written in place (reference: ``solve_backward(..., grad_out, lamda_out,
+        lamda_all_out, quad_all_out)``, solver.py:723-724): a dict with some of ``grad_out [B,p], lamda_out [B,n],
+        status, stats, lamda_all, quad_all`` or a sequence in return order."""
         if self._last_forward is None:
             raise SolverError("solve_backward called before solve_forward")
         self._set_retries(max_retries_bwd=max_retries)
@@ -658,18 +725,25 @@ class AdjointSolver(_EngineMixin):
         else:
             raise ValueError(f"grads must have shape ({n_t}, {n}) or ({B}, {n_t}, {n})")
         grads = self._gather(grads, gstride)                 # (ps / pr of the forward call are in handle order already)
-        grad_out = self._out((B, max(p, 1)))
-        lamda_out = self._out((B, max(n, 1)))
-        if not p:
-            grad_out.fill(0.0)          # (no differentiated parameter: the library writes nothing there)
-        if not n:
-            lamda_out.fill(0.0)
-        status = self._out((B,), np.int32)
-        stats = self._out((B, _native.N_STATS), np.int64)
-        lam_all = self._out((B, n_t, max(n, 1))) if return_all else None
-        quad_all = self._out((B, n_t, max(p, 1))) if return_all else None
-        if return_all and not p:
-            quad_all.fill(0.0)
+        names = ("grad_out", "lamda_out", "status", "stats", "lamda_all", "quad_all")
+        if out is not None and not return_all and (len(out) > 4 if not isinstance(out, dict)
+                                                   else {"lamda_all", "quad_all"} & set(out)):
+            raise ValueError("out= names lamda_all / quad_all but return_all is False")
+        # (the library wants at least one column: with p == 0 / n == 0 it writes into a private dummy)
+        g_pair = self._out("bwd.grad_out", (B, p), given=self._out_arg(out, 0, names)) if p else None
+        l_pair = self._out("bwd.lamda_out", (B, n), given=self._out_arg(out, 1, names)) if n else None
+        grad_out = g_pair[0] if p else np.zeros((B, 1))
+        lamda_out = l_pair[0] if n else np.zeros((B, 1))
+        st_pair = self._out("bwd.status", (B,), np.int32, self._out_arg(out, 2, names), small=True)
+        sa_pair = self._out("bwd.stats", (B, _native.N_STATS), np.int64, self._out_arg(out, 3, names), small=True)
+        status, stats = st_pair[0], sa_pair[0]
+        la_pair = qa_pair = None
+        lam_all = quad_all = None
+        if return_all:
+            la_pair = self._out("bwd.lamda_all", (B, n_t, n), given=self._out_arg(out, 4, names)) if n else None
+            qa_pair = self._out("bwd.quad_all", (B, n_t, p), given=self._out_arg(out, 5, names)) if p else None
+            lam_all = la_pair[0] if n else np.zeros((B, n_t, 1))
+            quad_all = qa_pair[0] if p else np.zeros((B, n_t, 1))
 
         def call(eng, lo, hi):
             eng.solve_backward(_native.SA_MEM_HOST, hi - lo, _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride), stride,
@@ -677,9 +751,13 @@ class AdjointSolver(_EngineMixin):
                                lamda_out[lo:hi], status[lo:hi], stats[lo:hi],
                                lam_all[lo:hi] if return_all else None, quad_all[lo:hi] if return_all else None)
         self._run_shards(shards, call)
-        grad_out, lamda_out, status, stats = (self._scatter(a) for a in (grad_out, lamda_out, status, stats))
+        # (p == 0 / n == 0: the caller's (B, 0) array, if any, has nothing to receive)
+        grad_out = self._scatter(g_pair) if p else self._zero_width(self._out_arg(out, 0, names), (B, 0))
+        lamda_out = self._scatter(l_pair) if n else self._zero_width(self._out_arg(out, 1, names), (B, 0))
+        status, stats = self._scatter(st_pair), self._scatter(sa_pair)
         if return_all:
-            lam_all, quad_all = self._scatter(lam_all), self._scatter(quad_all)
+            lam_all = self._scatter(la_pair) if n else self._zero_width(self._out_arg(out, 4, names), (B, n_t, 0))
+            quad_all = self._scatter(qa_pair) if p else self._zero_width(self._out_arg(out, 5, names), (B, n_t, 0))
         if (status == -9001).any():
             import warnings
             warnings.warn("solve_backward: %d instance(s) returned SA_STATUS_ARENA_FULL (a 64-instance group of stored "
@@ -687,5 +765,5 @@ class AdjointSolver(_EngineMixin):
                           "gradients are NaN -- raise AdjointSolver(arena_gib=..., max_steps=...)"
                           % (int((status == -9001).sum()), self._max_steps), RuntimeWarning, stacklevel=2)
         if return_all:
-            return grad_out[:, :p], lamda_out[:, :n], status, stats, lam_all[:, :, :n], quad_all[:, :, :p]
-        return grad_out[:, :p], lamda_out[:, :n], status, stats
+            return grad_out, lamda_out, status, stats, lam_all, quad_all
+        return grad_out, lamda_out, status, stats

@@ -10,15 +10,20 @@ as host functions (test oracle / CPU baseline).  Kept from the reference:
 * the output is zero-filled and only structurally non-zero entries are
   assigned (``lambdify.py:102-127``) -- we emit the explicit ``= 0.0`` stores;
 * helper functions ``logaddexp / expit / dexpit / CardinalBSpline(4, t)``
-  (``lambdify.py:59-77``);
+  (``lambdify.py:59-77``; the sympy classes are in ``symode/lambdify.py``);
 * non-finite outputs make the callback return 1 = "recoverable error"
   (``symode/problem.py:266-269``).
 
 Different from the reference on purpose: integer powers are expanded to
-products and no ``fastmath`` style re-association is allowed, so that host and
+products, no ``fastmath`` style re-association is allowed, and ``exp / log /
+sin / cos / tan / tanh / sinh / cosh / log1p / expm1 / pow`` are printed as
+calls of the deterministic implementations of ``csrc/sa_math.h`` (embedded
+into the generated header when used) instead of libm / ocml, so that host and
 device evaluate bit-identical arithmetic (both sides are compiled with
 ``-ffp-contract=off``); this is what makes the step/order bookkeeping of the
-HIP integrator comparable bit-for-bit with the CPU oracle.
+HIP integrator comparable bit-for-bit with the CPU oracle -- for rational AND
+transcendental right-hand sides.  Functions outside that list (``LIBM_ONLY``)
+still compile, through libm / ocml, without the bit-equality guarantee.
 
 Callback ABI (all arrays are flat ``double``):
 
@@ -182,20 +187,6 @@ HELPERS_C = r"""
 #define SA_FAM_STORE(S0, value) { const double v_ = (value); SA_STORE_DYN((S0) + sa_f, v_); chk += v_ * 0.0; }
 #define SA_FAM_END }
 #endif
-SA_FN double sa_logaddexp(double a, double b) {
-    double lo = fmin(a, b), hi = fmax(a, b);
-    return hi + log1p(exp(lo - hi));
-}
-SA_FN double sa_expit(double x) { return 1.0 / (1.0 + exp(-x)); }
-SA_FN double sa_dexpit(double x) { return sa_expit(x) * sa_expit(-x); }
-SA_FN double sa_cardinal_bspline4(double t) {
-    if (t >= 0.0 && t <= 1.0) return (1.0/24.0)*t*t*t*t;
-    if (t >= 1.0 && t <= 2.0) return t*(t*(t*(5.0/6.0 - 1.0/6.0*t) - 5.0/4.0) + 5.0/6.0) - 5.0/24.0;
-    if (t >= 2.0 && t <= 3.0) return t*(t*(t*((1.0/4.0)*t - 5.0/2.0) + 35.0/4.0) - 25.0/2.0) + 155.0/24.0;
-    if (t >= 3.0 && t <= 4.0) return t*(t*(t*(5.0/2.0 - 1.0/6.0*t) - 55.0/4.0) + 65.0/2.0) - 655.0/24.0;
-    if (t >= 4.0 && t <= 5.0) return t*(t*(t*((1.0/24.0)*t - 5.0/6.0) + 25.0/4.0) - 125.0/6.0) + 625.0/24.0;
-    return 0.0;
-}
 """
 
 
@@ -280,7 +271,44 @@ class HipExprPrinter(C99CodePrinter):
             return "sqrt(%s)" % self._print(base)
         if exp == sym.Rational(-1, 2):
             return "(1.0/sqrt(%s))" % self._print(base)
-        return "pow(%s, %s)" % (self._print(base), self._print(exp))
+        return "sa_pow(%s, %s)" % (self._print(base), self._print(exp))
+
+    # transcendental functions: the deterministic implementations of csrc/sa_math.h (embedded into the generated
+    # header, MATH_C below), never libm / ocml -- device and oracle must round identically
+    def _sa_call(self, name, expr):
+        return "sa_%s(%s)" % (name, ", ".join(self._print(a) for a in expr.args))
+
+    def _print_exp(self, expr):
+        return self._sa_call("exp", expr)
+
+    def _print_log(self, expr):
+        if len(expr.args) == 2:      # log(x, base)
+            return "(sa_log(%s)/sa_log(%s))" % (self._print(expr.args[0]), self._print(expr.args[1]))
+        return self._sa_call("log", expr)
+
+    def _print_log1p(self, expr):
+        return self._sa_call("log1p", expr)
+
+    def _print_expm1(self, expr):
+        return self._sa_call("expm1", expr)
+
+    def _print_sin(self, expr):
+        return self._sa_call("sin", expr)
+
+    def _print_cos(self, expr):
+        return self._sa_call("cos", expr)
+
+    def _print_tan(self, expr):
+        return self._sa_call("tan", expr)
+
+    def _print_tanh(self, expr):
+        return self._sa_call("tanh", expr)
+
+    def _print_sinh(self, expr):
+        return self._sa_call("sinh", expr)
+
+    def _print_cosh(self, expr):
+        return self._sa_call("cosh", expr)
 
     # helper functions of the reference (lambdify.py:59-77, 275-340)
     def _print_logaddexp(self, expr):
@@ -294,8 +322,8 @@ class HipExprPrinter(C99CodePrinter):
 
     def _print_CardinalBSpline(self, expr):
         degree, x = expr.args
-        if degree != 4:
-            return "(0.0/0.0)"      # the reference returns nan for degree != 4
+        if degree != 4:             # (the reference's helper returns nan here; symode/lambdify.py CardinalBSpline)
+            return "(%s)" % self._print(expr.as_sympy_expr())
         return "sa_cardinal_bspline4(%s)" % self._print(x)
 
     def _print_Heaviside(self, expr):
@@ -642,6 +670,16 @@ def _emit_rolled(name, signature, rolled, out_index, n_out, roller, names, matve
     return "\n".join(lines)
 
 
+def _temp_names(prefix: str, symbol_map: Dict[str, str]):
+    """Names of the CSE temporaries of one callback: ``<prefix><i>``, skipping every name a model symbol already has
+    (a parameter ``a`` of shape (5,) owns ``a_0 .. a_4``: the reference refuses such collisions,
+    lambdify.py:114-116; here the temporaries step aside)."""
+    for i in count():
+        name = "%s%d" % (prefix, i)
+        if name not in symbol_map:
+            yield sym.Symbol(name)
+
+
 def emit_function(
     name: str,
     signature: str,
@@ -660,7 +698,7 @@ def emit_function(
     dense matrix-vector product evaluated up front by ``SA_MATVEC``; the function is then emitted as ONE body whose
     output statements carry ``SA_OWNS(slot)`` guards (the kernels split those between wavefronts)."""
     flat = [sym.sympify(e) for e in np.asarray(expr, dtype=object).ravel()]
-    names = (sym.Symbol("%s%d" % (prefix, i)) for i in count())
+    names = _temp_names(prefix, symbol_map)
     # group structure: one member per lane (SA_FAM_BEGIN); small callbacks only -- the large ones have their own forms
     if out_array is not None and matvec is None and n_out <= 64:
         fam = find_lane_families(flat, out_index, n_out, symbol_map, leaf_axes, out_array)
@@ -788,7 +826,7 @@ def emit_matfill_function(name: str, signature: str, n: int, info: Dict[str, obj
     then one statement per exception slot."""
     axis, u, exceptions, offset = info["axis"], info["u"], info["exceptions"], info["offset"]
     keys = sorted(exceptions)
-    names = (sym.Symbol("%s%d" % (prefix, i)) for i in count())
+    names = _temp_names(prefix, symbol_map)
     roller = Roller(symbol_map, prefix)
     u_r = [roller.roll_sums(e) for e in u]
     x_r = [roller.roll_sums(exceptions[k]) for k in keys]
@@ -878,6 +916,7 @@ def generate_problem_source(
         "#define SA_N_SUB %d" % n_sub,
         "#define SA_N_REM %d" % n_rem,
         HELPERS_C,
+        None,           # MATH_C, when a callback calls one of its functions
         emit_function("sa_rhs", base, np.asarray(dydt, dtype=object).ravel(),
                       list(range(n)), n, symbol_map, "r_", matvec=mv("f"), leaf_axes=leaf_axes, out_array="SA_Y"),
         (emit_matfill_function("sa_jac", base, n, matfill["j"], symbol_map, "j_", "j") if "j" in matfill else
@@ -899,7 +938,31 @@ def generate_problem_source(
                       list(range(n_sub * n)), n_sub * n, symbol_map, "s_"),
         "",
     ]
+    uses_math = any(_MATH_CALL.search(part) for part in parts if part)
+    parts[6] = math_c() if uses_math else "/* (no transcendental function: csrc/sa_math.h not embedded) */"
     return "\n".join(parts)
+
+
+#: a call of one of the deterministic functions of csrc/sa_math.h in generated text
+_MATH_CALL = re.compile(r"\bsa_(exp|expm1|log|log1p|sin|cos|tan|tanh|sinh|cosh|pow|logaddexp|expit|dexpit|"
+                        r"cardinal_bspline4)\(")
+#: functions the C99 printer would hand to libm / ocml (not bit-reproducible between host and device)
+LIBM_ONLY = ("asin", "acos", "atan", "atan2", "asinh", "acosh", "atanh", "erf", "erfc", "tgamma", "lgamma", "cbrt",
+             "exp2", "log2", "log10", "hypot")
+
+
+def math_c() -> str:
+    """Text of csrc/sa_math.h (the deterministic exp / log / sin / pow ... shared by device and oracle)."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(os.path.dirname(here), "csrc", "sa_math.h")) as fh:
+        return fh.read()
+
+
+def libm_calls(source: str) -> List[str]:
+    """Names of libm-only functions a generated header calls: such a model integrates, but the device (ocml) and
+    the host (libm) may round them differently -- bit-equality with the oracle is then not guaranteed."""
+    return sorted({m for m in LIBM_ONLY if re.search(r"(?<![\w.])%s\(" % m, source)})
 
 
 def source_hash(text: str, extra: Iterable[str] = ()) -> str:

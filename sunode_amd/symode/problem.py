@@ -717,8 +717,21 @@ def _expit(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
+def _cardinal_bspline(degree, t):
+    """Cardinal B-spline of any degree by the Cox-de Boor recursion on the knots 0..degree+1 (host evaluation)."""
+    t = np.asarray(t, dtype=float)
+    d = int(degree)
+    basis = [((t >= i) & (t < i + 1)).astype(float) for i in range(d + 1)]
+    for k in range(1, d + 1):
+        basis = [((t - i) * basis[i] + (i + k + 1 - t) * basis[i + 1]) / k for i in range(d + 1 - k)]
+    return basis[0]
+
+
 _HOST_HELPERS = {
     "logaddexp": _logaddexp,
     "expit": _expit,
     "dexpit": lambda x: _expit(x) * _expit(-x),
+    "CardinalBSpline": _cardinal_bspline,
 }
+#: for ``sympy.lambdify(..., modules=[HOST_FUNCTIONS, "numpy"])`` of expressions that use symode/lambdify.py's functions
+HOST_FUNCTIONS = _HOST_HELPERS

@@ -3,8 +3,9 @@
 Calls go through the C ABI (libsunode_amd.so) via sunode_amd.solver.  Bars:
   * step/order bookkeeping (nst, nfe, nsetups, nje, nni, ncfn, netf, last order, stored
     points, quadrature counters, table rebuilds): bit-exact vs the oracle;
-  * states / gradients: bit-exact vs the oracle for rational right-hand sides (both sides
-    evaluate the same IEEE operation sequence, -ffp-contract=off, deterministic pow);
+  * states / gradients: bit-exact vs the oracle (both sides evaluate the same IEEE operation
+    sequence, -ffp-contract=off, deterministic pow; transcendental right-hand sides through the
+    embedded csrc/sa_math.h: tests/test_gpu_transcendental.py);
   * states / gradients vs truth fixtures: within the integration tolerance (written per test).
 """
 import os
@@ -54,7 +55,8 @@ def test_device_arithmetic_matches_host_bitwise():
     np.testing.assert_array_equal(pw[:k], ref)
 
 
-@pytest.mark.parametrize("name", ["lv", "robertson", "seir", "network8", "misc", "notebook"])
+@pytest.mark.parametrize("name", ["lv", "robertson", "seir", "network8", "misc", "notebook", "forcing", "mathfn_a",
+                                  "mathfn_b"])
 def test_device_callbacks_match_golden(name, golden_dir):
     """Generated device functions vs the reference's own lambdify output (golden vectors)."""
     import json
@@ -74,8 +76,9 @@ def test_device_callbacks_match_golden(name, golden_dir):
             want = np.array(p[key], float).reshape(got[key][i].shape)
             scale = float(np.max(np.abs(want))) if want.size else 0.0
             np.testing.assert_allclose(got[key][i], want, rtol=1e-13, atol=4e-15 * scale)
-            if name != "misc":       # rational rhs: device == host bit-for-bit
-                np.testing.assert_array_equal(got[key][i], host[key].reshape(got[key][i].shape))
+            # device == host bit for bit: rational right-hand sides AND (round 6) transcendental ones, whose
+            # exp / log / sin / pow are the embedded csrc/sa_math.h on both sides
+            np.testing.assert_array_equal(got[key][i], host[key].reshape(got[key][i].shape))
         assert got["codes"][i].tolist() == p["codes"]
 
 

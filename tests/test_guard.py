@@ -77,7 +77,7 @@ def test_guard_verifies_a_clean_model_and_keeps_the_verdict(monkeypatch):
     verdict = _forget_verdict(prob.native_source())
     sol = AdjointSolver(prob, **TOL)
     eng = sol._engine()
-    assert eng.guard_report["enabled"] and set(eng.guard_state()["pending"]) == {"plain", "adjoint"}
+    assert eng.guard_report["enabled"] and eng.guard_state()["pending"] == ["adjoint"]     # the kind this handle runs
     tv = d["tvals"]
     with warnings.catch_warnings():
         warnings.simplefilter("error")
@@ -104,7 +104,10 @@ def test_guard_verifies_a_clean_model_and_keeps_the_verdict(monkeypatch):
     for _ in range(3):
         assert "plain" in e3.guard_state()["pending"]
         plain.solve_batch(0.0, tv, d["y0"][:5], ps[:5], pr[:5])
-    assert e3.guard_state()["verified"] == ["plain", "adjoint"] and e3.guard_state()["n_sample"]["plain"] == 5
+    assert e3.guard_state()["verified"] == ["plain"] and e3.guard_state()["n_sample"]["plain"] == 5
+    assert not e3.guard_state()["pending"]
+    # a verdict from batches of five stays with the process: nothing about "plain" on disk
+    assert "plain" not in json.load(open(verdict))["kinds"]
 
 
 @pytest.mark.gpu
@@ -195,9 +198,10 @@ def _run_pair(eng, d, ps, pr, B):
 @pytest.mark.parametrize("where", ["FORWARD", "BACKWARD"])
 def test_guard_switches_to_the_other_build_on_any_difference(where, monkeypatch):
     """The C library's two mismatch paths, driven with a partner build that adds 1.0 to one output on purpose:
-    a difference in the forward pass switches before the batch is launched; a difference that only shows in the
-    backward pass switches there and repeats the batch's forward pass with the partner build before integrating
-    backward.  Afterwards the handle behaves exactly like a handle created on the partner build."""
+    a difference in the forward pass switches and launches the batch again with the partner build before the call
+    returns; a difference that only shows in the backward pass switches there and repeats the batch's forward pass
+    with the partner build before integrating backward.  Afterwards the handle behaves exactly like a handle
+    created on the partner build."""
     from sunode_amd import _native
     monkeypatch.setenv("SA_GUARD", "0")
     prob, d, ps, pr = _lv(200)
@@ -262,3 +266,161 @@ def test_guard_catches_the_round4_miscompile(monkeypatch):
     assert eng2.guard_report["using_conservative"] and not eng2.guard_state()["pending"]
     y2, S2, _, _ = sol2.solve_sens_batch(0.0, tv, d["y0"], d["ps"], d["pr"], sens0)
     np.testing.assert_array_equal(S2, So)
+
+
+@pytest.mark.gpu
+def test_guard_sample_is_chosen_from_the_batch_statistics(monkeypatch):
+    """A partner build that differs ONLY for instances with the batch's largest number of error-test failures, none of
+    which is among the first 64 draws: the round-5 guard (first 64 instances) could not see it; the sample chosen
+    from the batch's own counters does, and the batch the caller receives is the partner build's."""
+    from sunode_amd import _native
+    monkeypatch.setenv("SA_GUARD", "0")
+    B = 3000
+    prob, d, ps, pr = _lv(B)
+    ref = _native.NativeSolver(prob.native_source(), n_states=2, guard=False, rtol=1e-8, atol=1e-8, rtolB=1e-8,
+                               atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
+    tv = np.ascontiguousarray(d["tvals"])
+    y0_ = np.zeros((B, len(tv), 2)); st0 = np.zeros(B, np.int32); stats0 = np.zeros((B, 16), np.int64)
+    ref.solve(_native.SA_MEM_HOST, B, np.ascontiguousarray(d["y0"]), np.ascontiguousarray(ps), np.ascontiguousarray(pr),
+              pr.shape[1], 0.0, tv, len(tv), y0_, st0, stats0, adjoint=True)
+    netf = stats0[:, 6]
+    T = int(netf.max())
+    rare = np.flatnonzero(netf >= T)
+    assert T >= 2 and 0 < len(rare) <= 8 and rare.min() >= 64, (T, rare)       # rare, and outside the old prefix sample
+    eng, other = _attach_other_build(monkeypatch, prob, "-DSA_TEST_PERTURB_NETF=%d" % T)
+    y = np.zeros((B, len(tv), 2)); st = np.zeros(B, np.int32); stats = np.zeros((B, 16), np.int64)
+    eng.solve(_native.SA_MEM_HOST, B, np.ascontiguousarray(d["y0"]), np.ascontiguousarray(ps), np.ascontiguousarray(pr),
+              pr.shape[1], 0.0, tv, len(tv), y, st, stats, adjoint=True)
+    state = eng.guard_state()
+    assert state["differs"] == ["adjoint"] and state["using_conservative"]
+    inst = int(state["detail"].split("of instance ")[1].split()[0])
+    assert inst in rare                                    # the message names the batch index, not the sample row
+    want = y0_.copy()
+    want[rare, -1, 0] += 1.0
+    np.testing.assert_array_equal(y, want)                 # the batch was launched again with the partner build
+    # a prefix-only batch (B <= sample size) is used in place: same verdict machinery, nothing to gather
+    eng2, _ = _attach_other_build(monkeypatch, prob, "-DSA_TEST_PERTURB_NETF=%d" % T)
+    k = 40
+    y2 = np.zeros((k, len(tv), 2)); st2 = np.zeros(k, np.int32); stats2 = np.zeros((k, 16), np.int64)
+    eng2.solve(_native.SA_MEM_HOST, k, np.ascontiguousarray(d["y0"][:k]), np.ascontiguousarray(ps[:k]),
+               np.ascontiguousarray(pr[:k]), pr.shape[1], 0.0, tv, len(tv), y2, st2, stats2, adjoint=True)
+    assert not eng2.guard_state()["differs"]
+    np.testing.assert_array_equal(y2, y0_[:k])
+
+
+@pytest.mark.gpu
+def test_guard_rechecks_a_later_batch_with_a_status_the_sample_never_had(monkeypatch):
+    """Verified on a clean first batch; a later host-memory batch contains a FAILING instance (a status code the
+    verified sample never showed): the kind is checked once more on that batch (the failing instance is in the
+    sample), stays verified, and the window closes."""
+    from sunode_amd.solver import AdjointSolver
+    monkeypatch.setenv("SA_GUARD", "1")
+    prob, d, ps, pr = _lv(400)
+    _forget_verdict(prob.native_source())
+    tv = d["tvals"]
+    sol = AdjointSolver(prob, mxsteps=40, **TOL)
+    eng = sol._engine()
+    g1 = np.ones((len(tv), 2))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+        sol.solve_backward_batch(tv[-1], 0.0, tv, g1)
+        s1 = eng.guard_state()
+        assert s1["verified"] == ["adjoint"] and s1["recheck_open"] and not s1["pending"]
+        checks_before = eng.guard_report["kinds"]["adjoint"]["n_sample"]
+        y0 = d["y0"].copy()
+        y0[333] = [np.nan, 1.0]                           # this instance fails at once (non-finite rhs)
+        y, st, _ = sol.solve_forward_batch(0.0, tv, y0, ps, pr)
+        assert st[333] != 0 and (np.delete(st, 333) == 0).all()
+        s2 = eng.guard_state()
+        assert s2["pending"] == ["adjoint"] and not s2["recheck_open"]         # re-opened, the backward pass finishes it
+        sol.solve_backward_batch(tv[-1], 0.0, tv, g1)
+    s3 = eng.guard_state()
+    assert s3["verified"] == ["adjoint"] and not s3["pending"] and not s3["recheck_open"] and not s3["differs"]
+    assert checks_before == 64 and eng._guard_open is False
+
+
+@pytest.mark.gpu
+def test_forward_only_use_of_the_adjoint_solver_stops_paying_for_the_guard(monkeypatch):
+    """solve_forward_batch without a backward call cannot finish the adjoint check: after two such calls the shadows
+    are dropped and later forward calls only enqueue; the check resumes with the first forward call after a backward
+    call."""
+    from sunode_amd.solver import AdjointSolver
+    monkeypatch.setenv("SA_GUARD", "1")
+    prob, d, ps, pr = _lv(200)
+    _forget_verdict(prob.native_source())
+    tv = d["tvals"]
+    sol = AdjointSolver(prob, **TOL)
+    eng = sol._engine()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for _ in range(5):
+            y, st, _ = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+            assert (st == 0).all() and eng.guard_state()["pending"] == ["adjoint"]
+        sol.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 2)))        # no forward check in flight: nothing booked
+        assert eng.guard_state()["pending"] == ["adjoint"]
+        sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+        sol.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 2)))
+    assert eng.guard_state()["verified"] == ["adjoint"] and eng.guard_state()["n_sample"]["adjoint"] == 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["lv_fullsize", "tiled_arena", "two_handles_failing_shard", "constraints", "hermite"])
+def test_product_configuration_guard_on(case, monkeypatch):
+    """The configuration users run (guard ON, everything else default) through the paths the rest of the suite covers
+    with SA_GUARD=0: BASELINE config 2 at full size, tiled re-integration, two handles with a failing instance in one
+    shard, constraints, Hermite interpolation -- results equal the guard-off run bit for bit, the guard verifies, no
+    warning."""
+    from sunode_amd.solver import AdjointSolver
+    from tools.problems import robertson_batch
+    kw, B, name = dict(TOL), 2000, "lv"
+    if case == "lv_fullsize":
+        B = 65536
+    elif case == "tiled_arena":
+        name, B = "robertson", 4096
+        kw = dict(abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8, quad_abstol=1e-10,
+                  quad_reltol=1e-8, arena_gib=0.05)
+    elif case == "two_handles_failing_shard":
+        kw.update(devices=[0, 0], arena_gib=4)
+    elif case == "constraints":
+        kw.update(constraints=np.array([1.0, 1.0]))
+    elif case == "hermite":
+        kw.update(interpolation="hermite")
+    prob = make_problem(name)
+    if name == "lv":
+        d = lv_batch(B)
+        y0, ps, pr = d["y0"].copy(), d["params"][:, :2], d["params"][:, 2:]
+    else:
+        d = robertson_batch(B)
+        y0, ps, pr = d["y0"], d["params"], np.zeros(0)
+    if case == "two_handles_failing_shard":
+        y0[B - 7] = [np.nan, 1.0]
+    tv = d["tvals"]
+    n = prob.n_states
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(n)[None, :])
+    results = {}
+    for guard in ("0", "1"):
+        monkeypatch.setenv("SA_GUARD", guard)
+        if guard == "1":
+            from sunode_amd import _native
+            src = prob.native_source()
+            _forget_verdict(src, constraints=case == "constraints", hermite=case == "hermite",
+                            compact=_native.default_compact_trajectory(src, case == "hermite"))
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            sol = AdjointSolver(prob, **kw)
+            y, st, stats = sol.solve_forward_batch(0.0, tv, y0, ps, pr)
+            g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+        if guard == "1":
+            for eng in sol._engines():
+                state = eng.guard_state()
+                assert state["verified"] == ["adjoint"] and not state["differs"] and state["n_sample"]["adjoint"] == 64
+            if case == "tiled_arena":
+                assert sol._engine().arena_info()[2]          # the batch was re-integrated tile by tile
+        results[guard] = (y, st, stats[:, :9], g, lam, stb, statsb[:, :13])
+        for eng in sol._engines():
+            eng.close()
+    for a, b in zip(results["0"], results["1"]):
+        np.testing.assert_array_equal(a, b)
+    if case == "two_handles_failing_shard":
+        assert results["1"][1][B - 7] != 0 and (np.delete(results["1"][1], B - 7) == 0).all()

@@ -147,7 +147,7 @@ def test_matvec_form_of_dense_linear_blocks():
         np.testing.assert_allclose(got["adjjac"], want, rtol=1e-13, atol=1e-15)
         assert got["codes"].tolist() == [0, 0, 0, 0, 0]
     # a problem without such a block keeps the plain form
-    assert not make_problem("seir")._matvec and "SA_MATVEC(" not in make_problem("seir").native_source().split("sa_logaddexp")[1]
+    assert not make_problem("seir")._matvec and "SA_MATVEC(" not in make_problem("seir").native_source().split("SA_TEMPLATE SA_FN int sa_rhs")[1]
 
 
 def test_matvec_regrouping_of_an_unexpanded_rhs_is_exact():

@@ -272,3 +272,81 @@ def test_eight_handles_carry_the_global_batch_of_an_eight_gpu_node(name, B):
             for a, b in zip(ref, got):
                 np.testing.assert_array_equal(a, b)
         del sol
+
+
+def test_caller_allocated_outputs_and_the_opt_in_pool(fake_native):
+    """``out=`` on the batch API (the reference's convention: the caller allocates, the solver writes in place,
+    /root/reference/sunode/solver.py:682,723-724) and the lifetime rules of the results: by default every call
+    returns FRESH arrays (a result kept only through a raw pointer survives the next call); ``reuse_outputs=True`` is
+    the explicit opt-in to recycled arrays."""
+    import ctypes
+    from sunode_amd.solver import AdjointSolver, Solver
+    prob = make_problem("lv")
+    B = 11
+    d, ps, pr = _lv_inputs(B)
+    tv = d["tvals"]
+    want = d["y0"][:, None, :] * (1.0 + tv[None, :, None]) + ps[:, :1, None]
+    for devices, interleaved in (([0], False), ([0, 1, 2], False), ([0, 1, 2], True)):
+        sol = AdjointSolver(prob, devices=devices, interleaved=interleaved)
+        y_buf, st_buf = np.full((B, len(tv), 2), -1.0), np.full(B, 77, np.int32)
+        y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr, out={"y_out": y_buf, "status": st_buf})
+        assert y is y_buf and st is st_buf and stats.shape == (B, 16)
+        np.testing.assert_array_equal(y_buf, want)
+        assert (st_buf == 0).all()
+        g_buf, l_buf = np.empty((B, 2)), np.empty((B, 2))
+        g, lam, stb, _ = sol.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 2)), out=(g_buf, l_buf))
+        assert g is g_buf and lam is l_buf
+        np.testing.assert_array_equal(g_buf, ps * 2.0)
+        # default lifetime: a result held only through a raw pointer is not overwritten by the next call
+        y1, _, _ = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+        addr = y1.ctypes.data
+        keep = y1                                    # (keeps the memory alive; the solver cannot know about `addr`)
+        y2, _, _ = sol.solve_forward_batch(0.0, tv, 2.0 * d["y0"], ps, pr)
+        assert y2.ctypes.data != addr
+        seen = np.ctypeslib.as_array(ctypes.cast(addr, ctypes.POINTER(ctypes.c_double)), shape=y1.shape)
+        np.testing.assert_array_equal(seen, want)
+        del keep
+    # wrong shape / dtype / layout / read-only: refused before anything runs
+    sol = AdjointSolver(prob)
+    for bad in (np.empty((B, len(tv), 3)), np.empty((B, len(tv), 2), np.float32), np.empty((len(tv), B, 2)).transpose(1, 0, 2)):
+        with pytest.raises(ValueError):
+            sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr, out=[bad])
+    ro = np.empty((B, len(tv), 2)); ro.setflags(write=False)
+    with pytest.raises(ValueError):
+        sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr, out=[ro])
+    with pytest.raises(ValueError):
+        sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr, out={"y": np.empty((B, len(tv), 2))})
+    sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+    with pytest.raises(ValueError):
+        sol.solve_backward_batch(tv[-1], 0.0, tv, np.ones((len(tv), 2)), out={"lamda_all": np.empty((B, len(tv), 2))})
+    # the opt-in pool: same array again, contract = valid until the next call of the same method
+    sol = AdjointSolver(prob, reuse_outputs=True)
+    y1, _, _ = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+    y2, _, _ = sol.solve_forward_batch(0.0, tv, 2.0 * d["y0"], ps, pr)
+    assert y2 is y1
+    plain = Solver(prob)
+    y_buf = np.empty((B, len(tv), 2))
+    y, st, _ = plain.solve_batch(0.0, tv, d["y0"], ps, pr, out=[y_buf])
+    assert y is y_buf and (st == 0).all()
+    sens = Solver(prob, sens_mode="simultaneous")
+    s_buf = np.empty((B, len(tv), 2, 2))
+    _, s, _, _ = sens.solve_sens_batch(0.0, tv, d["y0"], ps, pr, np.zeros((2, 2)), out={"sens_out": s_buf})
+    assert s is s_buf
+
+
+def test_empty_time_grid_returns_zeroed_status_and_counters(fake_native, monkeypatch):
+    """The library returns early for n_t == 0 without writing anything: status / counters must not be uninitialised
+    memory."""
+    from sunode_amd.solver import AdjointSolver
+
+    def untouched(self, mem, B, y0, ps, pr, rem_stride, t0, tvals, n_t, y_out, status, stats, adjoint=False):
+        pass
+    monkeypatch.setattr(fake_native, "solve", untouched)
+    prob = make_problem("lv")
+    d, ps, pr = _lv_inputs(6)
+    for reuse in (False, True):
+        sol = AdjointSolver(prob, reuse_outputs=reuse)
+        for _ in range(3):
+            y, st, stats = sol.solve_forward_batch(0.0, np.zeros(0), d["y0"], ps, pr)
+            assert y.shape == (6, 0, 2) and (st == 0).all() and (stats == 0).all()
+            st[:] = 5; stats[:] = 9                   # (a recycled array shows this again unless it is re-zeroed)

@@ -39,9 +39,88 @@ def test_sweep_covers_every_mapping_family():
             ("bdf_mem.hip", 1, False)} <= seen
 
 
+# ---- an independent pin for the sweep's callbacks: the reference's own pipeline, one shape per kernel family ----
+PINNED = ["lv12", "rn7_4", "rnb15_9", "rn22_33", "rn65_4"]
+
+
+def _pinned_points(name, golden_dir):
+    """(fixture, t, y, lam, ps, pr) of tests/golden/callbacks_sweep.json (tools/make_golden_callbacks_sweep.py:
+    values from the reference's symbolic pipeline; inputs regenerated from the repo-owned streams)."""
+    import json
+    from tools.make_golden_callbacks_sweep import sweep_points
+    with open(os.path.join(golden_dir, "callbacks_sweep.json")) as fh:
+        fix = json.load(fh)[name]
+    prob = make_problem(name)
+    t, y, lam, par = sweep_points(name, fix["n"], fix["n_items"])
+    return fix, prob, t, y, lam, par[:, prob.params_subset.subset_index], par[:, prob.params_subset.remainder_index]
+
+
+def _check_against_reference(fix, got_of_point):
+    from tests.helpers import check_matrix_summary
+    n = fix["n"]
+    for k, pt in enumerate(fix["points"]):
+        got = got_of_point(k)
+        for key in ("rhs", "adj", "quad"):
+            want = np.array(pt[key], float)
+            scale = float(np.max(np.abs(want))) if want.size else 0.0
+            np.testing.assert_allclose(np.asarray(got[key]).ravel(), want, rtol=1e-13, atol=64 * 2.3e-16 * scale, err_msg=key)
+        # (oracle.eval / eval_callbacks hand the matrices back as M[i, j], row = output, like the fixture)
+        check_matrix_summary(np.asarray(got["jac"]).reshape(n, n), pt["jac"])
+        check_matrix_summary(np.asarray(got["adjjac"]).reshape(n, n), pt["adjjac"])
+        assert np.asarray(got["codes"]).tolist() == pt["codes"]
+
+
+@pytest.mark.parametrize("name", PINNED)
+def test_sweep_callbacks_match_the_reference_pipeline(name, golden_dir):
+    """CPU: the generated C of five sweep shapes (host build = the text the kernels include) vs values the
+    REFERENCE's symbolic pipeline produced for the same model -- the sweep's callbacks are no longer code generator
+    against itself (missing #7)."""
+    fix, prob, t, y, lam, ps, pr = _pinned_points(name, golden_dir)
+    orc = make_oracle(name)
+    _check_against_reference(fix, lambda k: orc.eval(t[k], y[k], lam[k], ps[k], pr[k]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PINNED)
+def test_device_sweep_callbacks_match_the_reference_pipeline(name, golden_dir):
+    """... and the DEVICE functions of the same shapes (every kernel family's callback staging), equal to the host
+    build bit for bit."""
+    from sunode_amd.solver import Solver
+    fix, prob, t, y, lam, ps, pr = _pinned_points(name, golden_dir)
+    eng = Solver(prob)._engine()
+    got = eng.eval_callbacks(t, y, lam, ps, pr)
+    _check_against_reference(fix, lambda k: {key: got[key][k] for key in ("rhs", "jac", "adj", "quad", "adjjac", "codes")})
+    orc = make_oracle(name)
+    for k in range(len(t)):
+        host = orc.eval(t[k], y[k], lam[k], ps[k], pr[k])
+        for key in ("rhs", "jac", "adj", "quad", "adjjac"):
+            np.testing.assert_array_equal(np.asarray(got[key][k]).ravel(), np.asarray(host[key]).ravel())
+
+
+@pytest.mark.parametrize("name", ["lv12", "rn12_4"])
+def test_oracle_gradients_of_sweep_shapes_match_truth(name, golden_dir):
+    """DOP853 truth (tools/make_golden_truth.py --sweep) for two sweep shapes: the oracle's states / gradients at the
+    SURVEY 8(c) bars -- the sweep's gradients were only asserted finite and non-zero."""
+    d = np.load(os.path.join(golden_dir, "truth_sweep_%s.npz" % name))
+    orc = make_oracle(name)
+    cfg = orc.config(rtol=1e-8, atol=1e-8, rtolB=1e-8, atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
+    tv = d["tvals"]
+    y, st, _ = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], float(d["t0"]), tv, nthreads=4)
+    g, lam, stb, _ = orc.solve_backward(cfg, tv[-1], float(d["t0"]), tv, d["grads"], nthreads=4)
+    assert (st == 0).all() and (stb == 0).all()
+    _truth_bars(y, g, lam, d)
+
+
+def _truth_bars(y, g, lam, d):
+    k = len(d["y_out"])
+    assert np.max(np.abs(y[:k] - d["y_out"]) / np.abs(d["y_out"]).max(axis=(0, 1))) < 1e-5
+    assert np.max(np.abs(g[:k] - d["grad_params"]) / np.abs(d["grad_params"]).max(axis=1, keepdims=True)) < 4e-6
+    assert np.max(np.abs(-lam[:k] - d["grad_y0"]) / np.abs(d["grad_y0"]).max(axis=1, keepdims=True)) < 4e-6
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,B", ADJOINT_CASES, ids=[c[0] for c in ADJOINT_CASES])
-def test_default_mapping_adjoint_equals_oracle(name, B):
+def test_default_mapping_adjoint_equals_oracle(name, B, golden_dir):
     from sunode_amd.solver import AdjointSolver
     assert not os.environ.get("SA_FORCE_GROUP")
     prob = make_problem(name)
@@ -66,6 +145,9 @@ def test_default_mapping_adjoint_equals_oracle(name, B):
     np.testing.assert_array_equal(g, go)
     np.testing.assert_array_equal(lam, lo)
     assert np.isfinite(g).all() and np.abs(g).max() > 0
+    truth = os.path.join(golden_dir, "truth_sweep_%s.npz" % name)
+    if os.path.exists(truth):           # lv12, rn12_4: the first draws of the batch against DOP853 truth
+        _truth_bars(y, g, lam, np.load(truth))
 
 
 @pytest.mark.gpu

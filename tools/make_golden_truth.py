@@ -29,13 +29,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from sunode_amd import SympyProblem  # noqa: E402
-from tools.problems import PROBLEMS, lv_batch, robertson_batch, seir_batch  # noqa: E402
+from sunode_amd.symode.problem import HOST_FUNCTIONS  # noqa: E402
+from tools.problems import (EXTRA_PROBLEMS, PROBLEMS, forcing_batch, logistic_switch_batch, lv_batch,  # noqa: E402
+                            misc_batch, robertson_batch, seir_batch)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def make(name):
-    s = PROBLEMS[name]
+    s = {**PROBLEMS, **EXTRA_PROBLEMS}[name]
     return SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
 
 
@@ -45,9 +47,9 @@ def augmented_rhs(prob):
     y = list(prob._sym_statevec)
     ps = list(prob._sym_deriv_paramsvec)
     pr = list(prob._sym_fixed_paramsvec)
-    f = sym.lambdify([prob._sym_time, y, ps, pr], list(prob._sym_dydt), modules="numpy", cse=True)
-    J = sym.lambdify([prob._sym_time, y, ps, pr], sym.Matrix(prob._sym_dydt_jac), modules="numpy", cse=True)
-    P = sym.lambdify([prob._sym_time, y, ps, pr], sym.Matrix(prob._sym_dydp), modules="numpy", cse=True) if p else None
+    f = sym.lambdify([prob._sym_time, y, ps, pr], list(prob._sym_dydt), modules=[HOST_FUNCTIONS, "numpy"], cse=True)
+    J = sym.lambdify([prob._sym_time, y, ps, pr], sym.Matrix(prob._sym_dydt_jac), modules=[HOST_FUNCTIONS, "numpy"], cse=True)
+    P = sym.lambdify([prob._sym_time, y, ps, pr], sym.Matrix(prob._sym_dydp), modules=[HOST_FUNCTIONS, "numpy"], cse=True) if p else None
 
     def rhs(t, z, psv, prv):
         yv = z[:n]
@@ -108,8 +110,40 @@ def dvode_run(f, jac, y0, tvals, rtol, atol, args):
                 nni=int(iw[19]), ncfn=int(iw[20]), netf=int(iw[21]), y=np.array(ys).tolist())
 
 
+def transcendental_truth():
+    """truth_<name>.npz for the models with transcendental right-hand sides (8 draws each, per-instance cotangents):
+    ``forcing`` (expit / logaddexp / spline input -- the B-spline evaluated by the Cox-de Boor recursion, i.e. NOT by
+    the polynomial pieces the generated code shares with the reference), ``logistic_switch``, ``misc``."""
+    for name, batch in (("forcing", forcing_batch), ("logistic_switch", logistic_switch_batch), ("misc", misc_batch)):
+        prob = make(name)
+        d = batch(8)
+        y_out, gp, gy0 = truth_batch(prob, d["y0"], d["ps"], d["pr"], d["t0"], d["tvals"], d["grads"], "DOP853")
+        np.savez(os.path.join(GOLD, "truth_%s.npz" % name), y0=d["y0"], ps=d["ps"], pr=d["pr"], t0=d["t0"],
+                 tvals=d["tvals"], grads=d["grads"], y_out=y_out, grad_params=gp, grad_y0=gy0)
+
+
+def sweep_truth():
+    """truth_sweep_<name>.npz for two shapes of the parity sweep (tests/test_shape_sweep.py): ``lv12`` (2 states, 12
+    differentiated parameters) and ``rn12_4`` (12 states): 4 draws each of the sweep's own batch."""
+    from tools.problem_cache import spec_of
+    from tools.sweep_cases import batch_of
+    for name in ("lv12", "rn12_4"):
+        s = spec_of(name)
+        prob = SympyProblem(s["params"], s["states"], s["rhs"], s["derivative_params"])
+        d = batch_of(name, 4)
+        y_out, gp, gy0 = truth_batch(prob, d["y0"], d["ps"], d["pr"], d["t0"], d["tvals"], d["grads"], "DOP853")
+        np.savez(os.path.join(GOLD, "truth_sweep_%s.npz" % name), y0=d["y0"], ps=d["ps"], pr=d["pr"], t0=d["t0"],
+                 tvals=d["tvals"], grads=d["grads"], y_out=y_out, grad_params=gp, grad_y0=gy0)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--transcendental" in sys.argv:          # only the round-6 fixtures (the others are unchanged)
+        transcendental_truth()
+        return
+    if "--sweep" in sys.argv:
+        sweep_truth()
+        return
     # ---------------- DVODE statistics ----------------
     def lv_f(t, y, a, b, c, d):
         return [a * y[0] - b * y[0] * y[1], d * y[0] * y[1] - c * y[1]]
@@ -197,6 +231,8 @@ def main():
     y_out, gp, gy0 = truth_batch(prob, d["y0"], d["ps"], d["pr"], d["t0"], d["tvals"], g, "DOP853")
     np.savez(os.path.join(GOLD, "truth_seir.npz"), y0=d["y0"], ps=d["ps"], pr=d["pr"], t0=d["t0"],
              tvals=d["tvals"], grads=g, y_out=y_out, grad_params=gp, grad_y0=gy0)
+    transcendental_truth()
+    sweep_truth()
     print("done")
 
 

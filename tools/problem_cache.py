@@ -17,7 +17,7 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DIR = os.path.join(ROOT, "sunode_amd", "_cache", "problems")
 _SOURCES = ["tools/problems.py", "sunode_amd/symode/problem.py", "sunode_amd/symode/codegen.py",
-            "sunode_amd/dtypesubset.py"]
+            "sunode_amd/symode/lambdify.py", "sunode_amd/csrc/sa_math.h", "sunode_amd/dtypesubset.py"]
 
 
 def spec_of(name):

@@ -69,6 +69,56 @@ def misc_functions(t, y, p):
     }
 
 
+def forcing(t, y, p):
+    """The normal PyMC model shape: log-parameterised rates, a smooth switch, a soft threshold and a time-varying
+    input through B-spline coefficients -- every helper of the reference's symode/lambdify.py
+    (/root/reference/sunode/symode/lambdify.py:275-352) in one right-hand side.  Written so that the REFERENCE can
+    derive it too (its expit has no usable derivative rule: the switch depends on time and fixed parameters only),
+    which is what makes reference-generated callback fixtures possible (tools/make_golden_callbacks.py)."""
+    import sympy as sym
+    from sunode.symode.lambdify import expit, interpolate_spline, logaddexp
+    r, K = sym.exp(p.log_r), sym.exp(p.log_K)
+    u = interpolate_spline(t, list(p.w), 0, 10, 4)
+    eaten = p.a * y.x * y.z / (1 + y.z)
+    return {
+        "x": r * y.x * (1 - y.x / K) * expit(p.k * (t - p.t_mid)) + u - eaten,
+        "z": logaddexp(sym.Integer(0), p.s * (y.x - y.z)) - r * y.z / 2,
+        "c": eaten,
+    }
+
+
+def logistic_switch(t, y, p):
+    """expit of a STATE and of differentiated parameters (d expit = dexpit, d dexpit = dexpit (1 - 2 expit): the rules
+    sunode_amd/symode/lambdify.py adds; the reference raises NameError on this model, lambdify.py:301,318), a spline
+    of a state (d B_4 = B_3 - shifted B_3) and a general power x^q with a differentiated exponent."""
+    import sympy as sym
+    from sunode.symode.lambdify import CardinalBSpline, expit
+    r, K = sym.exp(p.log_r), sym.exp(p.log_K)
+    gate = expit(p.k * (y.x - p.x_half))
+    return {
+        "x": r * y.x * (1 - y.x / K) - p.m * y.x * gate + CardinalBSpline(4, y.v + 2) / 4,
+        "v": gate - r * y.v ** p.q / 3,
+    }
+
+
+def mathfn_a(t, y, p):
+    """One deterministic function of csrc/sa_math.h per output (exp / log / log1p / expm1 / pow): the callback-level
+    pin of the function library -- device vs oracle bit for bit, both vs the reference's numpy values."""
+    import sympy as sym
+    from sympy.codegen.cfunctions import expm1, log1p
+    x, a = y.x, p.a
+    return {"x": [sym.exp(a[0] * x[0] - 3), sym.log(x[1]) + log1p(a[1] * x[1]), x[2] ** a[2],
+                  expm1(-a[3] * x[3]) + x[3] ** sym.Rational(-5, 3), 1 / (1 + x[4] ** sym.Rational(7, 2)) + a[4]]}
+
+
+def mathfn_b(t, y, p):
+    """... sin / cos / tan / tanh / sinh / cosh."""
+    import sympy as sym
+    x, a = y.x, p.a
+    return {"x": [sym.sin(10 * a[0] * x[0] + t), sym.cos(x[1] + a[1]), sym.tan(x[2] / 4), sym.tanh(a[3] * x[3] - 1),
+                  sym.sinh(x[4]) - sym.cosh(a[4])]}
+
+
 def huge_pivots(t, y, p):
     """Decay rates of 1e200 on components that are exactly zero: the Newton matrix I - gamma*J has diagonal entries
     around 1e200 (beyond 2^500) while the steps stay of order 1 -- the pivots' reciprocals leave the range in which the
@@ -127,6 +177,14 @@ PROBLEMS = {
         rhs=misc_functions,
         derivative_params=[("a",), ("c",)],
     ),
+    "forcing": dict(
+        params={"log_r": (), "log_K": (), "w": (5,), "k": (), "t_mid": (), "a": (), "s": ()},
+        states={"x": (), "z": (), "c": ()},
+        rhs=forcing,
+        derivative_params=[("log_r",), ("log_K",), ("w",), ("a",)],
+    ),
+    "mathfn_a": dict(params={"a": (5,)}, states={"x": (5,)}, rhs=mathfn_a, derivative_params=[("a",)]),
+    "mathfn_b": dict(params={"a": (5,)}, states={"x": (5,)}, rhs=mathfn_b, derivative_params=[("a",)]),
 }
 
 
@@ -157,6 +215,12 @@ def sir_two_groups(t, y, p):
 
 #: test-only problems without reference-generated golden fixtures
 EXTRA_PROBLEMS = {
+    "logistic_switch": dict(
+        params={"log_r": (), "log_K": (), "k": (), "x_half": (), "q": (), "m": ()},
+        states={"x": (), "v": ()},
+        rhs=logistic_switch,
+        derivative_params=[("log_r",), ("log_K",), ("k",), ("x_half",), ("q",)],
+    ),
     "sir2": dict(
         params={"beta": (2,), "C": (2, 2), "gamma": (), "pop": (2,)},
         states={"S": (2,), "I": (2,)},
@@ -274,6 +338,51 @@ def seir_batch(B: int, seed: int = SEED, idx=None):
     y0 = np.concatenate([pop - I0, np.zeros(4), I0, np.zeros(4)])
     return dict(ps=sub, pr=C.ravel(), y0=np.tile(y0, (len(z), 1)), tvals=np.linspace(0, 100, 51), t0=0.0,
                 rtol=1e-8, atol=1e-8)
+
+
+def _cotangents(B, n_t, n, idx=None):
+    """Per-instance cotangents dL/dy_out (non-degenerate, different for every draw)."""
+    k = np.arange(n_t)[None, :, None]
+    i = np.arange(n)[None, None, :]
+    b = np.arange(B)[:, None, None] if idx is None else np.asarray(idx)[:, None, None]
+    return 1.0 + 0.5 * np.cos(1.3 * k + 0.7 * i + 0.21 * b)
+
+
+def forcing_batch(B: int, seed: int = SEED, idx=None):
+    """Draws for ``forcing``: subset order (log_r, log_K, w[5], a), remainder (k, t_mid, s)."""
+    z = np.stack([std_normal(seed, 1200 + k, B, idx) for k in range(8)], axis=1)
+    base = np.array([np.log(0.8), np.log(5.0), 0.2, 0.5, 1.0, 0.3, 0.6, 0.4])
+    ps = base + 0.2 * z
+    ps[:, 2:7] = base[2:7] * np.exp(0.2 * z[:, 2:7])
+    ps[:, 7] = base[7] * np.exp(0.2 * z[:, 7])
+    zy = np.stack([std_normal(seed, 1220 + s, B, idx) for s in range(2)], axis=1)
+    y0 = np.concatenate([np.array([0.5, 0.2]) * np.exp(0.1 * zy), np.zeros((len(z), 1))], axis=1)
+    tvals = np.linspace(0, 10, 11)
+    return dict(ps=ps, pr=np.array([2.0, 3.0, 1.5]), y0=y0, tvals=tvals, t0=0.0,
+                grads=_cotangents(len(z), len(tvals), 3, idx), rtol=1e-8, atol=1e-8)
+
+
+def logistic_switch_batch(B: int, seed: int = SEED, idx=None):
+    """Draws for ``logistic_switch``: subset (log_r, log_K, k, x_half, q), remainder (m)."""
+    z = np.stack([std_normal(seed, 1240 + k, B, idx) for k in range(5)], axis=1)
+    base = np.array([np.log(0.9), np.log(4.0), 2.0, 1.5, 1.5])
+    ps = base + 0.1 * z
+    zy = np.stack([std_normal(seed, 1250 + s, B, idx) for s in range(2)], axis=1)
+    y0 = np.array([0.4, 0.3]) * np.exp(0.1 * zy)
+    tvals = np.linspace(0, 8, 9)
+    return dict(ps=ps, pr=np.array([0.7]), y0=y0, tvals=tvals, t0=0.0,
+                grads=_cotangents(len(z), len(tvals), 2, idx), rtol=1e-8, atol=1e-8)
+
+
+def misc_batch(B: int, seed: int = SEED, idx=None):
+    """Draws for ``misc`` (exp / sin / sqrt / log / x^(3/2) / tanh / cos): subset (a, c[2]), remainder (b)."""
+    z = np.stack([std_normal(seed, 1260 + k, B, idx) for k in range(3)], axis=1)
+    ps = np.array([0.5, 0.2, 1.0]) * np.exp(0.1 * z)
+    zy = np.stack([std_normal(seed, 1270 + s, B, idx) for s in range(2)], axis=1)
+    y0 = np.array([1.0, 0.5]) * np.exp(0.1 * zy)
+    tvals = np.linspace(0, 12, 13)
+    return dict(ps=ps, pr=np.array([2.0]), y0=y0, tvals=tvals, t0=0.0,
+                grads=_cotangents(len(z), len(tvals), 2, idx), rtol=1e-8, atol=1e-8)
 
 
 def network_batch(B: int, n: int = 100, seed: int = SEED, idx=None):

@@ -26,10 +26,12 @@ ADJOINT_CASES = [
     ("rn33_4", 24), ("rnb33_9", 24),
     ("rn48_17", 12),
     ("rn64_1", 8), ("rn64_33", 6),          # the lane groups' last size
-    ("rn65_4", 5),                          # 64 | 65: workgroup per instance
-    ("rn96_9", 5),
-    ("rn127_4", 3),
-    ("rn128_17", 3),                        # the workgroup's last size
+    # workgroup per instance: one workgroup per CU (LDS), 256 CUs -> batches beyond 256 so that workgroup slots are
+    # taken a second time within one launch (the r5 batches of 3-5 instances never left the first round)
+    ("rn65_4", 300),                        # 64 | 65: workgroup per instance
+    ("rn96_9", 300),
+    ("rn127_4", 260),
+    ("rn128_17", 260),                      # the workgroup's last size
     ("rn129_1", 40),                        # 128 | 129: memory-resident
 ]
 
