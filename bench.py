@@ -671,6 +671,22 @@ def host_api(name, prob, w, B, steps=5):
                     "wall clock; caller-allocated output arrays through out= (the reference's convention)"}
 
 
+def first_use(workload):
+    """What a NEW model costs before its first batch (VERDICT r5 missing #9): the symbolic derivation + C generation and
+    the default + conservative gfx950 code objects, from a cold cache.  `measured_here`: the headline workload, rebuilt
+    now on this box's host cores (force=True: the cached objects are replaced by identical ones); `recorded`: every
+    BASELINE config as measured by tools/first_use.py in the build container (profiles/r06_first_use.json --
+    network100 is a minute of sympy and more of clang: not repeated inside a bench run)."""
+    from tools.first_use import measure
+    out = {"measured_here": {workload: measure(workload)}, "host_cores": usable_cores()}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_first_use.json")) as fh:
+            out["recorded"] = json.load(fh)
+    except (OSError, ValueError):
+        out["recorded"] = None
+    return out
+
+
 def extra_configs(args):
     """BASELINE configs 3-5 on this GPU: a couple of steps each (N = 1 only; they are parity-test cases, the
     headline `value` is config 2)."""
@@ -761,6 +777,11 @@ def main(argv=None):
                     out["host_api"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             if not args.no_extra_configs and args.workload == "lv":
                 out["configs"] = extra_configs(args)
+            if not args.no_extra_configs:
+                try:
+                    out["first_use"] = first_use(args.workload)
+                except Exception as exc:        # noqa: BLE001 -- the headline line must not depend on it
+                    out["first_use"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         else:
             # the contract times the CPU baseline at N = 1 only; keep the pointer so an N > 1 line is self-describing
             out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": usable_cores(), "kind": "port",

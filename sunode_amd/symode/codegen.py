@@ -144,6 +144,9 @@ HELPERS_C = r"""
 #ifndef SA_STORE_DYN
 #define SA_STORE_DYN(slot, value) out[slot] = (value)
 #endif
+#ifndef SA_ZERO_RANGE        /* N consecutive structurally zero output slots from S0 on (codegen.ZERO_RUN_MIN) */
+#define SA_ZERO_RANGE(S0, N) for (int z_ = 0; z_ < (N); z_++) SA_STORE_DYN((S0) + z_, 0.0)
+#endif
 #ifndef SA_UVEC_ROLLED       /* the N line values from one expression in i_ */
 #define SA_UVEC_ROLLED(tag, N, expr) \
     for (int i_ = 0; i_ < (N); i_++) { const double v_ = (expr); SA_UVEC_SET(tag, i_, v_); chk += v_ * 0.0; }
@@ -670,6 +673,28 @@ def _emit_rolled(name, signature, rolled, out_index, n_out, roller, names, matve
     return "\n".join(lines)
 
 
+#: runs of at least this many consecutive structurally zero output slots are emitted as ONE SA_ZERO_RANGE loop (a
+#: banded 512 x 512 Jacobian is 260 000 zero stores otherwise: 15 MB of generated text); shorter runs -- every model of
+#: up to 8 x 8 -- keep the literal stores, which a register mapping folds away
+ZERO_RUN_MIN = 64
+
+
+def _zero_runs(slots: Sequence[int], written: Dict[int, str]) -> Dict[int, int]:
+    """{position in `slots`: run length at the first slot of a long zero run, 0 at its other slots}."""
+    out: Dict[int, int] = {}
+    k = 0
+    while k < len(slots):
+        e = k
+        while e < len(slots) and written.get(slots[e], "0.0") == "0.0" and (e == k or slots[e] == slots[e - 1] + 1):
+            e += 1
+        if e - k >= ZERO_RUN_MIN:
+            out[k] = e - k
+            for j in range(k + 1, e):
+                out[j] = 0
+        k = max(e, k + 1)
+    return out
+
+
 def _temp_names(prefix: str, symbol_map: Dict[str, str]):
     """Names of the CSE temporaries of one callback: ``<prefix><i>``, skipping every name a model symbol already has
     (a parameter ``a`` of shape (5,) owns ``a_0 .. a_4``: the reference refuses such collisions,
@@ -763,9 +788,15 @@ def emit_function(
                 lines += ["    SA_PREFETCH_PR(%d, %d, %d);" % (k, lo, hi) for k, (lo, hi) in enumerate(pieces)]
         lines += stmts
         lines.append("    double chk = 0.0;")
-        for slot in slots:
+        slots = list(slots)
+        zero_run = _zero_runs(slots, written)
+        for k, slot in enumerate(slots):
             text = written.get(slot, "0.0")
             if text == "0.0":
+                if k in zero_run:                      # a long run of structural zeros: one loop, not N statements
+                    if zero_run[k]:
+                        lines.append("    SA_ZERO_RANGE(%d, %d);" % (slot, zero_run[k]))
+                    continue
                 lines.append("    SA_STORE(%d, 0.0);" % slot)
             elif matvec is not None:
                 lines.append("    if (SA_OWNS(%d)) { const double v_ = %s; SA_STORE(%d, v_); chk += v_ * 0.0; } SA_STMT_END"
@@ -787,8 +818,14 @@ def emit_function(
         return len(written.get(slot, "0.0")) + 16 + sum(len(temp_text[tn]) for tn in temps)
 
     cost = [_cost(slot) for slot in range(n_out)]
+    # statements per slot: the slots of a long zero run are ONE statement together (SA_ZERO_RANGE)
+    runs = _zero_runs(list(range(n_out)), written)
+    stmt = [0 if runs.get(slot, 1) == 0 else 1 for slot in range(n_out)]
+    for slot in range(n_out):
+        if not stmt[slot]:
+            cost[slot] = 0
     total = sum(cost)
-    n_chunks = -(-n_out // CHUNK_STATEMENTS)
+    n_chunks = -(-sum(stmt) // CHUNK_STATEMENTS)
     if total > CHUNK_COST:
         n_chunks = max(n_chunks, min(MAX_COST_CHUNKS, -(-total // CHUNK_COST), n_out))
     if n_chunks <= 1 or matvec is not None:
@@ -799,12 +836,14 @@ def emit_function(
 
     # chunked form: same expressions, same evaluation order inside every statement; a temporary
     # needed by several chunks is recomputed in each (identical value)
-    bounds, acc, target = [0], 0, total / n_chunks
+    bounds, acc, target, in_chunk = [0], 0, total / n_chunks, 0
     for slot in range(n_out):
         acc += cost[slot]
-        full = (slot + 1 - bounds[-1]) >= CHUNK_STATEMENTS
+        in_chunk += stmt[slot]
+        full = in_chunk >= CHUNK_STATEMENTS
         if (acc >= target * len(bounds) or full) and slot + 1 < n_out and len(bounds) < n_chunks:
             bounds.append(slot + 1)
+            in_chunk = 0
     bounds.append(n_out)
     call_args = ", ".join(part.split()[-1].lstrip("*") for part in signature.split(","))
     parts, calls = [], []

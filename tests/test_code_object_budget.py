@@ -29,8 +29,28 @@ def test_budget_file_covers_the_default_builds_of_every_baseline_problem():
 def test_current_builds_stay_within_budget(label):
     """(cross-compiles for gfx950 on the CPU box; cached after the first build)"""
     hard, soft = cob.violations([label], split=True)
-    assert hard == []               # spill slots / scratch / LDS (+ slack); register counts only inform
+    assert hard == []               # spill slots / scratch / LDS (+ slack) and the occupancy class: ANY toolchain
     assert all("exceeds" in m or "informational" in m for m in soft)
+
+
+def test_memory_resident_scratch_does_not_grow_with_the_state_count():
+    """the controller's vector temporaries are workspace slots in bdf_mem.hip (bdf_core.h TMPV), not n-sized
+    per-lane arrays: a 512-state model stays under a few KB of scratch per lane."""
+    assert cob.mem_scratch_violations() == []
+
+
+def test_occupancy_class_is_a_hard_limit(monkeypatch):
+    from sunode_amd import _native
+    assert cob.register_class({"vgpr_count": 128, "agpr_count": 0}) == 4
+    assert cob.register_class({"vgpr_count": 256, "agpr_count": 0}) == 2
+    assert cob.register_class({"vgpr_count": 200, "agpr_count": 57}) == 1
+    doc = cob.load()
+    fake = {"toolchain": {"hash": "another-toolchain"}, "budgets": {"lv": {
+        k: dict(v, vgpr_count=100, agpr_count=0) for k, v in doc["budgets"]["lv"].items()}}}
+    monkeypatch.setattr(cob, "load", lambda: fake)
+    hard, soft = cob.violations(["lv"], split=True)          # recorded: <= 128 registers; built: more -> hard, even
+    assert any("occupancy class" in m for m in hard)         # though the toolchain hash differs
+    assert any("differs from the recorded one" in m for m in soft)
 
 
 def test_budget_check_notices_a_regression(tmp_path, monkeypatch):

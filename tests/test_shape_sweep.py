@@ -27,7 +27,8 @@ def test_sweep_covers_every_mapping_family():
         prob = make_problem(name) if name in ("lv12", "rn5_8", "rn6_1") else None
         import re
         m = re.fullmatch(r"rnb?(\d+)_(\d+)", name)
-        n, p = (2, 12) if name == "lv12" else (int(m.group(1)), int(m.group(2)))
+        c = re.fullmatch(r"chain(\d+)", name)
+        n, p = (2, 12) if name == "lv12" else ((int(c.group(1)), 2) if c else (int(m.group(1)), int(m.group(2))))
         src = "#define SA_N_STATES %d\n#define SA_N_SUB %d\n" % (n, p)
         fam = _native.kernel_variant(src)
         if prob is not None:
@@ -88,7 +89,8 @@ def test_device_sweep_callbacks_match_the_reference_pipeline(name, golden_dir):
     from sunode_amd.solver import Solver
     fix, prob, t, y, lam, ps, pr = _pinned_points(name, golden_dir)
     eng = Solver(prob)._engine()
-    got = eng.eval_callbacks(t, y, lam, ps, pr)
+    # (the engine-level call takes the remainder vector the generated source reads: hoisted / packed copies appended)
+    got = eng.eval_callbacks(t, y, lam, ps, np.array([prob.extend_remainder(row) for row in pr]))
     _check_against_reference(fix, lambda k: {key: got[key][k] for key in ("rhs", "jac", "adj", "quad", "adjjac", "codes")})
     orc = make_oracle(name)
     for k in range(len(t)):

@@ -2,7 +2,7 @@
 
 ``make_problem(name)`` is what tests/helpers.py, ``__graft_entry__.build()`` and tools/code_object_budget.py share
 (the build path must not import the test package).  Names: the keys of tools/problems.py ``PROBLEMS`` /
-``EXTRA_PROBLEMS``, ``network100``, ``lv12`` and the generated family ``rn<n>_<p>`` / ``rnb<n>_<p>`` (banded rate
+``EXTRA_PROBLEMS``, ``network100``, ``lv12``, ``chain<n>`` (bidiagonal decay chain) and the generated family ``rn<n>_<p>`` / ``rnb<n>_<p>`` (banded rate
 matrix, |i - j| <= 2) of ``random_network``.
 
 The derivation of a 128-state Jacobian takes sympy minutes; the pickled problem (cloudpickle: the right-hand sides are
@@ -26,6 +26,9 @@ def spec_of(name):
         return P.network100()
     if name == "lv12":
         return P.LV12
+    m = re.fullmatch(r"chain(\d+)", name)
+    if m:
+        return P.chain(int(m.group(1)))
     m = re.fullmatch(r"rn(b?)(\d+)_(\d+)", name)
     if m:
         return P.random_network(int(m.group(2)), int(m.group(3)), band=2 if m.group(1) else 0)

@@ -429,6 +429,30 @@ def make_random_network(n: int, p: int, band: int = 0):
     return rhs
 
 
+def make_chain(n: int):
+    """Linear decay chain x_0 -> x_1 -> ... with a source: n states, a bidiagonal Jacobian, two differentiated rates.
+    Cheap to derive at any size -- the memory-resident mapping's sizes (n > 128) without minutes of sympy."""
+    def rhs(t, y, p):
+        x = y.x
+        return {"x": [-p.k[0] * x[0] + p.k[1]]
+                + [p.k[0] * x[i - 1] - (p.k[0] + p.k[1] / (i + 1)) * x[i] for i in range(1, n)]}
+    return rhs
+
+
+def chain(n: int):
+    return dict(params={"k": (2,)}, states={"x": (n,)}, rhs=make_chain(n), derivative_params=[("k",)])
+
+
+def chain_batch(B: int, n: int, seed: int = SEED, idx=None):
+    z = np.stack([std_normal(seed, 1300 + s, B, idx) for s in range(2)], axis=1)
+    ps = np.array([1.5, 0.8]) * np.exp(0.2 * z)
+    y0 = np.zeros((len(z), n))
+    y0[:, 0] = 1.0
+    tvals = np.array([0.0, 0.5, 1.0, 2.0])
+    return dict(ps=ps, pr=np.zeros(0), y0=y0, tvals=tvals, t0=0.0,
+                grads=_cotangents(len(z), len(tvals), n, idx), rtol=1e-6, atol=1e-8)
+
+
 def random_network(n: int, p: int, band: int = 0):
     """Problem specification (the dict ``SympyProblem`` is built from) of the (n, p) member of the family."""
     return dict(params={"K": (n, n), "s": (p,)}, states={"x": (n,)}, rhs=make_random_network(n, p, band),

@@ -33,6 +33,7 @@ ADJOINT_CASES = [
     ("rn127_4", 260),
     ("rn128_17", 260),                      # the workgroup's last size
     ("rn129_1", 40),                        # 128 | 129: memory-resident
+    ("chain512", 24),                       # far beyond it (bidiagonal Jacobian: zero runs emitted as loops, codegen.ZERO_RUN_MIN)
 ]
 
 #: forward sensitivities (``Solver(sens_mode=...)``) through the default build of the same shapes
@@ -48,5 +49,8 @@ def batch_of(name, B):
     from tools import problems as P
     if name == "lv12":
         return P.lv12_batch(B)
+    m = re.fullmatch(r"chain(\d+)", name)
+    if m:
+        return P.chain_batch(B, int(m.group(1)))
     m = re.fullmatch(r"rnb?(\d+)_(\d+)", name)
     return P.random_network_batch(B, int(m.group(1)), int(m.group(2)))
