@@ -90,6 +90,33 @@ def test_forward_adjoint_bitexact_vs_oracle(name):
     np.testing.assert_array_equal(statsp[:, CMP[:8]], stpo[:, CMP[:8]])
 
 
+def test_forcing_large_batch_every_instance_equals_the_oracle():
+    """8 192 draws of ``forcing`` (128 wavefronts; parameters spread 5x wider than the fixture's): every instance's
+    statuses, counters, states and gradients equal the oracle's -- transcendental right-hand sides at batch scale."""
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("forcing")
+    B = 8192
+    d = forcing_batch(B)
+    rng = np.random.RandomState(3)
+    ps = d["ps"] + np.array([0.4, 0.4, 0, 0, 0, 0, 0, 0]) * rng.randn(B, 8)      # log_r, log_K over +-1
+    tv = d["tvals"]
+    sol = AdjointSolver(prob, **TOL)
+    y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"], ps, d["pr"])
+    g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, d["grads"])
+    orc = make_oracle("forcing")
+    cfg = orc.config(rtol=1e-8, atol=1e-8, rtolB=1e-8, atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], ps, d["pr"], 0.0, tv, nthreads=os.cpu_count() or 8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, d["grads"], nthreads=os.cpu_count() or 8)
+    np.testing.assert_array_equal(st, so)
+    np.testing.assert_array_equal(stb, sbo)
+    assert (st == 0).mean() > 0.99
+    np.testing.assert_array_equal(stats[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(statsb[:, CMP_B], stbo[:, CMP_B])
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+
+
 @pytest.mark.parametrize("name", ["forcing", "logistic_switch", "misc"])
 def test_forward_adjoint_matches_truth(name, golden_dir):
     """Device vs DOP853 truth (tests/golden/truth_<name>.npz): states <= 1e-5, gradients <= 4e-6 relative."""

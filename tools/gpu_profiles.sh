@@ -3,7 +3,7 @@
 # bench command and separate PMC passes (MI355X_MICROARCH.md: counters in their own runs) -- HBM bytes, instruction
 # mix, wave / active / wait cycles, lane utilisation inputs -- plus the FETCH_SIZE / WRITE_SIZE calibration.
 #     usage: tools/gpu_profiles.sh <tag>          -> gpurun_out/<tag>_*.txt   (then: python tools/make_pmc_traffic.py <tag>)
-tag=${1:-r05}
+tag=${1:-r06}
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$root"
 export TMPDIR=/tmp
