@@ -138,7 +138,8 @@ class GpuEngine:
         rt, at = tol
         self.eng = _native.NativeSolver(source, device=local_rank, rtol=rt, atol=at, rtolB=rt, atolB=at,
                                         rtolQB=rt, atolQB=at, n_states=n, arena_bytes=arena_bytes,
-                                        compact=_native.default_compact_trajectory(source))   # = AdjointSolver's default
+                                        compact=_native.default_compact_trajectory(source),   # = AdjointSolver's default
+                                        guard_kinds=("adjoint",))                            # the kind this engine runs
         # stream ordering (include/sunode_amd.h): the solver launches on the torch stream that owns the tensors
         self.stream = torch.cuda.Stream(device=self.dev)
         self.eng.set_stream(self.stream.cuda_stream)
