@@ -212,7 +212,7 @@ DEV void build_table(int order, double dt, const double (&hT)[QMAX + 1], double 
         SFOR_DOWN(j, QMAX, 1) {
             if constexpr (j >= i) {
                 if (j <= order) {
-                    double factor = dt / (hT[j] - hT[j - i]);
+                    double factor = SA_TABLE_DIV(dt, hT[j] - hT[j - i]);
                     SFOR(k, 0, NS) Y[j][k] = factor * (Y[j][k] - Y[j - 1][k]); SEND
                 }
             }

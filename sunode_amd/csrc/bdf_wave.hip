@@ -713,7 +713,7 @@ DEV void load_points(const Cw<BWD> &m, int indx, double (&hdr)[8], double (&Y)[Q
         SFOR_DOWN(j, QMAX, 1) {
             if constexpr (j >= i) {
                 if (j <= order) {
-                    const double factor = dt / (hT[j] - hT[j - i]);
+                    const double factor = SA_TABLE_DIV(dt, hT[j] - hT[j - i]);
                     SFOR(s, 0, RS) Y[j][s] = factor * (Y[j][s] - Y[j - 1][s]); SEND
                 }
             }
@@ -2498,7 +2498,7 @@ DEV void store_table(double *rec, int lane, int order, double dt, const double (
         SFOR_DOWN(j, QMAX, 1) {
             if constexpr (j >= i) {
                 if (j <= order) {
-                    double factor = dt / (hT[j] - hT[j - i]);
+                    double factor = SA_TABLE_DIV(dt, hT[j] - hT[j - i]);
                     SFOR(r, 0, RS) Y[j][r] = factor * (Y[j][r] - Y[j - 1][r]); SEND
                 }
             }

@@ -162,6 +162,15 @@ DEV double fdiv(double a, double b)
     return FMA(rem, r2, q0);
 }
 
+/* the divisions of the interpolation table (CVApolynomialGetY: factor = dt / (t_j - t_{j-i}), 15 per table): step
+   sizes over sums of step sizes, far from every exponent limit, so the lean division above returns the IEEE quotient
+   bit for bit.  -DSA_TABLE_FDIV selects it (A/B: profiles/r06_table_fdiv.txt) */
+#ifdef SA_TABLE_FDIV
+#define SA_TABLE_DIV(a, b) fdiv((a), (b))
+#else
+#define SA_TABLE_DIV(a, b) ((a) / (b))
+#endif
+
 /* ------------------------------------------------------------------------------------ */
 /* deterministic pow (pure +,-,*,/): same operation sequence as the CPU restatement       */
 /* ------------------------------------------------------------------------------------ */

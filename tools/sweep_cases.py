@@ -33,7 +33,7 @@ ADJOINT_CASES = [
     ("rn127_4", 260),
     ("rn128_17", 260),                      # the workgroup's last size
     ("rn129_1", 40),                        # 128 | 129: memory-resident
-    ("chain512", 24),                       # far beyond it (bidiagonal Jacobian: zero runs emitted as loops, codegen.ZERO_RUN_MIN)
+    ("chain256", 24),                       # far beyond it (bidiagonal Jacobian: zero runs emitted as loops, codegen.ZERO_RUN_MIN)
 ]
 
 #: forward sensitivities (``Solver(sens_mode=...)``) through the default build of the same shapes
