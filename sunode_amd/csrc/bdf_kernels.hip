@@ -360,7 +360,7 @@ DEV int interp_y(Cv<BWD> &m, double t)
         SFOR(f, 0, 8) hdr[f] = LT(m, f); SEND
         SFOR(i, 0, (QMAX) + 1) { SFOR(k, 0, NS) Yt[i][k] = LT(m, 8 + i * NS + k); SEND } SEND
         const int order = (int)hdr[0];
-        const double inv_dt = 1.0 / hdr[1];
+        const double inv_dt = SA_TABLE_DIV(1.0, hdr[1]);
         double cvals[QMAX + 1];
         cvals[0] = 1.0;
         SFOR(i, 0, QMAX) { const double v = cvals[i] * (t - hdr[2 + i]) * inv_dt; cvals[i + 1] = (i < order) ? v : 0.0; } SEND

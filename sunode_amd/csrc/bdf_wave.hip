@@ -845,7 +845,7 @@ DEV int interp_y(Cw<BWD> &m, double t)
         SFOR(f, 0, 8) hdr[f] = tab[f]; SEND
         SFOR(i, 0, (QMAX) + 1) { SFOR(s, 0, RS) ty[i][s] = tab[8 + i * NS + (IDX(m, s) < NS ? IDX(m, s) : 0)]; SEND } SEND
         const int order = (int)hdr[0];
-        const double inv_dt = 1.0 / hdr[1];
+        const double inv_dt = SA_TABLE_DIV(1.0, hdr[1]);
         double cvals[QMAX + 1];
         cvals[0] = 1.0;
         SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - hdr[2 + i]) * inv_dt : 0.0; SEND
@@ -877,7 +877,7 @@ DEV int interp_y(Cw<BWD> &m, double t)
     }
     {
         const int order = (int)m.tab_hdr[0];
-        const double inv_dt = 1.0 / m.tab_hdr[1];
+        const double inv_dt = SA_TABLE_DIV(1.0, m.tab_hdr[1]);
         double cvals[QMAX + 1];
         cvals[0] = 1.0;
         SFOR(i, 0, QMAX) cvals[i + 1] = (i < order) ? cvals[i] * (t - m.tab_hdr[2 + i]) * inv_dt : 0.0; SEND

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B: the 15 divisions of the interpolation table (CVApolynomialGetY) as IEEE divisions (default) or as the lean
+# A/B (run BEFORE the lean division became the default; the switch is -DSA_TABLE_IEEE_DIV now): IEEE divisions or the lean
 # division sa_common.h fdiv (-DSA_TABLE_FDIV; same quotients bit for bit in this operand range).
 #   bash tools/ab_table_fdiv.sh > gpurun_out/r06_table_fdiv.txt        (MI355X box; code objects pre-built)
 echo "# python bench.py --workload <w> --steps 5 --warmup 2, default build | SA_KERNEL_DEFINES=-DSA_TABLE_FDIV (r06, MI355X)"
