@@ -147,6 +147,52 @@ def test_solve_ivp_graph_and_adjoint_grad_chain_vs_oracle(ops):
     assert abs((lp - lm) / (2 * eps) - d_params[0]) < 2e-5 * max(1.0, abs(d_params[0]))
 
 
+def test_solve_ivp_graph_of_a_model_with_the_reference_helper_functions(ops):
+    """The normal PyMC model shape through the graph builder: log-parameterised rates, ``expit`` switch, ``logaddexp``
+    threshold and a degree-4 ``interpolate_spline`` input whose coefficients are a pytensor VECTOR -- imported under the
+    reference's names (``sunode.symode.lambdify``).  The evaluated graph equals the ORACLE's states and gradients bit
+    for bit (the helper functions run as csrc/sa_math.h on both sides) and a finite difference through the graph."""
+    pytensor = pytest.importorskip("pytensor")
+    if not hasattr(pytensor, "evaluate"):
+        pytest.skip("graph evaluation helper of the stub only")
+    from tests.helpers import make_oracle
+    from tools.problems import forcing, forcing_batch
+    pt = importlib.import_module("pytensor.tensor")
+    tol = 1e-8
+    log_r, log_K, a, w = pt.dscalar("log_r"), pt.dscalar("log_K"), pt.dscalar("a"), pt.dvector("w")
+    d = forcing_batch(1)
+    tv = d["tvals"]
+    sol, flat, problem, solver, y0_flat, ps_flat = ops.solve_ivp(
+        t0=0.0, y0={"x": np.array(d["y0"][0, 0]), "z": np.array(d["y0"][0, 1]), "c": np.array(0.0)},
+        params={"log_r": (log_r, ()), "log_K": (log_K, ()), "w": (w, (5,)), "k": np.array(2.0), "t_mid": np.array(3.0),
+                "a": (a, ()), "s": np.array(1.5)},
+        tvals=tv, rhs=forcing, derivatives="adjoint",
+        solver_kwargs=dict(abstol=tol, reltol=tol, backward_abstol=tol, backward_reltol=tol, quad_abstol=tol,
+                           quad_reltol=tol))
+    assert [".".join(p) for p in problem.params_subset.subset_paths] == ["log_r", "log_K", "w", "a"]
+    ps = d["ps"][0]
+    givens = {log_r: ps[0], log_K: ps[1], w: ps[2:7], a: ps[7]}
+    y = pytensor.evaluate(flat, givens)
+    g_out = d["grads"][0]
+    node = flat.owner
+    gl = node.op.grad(node.inputs, [pt.as_tensor_variable(g_out)])
+    d_y0, d_params = pytensor.evaluate([gl[0], gl[1]], givens)
+    orc = make_oracle("forcing")
+    cfg = orc.config(rtol=tol, atol=tol, rtolB=tol, atolB=tol, rtolQB=tol, atolQB=tol)
+    yo, so, _ = orc.solve_forward(cfg, d["y0"], d["ps"], d["pr"], 0.0, tv)
+    go, lo, sbo, _ = orc.solve_backward(cfg, tv[-1], 0.0, tv, g_out)
+    assert so[0] == 0 and sbo[0] == 0
+    np.testing.assert_array_equal(y, yo[0])
+    np.testing.assert_array_equal(d_params, go[0])
+    np.testing.assert_array_equal(d_y0, -lo[0])
+    eps = 1e-6
+    wp, wm = ps[2:7].copy(), ps[2:7].copy()
+    wp[2] += eps; wm[2] -= eps
+    lp = (pytensor.evaluate(flat, {**givens, w: wp}) * g_out).sum()
+    lm = (pytensor.evaluate(flat, {**givens, w: wm}) * g_out).sum()
+    assert abs((lp - lm) / (2 * eps) - d_params[4]) < 2e-5 * max(1.0, abs(d_params[4]))
+
+
 def test_solve_ivp_forward_sensitivity_grad_chain(ops):
     """derivatives='forward': SolveODE.grad contracts the sensitivities; a cotangent on the sensitivity output
     is refused like in the reference (:253)."""
