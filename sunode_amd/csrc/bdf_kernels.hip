@@ -638,6 +638,9 @@ template <bool BWD>
 DEV void dense_getrs(const Cv<BWD> &m, double (&b)[RS]) { dense_getrs(m.A, m.piv, m.inv_piv, b); }
 #ifdef SA_SENS
 #define SV(m, v, is, r) (m).sv[v][is][r]
+/* (measured and not kept, profiles/r06_sens_nounroll.txt: the parameter loop as a run-time loop -- the vectors then live in
+   scratch by dynamic indexing instead of spilling there, 254 registers and no spill slot -- Robertson 0.91 -> 0.51 M, LV
+   23 -> 6 M sensitivity solves/s) */
 #define SLOOP_BEGIN(is) SFOR(is, 0, NQ)
 #define SLOOP_END SEND
 #endif

@@ -187,7 +187,7 @@ DEV void bind_workspace(Cm<BWD> &m, double *ws, int64_t stride, int inst)
 #ifdef SA_SENS
 #define SENS_ON(m) (!BWD && (m).sensi)
 #define SV(m, v, is, r) W(m, O_SV, (((v) * NQ + (is)) * NS) + (r))
-#define SLOOP_BEGIN(is) for (int is = 0; is < NQ; is++) {
+#define SLOOP_BEGIN(is) _Pragma("nounroll") for (int is = 0; is < NQ; is++) {     /* (a loop: see bdf_wave.hip) */
 #define SLOOP_END }
 #endif
 

@@ -2243,7 +2243,14 @@ DEV void dense_getrs(Cw<BWD> &m, double (&b)[RS])
 static_assert(SA_LEAN, "the sensitivity corrector of bdf_wave.hip exists in the lean lane-group builds (n <= 21); larger: bdf_mem.hip");
 #define SENS_ON(m) (!BWD && (m).sensi)
 #define SV(m, v, is, r) (m).sws[(int64_t)(((v) * NQ + (is)) * RS + (r)) * 64]
+/* the loop over the parameters stays a LOOP: unrolled (what -O3 does with a trip count of 8) the loads of all
+   parameters' vectors are hoisted in front of the arithmetic and the kernel spills -- SEIR: 1 585 spill slots and 4 KB of
+   scratch per lane unrolled, 592 / 1 KB as a loop (profiles/r06_sens_nounroll.txt; -DSA_SENS_UNROLL: the round-5 form) */
+#ifdef SA_SENS_UNROLL
 #define SLOOP_BEGIN(is) for (int is = 0; is < NQ; is++) {
+#else
+#define SLOOP_BEGIN(is) _Pragma("nounroll") for (int is = 0; is < NQ; is++) {
+#endif
 #define SLOOP_END }
 
 /* out[is] = J ys[is] + dp[is] for the rows of this lane; J, dp: workspace copies the callbacks just wrote */

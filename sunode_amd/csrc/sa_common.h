@@ -139,7 +139,7 @@ DEV bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
 /* The forward-sensitivity builds keep the plain straight-line forms: measured with the shortcuts LV 25.1 -> 24.5 M,
    Robertson 0.91 -> 0.84 M, SEIR 43.9 -> 43.1 k sensitivity solves/s (their kernels live at the register limit:
    Robertson's sa_k_sens 1136 -> 1397 spill slots); adjoint / plain builds: LV +4 %, Robertson +2 %, network100 +3 %. */
-#ifdef SA_SENS
+#if defined(SA_SENS) && !defined(SA_SENS_SHORTCUT)
 #define SA_SHORTCUT(c) true
 #else
 #define SA_SHORTCUT(c) wave_any(c)
