@@ -239,7 +239,8 @@ def test_guard_catches_the_round4_miscompile(monkeypatch):
     from sunode_amd import _native
     from sunode_amd.solver import Solver
     monkeypatch.setenv("SA_GUARD", "1")
-    monkeypatch.setenv("SA_KERNEL_DEFINES", "-DSA_SENS_CTL_PARK")
+    monkeypatch.setenv("SA_KERNEL_DEFINES", "-DSA_SENS_CTL_PARK -DSA_SENS_UNROLL")     # (+ the round-4/5 form of the parameter loop:
+    # with the loop kept a loop -- round 6 -- this combination no longer trips the pass)
     monkeypatch.setenv("SA_CLANG_FLAGS", "-mllvm -disable-machine-licm")
     prob = make_problem("seir")
     assert _native.kernel_variant(prob.native_source(), sens=True) == ("bdf_wave.hip", 4)

@@ -24,7 +24,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-BAD_ENV = {"SA_KERNEL_DEFINES": "-DSA_SENS_CTL_PARK", "SA_CLANG_FLAGS": "-mllvm -disable-machine-licm", "SA_GUARD": "0"}
+BAD_ENV = {"SA_KERNEL_DEFINES": "-DSA_SENS_CTL_PARK -DSA_SENS_UNROLL", "SA_CLANG_FLAGS": "-mllvm -disable-machine-licm", "SA_GUARD": "0"}
 
 
 def make(outdir):

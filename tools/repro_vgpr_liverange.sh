@@ -19,6 +19,6 @@ export SA_GUARD=0        # (the differential guard would repair build 1)
 run() { echo "=== $1 | defines: $2 | flags: $3"; SA_CLANG_FLAGS="$3" SA_KERNEL_DEFINES="$2" timeout 900 python -m pytest $T -q -m gpu \
         -k "seir_lane_groups and None" 2>&1 | grep -E "passed|failed|Mismatched" | head -4; }
 F="-mllvm -disable-machine-licm"
-run "1. parked, machine LICM off" "-DSA_SENS_CTL_PARK" "$F"
-run "2. ... SIOptimizeVGPRLiveRange off" "-DSA_SENS_CTL_PARK" "$F -mllvm -amdgpu-opt-vgpr-liverange=0"
-run "3. ... at -O1" "-DSA_SENS_CTL_PARK" "$F -O1"
+run "1. parked, machine LICM off" "-DSA_SENS_CTL_PARK -DSA_SENS_UNROLL" "$F"
+run "2. ... SIOptimizeVGPRLiveRange off" "-DSA_SENS_CTL_PARK -DSA_SENS_UNROLL" "$F -mllvm -amdgpu-opt-vgpr-liverange=0"
+run "3. ... at -O1" "-DSA_SENS_CTL_PARK -DSA_SENS_UNROLL" "$F -O1"
