@@ -153,7 +153,8 @@ REGISTER_KERNEL_MAX_SUB = 8
 SENS_REGISTER_MAX_NP = 12
 
 
-def kernel_variant(native_source: str, sens: bool = False, constraints: bool = False, hermite: bool = False):
+def kernel_variant(native_source: str, sens: bool = False, constraints: bool = False, hermite: bool = False,
+                   group: Optional[str] = None):
     """(source file, lanes per instance) for a generated problem header.
 
     ``sens=True`` (forward sensitivities, ``Solver(sens_mode=...)``): the register kernel built with
@@ -167,11 +168,12 @@ def kernel_variant(native_source: str, sens: bool = False, constraints: bool = F
     larger: memory-resident thread-per-instance kernel (state in an HBM workspace, [element][instance]).
     SA_FORCE_GROUP=<G> or wave<G> forces G lanes per instance (tests run small problems through every mapping);
     SA_FORCE_GROUP=1 forces the register kernel, SA_FORCE_GROUP=wave the workgroup-per-instance one and
-    SA_FORCE_GROUP=mem the memory-resident one."""
+    SA_FORCE_GROUP=mem the memory-resident one.  ``group``: the same values as an argument (takes precedence over the
+    environment): how ``AdjointSolver`` asks for the small-batch mapping of a model (``small_batch_group``)."""
     import re
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     p = int(re.search(r"#define SA_N_SUB (\d+)", native_source).group(1))
-    forced = os.environ.get("SA_FORCE_GROUP")
+    forced = group if group is not None else os.environ.get("SA_FORCE_GROUP")
     # (Hermite interpolation: every family carries it -- since round 2 the register kernel too)
     if sens:
         # forward sensitivities: the register kernel keeps the p sensitivity Nordsieck arrays (14 n p doubles) next
@@ -226,14 +228,40 @@ def lane_group_size(n: int, p: int) -> int:
     return g
 
 
-def default_compact_trajectory(native_source: str, hermite: bool = False) -> bool:
+def small_batch_group(native_source: str, hermite: bool = False) -> Optional[str]:
+    """The mapping ``AdjointSolver`` switches to for SMALL batches, or None.
+
+    One lane per instance fills the chip only from 65 536 instances on (1 024 wavefronts); below that a 4-lane group per
+    instance uses four times as many SIMDs AND finishes an instance sooner when the model is large for one lane.
+    Measured, forward + adjoint, one lane vs four (profiles/r06_mapping_by_batch.txt): n = 4, p = 2: +12 ... 22 % for
+    every B <= 16 384; n = 4 / 5, p = 8: +30 ... 55 %; n = 5, p = 2: +8 ... 19 %; n = 3: equal (and slower with
+    transcendental callbacks, which every lane of a group evaluates); from 32 768 instances on one lane per instance
+    wins everywhere.  So: models the engine maps to one lane with n >= 4 states run in 4-lane groups while a handle's
+    batch is at most SMALL_BATCH_MAX.  Results are bit-identical in every mapping.  SA_FORCE_GROUP (a forced
+    mapping) and SA_BATCH_MAPPING=fixed switch this off."""
+    import re
+    if os.environ.get("SA_FORCE_GROUP") or os.environ.get("SA_BATCH_MAPPING", "auto") == "fixed":
+        return None
+    n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
+    if kernel_variant(native_source, hermite=hermite)[0] != "bdf_kernels.hip" or n < SMALL_BATCH_MIN_STATES:
+        return None
+    return "wave4"
+
+
+#: a handle's batch up to which ``small_batch_group`` applies (16 384 four-lane instances = one wavefront per SIMD)
+SMALL_BATCH_MAX = 16384
+SMALL_BATCH_MIN_STATES = 4
+
+
+def default_compact_trajectory(native_source: str, hermite: bool = False, group: Optional[str] = None) -> bool:
     """Arena record format AdjointSolver picks by default: compact {order, t, y[n]} records (table rebuilt by the
     backward kernel) from three states on, in the register-resident kernels -- measured, profiles/
     r03_compact_trajectory.txt: Robertson 73 -> 14 GB and +18 %; SEIR / network24 / network100 the same throughput
     (+-0.5 %) in a sixth of the arena; Lotka-Volterra (n = 2) -4 % -- table records there and in bdf_mem.hip."""
     import re
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
-    return (not hermite) and n >= 3 and kernel_variant(native_source, hermite=hermite)[0] in ("bdf_kernels.hip", "bdf_wave.hip")
+    return (not hermite) and n >= 3 and \
+        kernel_variant(native_source, hermite=hermite, group=group)[0] in ("bdf_kernels.hip", "bdf_wave.hip")
 
 
 def _size_defines(native_source: str):
@@ -246,8 +274,8 @@ def _size_defines(native_source: str):
 
 
 def code_object_path(native_source: str, sens: bool = False, constraints: bool = False,
-                     hermite: bool = False, compact: bool = False, safe: bool = False) -> str:
-    fname, group = kernel_variant(native_source, sens, constraints, hermite)
+                     hermite: bool = False, compact: bool = False, safe: bool = False, group: Optional[str] = None) -> str:
+    fname, group = kernel_variant(native_source, sens, constraints, hermite, group=group)
     kern = os.path.join(_CSRC, fname)
     deps = [kern] + [os.path.join(_CSRC, f) for f in ("sa_device_abi.h", "sa_common.h", "bdf_core.h")]
     deps = [d for d in deps if os.path.exists(d)]
@@ -265,17 +293,17 @@ def code_object_path(native_source: str, sens: bool = False, constraints: bool =
 
 def build_code_object(native_source: str, force: bool = False, keep_temps: bool = False,
                       sens: bool = False, constraints: bool = False, hermite: bool = False, compact: bool = False,
-                      safe: bool = False) -> str:
+                      safe: bool = False, group: Optional[str] = None) -> str:
     """Compile the integrator kernels for one problem to a gfx950 code object (cached).
     ``constraints=True`` builds the variant that enforces CVodeSetConstraints-style inequality
     constraints (a separate code object: the default build carries no trace of them).
     ``safe=True``: the CONSERVATIVE build -- same source, same defines, same flags, plus SAFETY_CODEGEN_FLAGS
     (SIOptimizeVGPRLiveRange off): the partner of the default build in the differential guard (NativeSolver)."""
     os.makedirs(_CACHE, exist_ok=True)
-    out = code_object_path(native_source, sens, constraints, hermite, compact, safe)
+    out = code_object_path(native_source, sens, constraints, hermite, compact, safe, group)
     if os.path.exists(out) and not force:
         return out
-    fname, group = kernel_variant(native_source, sens, constraints, hermite)
+    fname, group = kernel_variant(native_source, sens, constraints, hermite, group=group)
     kern = os.path.join(_CSRC, fname)
     hdr = out[:-6] + ".h"
     with open("%s.tmp%d" % (hdr, os.getpid()), "w") as fh:      # (concurrent ranks: private temporaries, atomic renames)
@@ -554,7 +582,7 @@ class NativeSolver:
                  atolB=1e-10, rtolQB=1e-10, atolQB=1e-10, mxstep=500, max_retries_fwd=5,
                  max_retries_bwd=50, traj_capacity=500_001, n_states: Optional[int] = None, sens: bool = False,
                  constraints=None, hermite: bool = False, arena_bytes: int = 0, compact: bool = False,
-                 guard: Optional[bool] = None, guard_sample: int = 64, guard_kinds=None):
+                 guard: Optional[bool] = None, guard_sample: int = 64, guard_kinds=None, group: Optional[str] = None):
         """``guard`` (default: on, SA_GUARD=0 turns it off): the differential guard -- the conservative build of the
         same source is compiled next to the default one and a sample of the first batch of every kind of call (chosen
         from the batch's own statuses and counters, include/sunode_amd.h) runs through both on the device; any
@@ -563,7 +591,8 @@ class NativeSolver:
         (``("adjoint",)`` under an AdjointSolver, ``("plain",)`` / ``("sens",)`` under a Solver; default: all) --
         kinds it never runs are not left pending, so the shadow handles go away once the used kind is verified."""
         self.L = load_library()
-        build_kw = dict(sens=sens, constraints=constraints is not None, hermite=hermite, compact=compact)
+        build_kw = dict(sens=sens, constraints=constraints is not None, hermite=hermite, compact=compact, group=group)
+        self.variant = kernel_variant(native_source, sens, constraints is not None, hermite, group=group)
         self._guard_open = False
         self._guard_safe = None
         self.guard_report = {"enabled": False}

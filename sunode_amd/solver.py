@@ -151,6 +151,8 @@ class _EngineMixin:
         self._devices = devices
         self._device = devices[0]
         self._natives = None
+        self._native_sets = {}
+        self._mapping = None
         self._pool = None
         self._outputs = _OutputPool() if getattr(self, "_reuse_outputs", False) else None
 
@@ -216,16 +218,24 @@ class _EngineMixin:
         return max(budget // sharing, 1)
 
     def _engines(self):
-        if self._natives is None:
+        """The handles of the ACTIVE mapping (one per entry of ``devices``), created on first use.  ``self._mapping`` is
+        None for the engine's own choice of kernel family, or a ``group`` value of ``_native.kernel_variant`` (the
+        small-batch mapping of an AdjointSolver, ``_select_mapping``): each mapping has its own code object and handles."""
+        sets = self.__dict__.setdefault("_native_sets", {})
+        key = getattr(self, "_mapping", None)
+        if key not in sets:
             kw = self._engine_kwargs()
+            if key is not None:
+                kw["group"] = key
             natives = []
             for d in self._devices:
                 k = dict(kw, device=d)
                 if "arena_bytes" in k:
                     k["arena_bytes"] = self._arena_share(d)
                 natives.append(_native.NativeSolver(self._source, n_states=self._problem.n_states, **k))
-            self._natives = natives
-            self._native = natives[0]
+            sets[key] = natives
+        self._natives = sets[key]
+        self._native = self._natives[0]
         return self._natives
 
     def _engine(self) -> _native.NativeSolver:
@@ -436,6 +446,8 @@ class Solver(_EngineMixin):
         _native.build_code_object(self._source, sens=self._compute_sens, constraints=self._constraints is not None)
         self._native = None
         self._natives = None
+        self._native_sets = {}
+        self._mapping = None
         self._pool = None
 
     def _engine_kwargs(self):
@@ -574,7 +586,9 @@ class AdjointSolver(_EngineMixin):
                  backward_reltol=1e-10, quad_abstol=1e-10, quad_reltol=1e-10, mxsteps: int = 500,
                  max_steps: Optional[int] = None, arena_gib: Optional[float] = None, device: int = 0,
                  compact_trajectory: Optional[bool] = None, devices=None, interleaved: bool = False,
-                 reuse_outputs: bool = False):
+                 reuse_outputs: bool = False, batch_mapping: str = "auto"):
+        if batch_mapping not in ("auto", "fixed"):
+            raise ValueError('batch_mapping must be "auto" or "fixed"')
         if solver not in ("BDF", "ADAMS"):
             raise ValueError(f"Unknown solver {solver}.")
         if adjoint_solver not in ("BDF", "ADAMS"):
@@ -609,6 +623,15 @@ class AdjointSolver(_EngineMixin):
                                   compact=self._compact)
         self._native = None
         self._last_forward = None
+        # small batches of a 4- / 5-state model run in 4-lane groups (measured: _native.small_batch_group); the code
+        # object of that mapping is built when the first such batch arrives
+        self._small_group = _native.small_batch_group(self._source, self._hermite) if batch_mapping == "auto" else None
+
+    def _select_mapping(self, B: int) -> None:
+        """Activate the handles this batch runs on: the small-batch mapping while every handle's share of the batch is
+        at most ``_native.SMALL_BATCH_MAX`` instances, the engine's own choice otherwise (bit-identical results)."""
+        per_handle = -(-int(B) // len(self._devices))
+        self._mapping = self._small_group if (self._small_group and per_handle <= _native.SMALL_BATCH_MAX) else None
 
     def _engine_kwargs(self):
         return dict(self._native_kwargs(), constraints=self._constraints, hermite=self._hermite,
@@ -681,6 +704,7 @@ class AdjointSolver(_EngineMixin):
         ``out``: caller-allocated outputs written in place (the reference's convention,
         /root/reference/sunode/solver.py:682: ``solve_forward(t0, tvals, y0, y_out)``): a dict with some of
         ``y_out, status, stats`` or a sequence in return order; see ``Solver.solve_batch``."""
+        self._select_mapping(np.shape(y0)[0] if np.ndim(y0) == 2 else 0)
         self._set_retries(max_retries_fwd=max_retries)
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
@@ -697,7 +721,7 @@ class AdjointSolver(_EngineMixin):
             eng.solve(_native.SA_MEM_HOST, hi - lo, y0[lo:hi], _rows(ps, lo, hi, p), _rows(pr, lo, hi, stride),
                       stride, t0, tvals, len(tvals), y_out[lo:hi], status[lo:hi], stats[lo:hi], adjoint=True)
         self._run_shards(shards, call)
-        self._last_forward = (B, ps, pr, stride, shards)     # every handle keeps ITS shard's trajectories
+        self._last_forward = (B, ps, pr, stride, shards, self._mapping)     # every handle keeps ITS shard's trajectories
         return self._scatter(y_pair), self._scatter(st_pair), self._scatter(sa_pair)
 
     def solve_backward_batch(self, t0, tend, tvals, grads, *, max_retries=50, return_all=False, out=None):
@@ -712,8 +736,8 @@ class AdjointSolver(_EngineMixin):
         status, stats, lamda_all, quad_all`` or a sequence in return order."""
         if self._last_forward is None:
             raise SolverError("solve_backward called before solve_forward")
+        B, ps, pr, stride, shards, self._mapping = self._last_forward      # (the handles that integrated forward)
         self._set_retries(max_retries_bwd=max_retries)
-        B, ps, pr, stride, shards = self._last_forward
         n, p = self._problem.n_states, self._problem.n_params
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
         n_t = len(tvals)

@@ -1220,7 +1220,7 @@ def test_lane_family_callbacks_in_the_one_lane_and_other_mappings(mapping, monke
     tv = np.linspace(0.0, 40.0, 9)
     grads = 1.0 + 0.5 * np.cos(1.1 * np.arange(9)[:, None] + 0.7 * np.arange(4)[None, :])
     tol = dict(abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8, quad_abstol=1e-8, quad_reltol=1e-8)
-    sol = AdjointSolver(prob, **tol)
+    sol = AdjointSolver(prob, batch_mapping="fixed", **tol)     # (the mapping under test, not the small-batch switch)
     orc = make_oracle("sir2")
     tpts, lam5 = np.linspace(0.0, 1.0, 5), rng.randn(5, 4)
     got = sol._engine().eval_callbacks(tpts, y0[:5], lam5, ps[:5], np.tile(pr, (5, 1)))

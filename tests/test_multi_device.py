@@ -350,3 +350,50 @@ def test_empty_time_grid_returns_zeroed_status_and_counters(fake_native, monkeyp
             y, st, stats = sol.solve_forward_batch(0.0, np.zeros(0), d["y0"], ps, pr)
             assert y.shape == (6, 0, 2) and (st == 0).all() and (stats == 0).all()
             st[:] = 5; stats[:] = 9                   # (a recycled array shows this again unless it is re-zeroed)
+
+
+def test_small_batch_mapping_selection(fake_native, monkeypatch):
+    """Which handles a batch runs on (AdjointSolver._select_mapping): 4-lane groups for a 4- / 5-state model the engine
+    maps to one lane, while a HANDLE's share of the batch is <= 16 384; never for 2 / 3 states, never under
+    SA_FORCE_GROUP, SA_BATCH_MAPPING=fixed or batch_mapping="fixed"; the backward call runs on the forward call's
+    handles whatever happens in between."""
+    from sunode_amd import _native
+    from sunode_amd.solver import AdjointSolver
+    monkeypatch.delenv("SA_FORCE_GROUP", raising=False)
+    monkeypatch.delenv("SA_BATCH_MAPPING", raising=False)
+    nb = make_problem("notebook")                       # 5 states, 3 differentiated parameters
+    src = nb.native_source()
+    assert _native.kernel_variant(src) == ("bdf_kernels.hip", 1) and _native.small_batch_group(src) == "wave4"
+    assert _native.kernel_variant(src, group="wave4") == ("bdf_wave.hip", 4)
+    assert _native.code_object_path(src, compact=True, group="wave4") != _native.code_object_path(src, compact=True)
+    assert _native.small_batch_group(make_problem("lv").native_source()) is None
+    assert _native.small_batch_group(make_problem("robertson").native_source()) is None
+    assert _native.small_batch_group(make_problem("seir").native_source()) is None       # lane groups already
+    monkeypatch.setenv("SA_FORCE_GROUP", "1")
+    assert _native.small_batch_group(src) is None
+    monkeypatch.delenv("SA_FORCE_GROUP")
+    monkeypatch.setenv("SA_BATCH_MAPPING", "fixed")
+    assert _native.small_batch_group(src) is None
+    monkeypatch.delenv("SA_BATCH_MAPPING")
+
+    def run(sol, B):
+        y0 = np.ones((B, 5)); ps = np.ones((B, 3)); pr = np.linspace(0, 1, 50); tv = np.arange(4) / 10
+        sol.solve_forward_batch(0.0, tv, y0, ps, pr)
+        return [h.kw.get("group") for h in fake_native.created]
+    sol = AdjointSolver(nb)
+    assert run(sol, 100) == ["wave4"]
+    assert run(sol, 16384) == ["wave4"]                                  # same handle again
+    assert run(sol, 16385) == ["wave4", None]                            # the one-lane handle appears
+    fwd_handle = fake_native.created[1]
+    assert run(sol, 10) == ["wave4", None]
+    sol.solve_forward_batch(0.0, np.arange(4) / 10, np.ones((20000, 5)), np.ones((20000, 3)), np.linspace(0, 1, 50))
+    sol.solve_backward_batch(0.3, 0.0, np.arange(4) / 10, np.ones((4, 5)))
+    assert fwd_handle.calls[-1][0] == "backward" and fwd_handle.calls[-2][0] == "forward"
+    fake_native.created.clear()
+    two = AdjointSolver(nb, devices=[0, 1])
+    assert run(two, 30000) == ["wave4", "wave4"]                         # 15 000 per handle
+    assert run(two, 40000) == ["wave4", "wave4", None, None]
+    fake_native.created.clear()
+    assert run(AdjointSolver(nb, batch_mapping="fixed"), 100) == [None]
+    with pytest.raises(ValueError):
+        AdjointSolver(nb, batch_mapping="sometimes")

@@ -129,7 +129,9 @@ def test_default_mapping_adjoint_equals_oracle(name, B, golden_dir):
     d = batch_of(name, B)
     tol = dict(abstol=d["atol"], reltol=d["rtol"], backward_abstol=d["atol"], backward_reltol=d["rtol"],
                quad_abstol=d["atol"], quad_reltol=d["rtol"])
-    sol = AdjointSolver(prob, **tol)
+    # batch_mapping="fixed": the family kernel_variant selects for (n, p) is what this sweep is about (the small-batch
+    # switch of 4- / 5-state models to lane groups has its own test below)
+    sol = AdjointSolver(prob, batch_mapping="fixed", **tol)
     tv = d["tvals"]
     y, st, stats = sol.solve_forward_batch(d["t0"], tv, d["y0"], d["ps"], d["pr"])
     g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], d["t0"], tv, d["grads"])
@@ -150,6 +152,44 @@ def test_default_mapping_adjoint_equals_oracle(name, B, golden_dir):
     truth = os.path.join(golden_dir, "truth_sweep_%s.npz" % name)
     if os.path.exists(truth):           # lv12, rn12_4: the first draws of the batch against DOP853 truth
         _truth_bars(y, g, lam, np.load(truth))
+
+
+@pytest.mark.gpu
+def test_small_batches_of_a_five_state_model_run_in_lane_groups():
+    """``batch_mapping="auto"`` (the default): a model the engine maps to one lane per instance with n >= 4 states runs
+    in 4-lane groups while a handle's batch is <= 16 384 (profiles/r06_mapping_by_batch.txt: +40 ... 55 % for n = 5,
+    p = 8), in the one-lane kernel above -- one solver object, both code objects, every result equal to the oracle's
+    and to the fixed mapping's."""
+    from sunode_amd import _native
+    from sunode_amd.solver import AdjointSolver
+    assert not os.environ.get("SA_FORCE_GROUP")
+    name = "rn5_8"
+    prob = make_problem(name)
+    assert _native.small_batch_group(prob.native_source()) == "wave4"
+    assert _native.small_batch_group(make_problem("lv12").native_source()) is None       # (lane groups already)
+    d = batch_of(name, 20000)
+    tol = dict(abstol=d["atol"], reltol=d["rtol"], backward_abstol=d["atol"], backward_reltol=d["rtol"],
+               quad_abstol=d["atol"], quad_reltol=d["rtol"])
+    auto, fixed = AdjointSolver(prob, **tol), AdjointSolver(prob, batch_mapping="fixed", **tol)
+    tv = d["tvals"]
+    orc = make_oracle(name)
+    cfg = orc.config(rtol=d["rtol"], atol=d["atol"], rtolB=d["rtol"], atolB=d["atol"], rtolQB=d["rtol"], atolQB=d["atol"])
+    for B, family in ((70, ("bdf_wave.hip", 4)), (20000, ("bdf_kernels.hip", 1)), (300, ("bdf_wave.hip", 4))):
+        res = {}
+        for tag, sol in (("auto", auto), ("fixed", fixed)):
+            y, st, stats = sol.solve_forward_batch(d["t0"], tv, d["y0"][:B], d["ps"][:B], d["pr"])
+            assert sol._engine().variant == (family if tag == "auto" else ("bdf_kernels.hip", 1))
+            g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], d["t0"], tv, d["grads"][:B])
+            res[tag] = (y, st, stats[:, CMP], g, lam, stb, statsb[:, CMP_B])
+        for a, b in zip(res["auto"], res["fixed"]):
+            np.testing.assert_array_equal(a, b)
+        k = min(B, 512)
+        yo, so, sto = orc.solve_forward(cfg, d["y0"][:k], d["ps"][:k], d["pr"], d["t0"], tv, nthreads=8)
+        go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], d["t0"], tv, d["grads"][:k], nthreads=8)
+        np.testing.assert_array_equal(res["auto"][0][:k], yo)
+        np.testing.assert_array_equal(res["auto"][3][:k], go)
+        np.testing.assert_array_equal(res["auto"][4][:k], lo)
+        np.testing.assert_array_equal(res["auto"][6][:k], stbo[:, CMP_B])
 
 
 @pytest.mark.gpu
