@@ -228,27 +228,39 @@ def lane_group_size(n: int, p: int) -> int:
     return g
 
 
-def small_batch_group(native_source: str, hermite: bool = False) -> Optional[str]:
-    """The mapping ``AdjointSolver`` switches to for SMALL batches, or None.
+def small_batch_group(native_source: str, hermite: bool = False, batch: int = 1) -> Optional[str]:
+    """The mapping ``AdjointSolver`` switches to for a SMALL batch (``batch`` = instances on one handle), or None for
+    the engine's own choice (``kernel_variant``).
 
-    One lane per instance fills the chip only from 65 536 instances on (1 024 wavefronts); below that a 4-lane group per
-    instance uses four times as many SIMDs AND finishes an instance sooner when the model is large for one lane.
-    Measured, forward + adjoint, one lane vs four (profiles/r06_mapping_by_batch.txt): n = 4, p = 2: +12 ... 22 % for
-    every B <= 16 384; n = 4 / 5, p = 8: +30 ... 55 %; n = 5, p = 2: +8 ... 19 %; n = 3: equal (and slower with
-    transcendental callbacks, which every lane of a group evaluates); from 32 768 instances on one lane per instance
-    wins everywhere.  So: models the engine maps to one lane with n >= 4 states run in 4-lane groups while a handle's
-    batch is at most SMALL_BATCH_MAX.  Results are bit-identical in every mapping.  SA_FORCE_GROUP (a forced
-    mapping) and SA_BATCH_MAPPING=fixed switch this off."""
+    The chip holds 1 024 wavefronts at one per SIMD -- the occupancy of every backward kernel here.  With G lanes per
+    instance a batch of B instances is B G / 64 wavefronts: one lane per instance fills the chip only from 65 536
+    instances on, 4-lane groups from 16 384.  Below that, more lanes per instance put more SIMDs to work AND finish an
+    instance sooner.  Measured, forward + adjoint (profiles/r06_mapping_by_batch.txt, r06_lanes_by_batch.txt):
+      * models the engine maps to ONE lane (n <= 5, p <= 8) with n >= 4 states, 4-lane groups instead, B <= 16 384:
+        n = 5, p = 8: +40 ... 55 %; n = 4, p = 8: +30 ... 50 %; n = 4 / 5, p = 2: +8 ... 22 %.  (n = 3: equal, and 7 ...
+        15 % slower with transcendental callbacks, which every lane of a group evaluates: not switched);
+      * models the engine maps to 4-lane groups (6 <= n <= 16), 16 lanes per instance instead while B <= 4 096: SEIR
+        +25 ... 37 %, 12 states +17 ... 28 %, 7 states +13 ... 18 %; 8 lanes while B <= 8 192: SEIR +22 ... 30 % at 4 096.
+      * at the next size up (16 384 / 65 536) the engine's own choice wins by 1.5 ... 4x: it stays the large-batch mapping.
+    Rule: the largest measured group size whose wavefront count B G / 64 still fits the chip.  Results are
+    bit-identical in every mapping.  SA_FORCE_GROUP (a forced mapping) and SA_BATCH_MAPPING=fixed switch this off."""
     import re
     if os.environ.get("SA_FORCE_GROUP") or os.environ.get("SA_BATCH_MAPPING", "auto") == "fixed":
         return None
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
-    if kernel_variant(native_source, hermite=hermite)[0] != "bdf_kernels.hip" or n < SMALL_BATCH_MIN_STATES:
-        return None
-    return "wave4"
+    fname, g = kernel_variant(native_source, hermite=hermite)
+    if fname == "bdf_kernels.hip":
+        return "wave4" if (n >= SMALL_BATCH_MIN_STATES and batch <= SMALL_BATCH_MAX) else None
+    if fname == "bdf_wave.hip" and g == 4:
+        if batch <= SMALL_BATCH_MAX // 4:
+            return "wave16"
+        if batch <= SMALL_BATCH_MAX // 2:
+            return "wave8"
+    return None
 
 
-#: a handle's batch up to which ``small_batch_group`` applies (16 384 four-lane instances = one wavefront per SIMD)
+#: a handle's batch up to which 4-lane groups replace one lane per instance (16 384 four-lane instances = one wavefront per
+#: SIMD); 8 / 16 lanes replace 4 up to a half / a quarter of it
 SMALL_BATCH_MAX = 16384
 SMALL_BATCH_MIN_STATES = 4
 

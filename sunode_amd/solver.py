@@ -623,15 +623,17 @@ class AdjointSolver(_EngineMixin):
                                   compact=self._compact)
         self._native = None
         self._last_forward = None
-        # small batches of a 4- / 5-state model run in 4-lane groups (measured: _native.small_batch_group); the code
-        # object of that mapping is built when the first such batch arrives
-        self._small_group = _native.small_batch_group(self._source, self._hermite) if batch_mapping == "auto" else None
+        # small batches run with more lanes per instance (measured: _native.small_batch_group); the code object of such a
+        # mapping is built when the first batch of that size arrives
+        self._batch_mapping = batch_mapping
 
     def _select_mapping(self, B: int) -> None:
-        """Activate the handles this batch runs on: the small-batch mapping while every handle's share of the batch is
-        at most ``_native.SMALL_BATCH_MAX`` instances, the engine's own choice otherwise (bit-identical results)."""
-        per_handle = -(-int(B) // len(self._devices))
-        self._mapping = self._small_group if (self._small_group and per_handle <= _native.SMALL_BATCH_MAX) else None
+        """Activate the handles this batch runs on: more lanes per instance while every handle's share of the batch is
+        small enough for the chip to hold them all at once (``_native.small_batch_group``), the engine's own choice
+        otherwise.  Bit-identical results either way."""
+        per_handle = max(1, -(-int(B) // len(self._devices)))
+        self._mapping = _native.small_batch_group(self._source, self._hermite, per_handle) \
+            if self._batch_mapping == "auto" else None
 
     def _engine_kwargs(self):
         return dict(self._native_kwargs(), constraints=self._constraints, hermite=self._hermite,

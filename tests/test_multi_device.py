@@ -364,11 +364,15 @@ def test_small_batch_mapping_selection(fake_native, monkeypatch):
     nb = make_problem("notebook")                       # 5 states, 3 differentiated parameters
     src = nb.native_source()
     assert _native.kernel_variant(src) == ("bdf_kernels.hip", 1) and _native.small_batch_group(src) == "wave4"
+    assert _native.small_batch_group(src, batch=16384) == "wave4" and _native.small_batch_group(src, batch=16385) is None
     assert _native.kernel_variant(src, group="wave4") == ("bdf_wave.hip", 4)
     assert _native.code_object_path(src, compact=True, group="wave4") != _native.code_object_path(src, compact=True)
     assert _native.small_batch_group(make_problem("lv").native_source()) is None
     assert _native.small_batch_group(make_problem("robertson").native_source()) is None
-    assert _native.small_batch_group(make_problem("seir").native_source()) is None       # lane groups already
+    seir = make_problem("seir").native_source()                     # 4-lane groups by default: 16 / 8 lanes for small batches
+    assert [_native.small_batch_group(seir, batch=b) for b in (1, 4096, 4097, 8192, 8193, 16384)] == \
+        ["wave16", "wave16", "wave8", "wave8", None, None]
+    assert _native.small_batch_group(make_problem("network24").native_source(), batch=8) is None    # (not measured: unchanged)
     monkeypatch.setenv("SA_FORCE_GROUP", "1")
     assert _native.small_batch_group(src) is None
     monkeypatch.delenv("SA_FORCE_GROUP")

@@ -166,7 +166,7 @@ def test_small_batches_of_a_five_state_model_run_in_lane_groups():
     name = "rn5_8"
     prob = make_problem(name)
     assert _native.small_batch_group(prob.native_source()) == "wave4"
-    assert _native.small_batch_group(make_problem("lv12").native_source()) is None       # (lane groups already)
+    assert _native.small_batch_group(make_problem("lv12").native_source(), batch=20000) is None
     d = batch_of(name, 20000)
     tol = dict(abstol=d["atol"], reltol=d["rtol"], backward_abstol=d["atol"], backward_reltol=d["rtol"],
                quad_abstol=d["atol"], quad_reltol=d["rtol"])
@@ -190,6 +190,38 @@ def test_small_batches_of_a_five_state_model_run_in_lane_groups():
         np.testing.assert_array_equal(res["auto"][3][:k], go)
         np.testing.assert_array_equal(res["auto"][4][:k], lo)
         np.testing.assert_array_equal(res["auto"][6][:k], stbo[:, CMP_B])
+
+
+@pytest.mark.gpu
+def test_small_batches_of_a_lane_group_model_get_more_lanes_per_instance():
+    """SEIR (16 states, 4 lanes per instance at BASELINE's batch): 16 lanes per instance up to 4 096 instances on a
+    handle, 8 up to 8 192 (profiles/r06_lanes_by_batch.txt: +25 ... 37 %), the 4-lane groups above -- chosen per call
+    by ``AdjointSolver``, all equal to the oracle."""
+    from sunode_amd.solver import AdjointSolver
+    from tools.problems import seir_batch
+    assert not os.environ.get("SA_FORCE_GROUP")
+    prob = make_problem("seir")
+    d = seir_batch(9000)
+    tv = d["tvals"][::5]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(16)[None, :])
+    tol = dict(abstol=1e-8, reltol=1e-8, backward_abstol=1e-8, backward_reltol=1e-8, quad_abstol=1e-8, quad_reltol=1e-8)
+    sol = AdjointSolver(prob, **tol)
+    orc = make_oracle("seir")
+    cfg = orc.config(rtol=1e-8, atol=1e-8, rtolB=1e-8, atolB=1e-8, rtolQB=1e-8, atolQB=1e-8)
+    k = 200
+    yo, so, sto = orc.solve_forward(cfg, d["y0"][:k], d["ps"][:k], d["pr"], 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    for B, lanes in ((70, 16), (5000, 8), (9000, 4), (k, 16)):
+        y, st, stats = sol.solve_forward_batch(0.0, tv, d["y0"][:B], d["ps"][:B], d["pr"])
+        assert sol._engine().variant == ("bdf_wave.hip", lanes)
+        g, lam, stb, statsb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+        m = min(B, k)
+        assert (st == 0).all() and (stb == 0).all()
+        np.testing.assert_array_equal(stats[:m, CMP], sto[:m, CMP])
+        np.testing.assert_array_equal(y[:m], yo[:m])
+        np.testing.assert_array_equal(statsb[:m, CMP_B], stbo[:m, CMP_B])
+        np.testing.assert_array_equal(g[:m], go[:m])
+        np.testing.assert_array_equal(lam[:m], lo[:m])
 
 
 @pytest.mark.gpu

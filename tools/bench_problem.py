@@ -14,7 +14,16 @@ def batch(name, B):
     from tools import problems as P
     from tools.sweep_cases import batch_of
     named = {"forcing": P.forcing_batch, "logistic_switch": P.logistic_switch_batch, "misc": P.misc_batch}
-    return named[name](B) if name in named else batch_of(name, B)
+    if name in named:
+        return named[name](B)
+    if name in ("seir", "robertson"):               # BASELINE configs 4 / 3 (shared cotangents as in the parity tests)
+        d = P.seir_batch(B) if name == "seir" else P.robertson_batch(B)
+        n = d["y0"].shape[1]
+        if name == "robertson":
+            d["ps"], d["pr"] = d["params"], np.zeros(0)
+        d["grads"] = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(d["tvals"]))[:, None] + 0.9 * np.arange(n)[None, :])
+        return d
+    return batch_of(name, B)
 
 
 def main():
