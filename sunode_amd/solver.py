@@ -241,6 +241,14 @@ class _EngineMixin:
     def _engine(self) -> _native.NativeSolver:
         return self._engines()[0]
 
+    def _select_mapping(self, B: int) -> None:
+        """Activate the handles this batch runs on: more lanes per instance while every handle's share of the batch is
+        small enough for the chip to hold them all at once (``_native.small_batch_group``), the engine's own choice
+        otherwise.  Bit-identical results either way."""
+        per_handle = max(1, -(-int(B) // len(self._devices)))
+        self._mapping = _native.small_batch_group(self._source, getattr(self, "_hermite", False), per_handle) \
+            if getattr(self, "_batch_mapping", "fixed") == "auto" else None
+
     def _shards(self, B: int):
         """[(handle, lo, hi)] -- contiguous balanced instance ranges, empty ones dropped.  With ``interleaved=True``
         the ranges refer to the batch in HANDLE-MAJOR order (see _gather / _scatter)."""
@@ -390,7 +398,10 @@ class Solver(_EngineMixin):
     def __init__(self, problem, *, abstol: float = 1e-10, reltol: float = 1e-10, sens_mode: Optional[str] = None,
                  scaling_factors: Optional[np.ndarray] = None, constraints: Optional[np.ndarray] = None,
                  solver="BDF", linear_solver="dense", linear_solver_kwargs=None, mxsteps: int = 500,
-                 device: int = 0, devices=None, interleaved: bool = False, reuse_outputs: bool = False):
+                 device: int = 0, devices=None, interleaved: bool = False, reuse_outputs: bool = False,
+                 batch_mapping: str = "auto"):
+        if batch_mapping not in ("auto", "fixed"):
+            raise ValueError('batch_mapping must be "auto" or "fixed"')
         if sens_mode in (None, False):
             sens_mode = None
         elif sens_mode == "staggered1":
@@ -433,9 +444,11 @@ class Solver(_EngineMixin):
         self._scaling_factors = scaling_factors
         self._mxsteps = mxsteps
         self._reuse_outputs = bool(reuse_outputs)
+        # (the sensitivity builds keep one mapping: their lane-group form exists for 4 / 8 lanes only)
+        self._batch_mapping = batch_mapping if sens_mode is None else "fixed"
         self._init_devices(device, devices, interleaved)
         self._set_tolerances(abstol, reltol)
-        self._state_names = ["_problem", "_user_data", "_constraints", "_abstol", "_reltol",
+        self._state_names = ["_problem", "_user_data", "_constraints", "_abstol", "_reltol", "_batch_mapping",
                              "_linear_solver_kind", "_linear_solver_kwargs", "_sens_mode", "_scaling_factors",
                              "_mxsteps", "_device", "_devices", "_interleaved", "_reuse_outputs", "_state_names"]
         self._init_native()
@@ -460,6 +473,7 @@ class Solver(_EngineMixin):
     def __setstate__(self, state):
         self.__dict__.update(state)
         self._reuse_outputs = state.get("_reuse_outputs", False)
+        self._batch_mapping = state.get("_batch_mapping", "auto" if self._sens_mode is None else "fixed")
         self._outputs = _OutputPool() if self._reuse_outputs else None
         self._compute_sens = self._sens_mode is not None
         self._set_tolerances(self._abstol, self._reltol)
@@ -545,6 +559,7 @@ class Solver(_EngineMixin):
         (``solve(t0, tvals, y0, y_out)``, /root/reference/sunode/solver.py:467) carried over to the batch: a dict
         ``{"y_out": ..., "status": ..., "stats": ...}`` or a sequence in return order, entries may be missing / None.
         Arrays must be C-contiguous float64 (status int32, stats int64) of the exact shape."""
+        self._select_mapping(np.shape(y0)[0] if np.ndim(y0) == 2 else 0)
         self._set_retries(max_retries_fwd=max_retries)
         B, y0, ps, pr, stride = self._batch_inputs(y0, params_sub, params_rem)
         tvals = np.ascontiguousarray(tvals, dtype=np.float64)
@@ -626,14 +641,6 @@ class AdjointSolver(_EngineMixin):
         # small batches run with more lanes per instance (measured: _native.small_batch_group); the code object of such a
         # mapping is built when the first batch of that size arrives
         self._batch_mapping = batch_mapping
-
-    def _select_mapping(self, B: int) -> None:
-        """Activate the handles this batch runs on: more lanes per instance while every handle's share of the batch is
-        small enough for the chip to hold them all at once (``_native.small_batch_group``), the engine's own choice
-        otherwise.  Bit-identical results either way."""
-        per_handle = max(1, -(-int(B) // len(self._devices)))
-        self._mapping = _native.small_batch_group(self._source, self._hermite, per_handle) \
-            if self._batch_mapping == "auto" else None
 
     def _engine_kwargs(self):
         return dict(self._native_kwargs(), constraints=self._constraints, hermite=self._hermite,
