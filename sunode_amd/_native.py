@@ -238,7 +238,8 @@ def small_batch_group(native_source: str, hermite: bool = False, batch: int = 1)
     instance sooner.  Measured, forward + adjoint (profiles/r06_mapping_by_batch.txt, r06_lanes_by_batch.txt):
       * models the engine maps to ONE lane (n <= 5, p <= 8) with n >= 4 states, 4-lane groups instead, B <= 16 384:
         n = 5, p = 8: +40 ... 55 %; n = 4, p = 8: +30 ... 50 %; n = 4 / 5, p = 2: +8 ... 22 %.  (n = 3: equal, and 7 ...
-        15 % slower with transcendental callbacks, which every lane of a group evaluates: not switched);
+        15 % slower with transcendental callbacks, which every lane of a group evaluates: not switched); 8 / 16 lanes add
+        another +5 ... 23 % up to 4 096 instances (profiles/r06_lanes_small_models.txt);
       * models the engine maps to 4-lane groups (6 <= n <= 16), 16 lanes per instance instead while B <= 4 096: SEIR
         +25 ... 37 %, 12 states +17 ... 28 %, 7 states +13 ... 18 %; 8 lanes while B <= 8 192: SEIR +22 ... 30 % at 4 096.
       * at the next size up (16 384 / 65 536) the engine's own choice wins by 1.5 ... 4x: it stays the large-batch mapping.
@@ -249,13 +250,14 @@ def small_batch_group(native_source: str, hermite: bool = False, batch: int = 1)
         return None
     n = int(re.search(r"#define SA_N_STATES (\d+)", native_source).group(1))
     fname, g = kernel_variant(native_source, hermite=hermite)
-    if fname == "bdf_kernels.hip":
-        return "wave4" if (n >= SMALL_BATCH_MIN_STATES and batch <= SMALL_BATCH_MAX) else None
-    if fname == "bdf_wave.hip" and g == 4:
+    one_lane = fname == "bdf_kernels.hip" and n >= SMALL_BATCH_MIN_STATES
+    if one_lane or (fname == "bdf_wave.hip" and g == 4):
         if batch <= SMALL_BATCH_MAX // 4:
             return "wave16"
         if batch <= SMALL_BATCH_MAX // 2:
             return "wave8"
+        if one_lane and batch <= SMALL_BATCH_MAX:
+            return "wave4"
     return None
 
 

@@ -363,8 +363,9 @@ def test_small_batch_mapping_selection(fake_native, monkeypatch):
     monkeypatch.delenv("SA_BATCH_MAPPING", raising=False)
     nb = make_problem("notebook")                       # 5 states, 3 differentiated parameters
     src = nb.native_source()
-    assert _native.kernel_variant(src) == ("bdf_kernels.hip", 1) and _native.small_batch_group(src) == "wave4"
-    assert _native.small_batch_group(src, batch=16384) == "wave4" and _native.small_batch_group(src, batch=16385) is None
+    assert _native.kernel_variant(src) == ("bdf_kernels.hip", 1)
+    assert [_native.small_batch_group(src, batch=b) for b in (1, 4096, 4097, 8192, 8193, 16384, 16385)] == \
+        ["wave16", "wave16", "wave8", "wave8", "wave4", "wave4", None]
     assert _native.kernel_variant(src, group="wave4") == ("bdf_wave.hip", 4)
     assert _native.code_object_path(src, compact=True, group="wave4") != _native.code_object_path(src, compact=True)
     assert _native.small_batch_group(make_problem("lv").native_source()) is None
@@ -385,11 +386,12 @@ def test_small_batch_mapping_selection(fake_native, monkeypatch):
         sol.solve_forward_batch(0.0, tv, y0, ps, pr)
         return [h.kw.get("group") for h in fake_native.created]
     sol = AdjointSolver(nb)
-    assert run(sol, 100) == ["wave4"]
-    assert run(sol, 16384) == ["wave4"]                                  # same handle again
-    assert run(sol, 16385) == ["wave4", None]                            # the one-lane handle appears
-    fwd_handle = fake_native.created[1]
-    assert run(sol, 10) == ["wave4", None]
+    assert run(sol, 100) == ["wave16"]
+    assert run(sol, 4096) == ["wave16"]                                  # same handle again
+    assert run(sol, 16384) == ["wave16", "wave4"]
+    assert run(sol, 16385) == ["wave16", "wave4", None]                  # the one-lane handle appears
+    fwd_handle = fake_native.created[2]
+    assert run(sol, 10) == ["wave16", "wave4", None]
     sol.solve_forward_batch(0.0, np.arange(4) / 10, np.ones((20000, 5)), np.ones((20000, 3)), np.linspace(0, 1, 50))
     sol.solve_backward_batch(0.3, 0.0, np.arange(4) / 10, np.ones((4, 5)))
     assert fwd_handle.calls[-1][0] == "backward" and fwd_handle.calls[-2][0] == "forward"
@@ -397,7 +399,9 @@ def test_small_batch_mapping_selection(fake_native, monkeypatch):
     two = AdjointSolver(nb, devices=[0, 1])
     assert run(two, 30000) == ["wave4", "wave4"]                         # 15 000 per handle
     assert run(two, 40000) == ["wave4", "wave4", None, None]
+    assert run(two, 8000) == ["wave4", "wave4", None, None, "wave16", "wave16"]
     fake_native.created.clear()
     assert run(AdjointSolver(nb, batch_mapping="fixed"), 100) == [None]
+    assert _native.small_batch_group(src) == "wave16"
     with pytest.raises(ValueError):
         AdjointSolver(nb, batch_mapping="sometimes")

@@ -157,15 +157,15 @@ def test_default_mapping_adjoint_equals_oracle(name, B, golden_dir):
 @pytest.mark.gpu
 def test_small_batches_of_a_five_state_model_run_in_lane_groups():
     """``batch_mapping="auto"`` (the default): a model the engine maps to one lane per instance with n >= 4 states runs
-    in 4-lane groups while a handle's batch is <= 16 384 (profiles/r06_mapping_by_batch.txt: +40 ... 55 % for n = 5,
-    p = 8), in the one-lane kernel above -- one solver object, both code objects, every result equal to the oracle's
+    with 16 / 8 / 4 lanes per instance while a handle's batch is <= 4 096 / 8 192 / 16 384 (profiles/
+    r06_mapping_by_batch.txt, r06_lanes_small_models.txt: +40 ... 75 % for n = 5, p = 8), in the one-lane kernel above -- one solver object, both code objects, every result equal to the oracle's
     and to the fixed mapping's."""
     from sunode_amd import _native
     from sunode_amd.solver import AdjointSolver
     assert not os.environ.get("SA_FORCE_GROUP")
     name = "rn5_8"
     prob = make_problem(name)
-    assert _native.small_batch_group(prob.native_source()) == "wave4"
+    assert _native.small_batch_group(prob.native_source(), batch=12000) == "wave4"
     assert _native.small_batch_group(make_problem("lv12").native_source(), batch=20000) is None
     d = batch_of(name, 20000)
     tol = dict(abstol=d["atol"], reltol=d["rtol"], backward_abstol=d["atol"], backward_reltol=d["rtol"],
@@ -174,7 +174,8 @@ def test_small_batches_of_a_five_state_model_run_in_lane_groups():
     tv = d["tvals"]
     orc = make_oracle(name)
     cfg = orc.config(rtol=d["rtol"], atol=d["atol"], rtolB=d["rtol"], atolB=d["atol"], rtolQB=d["rtol"], atolQB=d["atol"])
-    for B, family in ((70, ("bdf_wave.hip", 4)), (20000, ("bdf_kernels.hip", 1)), (300, ("bdf_wave.hip", 4))):
+    for B, family in ((70, ("bdf_wave.hip", 16)), (20000, ("bdf_kernels.hip", 1)), (6000, ("bdf_wave.hip", 8)),
+                      (12000, ("bdf_wave.hip", 4)), (300, ("bdf_wave.hip", 16))):
         res = {}
         for tag, sol in (("auto", auto), ("fixed", fixed)):
             y, st, stats = sol.solve_forward_batch(d["t0"], tv, d["y0"][:B], d["ps"][:B], d["pr"])

@@ -29,8 +29,8 @@ def _compile(name, kind):
         out = _native.build_code_object(src, sens=True)
     elif kind == "conservative":        # the differential guard's partner build (tests/test_guard.py runs the sweep's shapes through it)
         out = _native.build_code_object(src, compact=_native.default_compact_trajectory(src), safe=True)
-    elif kind == "small-batch":        # AdjointSolver's mapping for batches <= 16 384 of a 4- / 5-state model (4-lane groups)
-        out = _native.build_code_object(src, compact=True, group=_native.small_batch_group(src))
+    elif kind.startswith("small-batch"):     # AdjointSolver's mappings for small batches (_native.small_batch_group)
+        out = _native.build_code_object(src, compact=True, group=kind.split(":")[1])
     else:
         out = _native.build_code_object(src, compact=_native.default_compact_trajectory(src))
     return "%s [%s]" % (name, kind), out, time.time() - t
@@ -48,7 +48,7 @@ def build(names=None, verbose=True):
             if verbose and dt > 5:
                 print("problem [%s]: %.0f s of sympy" % (name, dt))
     jobs = [(n, "oracle") for n in every] + [(n, "adjoint") for n in adj] + [(n, "sens") for n in sens] \
-        + [(n, "conservative") for n in adj] + [(n, "small-batch") for n in adj if n == "rn5_8"]
+        + [(n, "conservative") for n in adj] + [(n, "small-batch:" + g) for n in adj if n == "rn5_8" for g in ("wave16", "wave8", "wave4")]
     failed = []
     with ThreadPoolExecutor(max_workers=workers) as pool:           # compiler subprocesses: threads
         futs = [(j, pool.submit(_compile, *j)) for j in jobs]
