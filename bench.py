@@ -329,13 +329,18 @@ def run_rank(args, *, backend="nccl", make_engine=None):
         dist.barrier()
     fwd_ms, bwd_ms = [], []
     t0 = time.perf_counter()
+    trace = []                                      # per-step wall clock (SA_BENCH_TRACE=1 prints it to stderr)
     for _ in range(args.steps):
         eng.step()
         f, b = eng.kernel_ms()
         fwd_ms.append(f)
         bwd_ms.append(b)
+        trace.append(time.perf_counter())
     eng.sync()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("SA_BENCH_TRACE"):
+        print("bench.py step wall ms: " + " ".join("%.3f" % (1e3 * (b_ - a_)) for a_, b_ in zip([t0] + trace, trace))
+              + " | kernel ms: " + " ".join("%.3f" % (x + y) for x, y in zip(fwd_ms, bwd_ms)), file=sys.stderr, flush=True)
     own = elapsed                                   # this rank's time before it waited for the others
     if use_dist:
         dist.barrier()

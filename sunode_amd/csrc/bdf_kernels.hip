@@ -59,6 +59,45 @@ constexpr int sa_tau_c(int f, int j) { return j == 0 ? f : (j == f ? 0 : j); }
 #define PROF_DECL
 #define PHASE(m, k) do { } while (0)
 #endif
+/* -DSA_ABLATE_PROFILE -DSA_INTERP_PROFILE: the interpolation of the backward kernel split further (slots 1..5: index
+   search | the rebuild's point loads until they have arrived | table arithmetic | table + touches stored | evaluation);
+   every other mark of the attempt loop is booked on slot 0, the interval ends stay on slot 7 (tools/profile_lv.py) */
+/* -DSA_SEARCH_COUNT: the index search's dependent global loads are counted INSTEAD of the interpolations / rebuilds
+   (stats slots 11 / 12: loads of moves to the left / to the right) -- a diagnostic build, tools/profile_lv.py */
+#ifdef SA_SEARCH_COUNT
+#define SEARCH_COUNT(c) (c)++
+#define INTERP_COUNT(c) do { } while (0)
+#else
+#define SEARCH_COUNT(c) do { } while (0)
+#define INTERP_COUNT(c) (c)++
+#endif
+/* Index search of the backward interpolation (interp_y): CVAfindIndex walks from the last index one stored point at a
+   time, and on this device every further point is a DEPENDENT global load (~1 us) that the whole wavefront waits for.
+   Where the backward steps are long against the forward steps (Robertson: 801 + 258 such loads per instance in 1 235
+   attempts, some lane of the 64 in nearly every iteration; profiles/r06_interp_search.txt) that walk was 21 % of the
+   backward kernel.  SA_SEARCH_CACHE: the same index without the walk -- times from the current table, the remembered
+   right neighbour, then galloping + section search with independent probes (search_left / search_right below).
+   On for the compact-record builds (three states and more); the table-record builds (two states: 13 backward steps per
+   stored point, 8 + 9 such loads per instance) keep the plain walk, which is 1 % faster there.  Hermite builds: off
+   (no divided-difference table to take the times from). */
+#ifndef SA_SEARCH_CACHE
+#if defined(SA_COMPACT_TRAJ) && !defined(SA_HERMITE)
+#define SA_SEARCH_CACHE 1
+#else
+#define SA_SEARCH_CACHE 0
+#endif
+#endif
+/* SA_SEARCH_WINDOW: that many more times to the left of the table's six (t[cur_idx - 6 - j]) ride along with the point
+   loads of every rebuild into the lane's LDS column, so that moves of up to 5 + SA_SEARCH_WINDOW indices need no
+   dependent load at all (compact-record builds with the table in LDS only) */
+#ifndef SA_SEARCH_WINDOW
+#define SA_SEARCH_WINDOW 0
+#endif
+#if defined(SA_ABLATE_PROFILE) && defined(SA_INTERP_PROFILE)
+#define IPH(m, k) PHASE(m, k)
+#else
+#define IPH(m, k) do { } while (0)
+#endif
 
 /* ------------------------------------------------------------------------------------ */
 /* per-lane integrator state                                                              */
@@ -136,6 +175,9 @@ struct Cv {
     double tabr[8 + 6 * NS];          /* ... or the table in registers (see SA_TAB_REGS) */
 #endif
     double tlo2;                      /* t[ilast-2] */
+#if SA_SEARCH_CACHE
+    double thi2; int thi2_idx;        /* t[thi2_idx], the time right of the bracket after a move to the left (-1: unknown) */
+#endif
     int np;
     double tfinal;
     int ilast, newdata, have_last;
@@ -220,6 +262,125 @@ DEV void build_table(int order, double dt, const double (&hT)[QMAX + 1], double 
     } SEND
 }
 
+#if defined(SA_ABLATE_PROFILE) && defined(SA_INTERP_PROFILE)
+/* the values have ARRIVED (loads) / are COMPUTED before the clock is read */
+DEV void prof_pin(const double (&hT)[QMAX + 1], const double (&Y)[QMAX + 1][NSD])
+{
+#pragma unroll
+    for (int j = 0; j <= QMAX; j++) {
+        asm volatile("" :: "v"(hT[j]));
+#pragma unroll
+        for (int k = 0; k < NS; k++) asm volatile("" :: "v"(Y[j][k]));
+    }
+}
+#endif
+
+#if SA_SEARCH_CACHE
+/* The index CVAfindIndex's walk to the LEFT ends at, without walking: the first k in [0, hi] with (t - t[k]) <= 0, given
+   that the comparison holds at hi (thv = t[hi] on entry).  The stored times increase strictly, so the walk's
+   comparisons are monotone in k and any probing order finds the same index: SA_SEARCH_PROBES independent loads per round
+   (one memory latency per round, not per probe) -- galloping to the left of hi (distances 2, 4, 8, ...), then a section
+   search of the bracket.  On return thv = t[k] and, for k > 0, tlv = t[k-1] (both were probed on the way). */
+#ifndef SA_SEARCH_PROBES
+#define SA_SEARCH_PROBES 4
+#endif
+template <bool BWD>
+DEV int search_left(Cv<BWD> &m, double t, int hi, double &thv, double &tlv)
+{
+    constexpr int NP = SA_SEARCH_PROBES;
+    int lo = -1;
+    int64_t step = 2;
+    while (lo < 0 && hi > 0) {
+        int k[NP];
+        double v[NP];
+        SFOR(j, 0, NP) {
+            const int64_t kk = (int64_t)hi - (step << j);
+            k[j] = kk > 0 ? (int)kk : 0;
+            v[j] = point_time(m, k[j]); SEARCH_COUNT(m.n_interp);
+        } SEND
+        bool stop = false;
+        SFOR(j, 0, NP) {                      /* nearest first */
+            if (!stop) {
+                if ((t - v[j]) <= 0.0) { hi = k[j]; thv = v[j]; }
+                else { lo = k[j]; tlv = v[j]; stop = true; }
+            }
+        } SEND
+        step = (step < ((int64_t)1 << 40)) ? (step << NP) : step;
+    }
+    while (hi - lo > 1) {
+        const int n = hi - lo, lo0 = lo, hi0 = hi;
+        int k[NP];
+        double v[NP];
+        SFOR(j, 0, NP) {
+            int kk = lo0 + (int)(((int64_t)n * (j + 1)) / (NP + 1));
+            kk = kk < lo0 + 1 ? lo0 + 1 : kk;
+            kk = kk > hi0 - 1 ? hi0 - 1 : kk;
+            k[j] = kk;
+            v[j] = point_time(m, kk); SEARCH_COUNT(m.n_interp);
+        } SEND
+        bool found = false;
+        SFOR(j, 0, NP) {                      /* ascending */
+            if (!found) {
+                if ((t - v[j]) <= 0.0) { hi = k[j]; thv = v[j]; found = true; }
+                else { lo = k[j]; tlv = v[j]; }
+            }
+        } SEND
+    }
+    return hi;
+}
+/* ... to the RIGHT: the first k in (lo, np-1] with (t - t[k]) <= 0, or np-1 when there is none (the walk stops at the
+   last point); (t - t[lo]) > 0 on entry with tlv = t[lo].  On return thv = t[k], tlv = t[k-1]. */
+template <bool BWD>
+DEV int search_right(Cv<BWD> &m, double t, int lo, double &tlv, double &thv)
+{
+    constexpr int NP = SA_SEARCH_PROBES;
+    const int last = m.np - 1;
+    int hi = -1;
+    int64_t step = 1;
+    bool ran_off = false;
+    while (hi < 0) {
+        int k[NP];
+        double v[NP];
+        SFOR(j, 0, NP) {
+            const int64_t kk = (int64_t)lo + (step << j);
+            k[j] = kk < last ? (int)kk : last;
+            v[j] = point_time(m, k[j]); SEARCH_COUNT(m.n_rebuild);
+        } SEND
+        bool stop = false;
+        SFOR(j, 0, NP) {                      /* nearest first */
+            if (!stop) {
+                if ((t - v[j]) > 0.0) {
+                    lo = k[j]; tlv = v[j];
+                    if (k[j] == last) { hi = last; thv = v[j]; stop = true; ran_off = true; }
+                } else { hi = k[j]; thv = v[j]; stop = true; }
+            }
+        } SEND
+        step = (step < ((int64_t)1 << 40)) ? (step << NP) : step;
+    }
+    if (ran_off) { lo = last - 1; tlv = point_time(m, lo); }    /* (t beyond the last stored point) */
+    while (hi - lo > 1) {
+        const int n = hi - lo, lo0 = lo, hi0 = hi;
+        int k[NP];
+        double v[NP];
+        SFOR(j, 0, NP) {
+            int kk = lo0 + (int)(((int64_t)n * (j + 1)) / (NP + 1));
+            kk = kk < lo0 + 1 ? lo0 + 1 : kk;
+            kk = kk > hi0 - 1 ? hi0 - 1 : kk;
+            k[j] = kk;
+            v[j] = point_time(m, kk); SEARCH_COUNT(m.n_rebuild);
+        } SEND
+        bool found = false;
+        SFOR(j, 0, NP) {                      /* ascending */
+            if (!found) {
+                if ((t - v[j]) > 0.0) { lo = k[j]; tlv = v[j]; }
+                else { hi = k[j]; thv = v[j]; found = true; }
+            }
+        } SEND
+    }
+    return hi;
+}
+#endif
+
 /* CVAfindIndex + CVApolynomialGetY (forward integration direction), with the wrappers'
    repeated interpolation at an unchanged t evaluated once. */
 template <bool BWD>
@@ -231,7 +392,8 @@ DEV int interp_y(Cv<BWD> &m, double t)
     SFOR(i, 0, NS) m.ytmp[i] = 1.0 + 0.001 * t; SEND
     return CV_SUCCESS;
 #endif
-    m.n_interp++;
+    INTERP_COUNT(m.n_interp);
+    IPH(m, 0);
     int newpoint = 0, indx;
     if (m.newdata) {
         m.ilast = m.np - 1; newpoint = 1; m.newdata = 0;
@@ -246,14 +408,51 @@ DEV int interp_y(Cv<BWD> &m, double t)
         newpoint = 1;
         double tprev = m.tlo;                 /* t[indx-1] */
         double tcur = m.thi;                  /* t[indx]   */
+#if SA_SEARCH_CACHE
+        /* CVAfindIndex walks one index at a time; here the walk costs no dependent global load for the first QMAX
+           indices (their times are in the table of the current index, T[j] = t[cur_idx - j], read once) and continues
+           as a galloping + binary search (search_left) -- the same index, t[indx-1] and t[indx] as the walk's */
+        const bool tab_ok = (m.cur_idx == ilast);
+        const double tb3 = LT(m, 5), tb4 = LT(m, 6), tb5 = LT(m, 7);
+        double tright = m.thi2;
+        bool far = false;
+        for (;;) {
+            if (indx == 0) break;
+            if ((t - tprev) <= 0.0) {
+                indx--;
+                tright = tcur;                /* t[indx+1] */
+                tcur = tprev;
+                if (indx > 0) {
+                    const int back = ilast - indx + 1;            /* t[indx-1] = t[ilast - back] */
+                    if (back == 2) tprev = m.tlo2;
+                    else if (tab_ok && back <= QMAX) tprev = (back == 3) ? tb3 : ((back == 4) ? tb4 : tb5);
+#if SA_SEARCH_WINDOW > 0 && SA_COMPACT && !SA_TAB_REGS
+                    else if (tab_ok && back <= QMAX + SA_SEARCH_WINDOW) tprev = m.ltab[(TTAB + back - QMAX - 1) * 64];
+#endif
+                    else { far = true; break; }
+                }
+            } else break;
+        }
+        int right_idx = indx + 1;
+        if (far) {                            /* t <= t[indx] = tcur, t[indx-1] not at hand */
+            const int k = search_left(m, t, indx, tcur, tprev);
+            if (k != indx) right_idx = -1;
+            indx = k;
+        }
+        m.thi2 = tright; m.thi2_idx = right_idx;
+#else
         for (;;) {
             if (indx == 0) break;
             if ((t - tprev) <= 0.0) {
                 indx--;
                 tcur = tprev;
-                if (indx > 0) tprev = (indx == ilast - 1) ? m.tlo2 : point_time(m, indx - 1);
+                if (indx > 0) {
+                    if (indx == ilast - 1) tprev = m.tlo2;
+                    else { tprev = point_time(m, indx - 1); SEARCH_COUNT(m.n_interp); }
+                }
             } else break;
         }
+#endif
         m.ilast = (indx == 0) ? 1 : indx;
         if (indx == 0) {
             /* tcur = t[0]; CVODES leaves ilast = 1 here */
@@ -266,20 +465,34 @@ DEV int interp_y(Cv<BWD> &m, double t)
         newpoint = 1;
         double tcur = m.thi;                  /* t[indx] */
         double tprev = m.tlo;
+#if SA_SEARCH_CACHE
+        /* the first index to the right: t[ilast+1] is remembered from the last move to the left (the retry of a
+           rejected attempt steps back over it); further: galloping + binary search (search_right) */
+        if (indx < m.np - 1) {                /* ((t - tcur) > 0 holds: to_right) */
+            indx++;
+            tprev = tcur;
+            if (indx == m.thi2_idx) tcur = m.thi2;
+            else { tcur = point_time(m, indx); SEARCH_COUNT(m.n_rebuild); }
+            if (indx < m.np - 1 && (t - tcur) > 0.0) { tprev = tcur; indx = search_right(m, t, indx, tprev, tcur); }
+        }
+        m.thi2_idx = -1;                      /* t[indx+1] is not known after a move to the right */
+#else
         for (;;) {
             if (indx >= m.np - 1) break;
             if ((t - tcur) > 0.0) {
                 indx++;
                 tprev = tcur;
-                tcur = point_time(m, indx);
+                tcur = point_time(m, indx); SEARCH_COUNT(m.n_rebuild);
             } else break;
         }
+#endif
         m.ilast = indx;
         m.tlo = tprev; m.thi = tcur;
         if ((t - m.thi) > FUZZ_FACTOR_ADJ * UROUND * (fabs(m.tfinal) + 1.0)) return CV_GETY_BADT;
     }
     m.have_last = 1;
     m.last_t = t;
+    IPH(m, 1);
     if (indx == 0) {
         SFOR(i, 0, NS) m.ytmp[i] = m.traj[TREC_Y + i]; SEND   /* record 0: Y[0] = y(t0) */
         return CV_SUCCESS;
@@ -287,7 +500,7 @@ DEV int interp_y(Cv<BWD> &m, double t)
 #ifdef SA_HERMITE
     {   /* CVAhermiteGetY (see the oracle; same arithmetic as bdf_wave.hip / bdf_mem.hip) */
         if (newpoint) {
-            m.n_rebuild++;
+            INTERP_COUNT(m.n_rebuild);
             m.cur_idx = indx;
             const double *r0 = m.traj + (int64_t)(indx - 1) * m.trow, *r1 = m.traj + (int64_t)indx * m.trow;
             m.h_t0 = r0[2]; m.h_t1 = r1[2];
@@ -316,7 +529,7 @@ DEV int interp_y(Cv<BWD> &m, double t)
     }
 #endif
     if (newpoint) {
-        m.n_rebuild++;
+        INTERP_COUNT(m.n_rebuild);
         m.cur_idx = indx;                     /* the table CVODES would rebuild now */
         const double *r = m.traj + (int64_t)indx * m.trow;
         /* the touches issued at the previous move have long landed: retire them (keeps their
@@ -334,12 +547,30 @@ DEV int interp_y(Cv<BWD> &m, double t)
                 hT[j] = rj[TREC_T];
                 SFOR(k, 0, NS) { const double v = rj[TREC_Y + k]; Y[j][k] = (j <= order) ? v : 0.0; } SEND
             } SEND
+#if defined(SA_ABLATE_PROFILE) && defined(SA_INTERP_PROFILE)
+            prof_pin(hT, Y);
+            IPH(m, 2);
+#endif
+#if SA_SEARCH_WINDOW > 0 && SA_SEARCH_CACHE && !SA_TAB_REGS
+            double tw[SA_SEARCH_WINDOW];      /* t[indx - 6 - j]: the index search's window beyond the table's own times */
+            SFOR(j, 0, SA_SEARCH_WINDOW) {
+                const int q = indx - (QMAX + 1) - j;
+                tw[j] = m.traj[(int64_t)(q > 0 ? q : 0) * m.trow + TREC_T];
+            } SEND
+#endif
             const double dt = fabs(hT[0] - hT[1]);
             build_table(order, dt, hT, Y);
+#if defined(SA_ABLATE_PROFILE) && defined(SA_INTERP_PROFILE)
+            prof_pin(hT, Y);
+            IPH(m, 3);
+#endif
             LT(m, 0) = (double)order;
             LT(m, 1) = dt;
             SFOR(j, 0, (QMAX) + 1) LT(m, 2 + j) = hT[j]; SEND
             SFOR(j, 0, (QMAX) + 1) { SFOR(k, 0, NS) LT(m, 8 + j * NS + k) = Y[j][k]; SEND } SEND
+#if SA_SEARCH_WINDOW > 0 && SA_SEARCH_CACHE && !SA_TAB_REGS
+            SFOR(j, 0, SA_SEARCH_WINDOW) LT(m, TTAB + j) = tw[j]; SEND
+#endif
             const double *rn = r - (indx > QMAX + 1 ? (QMAX + 1) * m.trow : 0);     /* the point the next move adds */
             m.pf[0] = rn[0]; m.pf[1] = rn[TREC - 1]; m.pf[2] = m.pf[0]; m.pf[3] = m.pf[1];
         }
@@ -352,6 +583,7 @@ DEV int interp_y(Cv<BWD> &m, double t)
 #endif
         if (LT(m, 0) > (double)indx) return CV_GETY_BADT;    /* CVODES would shift the base; cannot occur */
         if (indx == m.ilast) m.tlo2 = LT(m, 4);              /* T[2] = t[ilast-2] for the next move */
+        IPH(m, 4);
     }
     {
         /* every LDS read of the record up front, in ONE batch: with the reads inside the conditional expressions
@@ -623,7 +855,11 @@ DEV int cv_lsetup(Cv<BWD> &m, int convfail)
 #define COLD_STORE(m)
 #define COLD_LOAD(m)
 #define PH_T0
+#if defined(SA_ABLATE_PROFILE) && defined(SA_INTERP_PROFILE)
+#define PH_ADD(m, k) PHASE(m, ((k) == 2 ? 5 : 0));
+#else
 #define PH_ADD(m, k) PHASE(m, k);
+#endif
 #define SA_RESCALE_ALWAYS 1          /* cv_attempt: the rescale runs for every lane (eta = 1: exact no-op), see there */
 #define SA_PRESTEP_FUSED 1           /* cv_pre_step: weights + accuracy test as one straight line (wrms2_n / wrms2_q below) */
 template <bool BWD>
@@ -733,6 +969,9 @@ extern "C" __global__ void __launch_bounds__(64) SA_FWD_ATTR sa_k_forward(sa_fwd
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0;
     m.last_t = 0.0; m.n_interp = 0; m.n_rebuild = 0; m.tlo = 0.0; m.thi = 0.0;
     m.traj = nullptr; m.trow = 0; m.cur_idx = 0; m.tlo2 = 0.0; m.ltab = nullptr;
+#if SA_SEARCH_CACHE
+    m.thi2 = 0.0; m.thi2_idx = -1;
+#endif
     m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
 #ifdef SA_SENS
     m.sensi = 0; m.ism = 0;
@@ -873,6 +1112,9 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
     m.np = 0; m.tfinal = 0.0; m.ilast = 0; m.newdata = 0; m.have_last = 0;
     m.last_t = 0.0; m.n_interp = 0; m.n_rebuild = 0; m.tlo = 0.0; m.thi = 0.0;
     m.traj = nullptr; m.trow = 0; m.cur_idx = 0; m.tlo2 = 0.0; m.ltab = nullptr;
+#if SA_SEARCH_CACHE
+    m.thi2 = 0.0; m.thi2_idx = -1;
+#endif
     m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
     m.sensi = 1; m.ism = a.ism;
 
@@ -971,7 +1213,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
 extern "C" __global__ void __launch_bounds__(64) SA_BWD_ATTR sa_k_backward(sa_bwd_args a)
 {
 #if !SA_TAB_REGS
-    __shared__ double ltab[TTAB * 64];        /* per-lane copy of the current divided-difference table */
+    __shared__ double ltab[(TTAB + SA_SEARCH_WINDOW) * 64];    /* per-lane copy of the current divided-difference table (+ the search window) */
 #endif
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
@@ -992,6 +1234,9 @@ extern "C" __global__ void __launch_bounds__(64) SA_BWD_ATTR sa_k_backward(sa_bw
     m.np = np;
     m.tfinal = (status == CV_SUCCESS) ? m.traj[(int64_t)(np - 1) * m.trow + TREC_T] : a.tinitial;
     m.cur_idx = 0; m.tlo2 = 0.0;
+#if SA_SEARCH_CACHE
+    m.thi2 = 0.0; m.thi2_idx = -1;
+#endif
     m.pf[0] = m.pf[1] = m.pf[2] = m.pf[3] = 0.0;
 #ifdef SA_ABLATE_PROFILE
     SFOR(k, 0, 8) m.prof[k] = 0; SEND

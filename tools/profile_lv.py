@@ -41,6 +41,14 @@ def main():
     names = ["step tail + output checks + rejected attempts", "pre_step + adjust + predict + cvSet", "interpolation",
              "newton", "error test + quadrature", "complete + prepare", "(unused)",
              "waiting for the slowest lane of the wavefront at the end of an observation interval + restart"]
+    if "SA_SEARCH_COUNT" in os.environ.get("SA_KERNEL_DEFINES", ""):
+        print("index search, dependent global loads per instance: moves to the left %.1f, to the right %.1f (of %.0f attempts)"
+              % (statsb[:, 11].mean(), statsb[:, 12].mean(), statsb[:, 14].mean()))
+        return
+    if "SA_INTERP_PROFILE" in os.environ.get("SA_KERNEL_DEFINES", ""):
+        names = ["everything but the interpolation", "index search", "point loads of a rebuild (until they have arrived)",
+                 "table arithmetic", "table stored + touches issued", "evaluation (table reads + Horner)", "(unused)",
+                 names[7]]
     p = statsb[:, 8:16].astype(float)
     tot = p.sum(axis=1).mean()
     print("bwd: steps %.0f, nfe %.0f, nsetups %.0f, nni %.0f, netf %.0f"
