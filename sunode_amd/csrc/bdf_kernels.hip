@@ -284,12 +284,33 @@ DEV void prof_pin(const double (&hT)[QMAX + 1], const double (&Y)[QMAX + 1][NSD]
 #ifndef SA_SEARCH_PROBES
 #define SA_SEARCH_PROBES 4
 #endif
+#ifndef SA_SEARCH_LINEAR
+#define SA_SEARCH_LINEAR 0
+#endif
 template <bool BWD>
 DEV int search_left(Cv<BWD> &m, double t, int hi, double &thv, double &tlv)
 {
     constexpr int NP = SA_SEARCH_PROBES;
     int lo = -1;
     int64_t step = 2;
+#if SA_SEARCH_LINEAR > 0
+    if (hi > 0) {                             /* first round: the next SA_SEARCH_LINEAR points, one by one (settles short moves in ONE round) */
+        int k[SA_SEARCH_LINEAR];
+        double v[SA_SEARCH_LINEAR];
+        SFOR(j, 0, SA_SEARCH_LINEAR) {
+            const int kk = hi - 1 - j;
+            k[j] = kk > 0 ? kk : 0;
+            v[j] = point_time(m, k[j]); SEARCH_COUNT(m.n_interp);
+        } SEND
+        bool stop = false;
+        SFOR(j, 0, SA_SEARCH_LINEAR) {
+            if (!stop) {
+                if ((t - v[j]) <= 0.0) { hi = k[j]; thv = v[j]; }
+                else { lo = k[j]; tlv = v[j]; stop = true; }
+            }
+        } SEND
+    }
+#endif
     while (lo < 0 && hi > 0) {
         int k[NP];
         double v[NP];
@@ -338,6 +359,26 @@ DEV int search_right(Cv<BWD> &m, double t, int lo, double &tlv, double &thv)
     int hi = -1;
     int64_t step = 1;
     bool ran_off = false;
+#if SA_SEARCH_LINEAR > 0
+    {                                         /* first round: the next SA_SEARCH_LINEAR points, one by one */
+        int k[SA_SEARCH_LINEAR];
+        double v[SA_SEARCH_LINEAR];
+        SFOR(j, 0, SA_SEARCH_LINEAR) {
+            const int kk = lo + 1 + j;
+            k[j] = kk < last ? kk : last;
+            v[j] = point_time(m, k[j]); SEARCH_COUNT(m.n_rebuild);
+        } SEND
+        bool stop = false;
+        SFOR(j, 0, SA_SEARCH_LINEAR) {
+            if (!stop) {
+                if ((t - v[j]) > 0.0) {
+                    lo = k[j]; tlv = v[j];
+                    if (k[j] == last) { hi = last; thv = v[j]; stop = true; ran_off = true; }
+                } else { hi = k[j]; thv = v[j]; stop = true; }
+            }
+        } SEND
+    }
+#endif
     while (hi < 0) {
         int k[NP];
         double v[NP];
