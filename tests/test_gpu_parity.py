@@ -1012,6 +1012,39 @@ def test_compact_trajectory_equals_table_records(name):
     assert res[1][5] * 4 < res[0][5]            # arena bytes: (n + 2) against (8 + 6 n) doubles per point
 
 
+@pytest.mark.parametrize("name,compact", [("robertson", None), ("lv", True)])
+def test_index_search_equals_cvodes_walk(name, compact, monkeypatch):
+    """Round 6: the compact-record builds of the one-lane mapping find the interpolation index by table times + the
+    remembered right neighbour + galloping / section search (bdf_kernels.hip SA_SEARCH_CACHE, search_left / search_right)
+    instead of CVAfindIndex' walk over the stored points.  Same index, same bracket times: states, gradients and EVERY
+    counter (interpolations and table rebuilds included) equal the -DSA_SEARCH_CACHE=0 build, which walks like CVODES and
+    the oracle -- on Robertson (801 + 258 points walked per instance) and on LV with compact records (table in
+    registers).  The algorithm itself: tests/test_index_search.py."""
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem(name)
+    B = 320
+    if name == "lv":
+        d = lv_batch(B); ps, pr = d["params"][:, :2], d["params"][:, 2:]; rt, at = 1e-8, 1e-8
+    else:
+        d = robertson_batch(B); ps, pr = d["params"], np.zeros(0); rt, at = 1e-8, 1e-10
+    tv = d["tvals"]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(prob.n_states)[None, :])
+    res = []
+    for defines in ("", "-DSA_SEARCH_CACHE=0"):
+        if defines:
+            monkeypatch.setenv("SA_KERNEL_DEFINES", defines)
+        sol = AdjointSolver(prob, abstol=at, reltol=rt, backward_abstol=at, backward_reltol=rt, quad_abstol=at,
+                            quad_reltol=rt, compact_trajectory=compact)
+        y, st, sf = sol.solve_forward_batch(0.0, tv, d["y0"], ps, pr)
+        g, lam, stb, sb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+        assert (st == 0).all() and (stb == 0).all()
+        res.append((y, sf[:, :14], g, lam, sb[:, :14]))
+        sol._engine().close()
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
+    assert res[0][4][:, 12].min() > 0              # (the table was rebuilt: the index did move)
+
+
 @pytest.mark.parametrize("name", ["lv", "robertson", "seir"])
 def test_randomized_sweep_matches_oracle(name):
     """Draws far outside the BASELINE batches: parameters spread over an order of magnitude (including draws whose
