@@ -1045,6 +1045,36 @@ def test_index_search_equals_cvodes_walk(name, compact, monkeypatch):
     assert res[0][4][:, 12].min() > 0              # (the table was rebuilt: the index did move)
 
 
+def test_stiff_five_state_model_equals_oracle():
+    """robertson5 (tools/problems.py): a stiff model with five states and four quadratures in the one-lane mapping, compact
+    records -- 1 260 backward steps over 720 stored points, the index moves in a third of the attempts and then by
+    several points (the far path of the index search at another vector length than Robertson's).  States, gradients,
+    adjoint states and every counter equal the oracle's, which walks like CVAfindIndex."""
+    from sunode_amd.solver import AdjointSolver
+    from tools.problems import robertson5_batch
+    prob = make_problem("robertson5")
+    B = 200
+    d = robertson5_batch(B)
+    tv = d["tvals"]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(5)[None, :])
+    sol = AdjointSolver(prob, abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8,
+                        quad_abstol=1e-10, quad_reltol=1e-8)
+    y, st, sf = sol.solve_forward_batch(0.0, tv, d["y0"], d["params"], np.zeros(0))
+    g, lam, stb, sb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+    orc = make_oracle("robertson5")
+    cfg = orc.config(rtol=1e-8, atol=1e-10, rtolB=1e-8, atolB=1e-10, rtolQB=1e-8, atolQB=1e-10)
+    yo, so, sto = orc.solve_forward(cfg, d["y0"], d["params"], np.zeros(0), 0.0, tv, nthreads=8)
+    go, lo, sbo, stbo = orc.solve_backward(cfg, tv[-1], 0.0, tv, grads, nthreads=8)
+    assert (st == 0).all() and (stb == 0).all()
+    np.testing.assert_array_equal(st, so); np.testing.assert_array_equal(stb, sbo)
+    np.testing.assert_array_equal(y, yo)
+    np.testing.assert_array_equal(g, go)
+    np.testing.assert_array_equal(lam, lo)
+    np.testing.assert_array_equal(sf[:, CMP], sto[:, CMP])
+    np.testing.assert_array_equal(sb[:, CMP_B], stbo[:, CMP_B])
+    assert sb[:, 12].mean() * 2 < sb[:, 0].mean()          # fewer table rebuilds than steps: the index jumps
+
+
 @pytest.mark.parametrize("name", ["lv", "robertson", "seir"])
 def test_randomized_sweep_matches_oracle(name):
     """Draws far outside the BASELINE batches: parameters spread over an order of magnitude (including draws whose

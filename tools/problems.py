@@ -31,6 +31,19 @@ def robertson(t, y, p):
     }
 
 
+def robertson5(t, y, p):
+    """Robertson with two slow tracer states fed by y1 (five states, four differentiated parameters): a STIFF model at the
+    upper end of the one-lane mapping -- its backward steps move over many stored points, i.e. the far path of the index
+    search (csrc/bdf_kernels.hip search_left / search_right) at another vector length than config 3's."""
+    return {
+        "y1": -p.k1 * y.y1 + p.k2 * y.y2 * y.y3,
+        "y2": p.k1 * y.y1 - p.k2 * y.y2 * y.y3 - p.k3 * y.y2 ** 2,
+        "y3": p.k3 * y.y2 ** 2,
+        "w1": p.k1 * y.y1 - p.r * y.w1,
+        "w2": p.r * y.w1 * y.y3,
+    }
+
+
 def seir(t, y, p):
     N = y.S + y.E + y.I + y.R
     force = [sum(p.beta[i] * p.C[i, j] * y.I[j] / N[j] for j in range(4)) for i in range(4)]
@@ -152,6 +165,12 @@ PROBLEMS = {
         states={"y1": (), "y2": (), "y3": ()},
         rhs=robertson,
         derivative_params=[("k1",), ("k2",), ("k3",)],
+    ),
+    "robertson5": dict(
+        params={"k1": (), "k2": (), "k3": (), "r": ()},
+        states={"y1": (), "y2": (), "y3": (), "w1": (), "w2": ()},
+        rhs=robertson5,
+        derivative_params=[("k1",), ("k2",), ("k3",), ("r",)],
     ),
     "seir": dict(
         params={"beta": (4,), "C": (4, 4), "rates": {"sigma": (), "gamma": (), "mu": (), "nu": ()}},
@@ -320,6 +339,16 @@ def robertson_batch(B: int, seed: int = SEED, idx=None):
     params = k0 * np.exp(0.1 * z)
     y0 = np.tile(np.array([1.0, 0.0, 0.0]), (len(z), 1))
     tvals = np.array([0.0] + [0.4 * 10.0 ** k for k in range(6)])
+    return dict(params=params, y0=y0, tvals=tvals, t0=0.0, rtol=1e-8, atol=1e-10)
+
+
+def robertson5_batch(B: int, seed: int = SEED, idx=None):
+    """robertson5: k = k0*exp(0.1 z), r = 0.05*exp(0.2 z'), y0 = (1, 0, 0, 0, 0), T = 4e3, rtol 1e-8 / atol 1e-10."""
+    k0 = np.array([0.04, 1e4, 3e7])
+    z = np.stack([std_normal(seed, 80 + s, B, idx) for s in range(4)], axis=1)
+    params = np.concatenate([k0 * np.exp(0.1 * z[:, :3]), 0.05 * np.exp(0.2 * z[:, 3:])], axis=1)
+    y0 = np.tile(np.array([1.0, 0.0, 0.0, 0.0, 0.0]), (len(z), 1))
+    tvals = np.array([0.0] + [0.4 * 10.0 ** k for k in range(5)])
     return dict(params=params, y0=y0, tvals=tvals, t0=0.0, rtol=1e-8, atol=1e-10)
 
 
