@@ -16,10 +16,10 @@ def batch(name, B):
     named = {"forcing": P.forcing_batch, "logistic_switch": P.logistic_switch_batch, "misc": P.misc_batch}
     if name in named:
         return named[name](B)
-    if name in ("seir", "robertson"):               # BASELINE configs 4 / 3 (shared cotangents as in the parity tests)
-        d = P.seir_batch(B) if name == "seir" else P.robertson_batch(B)
+    if name in ("seir", "robertson", "robertson5"):   # BASELINE configs 4 / 3 (shared cotangents as in the parity tests)
+        d = P.seir_batch(B) if name == "seir" else (P.robertson_batch(B) if name == "robertson" else P.robertson5_batch(B))
         n = d["y0"].shape[1]
-        if name == "robertson":
+        if name != "seir":
             d["ps"], d["pr"] = d["params"], np.zeros(0)
         d["grads"] = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(d["tvals"]))[:, None] + 0.9 * np.arange(n)[None, :])
         return d
