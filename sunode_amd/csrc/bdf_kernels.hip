@@ -77,6 +77,8 @@ constexpr int sa_tau_c(int f, int j) { return j == 0 ? f : (j == f ? 0 : j); }
    attempts, some lane of the 64 in nearly every iteration; profiles/r06_interp_search.txt) that walk was 21 % of the
    backward kernel.  SA_SEARCH_CACHE: the same index without the walk -- times from the current table, the remembered
    right neighbour, then galloping + section search with independent probes (search_left / search_right below).
+   Measured beside it and not kept (same file): 1 / 2 / 8 probes per round, a contiguous first round, 8 / 16 further times
+   parked in LDS at every rebuild (fewer walks, but the extra scattered loads of every rebuild cost more).
    On for the compact-record builds (three states and more); the table-record builds (two states: 13 backward steps per
    stored point, 8 + 9 such loads per instance) keep the plain walk, which is 1 % faster there.  Hermite builds: off
    (no divided-difference table to take the times from). */
@@ -86,12 +88,6 @@ constexpr int sa_tau_c(int f, int j) { return j == 0 ? f : (j == f ? 0 : j); }
 #else
 #define SA_SEARCH_CACHE 0
 #endif
-#endif
-/* SA_SEARCH_WINDOW: that many more times to the left of the table's six (t[cur_idx - 6 - j]) ride along with the point
-   loads of every rebuild into the lane's LDS column, so that moves of up to 5 + SA_SEARCH_WINDOW indices need no
-   dependent load at all (compact-record builds with the table in LDS only) */
-#ifndef SA_SEARCH_WINDOW
-#define SA_SEARCH_WINDOW 0
 #endif
 #if defined(SA_ABLATE_PROFILE) && defined(SA_INTERP_PROFILE)
 #define IPH(m, k) PHASE(m, k)
@@ -284,33 +280,12 @@ DEV void prof_pin(const double (&hT)[QMAX + 1], const double (&Y)[QMAX + 1][NSD]
 #ifndef SA_SEARCH_PROBES
 #define SA_SEARCH_PROBES 4
 #endif
-#ifndef SA_SEARCH_LINEAR
-#define SA_SEARCH_LINEAR 0
-#endif
 template <bool BWD>
 DEV int search_left(Cv<BWD> &m, double t, int hi, double &thv, double &tlv)
 {
     constexpr int NP = SA_SEARCH_PROBES;
     int lo = -1;
     int64_t step = 2;
-#if SA_SEARCH_LINEAR > 0
-    if (hi > 0) {                             /* first round: the next SA_SEARCH_LINEAR points, one by one (settles short moves in ONE round) */
-        int k[SA_SEARCH_LINEAR];
-        double v[SA_SEARCH_LINEAR];
-        SFOR(j, 0, SA_SEARCH_LINEAR) {
-            const int kk = hi - 1 - j;
-            k[j] = kk > 0 ? kk : 0;
-            v[j] = point_time(m, k[j]); SEARCH_COUNT(m.n_interp);
-        } SEND
-        bool stop = false;
-        SFOR(j, 0, SA_SEARCH_LINEAR) {
-            if (!stop) {
-                if ((t - v[j]) <= 0.0) { hi = k[j]; thv = v[j]; }
-                else { lo = k[j]; tlv = v[j]; stop = true; }
-            }
-        } SEND
-    }
-#endif
     while (lo < 0 && hi > 0) {
         int k[NP];
         double v[NP];
@@ -359,26 +334,6 @@ DEV int search_right(Cv<BWD> &m, double t, int lo, double &tlv, double &thv)
     int hi = -1;
     int64_t step = 1;
     bool ran_off = false;
-#if SA_SEARCH_LINEAR > 0
-    {                                         /* first round: the next SA_SEARCH_LINEAR points, one by one */
-        int k[SA_SEARCH_LINEAR];
-        double v[SA_SEARCH_LINEAR];
-        SFOR(j, 0, SA_SEARCH_LINEAR) {
-            const int kk = lo + 1 + j;
-            k[j] = kk < last ? kk : last;
-            v[j] = point_time(m, k[j]); SEARCH_COUNT(m.n_rebuild);
-        } SEND
-        bool stop = false;
-        SFOR(j, 0, SA_SEARCH_LINEAR) {
-            if (!stop) {
-                if ((t - v[j]) > 0.0) {
-                    lo = k[j]; tlv = v[j];
-                    if (k[j] == last) { hi = last; thv = v[j]; stop = true; ran_off = true; }
-                } else { hi = k[j]; thv = v[j]; stop = true; }
-            }
-        } SEND
-    }
-#endif
     while (hi < 0) {
         int k[NP];
         double v[NP];
@@ -467,9 +422,6 @@ DEV int interp_y(Cv<BWD> &m, double t)
                     const int back = ilast - indx + 1;            /* t[indx-1] = t[ilast - back] */
                     if (back == 2) tprev = m.tlo2;
                     else if (tab_ok && back <= QMAX) tprev = (back == 3) ? tb3 : ((back == 4) ? tb4 : tb5);
-#if SA_SEARCH_WINDOW > 0 && SA_COMPACT && !SA_TAB_REGS
-                    else if (tab_ok && back <= QMAX + SA_SEARCH_WINDOW) tprev = m.ltab[(TTAB + back - QMAX - 1) * 64];
-#endif
                     else { far = true; break; }
                 }
             } else break;
@@ -592,13 +544,6 @@ DEV int interp_y(Cv<BWD> &m, double t)
             prof_pin(hT, Y);
             IPH(m, 2);
 #endif
-#if SA_SEARCH_WINDOW > 0 && SA_SEARCH_CACHE && !SA_TAB_REGS
-            double tw[SA_SEARCH_WINDOW];      /* t[indx - 6 - j]: the index search's window beyond the table's own times */
-            SFOR(j, 0, SA_SEARCH_WINDOW) {
-                const int q = indx - (QMAX + 1) - j;
-                tw[j] = m.traj[(int64_t)(q > 0 ? q : 0) * m.trow + TREC_T];
-            } SEND
-#endif
             const double dt = fabs(hT[0] - hT[1]);
             build_table(order, dt, hT, Y);
 #if defined(SA_ABLATE_PROFILE) && defined(SA_INTERP_PROFILE)
@@ -609,9 +554,6 @@ DEV int interp_y(Cv<BWD> &m, double t)
             LT(m, 1) = dt;
             SFOR(j, 0, (QMAX) + 1) LT(m, 2 + j) = hT[j]; SEND
             SFOR(j, 0, (QMAX) + 1) { SFOR(k, 0, NS) LT(m, 8 + j * NS + k) = Y[j][k]; SEND } SEND
-#if SA_SEARCH_WINDOW > 0 && SA_SEARCH_CACHE && !SA_TAB_REGS
-            SFOR(j, 0, SA_SEARCH_WINDOW) LT(m, TTAB + j) = tw[j]; SEND
-#endif
             const double *rn = r - (indx > QMAX + 1 ? (QMAX + 1) * m.trow : 0);     /* the point the next move adds */
             m.pf[0] = rn[0]; m.pf[1] = rn[TREC - 1]; m.pf[2] = m.pf[0]; m.pf[3] = m.pf[1];
         }
@@ -1254,7 +1196,7 @@ extern "C" __global__ void __launch_bounds__(64) sa_k_sens(sa_sens_args a)
 extern "C" __global__ void __launch_bounds__(64) SA_BWD_ATTR sa_k_backward(sa_bwd_args a)
 {
 #if !SA_TAB_REGS
-    __shared__ double ltab[(TTAB + SA_SEARCH_WINDOW) * 64];    /* per-lane copy of the current divided-difference table (+ the search window) */
+    __shared__ double ltab[TTAB * 64];        /* per-lane copy of the current divided-difference table */
 #endif
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;

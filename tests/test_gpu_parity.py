@@ -1045,6 +1045,37 @@ def test_index_search_equals_cvodes_walk(name, compact, monkeypatch):
     assert res[0][4][:, 12].min() > 0              # (the table was rebuilt: the index did move)
 
 
+@pytest.mark.parametrize("defines", ["-DSA_SEARCH_COUNT", "-DSA_ABLATE_PROFILE -DSA_INTERP_PROFILE"])
+def test_diagnostic_builds_of_the_one_lane_kernel_integrate_like_the_default_build(defines, monkeypatch):
+    """tools/profile_lv.py's builds of bdf_kernels.hip (the numbers in profiles/r06_interp_search.txt and *_lv_phases.txt
+    come from them): -DSA_SEARCH_COUNT counts the index search's dependent loads in the statistics slots of the
+    interpolations / rebuilds, -DSA_ABLATE_PROFILE -DSA_INTERP_PROFILE puts clock readings into slots 8..15.  Neither may
+    change a result: states, gradients, adjoint states and the CVODES counters equal the default build's."""
+    from sunode_amd.solver import AdjointSolver
+    prob = make_problem("robertson")
+    B = 96
+    d = robertson_batch(B)
+    tv = d["tvals"]
+    grads = 1.0 + 0.5 * np.cos(1.7 * np.arange(len(tv))[:, None] + 0.9 * np.arange(3)[None, :])
+    res = []
+    for env in ("", defines):
+        if env:
+            monkeypatch.setenv("SA_KERNEL_DEFINES", env)
+        sol = AdjointSolver(prob, abstol=1e-10, reltol=1e-8, backward_abstol=1e-10, backward_reltol=1e-8,
+                            quad_abstol=1e-10, quad_reltol=1e-8)
+        y, st, sf = sol.solve_forward_batch(0.0, tv, d["y0"], d["params"], np.zeros(0))
+        g, lam, stb, sb = sol.solve_backward_batch(tv[-1], 0.0, tv, grads)
+        assert (st == 0).all() and (stb == 0).all()
+        res.append((y, g, lam, sf[:, :8], sb[:, :8], sb))
+        sol._engine().close()
+    for a, b in zip(res[0][:5], res[1][:5]):
+        np.testing.assert_array_equal(a, b)
+    if "COUNT" in defines:
+        assert res[1][5][:, 11].sum() > 0 and res[1][5][:, 12].sum() > 0      # far moves to the left and to the right happened
+    else:
+        assert res[1][5][:, 9].min() > 0                                       # the search's timer did run
+
+
 def test_stiff_five_state_model_equals_oracle():
     """robertson5 (tools/problems.py): a stiff model with five states and four quadratures in the one-lane mapping, compact
     records -- 1 260 backward steps over 720 stored points, the index moves in a third of the attempts and then by
